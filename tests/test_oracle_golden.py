@@ -1,0 +1,169 @@
+"""Pins the CPU oracle (oracle/torch_oracle.py) against golden vectors captured from the
+imported reference (oracle/make_golden.py).  Tolerance: same ATen ops => <=1e-6 relative;
+schedule tables bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_oracle as O
+from shapegen_amd import specs
+from helpers import point_sd, latent_sd, sab_sd, una_sd, rel_l2, voxels_from_idx
+
+torch.set_grad_enabled(False)
+
+
+def test_schedule_tables_bit_exact(golden):
+    g = golden("schedule.npz")
+    n, s = O.offset_cosine_schedule(torch.from_numpy(g["cos_t"]))
+    assert np.array_equal(n.numpy(), g["cos_noise"]) and np.array_equal(s.numpy(), g["cos_signal"])
+    # SURVEY A.1 probe values
+    assert abs(g["cos_noise"][-1] - 0.99979997) < 1e-7 and abs(g["cos_signal"][2] - 0.59447980) < 1e-7
+    n, s = O.linear_schedule(torch.from_numpy(g["lin_t"]))
+    assert np.array_equal(n.numpy(), g["lin_noise"]) and np.array_equal(s.numpy(), g["lin_signal"])
+
+
+@pytest.mark.parametrize("T", [50, 100, 1000])
+def test_sampler_time_sequences_bit_exact(golden, T):
+    g = golden("schedule.npz")
+    dummy = lambda x, t: torch.zeros_like(x)
+    tr = []
+    O.ddim_sample(dummy, torch.zeros(1, 1, 3), T, trace=tr)
+    assert np.array_equal(np.asarray(tr, np.float32), g[f"sample_T{T}"])
+    tr = []
+    O.ddpm_sample(dummy, torch.zeros(1, 1, 3), T, [torch.zeros(1, 1, 3)] * (T - 1), trace=tr)
+    got, want = np.asarray(tr, np.float32), g[f"sample2_T{T}"].copy()
+    # column 3 of the golden holds sqrt(n_prev/n); the oracle trace holds n_prev
+    want_coef = want[:-1, 3]
+    got_coef = np.sqrt(got[:-1, 3] / got[:-1, 1]).astype(np.float32)
+    np.testing.assert_allclose(got_coef, want_coef, rtol=2e-7)
+    assert np.array_equal(got[:, [0, 1, 2]], want[:, [0, 1, 2]])
+    assert np.array_equal(got[:-1, 4], want[:-1, 4])
+
+
+def test_sample3_time_sequence_bit_exact(golden):
+    g = golden("schedule.npz")
+    dummy = lambda x, t: torch.zeros_like(x)
+    for key, T, start in (("sample3_T1000_from0.01", 1000, 0.01), ("sample3_T100_from1", 100, 1.0)):
+        tr = []
+        O.ddim_from_state(dummy, torch.zeros(2, 1, 3), torch.ones(2) * start, T, trace=tr)
+        assert np.array_equal(np.asarray(tr, np.float32), g[key], equal_nan=True)
+
+
+def test_time_embedding(golden):
+    g = golden("point_unet.npz")
+    sd = point_sd()
+    emb = O.timestep_embedding(torch.from_numpy(g["temb_t"]), 256)
+    assert np.array_equal(emb.numpy(), g["temb_sin"])
+    np.testing.assert_allclose(O.time_mlp(sd, "model.", emb).numpy(), g["temb_mlp"], rtol=1e-6, atol=1e-6)
+
+
+def test_point_unet_forward_and_taps(golden):
+    g = golden("point_unet.npz")
+    sd = point_sd()
+    taps = {}
+    eps = O.unet_pointnet_large(sd, "model.", torch.from_numpy(g["fw_small_x"]),
+                                torch.from_numpy(g["fw_small_t"]), taps=taps)
+    assert rel_l2(eps, g["fw_small_eps"]) < 1e-6
+    for mine, ref in (("x1", "enc1"), ("x2", "enc2"), ("x3", "enc3"), ("x4", "enc4"), ("pooled", "pooled"),
+                      ("d4", "dec4"), ("d3", "dec3"), ("d2", "dec2"), ("d1", "dec1")):
+        assert rel_l2(taps[mine], g["fw_small_" + ref]) < 1e-6, mine
+    eps = O.unet_pointnet_large(sd, "model.", torch.from_numpy(g["fw_mid_x"]), torch.from_numpy(g["fw_mid_t"]))
+    assert rel_l2(eps, g["fw_mid_eps"]) < 1e-6
+    assert float(torch.from_numpy(g["fw_mid_eps"]).std()) > 0.05  # the fixture is not degenerate
+
+
+def test_single_steps(golden):
+    g = golden("point_unet.npz")
+    x, eps, z = map(torch.from_numpy, (g["fw_small_x"], g["fw_small_eps"], g["step_z"]))
+    n, s, nn_, sn = [torch.full((2,), float(v)) for v in g["step_rates"]]
+    x0 = O.remove_noise(x, eps, n, s)
+    np.testing.assert_allclose(x0.numpy(), g["step_x0"], rtol=1e-6, atol=1e-6)
+    ddim = sn.view(-1, 1, 1) * x0 + nn_.view(-1, 1, 1) * eps
+    np.testing.assert_allclose(ddim.numpy(), g["step_ddim"], rtol=1e-6, atol=1e-6)
+    ddpm = sn.view(-1, 1, 1) * x0 + torch.sqrt(nn_ / n).view(-1, 1, 1) * n.view(-1, 1, 1) * z
+    np.testing.assert_allclose(ddpm.numpy(), g["step_ddpm"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("T", [5, 50])
+def test_ddim_sampler(golden, T):
+    g = golden("point_samplers.npz")
+    sd = point_sd()
+    model = lambda x, t: O.unet_pointnet_large(sd, "model.", x, t)
+    out = O.ddim_sample(model, torch.from_numpy(g[f"sample_T{T}_xT"]), T)
+    assert rel_l2(out, g[f"sample_T{T}_out"]) < 1e-5
+
+
+def test_ddpm_and_from_state_samplers(golden):
+    g = golden("point_samplers.npz")
+    sd = point_sd()
+    model = lambda x, t: O.unet_pointnet_large(sd, "model.", x, t)
+    out = O.ddpm_sample(model, torch.from_numpy(g["s2_xT"]), 20, list(torch.from_numpy(g["s2_z"])))
+    assert rel_l2(out, g["s2_out"]) < 1e-5
+    noisy, n, s = O.add_noise(torch.from_numpy(g["s3_x0"]), torch.ones(2) * 0.01, torch.from_numpy(g["s3_noise"]))
+    np.testing.assert_allclose(noisy.numpy(), g["s3_noisy"], rtol=1e-6, atol=1e-7)
+    out = O.ddim_from_state(model, noisy, torch.ones(2), 20)
+    assert rel_l2(out, g["s3_T20_from1_out"]) < 1e-5
+
+
+def test_latent_unet_and_vae(golden):
+    g = golden("latent.npz")
+    sd = latent_sd()
+    eps = O.latent_unet(sd, "model.", torch.from_numpy(g["lat_z"]), torch.from_numpy(g["lat_t"]))
+    assert rel_l2(eps, g["lat_eps"]) < 1e-6
+    vox = voxels_from_idx([g["vae_occ_idx"], g["vae_occ_idx1"]])
+    mu, logvar = O.vae_encode(sd, "vae.", vox, specs.VAE_ENC)
+    assert rel_l2(mu, g["vae_mu"]) < 1e-5 and rel_l2(logvar, g["vae_logvar"]) < 1e-5
+    dec = O.vae_decode(sd, "vae.", torch.from_numpy(g["vae_mu"]), specs.VAE_DEC)
+    assert rel_l2(dec, g["vae_dec"]) < 1e-5
+    for thr in (0.4, 0.5):
+        pcs = O.voxel_tensor_to_point_clouds(torch.from_numpy(g["vae_dec"]), thr)
+        for i, pc in enumerate(pcs):
+            assert np.array_equal(pc.numpy(), g[f"v2p_thr{thr}_{i}"])  # integer-derived: bit exact
+
+
+def test_latent_ddim(golden):
+    g = golden("latent.npz")
+    sd = latent_sd()
+    model = lambda z, t: O.latent_unet(sd, "model.", z, t)
+    z0 = O.ddim_sample(model, torch.from_numpy(g["ldm_T5_zT"]), 5)
+    assert rel_l2(z0, g["ldm_T5_z0"]) < 1e-5
+    pcs = O.voxel_tensor_to_point_clouds(O.vae_decode(sd, "vae.", z0, specs.VAE_DEC), 0.4)
+    assert [len(p) for p in pcs] == list(g["ldm_T5_counts"])
+    assert np.array_equal(pcs[0].numpy(), g["ldm_T5_pc0"])
+
+
+def test_metrics_units_known_answers(golden):
+    """reference units.py:8-26 inputs; SURVEY section 4 probe values."""
+    g = golden("metrics.npz")
+    x, y = torch.from_numpy(g["units_x"]), torch.from_numpy(g["units_y"])
+    assert abs(float(g["units_cd"]) - 142.7139) < 1e-3
+    assert abs(float(g["units_emd_cpu"]) - 44.3071) < 1e-3
+    assert abs(float(g["units_emd_sinkhorn"]) - 5.9952) < 1e-3
+    assert abs(float(O.chamfer_distance(x, y)) - float(g["units_cd"])) < 1e-3
+    assert abs(float(O.earth_mover_distance_cpu(x, y)) - float(g["units_emd_cpu"])) < 1e-4
+    assert abs(float(O.earth_mover_distance_sinkhorn(x, y)) - float(g["units_emd_sinkhorn"])) < 1e-4
+    assert abs(float(O.chamfer_distance_exact(x, y)) - float(g["units_cd"])) < 1e-2
+
+
+def test_metrics_fixtures(golden):
+    g = golden("metrics.npz")
+    a, b = torch.from_numpy(g["m_a"]), torch.from_numpy(g["m_b"])
+    assert np.array_equal(O.normalize_to_cube(a).numpy(), g["m_norm_a"])
+    assert abs(float(O.chamfer_distance(a, b)) - float(g["m_cd_batch"])) < 1e-3
+    assert abs(float(O.chamfer_distance(a, b, 1)) - float(g["m_cd_s1"])) < 1e-6
+    vox = O.voxelize(a).numpy().reshape(3, -1)
+    assert np.array_equal(np.flatnonzero(vox[0]).astype(np.int32), g["m_vox_a_idx"])
+    assert np.array_equal(vox.sum(1).astype(np.int64), g["m_vox_counts"])
+    for i in range(3):
+        tr = O.compute_metrics(a[i], b[i])
+        np.testing.assert_allclose([float(v) for v in tr], g["m_triples"][i], rtol=1e-5, atol=1e-5)
+    assert abs(float(O.earth_mover_distance_sinkhorn(a, b)) - float(g["m_emd_sinkhorn_batch"])) < 1e-5
+
+
+def test_set_attention(golden):
+    g = golden("attention.npz")
+    for C in (64, 128, 256):
+        out = O.set_attention_block(sab_sd(C), "", torch.from_numpy(g[f"sab{C}_x"]), 4)
+        assert rel_l2(out, g[f"sab{C}_out"]) < 2e-6, C
+    eps = O.unet_attention(una_sd(), "", torch.from_numpy(g["una_x"]), torch.from_numpy(g["una_t"]))
+    assert rel_l2(eps, g["una_eps"]) < 1e-5
