@@ -1,0 +1,135 @@
+"""ctypes binding of the gfx950 shared library (C ABI: include/pcd_hip.h).
+
+The product path has NO fallback: if `libpcd_hip.so` is missing or a call returns an
+error, a RuntimeError is raised.  Build the library with `python __graft_entry__.py build`
+(or `make -C 3d-shape-generation_amd/csrc`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpcd_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+vp = C.c_void_p
+i32, i64, u64, f32, sz = C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
+
+PCD_UNET_NLIN = 26
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("a1", vp), ("lda1", i64), ("k1", i32),
+                ("a2", vp), ("lda2", i64), ("k2", i32),
+                ("w", vp), ("ldw", i64),
+                ("bias", vp), ("shape_bias", vp), ("rows_per_shape", i32),
+                ("relu", i32), ("m", i32), ("c", i32)]
+
+
+class LinearDesc(C.Structure):
+    _fields_ = [("w", vp), ("b", vp), ("k", i32), ("c", i32)]
+
+
+class UnetDesc(C.Structure):
+    _fields_ = [("time_dim", i32), ("dim", i32), ("freqs", vp),
+                ("tw0", vp), ("tb0", vp), ("tw2", vp), ("tb2", vp),
+                ("e1w_xyz", vp), ("e1w_t", vp), ("e1b", vp),
+                ("lin", LinearDesc * PCD_UNET_NLIN),
+                ("wg", vp), ("wg_k", i32), ("wg_c", i32),
+                ("head_w", vp), ("head_b", vp)]
+
+
+# name -> (restype, argtypes).  Kept in the order of include/pcd_hip.h.
+_SIGS = {
+    "pcd_last_error": (C.c_char_p, []),
+    "pcd_abi_version": (i32, []),
+    "pcd_device_check": (i32, []),
+    "pcd_gemm_f16": (i32, [C.POINTER(GemmDesc), vp, i64, vp]),
+    "pcd_gemm_f16_out32": (i32, [C.POINTER(GemmDesc), vp, i64, vp]),
+    "pcd_gemm_f16_residual": (i32, [C.POINTER(GemmDesc), vp, i64, vp, i64, vp]),
+    "pcd_gemm_f16_colmax": (i32, [C.POINTER(GemmDesc), vp, i32, vp]),
+    "pcd_fill_zero": (i32, [vp, sz, vp]),
+    "pcd_f32_to_f16": (i32, [vp, vp, i64, vp]),
+    "pcd_f16_to_f32": (i32, [vp, vp, i64, vp]),
+    "pcd_time_embed": (i32, [vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]),
+    "pcd_linear_f32": (i32, [vp, i32, i32, vp, vp, i32, vp, vp]),
+    "pcd_enc1_xyz": (i32, [vp, i64, i32, vp, i32, vp, i32, vp, vp]),
+    "pcd_add_noise": (i32, [vp, vp, vp, vp, i32, i64, i64, vp, vp]),
+    "pcd_remove_noise": (i32, [vp, vp, vp, vp, i32, i64, i64, vp, vp]),
+    "pcd_ddim_update": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i64, vp, vp, vp]),
+    "pcd_ddpm_update": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i64, i64, vp, vp, vp]),
+    "pcd_randn": (i32, [vp, i64, u64, u64, vp]),
+    "pcd_head3": (i32, [vp, i64, i32, vp, vp, vp, vp]),
+    "pcd_unet_create": (i32, [C.POINTER(UnetDesc), C.POINTER(vp)]),
+    "pcd_unet_destroy": (None, [vp]),
+    "pcd_unet_workspace_bytes": (sz, [i32, i32]),
+    "pcd_unet_forward": (i32, [vp, vp, i32, i32, vp, i32, vp, vp, sz, vp]),
+    "pcd_unet_profile": (i32, [vp, i32]),
+    "pcd_unet_profile_read": (i32, [vp, C.POINTER(C.c_double), C.POINTER(i32)]),
+    "pcd_unet_tap": (i32, [vp, C.c_char_p, i32, i32, vp, vp, sz, vp]),
+    "pcd_layernorm_f16": (i32, [vp, i64, i32, vp, vp, vp, vp]),
+    "pcd_set_attention_workspace_bytes": (sz, [i32, i32, i32]),
+    "pcd_set_attention_f16": (i32, [vp, i32, i32, i32, i32, vp, vp, sz, vp]),
+    "pcd_normalize_to_cube": (i32, [vp, i32, i32, vp, vp]),
+    "pcd_chamfer_sums": (i32, [vp, vp, i32, i32, i32, vp, vp]),
+    "pcd_voxelize": (i32, [vp, i32, i32, i32, vp, vp]),
+    "pcd_voxels_to_points": (i32, [vp, i32, i32, i32, i32, f32, vp, vp, vp]),
+    "pcd_binary_bce_mean": (i32, [vp, vp, i64, vp, vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building libpcd_hip.so failed:\n" + res.stdout[-4000:] + res.stderr[-4000:])
+    if verbose:
+        print(res.stdout)
+    return LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load the library (once) and attach prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension is required (no CPU fallback). "
+            "Run `python __graft_entry__.py build`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)   # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().pcd_last_error()
+        raise RuntimeError(f"pcd_hip {what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (or 0 for None)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def stream_ptr() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu() -> None:
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("an MI355X (gfx950) device is required: this framework has no CPU path")
+    check(load().pcd_device_check(), "device_check")

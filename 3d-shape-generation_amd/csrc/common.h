@@ -1,0 +1,47 @@
+// Shared helpers for the gfx950 library (internal; the public ABI is include/pcd_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/pcd_hip.h"
+
+namespace pcd {
+
+void set_error(const char* fmt, ...);
+
+#define PCD_CHECK_ARG(cond)                                                        \
+    do {                                                                           \
+        if (!(cond)) {                                                             \
+            ::pcd::set_error("%s:%d: bad argument: %s", __FILE__, __LINE__, #cond); \
+            return PCD_ERR_ARG;                                                    \
+        }                                                                          \
+    } while (0)
+
+#define PCD_CHECK_HIP(expr)                                                              \
+    do {                                                                                 \
+        hipError_t e__ = (expr);                                                         \
+        if (e__ != hipSuccess) {                                                         \
+            ::pcd::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,               \
+                             hipGetErrorString(e__));                                    \
+            return PCD_ERR_HIP;                                                          \
+        }                                                                                \
+    } while (0)
+
+#define PCD_CHECK_LAUNCH() PCD_CHECK_HIP(hipGetLastError())
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ half_t to_half_sat(float v) {
+    // keep fp16 activations finite: clamp to the largest normal instead of +-inf
+    v = __builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f);
+    return (half_t)v;
+}
+
+}  // namespace pcd

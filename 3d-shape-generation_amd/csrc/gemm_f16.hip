@@ -1,0 +1,315 @@
+// K1: fp16-in / fp32-accumulate MFMA GEMM for gfx950 with fused epilogues.
+//
+//   out[m][c] = act( sum_k A[m][k] * W[c][k] + bias[c] + shape_bias[m / rps][c] )
+//
+// Replaces Conv1d(k=1)+BatchNorm1d(eval)+ReLU (reference networks.py:46-48) and the
+// Linear layers; BN is folded into W/bias on the host.  Both operands are K-major, so
+// activation rows and weight rows are staged identically: global -> LDS with
+// global_load_lds (16 B/lane), XOR-swizzled through the *source* address (the LDS image
+// written by an LDS-DMA is lane-linear), read back with ds_read_b128 conflict-free, and
+// fed to v_mfma_f32_16x16x32_f16.  Double-buffered, one barrier per 64-deep K tile.
+//
+// Tile: BM x BN x 64, 256 threads = 4 waves as 2(M) x 2(N).
+#include "common.h"
+
+namespace pcd {
+
+enum { EPI_F16 = 0, EPI_F32 = 1, EPI_COLMAX = 2, EPI_RESID = 3 };
+
+struct GemmParams {
+    const half_t* a1; int64_t lda1; int k1;
+    const half_t* a2; int64_t lda2; int k2;
+    const half_t* w; int64_t ldw;
+    const float* bias; const float* shape_bias; int rows_per_shape;
+    int relu; int m; int c;
+    half_t* out16; float* out32; int64_t ldo;
+    const half_t* resid; int64_t ldr;
+    float* colmax; int cm_rps;
+    int tiles_m; int tiles_n;
+};
+
+constexpr int BK = 64;          // halfs per K tile = 128 B per row
+constexpr int ROWB = BK * 2;    // bytes per staged row
+
+__device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// Stage ROWS x 64 halfs (row-major, ld elements per row) into a lane-linear LDS image whose
+// 16-B chunk j of row r holds logical chunk j ^ ((r>>1)&7).
+template <int ROWS>
+__device__ __forceinline__ void stage_rows(const half_t* __restrict__ src, int64_t ld, int row0, int row_limit,
+                                           int kofs, char* lds_tile, int wave, int lane) {
+    constexpr int ROUNDS = ROWS / 32;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int row = r * 32 + wave * 8 + (lane >> 3);
+        const int logical = (lane & 7) ^ ((row >> 1) & 7);
+        int grow = row0 + row;
+        grow = grow < row_limit ? grow : row_limit - 1;   // clamp: rows past the edge are masked in the epilogue
+        const half_t* g = src + (int64_t)grow * ld + kofs + logical * 8;
+        glds16(g, lds_tile + (r * 32 + wave * 8) * ROWB);
+    }
+}
+
+template <int BM, int BN, int EPI>
+__global__ __launch_bounds__(256) void gemm_f16_kernel(GemmParams p) {
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int MI = WM / 16, NI = WN / 16;
+    constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+    constexpr int OUT_LD = BN * 2 + 16;  // bytes per staged output row (fp16), keeps 16-B alignment
+    constexpr int LDS_BYTES = (2 * STAGE_BYTES > BM * OUT_LD) ? 2 * STAGE_BYTES : BM * OUT_LD;
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // tile order: n fastest so neighbouring blocks share the activation row panel
+    const int bid = blockIdx.x;
+    const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int nk1 = p.k1 / BK, nk = (p.k1 + p.k2) / BK;
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto stage = [&](int kt, int buf) {
+        char* base = smem + buf * STAGE_BYTES;
+        if (kt < nk1) stage_rows<BM>(p.a1, p.lda1, m0, p.m, kt * BK, base, wave, lane);
+        else          stage_rows<BM>(p.a2, p.lda2, m0, p.m, (kt - nk1) * BK, base, wave, lane);
+        stage_rows<BN>(p.w, p.ldw, n0, p.c, kt * BK, base + BM * ROWB, wave, lane);
+    };
+
+    // per-lane fragment read offsets (bytes) inside a staged tile
+    const int ra = wm * WM + (lane & 15);
+    const int rb = wn * WN + (lane & 15);
+    const int swa = (ra >> 1) & 7, swb = (rb >> 1) & 7;
+    const int q = lane >> 4;
+    int offa[2], offb[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        offa[ks] = ra * ROWB + (((ks * 4 + q) ^ swa) << 4);
+        offb[ks] = BM * ROWB + rb * ROWB + (((ks * 4 + q) ^ swb) << 4);
+    }
+
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        const char* base = smem + (kt & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 af[MI], bf[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *(const half8*)(base + offa[ks] + i * 16 * ROWB);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bf[j] = *(const half8*)(base + offb[ks] + j * 16 * ROWB);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    // accumulator element (i, j, r): row = wm*WM + i*16 + q*4 + r, col = wn*WN + j*16 + (lane&15)
+    const int colq = lane & 15;
+    float bcol[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int col = n0 + wn * WN + j * 16 + colq;
+        bcol[j] = (p.bias != nullptr && col < p.c) ? p.bias[col] : 0.f;
+    }
+
+    if constexpr (EPI == EPI_COLMAX) {
+        // values are post-ReLU (>= 0): float bits order like unsigned ints, colmax pre-zeroed
+        unsigned* cm = reinterpret_cast<unsigned*>(p.colmax);
+        const int wrow0 = m0 + wm * WM;
+        const bool fast = (p.cm_rps % WM == 0) && (wrow0 + WM <= p.m);
+        if (fast) {
+            const int shape = wrow0 / p.cm_rps;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int col = n0 + wn * WN + j * 16 + colq;
+                float sb = 0.f;
+                if (p.shape_bias != nullptr && col < p.c)
+                    sb = p.shape_bias[(int64_t)(wrow0 / p.rows_per_shape) * p.c + col];
+                float mx = 0.f;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[i][j][r] + bcol[j] + sb);
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                if (q == 0 && col < p.c) atomicMax(cm + (int64_t)shape * p.c + col, __float_as_uint(mx));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = m0 + wm * WM + i * 16 + q * 4 + r;
+                        const int col = n0 + wn * WN + j * 16 + colq;
+                        if (row < p.m && col < p.c) {
+                            float v = acc[i][j][r] + bcol[j];
+                            if (p.shape_bias != nullptr)
+                                v += p.shape_bias[(int64_t)(row / p.rows_per_shape) * p.c + col];
+                            v = fmaxf(v, 0.f);
+                            atomicMax(cm + (int64_t)(row / p.cm_rps) * p.c + col, __float_as_uint(v));
+                        }
+                    }
+        }
+        return;
+    } else if constexpr (EPI == EPI_F32) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + wm * WM + i * 16 + q * 4 + r;
+                    const int col = n0 + wn * WN + j * 16 + colq;
+                    if (row < p.m && col < p.c) {
+                        float v = acc[i][j][r] + bcol[j];
+                        if (p.shape_bias != nullptr)
+                            v += p.shape_bias[(int64_t)(row / p.rows_per_shape) * p.c + col];
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        p.out32[(int64_t)row * p.ldo + col] = v;
+                    }
+                }
+        return;
+    } else {
+        // stage the fp16 tile through LDS so global stores are whole 16-B pieces of a row
+        __syncthreads();  // all waves done reading the last K tile
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lrow = wm * WM + i * 16 + q * 4 + r;
+                const int row = m0 + lrow;
+                const float* sbrow = nullptr;
+                if (p.shape_bias != nullptr && row < p.m)
+                    sbrow = p.shape_bias + (int64_t)(row / p.rows_per_shape) * p.c;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int lcol = wn * WN + j * 16 + colq;
+                    float v = acc[i][j][r] + bcol[j];
+                    if (sbrow != nullptr && n0 + lcol < p.c) v += sbrow[n0 + lcol];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    *(half_t*)(smem + lrow * OUT_LD + lcol * 2) = to_half_sat(v);
+                }
+            }
+        __syncthreads();
+        constexpr int CHUNKS_PER_ROW = BN / 8;
+        constexpr int TOTAL = BM * CHUNKS_PER_ROW;
+#pragma unroll
+        for (int it = 0; it < TOTAL / 256; ++it) {
+            const int idx = it * 256 + tid;
+            const int lrow = idx / CHUNKS_PER_ROW, ch = idx - lrow * CHUNKS_PER_ROW;
+            const int row = m0 + lrow, col = n0 + ch * 8;
+            if (row < p.m && col < p.c) {
+                half8 v = *(const half8*)(smem + lrow * OUT_LD + ch * 16);
+                if constexpr (EPI == EPI_RESID) {
+                    const half8 rsd = *(const half8*)(p.resid + (int64_t)row * p.ldr + col);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = to_half_sat((float)v[e] + (float)rsd[e]);
+                }
+                *(half8*)(p.out16 + (int64_t)row * p.ldo + col) = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int EPI>
+static int launch(const GemmParams& p0, hipStream_t s) {
+    GemmParams p = p0;
+    p.tiles_m = (int)ceil_div(p.m, BM);
+    p.tiles_n = (int)ceil_div(p.c, BN);
+    const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n;
+    if (blocks <= 0 || blocks > 0x7fffffff) { set_error("gemm: grid out of range"); return PCD_ERR_ARG; }
+    hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, EPI>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+template <int EPI>
+static int dispatch(const GemmParams& p, hipStream_t s) {
+    // narrow outputs (C <= 64) use a 128x64 tile so no MFMA work is spent on masked columns
+    if (p.c <= 64) return launch<128, 64, EPI>(p, s);
+    return launch<128, 128, EPI>(p, s);
+}
+
+static int fill(const pcd_gemm_desc_t* d, GemmParams& p) {
+    PCD_CHECK_ARG(d != nullptr);
+    PCD_CHECK_ARG(d->a1 != nullptr && d->w != nullptr);
+    PCD_CHECK_ARG(d->m > 0 && d->c > 0);
+    PCD_CHECK_ARG(d->k1 > 0 && d->k1 % BK == 0);
+    PCD_CHECK_ARG(d->k2 >= 0 && d->k2 % BK == 0);
+    PCD_CHECK_ARG(d->k2 == 0 || d->a2 != nullptr);
+    PCD_CHECK_ARG(d->lda1 >= d->k1 && (d->k2 == 0 || d->lda2 >= d->k2));
+    PCD_CHECK_ARG(d->ldw >= d->k1 + d->k2);
+    PCD_CHECK_ARG(d->lda1 % 8 == 0 && d->ldw % 8 == 0 && (d->k2 == 0 || d->lda2 % 8 == 0));
+    PCD_CHECK_ARG(d->shape_bias == nullptr || d->rows_per_shape > 0);
+    p = GemmParams{};
+    p.a1 = (const half_t*)d->a1; p.lda1 = d->lda1; p.k1 = d->k1;
+    p.a2 = (const half_t*)d->a2; p.lda2 = d->lda2; p.k2 = d->k2;
+    p.w = (const half_t*)d->w; p.ldw = d->ldw;
+    p.bias = d->bias; p.shape_bias = d->shape_bias;
+    p.rows_per_shape = d->rows_per_shape > 0 ? d->rows_per_shape : 1;
+    p.relu = d->relu; p.m = d->m; p.c = d->c;
+    p.cm_rps = 1;
+    return PCD_OK;
+}
+
+}  // namespace pcd
+
+using namespace pcd;
+
+extern "C" int pcd_gemm_f16(const pcd_gemm_desc_t* d, void* out, int64_t ldo, void* stream) {
+    GemmParams p;
+    int rc = fill(d, p);
+    if (rc) return rc;
+    PCD_CHECK_ARG(out != nullptr && ldo >= d->c && ldo % 8 == 0 && d->c % 8 == 0);
+    p.out16 = (half_t*)out; p.ldo = ldo;
+    return dispatch<EPI_F16>(p, (hipStream_t)stream);
+}
+
+extern "C" int pcd_gemm_f16_out32(const pcd_gemm_desc_t* d, float* out, int64_t ldo, void* stream) {
+    GemmParams p;
+    int rc = fill(d, p);
+    if (rc) return rc;
+    PCD_CHECK_ARG(out != nullptr && ldo >= d->c);
+    p.out32 = out; p.ldo = ldo;
+    return dispatch<EPI_F32>(p, (hipStream_t)stream);
+}
+
+extern "C" int pcd_gemm_f16_residual(const pcd_gemm_desc_t* d, const void* resid, int64_t ldr,
+                                     void* out, int64_t ldo, void* stream) {
+    GemmParams p;
+    int rc = fill(d, p);
+    if (rc) return rc;
+    PCD_CHECK_ARG(out != nullptr && resid != nullptr);
+    PCD_CHECK_ARG(ldo >= d->c && ldo % 8 == 0 && ldr >= d->c && ldr % 8 == 0 && d->c % 8 == 0);
+    p.out16 = (half_t*)out; p.ldo = ldo; p.resid = (const half_t*)resid; p.ldr = ldr;
+    return dispatch<EPI_RESID>(p, (hipStream_t)stream);
+}
+
+extern "C" int pcd_gemm_f16_colmax(const pcd_gemm_desc_t* d, float* colmax, int rows_per_shape, void* stream) {
+    GemmParams p;
+    int rc = fill(d, p);
+    if (rc) return rc;
+    PCD_CHECK_ARG(colmax != nullptr && rows_per_shape > 0 && d->relu == 1);
+    p.colmax = colmax; p.cm_rps = rows_per_shape;
+    return dispatch<EPI_COLMAX>(p, (hipStream_t)stream);
+}

@@ -1,0 +1,232 @@
+// a7: UNetPointNetLarge.forward (reference networks.py:779-818) as one enqueue.
+//
+// Host-side sequencing only: every launch goes through the public layer-level entry
+// points of this library.  Algebra applied by the host packer:
+//   (i)  time channels of enc1.conv1 are constant over the N points of a shape
+//        -> per-shape bias `tbias` (pcd_time_embed), the K=3 xyz half runs in pcd_enc1_xyz;
+//   (ii) refine_k (bare conv) followed by the skip half of dec_k.conv1 is one matrix
+//        -> folded into lin[13,16,19,22] weights at load;
+//   (iii) the 4096 global-feature channels of dec4.conv1 are constant over N
+//        -> per-shape bias from a [B x 4096] x [4096 x 1024] product (`wg`);
+//   (iv) max over N is fused in the epilogue of global_feat.3 (pcd_gemm_f16_colmax),
+//        the (B,4096,N) tensor and its repeat/cat are never materialised.
+//
+// lin[] execution order (K -> C):
+//   0 enc1.conv2 64->64      1 enc1.conv3 64->128 (x1)
+//   2 enc2.conv1 128->128    3 enc2.conv2 128->128   4 enc2.conv3 128->256 (x2)
+//   5 enc3.conv1 256->256    6 enc3.conv2 256->256   7 enc3.conv3 256->512 (x3)
+//   8 enc4.conv1 512->512    9 enc4.conv2 512->512  10 enc4.conv3 512->1024 (x4)
+//  11 global_feat.0 1024->2048                      12 global_feat.3 2048->4096 (+max)
+//  13 dec4.conv1 skip half x4:1024->1024 (bias -> per-shape, holds the folded bias)
+//  14 dec4.conv2 1024->1024 15 dec4.conv3 1024->512
+//  16 dec3.conv1 [512|x3 512]->512   17 dec3.conv2   18 dec3.conv3 512->256
+//  19 dec2.conv1 [256|x2 256]->256   20 dec2.conv2   21 dec2.conv3 256->128
+//  22 dec1.conv1 [128|x1 128]->128   23 dec1.conv2   24 dec1.conv3 128->64
+//  25 output.0 64->64 (+BN+ReLU)      head: output.3 64->3 (fp32)
+#include <string.h>
+#include <new>
+#include "common.h"
+
+struct pcd_unet {
+    pcd_unet_desc_t d;
+    // optional HIP-event timing of the dominant kernel (global_feat.3 + max), see pcd_unet_profile
+    static constexpr int kMaxEv = 4096;
+    int prof_on = 0;
+    int prof_n = 0;
+    hipEvent_t ev0[kMaxEv];
+    hipEvent_t ev1[kMaxEv];
+    int ev_created = 0;
+};
+
+namespace pcd {
+
+static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+struct UnetWs {
+    size_t x1, x2, x3, x4, s0, s1, pooled, pooled16, gbias, total;
+};
+
+static UnetWs carve(int64_t batch, int64_t n) {
+    const size_t m = (size_t)batch * (size_t)n;
+    UnetWs w{};
+    size_t o = 0;
+    w.x1 = o; o += align_up(m * 128 * 2);
+    w.x2 = o; o += align_up(m * 256 * 2);
+    w.x3 = o; o += align_up(m * 512 * 2);
+    w.x4 = o; o += align_up(m * 1024 * 2);
+    w.s0 = o; o += align_up(m * 2048 * 2);
+    w.s1 = o; o += align_up(m * 1024 * 2);
+    w.pooled = o; o += align_up((size_t)batch * 4096 * 4);
+    w.pooled16 = o; o += align_up((size_t)batch * 4096 * 2);
+    w.gbias = o; o += align_up((size_t)batch * 1024 * 4);
+    w.total = o;
+    return w;
+}
+
+}  // namespace pcd
+
+using namespace pcd;
+
+static const int kLinK[PCD_UNET_NLIN] = {64, 64, 128, 128, 128, 256, 256, 256, 512, 512, 512, 1024, 2048,
+                                         1024, 1024, 1024, 1024, 512, 512, 512, 256, 256, 256, 128, 128, 64};
+static const int kLinC[PCD_UNET_NLIN] = {64, 128, 128, 128, 256, 256, 256, 512, 512, 512, 1024, 2048, 4096,
+                                         1024, 1024, 512, 512, 512, 256, 256, 256, 128, 128, 128, 64, 64};
+
+extern "C" int pcd_unet_create(const pcd_unet_desc_t* desc, pcd_unet_t** out) {
+    PCD_CHECK_ARG(desc != nullptr && out != nullptr);
+    PCD_CHECK_ARG(desc->freqs && desc->tw0 && desc->tb0 && desc->tw2 && desc->tb2);
+    PCD_CHECK_ARG(desc->e1w_xyz && desc->e1w_t && desc->e1b && desc->wg && desc->head_w && desc->head_b);
+    PCD_CHECK_ARG(desc->wg_k == 4096 && desc->wg_c == 1024);
+    for (int i = 0; i < PCD_UNET_NLIN; ++i) {
+        if (desc->lin[i].w == nullptr || desc->lin[i].b == nullptr || desc->lin[i].k != kLinK[i] ||
+            desc->lin[i].c != kLinC[i]) {
+            set_error("pcd_unet_create: layer %d expects %d->%d, got %d->%d (or null pointers)", i, kLinK[i],
+                      kLinC[i], desc->lin[i].k, desc->lin[i].c);
+            return PCD_ERR_ARG;
+        }
+    }
+    pcd_unet* h = new (std::nothrow) pcd_unet;
+    PCD_CHECK_ARG(h != nullptr);
+    h->d = *desc;
+    *out = h;
+    return PCD_OK;
+}
+
+extern "C" void pcd_unet_destroy(pcd_unet_t* h) {
+    if (h == nullptr) return;
+    for (int i = 0; i < h->ev_created; ++i) { (void)hipEventDestroy(h->ev0[i]); (void)hipEventDestroy(h->ev1[i]); }
+    delete h;
+}
+
+extern "C" int pcd_unet_profile(pcd_unet_t* h, int enable) {
+    PCD_CHECK_ARG(h != nullptr);
+    h->prof_on = enable ? 1 : 0;
+    h->prof_n = 0;
+    return PCD_OK;
+}
+
+extern "C" int pcd_unet_profile_read(pcd_unet_t* h, double* total_ms, int* launches) {
+    PCD_CHECK_ARG(h && total_ms && launches);
+    double tot = 0.0;
+    for (int i = 0; i < h->prof_n; ++i) {
+        PCD_CHECK_HIP(hipEventSynchronize(h->ev1[i]));
+        float ms = 0.f;
+        PCD_CHECK_HIP(hipEventElapsedTime(&ms, h->ev0[i], h->ev1[i]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = h->prof_n;
+    return PCD_OK;
+}
+
+extern "C" size_t pcd_unet_workspace_bytes(int batch, int n_points) {
+    if (batch <= 0 || n_points <= 0) return 0;
+    return carve(batch, n_points).total;
+}
+
+static int run_lin(const pcd_unet_desc_t& d, int idx, int64_t m, const void* a1, const void* a2, int k2,
+                   const float* shape_bias, int rps, void* out, hipStream_t s) {
+    pcd_gemm_desc_t g{};
+    const pcd_linear_desc_t& L = d.lin[idx];
+    g.a1 = a1; g.k1 = L.k - k2; g.lda1 = g.k1;
+    g.a2 = a2; g.k2 = k2; g.lda2 = k2;
+    g.w = L.w; g.ldw = L.k;
+    g.bias = shape_bias ? nullptr : L.b;
+    g.shape_bias = shape_bias; g.rows_per_shape = rps;
+    g.relu = 1; g.m = (int)m; g.c = L.c;
+    return pcd_gemm_f16(&g, out, L.c, s);
+}
+
+extern "C" int pcd_unet_forward(pcd_unet_t* h, const float* x, int batch, int n_points, const float* tbias,
+                                int tbias_shape_stride, float* eps, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+    PCD_CHECK_ARG(h && x && tbias && eps && workspace);
+    PCD_CHECK_ARG(batch > 0 && n_points > 0);
+    const int64_t m = (int64_t)batch * n_points;
+    PCD_CHECK_ARG(m <= 0x7fffffff);
+    const UnetWs w = carve(batch, n_points);
+    if (workspace_bytes < w.total) {
+        set_error("pcd_unet_forward: workspace %zu < required %zu", workspace_bytes, w.total);
+        return PCD_ERR_WORKSPACE;
+    }
+    char* ws = (char*)workspace;
+    void *x1 = ws + w.x1, *x2 = ws + w.x2, *x3 = ws + w.x3, *x4 = ws + w.x4, *s0 = ws + w.s0, *s1 = ws + w.s1;
+    float* pooled = (float*)(ws + w.pooled);
+    void* pooled16 = ws + w.pooled16;
+    float* gbias = (float*)(ws + w.gbias);
+    hipStream_t s = (hipStream_t)stream;
+    const pcd_unet_desc_t& d = h->d;
+    int rc;
+#define RUN(expr) do { rc = (expr); if (rc) return rc; } while (0)
+    RUN(pcd_enc1_xyz(x, m, n_points, d.e1w_xyz, 64, tbias, tbias_shape_stride, s0, s));
+    RUN(run_lin(d, 0, m, s0, nullptr, 0, nullptr, 0, s1, s));
+    RUN(run_lin(d, 1, m, s1, nullptr, 0, nullptr, 0, x1, s));
+    RUN(run_lin(d, 2, m, x1, nullptr, 0, nullptr, 0, s0, s));
+    RUN(run_lin(d, 3, m, s0, nullptr, 0, nullptr, 0, s1, s));
+    RUN(run_lin(d, 4, m, s1, nullptr, 0, nullptr, 0, x2, s));
+    RUN(run_lin(d, 5, m, x2, nullptr, 0, nullptr, 0, s0, s));
+    RUN(run_lin(d, 6, m, s0, nullptr, 0, nullptr, 0, s1, s));
+    RUN(run_lin(d, 7, m, s1, nullptr, 0, nullptr, 0, x3, s));
+    RUN(run_lin(d, 8, m, x3, nullptr, 0, nullptr, 0, s0, s));
+    RUN(run_lin(d, 9, m, s0, nullptr, 0, nullptr, 0, s1, s));
+    RUN(run_lin(d, 10, m, s1, nullptr, 0, nullptr, 0, x4, s));
+    RUN(run_lin(d, 11, m, x4, nullptr, 0, nullptr, 0, s0, s));
+    {   // global_feat.3 + max over the N points of each shape
+        RUN(pcd_fill_zero(pooled, (size_t)batch * 4096 * sizeof(float), s));
+        pcd_gemm_desc_t g{};
+        g.a1 = s0; g.k1 = 2048; g.lda1 = 2048; g.w = d.lin[12].w; g.ldw = 2048; g.bias = d.lin[12].b;
+        g.relu = 1; g.m = (int)m; g.c = 4096;
+        const bool prof = h->prof_on && h->prof_n < pcd_unet::kMaxEv;
+        if (prof) {
+            if (h->prof_n >= h->ev_created) {
+                PCD_CHECK_HIP(hipEventCreate(&h->ev0[h->ev_created]));
+                PCD_CHECK_HIP(hipEventCreate(&h->ev1[h->ev_created]));
+                ++h->ev_created;
+            }
+            PCD_CHECK_HIP(hipEventRecord(h->ev0[h->prof_n], s));
+        }
+        RUN(pcd_gemm_f16_colmax(&g, pooled, n_points, s));
+        if (prof) { PCD_CHECK_HIP(hipEventRecord(h->ev1[h->prof_n], s)); ++h->prof_n; }
+    }
+    {   // hoisted global half of dec4.conv1: per-shape bias [B][1024]
+        RUN(pcd_f32_to_f16(pooled, pooled16, (int64_t)batch * 4096, s));
+        pcd_gemm_desc_t g{};
+        g.a1 = pooled16; g.k1 = 4096; g.lda1 = 4096; g.w = d.wg; g.ldw = 4096; g.bias = d.lin[13].b;
+        g.relu = 0; g.m = batch; g.c = 1024;
+        RUN(pcd_gemm_f16_out32(&g, gbias, 1024, s));
+    }
+    RUN(run_lin(d, 13, m, x4, nullptr, 0, gbias, n_points, s1, s));
+    RUN(run_lin(d, 14, m, s1, nullptr, 0, nullptr, 0, s0, s));
+    RUN(run_lin(d, 15, m, s0, nullptr, 0, nullptr, 0, s1, s));
+    RUN(run_lin(d, 16, m, s1, x3, 512, nullptr, 0, s0, s));
+    RUN(run_lin(d, 17, m, s0, nullptr, 0, nullptr, 0, s1, s));
+    RUN(run_lin(d, 18, m, s1, nullptr, 0, nullptr, 0, s0, s));
+    RUN(run_lin(d, 19, m, s0, x2, 256, nullptr, 0, s1, s));
+    RUN(run_lin(d, 20, m, s1, nullptr, 0, nullptr, 0, s0, s));
+    RUN(run_lin(d, 21, m, s0, nullptr, 0, nullptr, 0, s1, s));
+    RUN(run_lin(d, 22, m, s1, x1, 128, nullptr, 0, s0, s));
+    RUN(run_lin(d, 23, m, s0, nullptr, 0, nullptr, 0, s1, s));
+    RUN(run_lin(d, 24, m, s1, nullptr, 0, nullptr, 0, s0, s));
+    RUN(run_lin(d, 25, m, s0, nullptr, 0, nullptr, 0, s1, s));
+    RUN(pcd_head3(s1, m, 64, d.head_w, d.head_b, eps, s));
+#undef RUN
+    return PCD_OK;
+}
+
+extern "C" int pcd_unet_tap(pcd_unet_t* h, const char* name, int batch, int n_points, const void* workspace,
+                            void* dst, size_t dst_bytes, void* stream) {
+    PCD_CHECK_ARG(h && name && workspace && dst && batch > 0 && n_points > 0);
+    const UnetWs w = carve(batch, n_points);
+    const size_t m = (size_t)batch * n_points;
+    size_t off = 0, bytes = 0;
+    if (!strcmp(name, "x1")) { off = w.x1; bytes = m * 128 * 2; }
+    else if (!strcmp(name, "x2")) { off = w.x2; bytes = m * 256 * 2; }
+    else if (!strcmp(name, "x3")) { off = w.x3; bytes = m * 512 * 2; }
+    else if (!strcmp(name, "x4")) { off = w.x4; bytes = m * 1024 * 2; }
+    else if (!strcmp(name, "pooled")) { off = w.pooled; bytes = (size_t)batch * 4096 * 4; }
+    else if (!strcmp(name, "gbias")) { off = w.gbias; bytes = (size_t)batch * 1024 * 4; }
+    else { set_error("pcd_unet_tap: unknown tap '%s'", name); return PCD_ERR_ARG; }
+    PCD_CHECK_ARG(dst_bytes >= bytes);
+    PCD_CHECK_HIP(hipMemcpyAsync(dst, (const char*)workspace + off, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return PCD_OK;
+}

@@ -1,0 +1,303 @@
+"""Diffusion processes with the reference's Python surface (reference diffusion.py):
+`PointCloudDiffusion` (:14-358) and `LatentDiffusion` (:361-734).
+
+Host code only sequences the loop: the per-step constants (continuous-time t sequence,
+noise/signal rates) are computed on the host CPU with the reference's exact torch ops so
+that step indexing is bit-exact, uploaded once per call, and every
+per-timestep computation runs in HIP kernels (`_lib`).  Training hooks are out of scope.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .networks import UNetPointNetLarge
+
+
+class _HParams(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+# ------------------------------------------------------------------ host schedule math
+def _offset_cosine(t: torch.Tensor, min_signal: float, max_signal: float):
+    """diffusion.py:208-223, on CPU tensors."""
+    a0 = torch.acos(torch.tensor(max_signal))
+    a1 = torch.acos(torch.tensor(min_signal))
+    ang = a0 + t * (a1 - a0)
+    return torch.sin(ang), torch.cos(ang)
+
+
+def _linear(t: torch.Tensor, lo: float, hi: float):
+    """diffusion.py:189-205 (bug-for-bug: cumprod over the batch axis)."""
+    betas = lo + t.clone() * (hi - lo)
+    abar = torch.cumprod(1 - betas, dim=0)
+    return 1 - abar, abar
+
+
+class StepTable:
+    """Per-step scalars of one sampler run as fp32 device matrices (T, R): R = 1 when every
+    shape shares the rates (cosine schedule), R = batch for the linear schedule whose
+    batch-axis cumprod (diffusion.py:202) gives each shape its own rates."""
+
+    def __init__(self, t, n, s, a, b, device):
+        def f(rows):
+            return torch.stack([torch.as_tensor(x, dtype=torch.float32).reshape(-1) for x in rows]).contiguous().to(device)
+        self.t, self.n, self.s, self.a, self.b = f([x.reshape(-1)[:1] for x in t]), f(n), f(s), f(a), f(b)
+        self.t = self.t.reshape(-1)
+        self.steps = len(t)
+        self.width = self.n.shape[1]
+        self.stride = 0 if self.width == 1 else 1
+
+    def offset(self, k: int) -> int:
+        return 4 * k * self.width
+
+
+class _DiffusionBase(nn.Module):
+    """Schedule + elementwise ops + the three sampler loops, shared by both processes."""
+
+    def _init_schedule(self, noise_schedule: str):
+        self.noise_schedule = noise_schedule
+        self.linear_min_rate, self.linear_max_rate = 0.0001, 0.02
+        self.cosine_min_signal_rate, self.cosine_max_signal_rate = 0.02, 0.95
+        self.diffusion_schedule = (self.offset_cosine_diffusion_schedule if noise_schedule == "cosine"
+                                   else self.linear_diffusion_schedule)
+
+    @property
+    def device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    # reference diffusion.py:208-223 / 189-205: computed on the host, returned on t's device
+    def offset_cosine_diffusion_schedule(self, diffusion_times: torch.Tensor):
+        n, s = _offset_cosine(diffusion_times.detach().to("cpu", torch.float32),
+                              self.cosine_min_signal_rate, self.cosine_max_signal_rate)
+        return n.to(diffusion_times.device), s.to(diffusion_times.device)
+
+    def linear_diffusion_schedule(self, diffusion_times: torch.Tensor):
+        n, s = _linear(diffusion_times.detach().to("cpu", torch.float32), self.linear_min_rate, self.linear_max_rate)
+        return n.to(diffusion_times.device), s.to(diffusion_times.device)
+
+    # ------------------------------------------------------------------ elementwise ops
+    def _rates(self, v: torch.Tensor, batch: int) -> Tuple[torch.Tensor, int]:
+        v = v.to(self.device, torch.float32).reshape(-1).contiguous()
+        if v.numel() == 1:
+            return v, 0
+        if v.numel() != batch:
+            raise ValueError(f"rates have {v.numel()} entries for a batch of {batch}")
+        return v, 1
+
+    def _randn_like(self, x: torch.Tensor) -> torch.Tensor:
+        out = torch.empty_like(x, dtype=torch.float32)
+        seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        self._philox_offset = getattr(self, "_philox_offset", 0)
+        _lib.check(_lib.load().pcd_randn(out.data_ptr(), out.numel(), seed, self._philox_offset, _lib.stream_ptr()), "randn")
+        self._philox_offset += (out.numel() + 3) // 4
+        return out
+
+    def add_noise(self, x_0: torch.Tensor, t: torch.Tensor, noise: Optional[torch.Tensor] = None):
+        """diffusion.py:138-152 -> (x_t, noise, noise_rates, signal_rates).  `noise` may be injected."""
+        self._require_cuda(x_0)
+        x_0 = x_0.to(torch.float32).contiguous()
+        if noise is None:
+            noise = self._randn_like(x_0)
+        noise = noise.to(self.device, torch.float32).contiguous()
+        noise_rates, signal_rates = self.diffusion_schedule(t)
+        b = x_0.shape[0] if x_0.dim() > self._sample_dims else 1
+        n, st = self._rates(noise_rates, b)
+        s, _ = self._rates(signal_rates, b)
+        x_t = torch.empty_like(x_0)
+        _lib.check(_lib.load().pcd_add_noise(x_0.data_ptr(), noise.data_ptr(), n.data_ptr(), s.data_ptr(), st,
+                                             x_0.numel(), x_0.numel() // b, x_t.data_ptr(), _lib.stream_ptr()), "add_noise")
+        if x_0.dim() == self._sample_dims:   # the reference's rates.view(-1,1,1) broadcast adds a batch axis
+            x_t = x_t.unsqueeze(0)
+        return x_t, noise, noise_rates, signal_rates
+
+    def remove_noise(self, x_t, predicted_noise, noise_rates, signal_rates):
+        """diffusion.py:154-168."""
+        self._require_cuda(x_t, predicted_noise)
+        x_t = x_t.to(torch.float32).contiguous()
+        eps = predicted_noise.to(torch.float32).contiguous()
+        b = x_t.shape[0]
+        n, st = self._rates(noise_rates, b)
+        s, _ = self._rates(signal_rates, b)
+        x0 = torch.empty_like(x_t)
+        _lib.check(_lib.load().pcd_remove_noise(x_t.data_ptr(), eps.data_ptr(), n.data_ptr(), s.data_ptr(), st,
+                                                x_t.numel(), x_t.numel() // b, x0.data_ptr(), _lib.stream_ptr()), "remove_noise")
+        return x0
+
+    def _require_cuda(self, *ts):
+        if self.device.type != "cuda":
+            raise RuntimeError("this framework runs only on an MI355X device: call .to('cuda') first")
+        for t in ts:
+            if t is not None and t.device != self.device:
+                raise RuntimeError(f"tensor on {t.device}, model on {self.device}")
+        _lib.load()
+
+    # --------------------------------------------------------------- per-step tables
+    def _width(self, batch: int) -> int:
+        return 1 if self.noise_schedule == "cosine" else batch
+
+    def _host_schedule(self, t_cpu: torch.Tensor):
+        if self.noise_schedule == "cosine":
+            return _offset_cosine(t_cpu, self.cosine_min_signal_rate, self.cosine_max_signal_rate)
+        return _linear(t_cpu, self.linear_min_rate, self.linear_max_rate)
+
+    def ddim_table(self, num_steps: int, batch: int = 1) -> StepTable:
+        """`sample` (diffusion.py:277-286): t_k = 1 - k/T, next_t = t_k - 1/T."""
+        w = self._width(batch)
+        step = 1.0 / num_steps
+        ts, ns, ss, n2, s2 = [], [], [], [], []
+        for k in range(num_steps):
+            t = torch.ones(w) - k * step
+            n, s = self._host_schedule(t)
+            nn_, sn = self._host_schedule(t - step)
+            ts.append(t); ns.append(n); ss.append(s); n2.append(nn_); s2.append(sn)
+        return StepTable(ts, ns, ss, n2, s2, self.device)
+
+    def ddpm_table(self, num_steps: int, batch: int = 1) -> StepTable:
+        """`sample2` (diffusion.py:241-255): t = i/T for i = T-1..0; a = sqrt(n_prev/n), b = s_prev."""
+        w = self._width(batch)
+        ts, ns, ss, co, s2 = [], [], [], [], []
+        for i in reversed(range(num_steps)):
+            t = torch.ones(w) * i / num_steps
+            n, s = self._host_schedule(t)
+            ts.append(t); ns.append(n); ss.append(s)
+            if i > 0:
+                npv, sp = self._host_schedule(torch.ones(w) * (i - 1) / num_steps)
+                co.append(torch.sqrt(npv / n)); s2.append(sp)
+            else:
+                co.append(torch.zeros(w)); s2.append(torch.zeros(w))
+        return StepTable(ts, ns, ss, co, s2, self.device)
+
+    def from_state_table(self, start_t0, num_steps: int) -> StepTable:
+        """`sample3` (diffusion.py:323-335): linspace(start_t[0], 0, T); only start_t[0] is used,
+        and the schedule sees a 0-d t, so the rates are shared by the batch for both schedules."""
+        steps = torch.linspace(torch.as_tensor(start_t0, dtype=torch.float32).cpu().reshape(()),
+                               torch.zeros(1)[0], num_steps)
+        ts, ns, ss, n2, s2 = [], [], [], [], []
+        for i in range(num_steps):
+            n, s = self._host_schedule(steps[i])
+            ts.append(steps[i]); ns.append(n); ss.append(s)
+            if i < num_steps - 1:
+                nn_, sn = self._host_schedule(steps[i + 1])
+                n2.append(nn_); s2.append(sn)
+            else:
+                n2.append(torch.zeros(())); s2.append(torch.zeros(()))
+        return StepTable(ts, ns, ss, n2, s2, self.device)
+
+    # ------------------------------------------------------------------ step kernels
+    def _ddim_step(self, x, eps, tab: StepTable, k: int, last_no_update: bool, x0, x_next):
+        lib = _lib.load()
+        fl = tab.offset(k)
+        nxt = 0 if last_no_update else x_next.data_ptr()
+        _lib.check(lib.pcd_ddim_update(x.data_ptr(), eps.data_ptr(), tab.n.data_ptr() + fl, tab.s.data_ptr() + fl,
+                                       tab.a.data_ptr() + fl, tab.b.data_ptr() + fl, tab.stride, x.numel(),
+                                       x.numel() // x.shape[0], x0.data_ptr(), nxt, _lib.stream_ptr()), "ddim_update")
+
+    def _ddpm_step(self, x, eps, z, tab: StepTable, k: int, last: bool, x0, x_next):
+        lib = _lib.load()
+        fl = tab.offset(k)
+        _lib.check(lib.pcd_ddpm_update(x.data_ptr(), eps.data_ptr(), 0 if last else z.data_ptr(),
+                                       tab.n.data_ptr() + fl, tab.s.data_ptr() + fl, tab.a.data_ptr() + fl,
+                                       tab.b.data_ptr() + fl, tab.stride, x.numel(), x.numel() // x.shape[0],
+                                       x0.data_ptr(), 0 if last else x_next.data_ptr(), _lib.stream_ptr()), "ddpm_update")
+
+    # generic loops; `denoise(x, k)` returns eps for step k
+    def _run_ddim(self, x, tab: StepTable, denoise, skip_last_update: bool):
+        x0 = torch.empty_like(x)
+        x_next = torch.empty_like(x)
+        for k in range(tab.steps):
+            eps = denoise(x, k)
+            last = skip_last_update and k == tab.steps - 1
+            self._ddim_step(x, eps, tab, k, last, x0, x_next)
+            if not last:
+                x, x_next = x_next, x
+        return x0
+
+    def _run_ddpm(self, x, tab: StepTable, denoise, noises):
+        x0 = torch.empty_like(x)
+        x_next = torch.empty_like(x)
+        for k in range(tab.steps):
+            eps = denoise(x, k)
+            last = k == tab.steps - 1
+            z = None
+            if not last:
+                z = noises[k].to(self.device, torch.float32).contiguous() if noises is not None else self._randn_like(x)
+            self._ddpm_step(x, eps, z, tab, k, last, x0, x_next)
+            if not last:
+                x, x_next = x_next, x
+        return x0   # at i == 0 the reference sets x_t = x_0 and returns it
+
+
+class PointCloudDiffusion(_DiffusionBase):
+    """Drop-in for reference diffusion.py:14-358 (sampling surface)."""
+    _sample_dims = 2   # one sample is (N, 3)
+
+    def __init__(self, num_points, dim=256, time_dim=256, lr=1e-4, noise_schedule="cosine"):
+        super().__init__()
+        self.hparams = _HParams(num_points=num_points, dim=dim, time_dim=time_dim, lr=lr,
+                                noise_schedule=noise_schedule)
+        self.model = UNetPointNetLarge(dim, time_dim)
+        self.num_points = num_points
+        self.lr = lr
+        self._init_schedule(noise_schedule)
+
+    @classmethod
+    def load_from_checkpoint(cls, path, map_location="cpu", **kwargs):
+        """Lightning-free loader for the reference's `.ckpt` layout (test_point_ddpm.py:161)."""
+        from .checkpoint import load_lightning_checkpoint
+        hp, sd = load_lightning_checkpoint(path, map_location)
+        hp.update(kwargs)
+        obj = cls(**{k: hp[k] for k in ("num_points", "dim", "time_dim", "lr", "noise_schedule") if k in hp})
+        obj.load_state_dict(sd, strict=True)
+        return obj
+
+    def _denoiser(self, tab: StepTable):
+        tb = self.model.time_bias(tab.t)          # (T, 64): one launch for all steps (K3)
+        eps = [None]
+
+        def denoise(x, k):
+            if eps[0] is None:
+                eps[0] = torch.empty_like(x)
+            return self.model.forward_with_bias(x, tb[k], 0, out=eps[0])
+        return denoise
+
+    def _start(self, num_samples, num_points, x_T):
+        self.eval()
+        self._require_cuda(x_T)
+        if x_T is None:
+            return self._randn_like(torch.empty(num_samples, num_points, 3, device=self.device))
+        if tuple(x_T.shape) != (num_samples, num_points, 3):
+            raise ValueError(f"x_T must be {(num_samples, num_points, 3)}, got {tuple(x_T.shape)}")
+        return x_T.to(torch.float32).contiguous().clone()
+
+    @torch.no_grad()
+    def sample(self, num_samples, num_points, num_steps=1000, x_T=None):
+        """DDIM (diffusion.py:261-289).  Returns the last x_0.  `x_T` injects the start noise."""
+        x = self._start(num_samples, num_points, x_T)
+        tab = self.ddim_table(num_steps, num_samples)
+        return self._run_ddim(x, tab, self._denoiser(tab), skip_last_update=False)
+
+    @torch.no_grad()
+    def sample2(self, num_samples, num_points, num_steps=1000, x_T=None, noises=None):
+        """DDPM ancestral sampling (diffusion.py:225-259).  `noises[j]` injects the j-th draw."""
+        x = self._start(num_samples, num_points, x_T)
+        tab = self.ddpm_table(num_steps, num_samples)
+        return self._run_ddpm(x, tab, self._denoiser(tab), noises)
+
+    @torch.no_grad()
+    def sample3(self, num_samples, num_points, x=None, start_t=None, num_steps=1000):
+        """DDIM from a given state/time (diffusion.py:291-337)."""
+        self.eval()
+        if x is None:
+            x = self._start(num_samples, num_points, None)
+            start_t = torch.ones(num_samples)
+        else:
+            x = x.to(self.device, torch.float32).contiguous().clone()
+            if start_t is None:
+                start_t = torch.ones(num_samples)
+        tab = self.from_state_table(start_t.reshape(-1)[0], num_steps)
+        return self._run_ddim(x, tab, self._denoiser(tab), skip_last_update=True)

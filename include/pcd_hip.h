@@ -1,0 +1,197 @@
+/*
+ * pcd_hip.h -- C ABI of the MI355X (gfx950) point-cloud diffusion sampler library.
+ *
+ * The reference (dhillon24/3d-shape-generation) has no FFI/plugin layer: its
+ * boundary is the Python object API of diffusion.py / networks.py / metrics.py
+ * (SURVEY.md section 8(b)).  This header is the C-ABI shared-library boundary
+ * that sits UNDER a re-implementation of that Python API; each entry point
+ * cites the reference code it replaces.  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless its name ends in _host;
+ *  - the caller owns all memory; nothing is retained except by *_create handles,
+ *    which keep the pointers given in their descriptor (they must outlive the handle);
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued, never synchronised;
+ *  - return value: 0 = ok, negative = error, message via pcd_last_error() (thread local);
+ *  - activations are point-major: row m = b*N + n holds the C channels of point n
+ *    of shape b, fp16 ("f16") unless stated; weights are [C_out][K] fp16 row-major
+ *    (the reference's Conv1d (C_out, C_in, 1) / Linear (out, in) layout, K contiguous).
+ */
+#ifndef PCD_HIP_H
+#define PCD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCD_OK 0
+#define PCD_ERR_ARG (-1)
+#define PCD_ERR_HIP (-2)
+#define PCD_ERR_WORKSPACE (-3)
+
+const char* pcd_last_error(void);
+/* library/ABI version, bumped when a signature changes */
+int pcd_abi_version(void);
+/* 0 if a gfx950 device is usable by this process, negative otherwise */
+int pcd_device_check(void);
+
+/* ------------------------------------------------------------------ GEMM (K1)
+ * out[m][c] = act( sum_k A[m][k] * W[c][k] + bias[c] + shape_bias[m / rows_per_shape][c] )
+ * Replaces every Conv1d(k=1)+BatchNorm1d(eval)+ReLU of networks.py:46-48 (BN folded
+ * into W,bias by the host) and the Linear layers of networks.py:64-66.
+ * A may be the K-concatenation of two sources [A1 (K1 cols) | A2 (K2 cols)]
+ * (the torch.cat skip inputs of networks.py:811-814) without materialising it.
+ * K1, K2 multiples of 64; C multiple of 8.
+ */
+typedef struct {
+    const void* a1; int64_t lda1; int k1;      /* fp16 [M][lda1] */
+    const void* a2; int64_t lda2; int k2;      /* optional second source, NULL/0 */
+    const void* w;  int64_t ldw;               /* fp16 [C][ldw], ldw >= k1+k2 */
+    const float* bias;                         /* fp32 [C] or NULL */
+    const float* shape_bias; int rows_per_shape; /* fp32 [ceil(M/rows_per_shape)][C] or NULL */
+    int relu;                                  /* 1: max(.,0) */
+    int m, c;
+} pcd_gemm_desc_t;
+
+/* epilogue: store fp16 out[m][ldo] */
+int pcd_gemm_f16(const pcd_gemm_desc_t* d, void* out, int64_t ldo, void* stream);
+/* epilogue: store fp32 out[m][ldo] */
+int pcd_gemm_f16_out32(const pcd_gemm_desc_t* d, float* out, int64_t ldo, void* stream);
+/* epilogue: residual add, out[m][c] = resid[m][c] + (A W^T + bias), fp16 in/out (networks.py:81-82) */
+int pcd_gemm_f16_residual(const pcd_gemm_desc_t* d, const void* resid, int64_t ldr,
+                          void* out, int64_t ldo, void* stream);
+/* epilogue: per-shape column max, colmax[s][c] = max over the rows of shape s (post-ReLU,
+ * so values >= 0); replaces torch.max(global_feat, 2) of networks.py:807 without ever
+ * writing the (B,4096,N) tensor.  colmax fp32 [n_shapes][C] must be zeroed by the caller
+ * (pcd_fill_zero) before the call; requires d->relu == 1. */
+int pcd_gemm_f16_colmax(const pcd_gemm_desc_t* d, float* colmax, int rows_per_shape, void* stream);
+
+int pcd_fill_zero(void* p, size_t bytes, void* stream);
+int pcd_f32_to_f16(const float* src, void* dst, int64_t n, void* stream);
+int pcd_f16_to_f32(const void* src, float* dst, int64_t n, void* stream);
+
+/* ------------------------------------------------- time embedding + enc1 (K3)
+ * For each of n_t time values: sinusoidal embedding (networks.py:820-838, freqs
+ * passed in, computed on the host with the reference's torch ops) -> time_mlp
+ * Linear/SiLU/Linear (networks.py:737-741) -> temb[n_t][dim].
+ * If e1w_t != NULL also the hoisted time half of enc1.conv1:
+ * tbias[i][c] = sum_j e1w_t[c][j]*temb[i][j] + e1b[c]   (BN already folded), c < c1.
+ * All fp32.
+ */
+int pcd_time_embed(const float* t, int n_t, const float* freqs, int time_dim, int dim,
+                   const float* w0, const float* b0, const float* w2, const float* b2,
+                   float* temb,
+                   const float* e1w_t, const float* e1b, int c1, float* tbias, void* stream);
+
+/* small fp32 linear: y[r][c] = sum_k x[r][k] w[c][k] + b[c]  (emb* layers networks.py:613-618) */
+int pcd_linear_f32(const float* x, int rows, int k, const float* w, const float* b, int c,
+                   float* y, void* stream);
+
+/* enc1.conv1 xyz half (K=3) + per-shape time bias + ReLU -> fp16 [M][c1]
+ * x fp32 [M][3]; w_xyz fp32 [c1][3]; tbias fp32 [n_t][c1] with row index
+ * (m / rows_per_shape) * tbias_shape_stride (stride 0 = same t for all shapes). */
+int pcd_enc1_xyz(const float* x, int64_t m, int rows_per_shape, const float* w_xyz, int c1,
+                 const float* tbias, int tbias_shape_stride, void* out, void* stream);
+
+/* ---------------------------------------------- elementwise diffusion ops (K4)
+ * All fp32, bit-exact with the reference's torch-CPU expression order.
+ * rates are per shape: r[b * stride], stride 0 or 1. `per_shape` = elements per shape.
+ */
+/* diffusion.py:151  x_t = s*x0 + n*noise */
+int pcd_add_noise(const float* x0, const float* noise, const float* n, const float* s, int stride,
+                  int64_t total, int64_t per_shape, float* x_t, void* stream);
+/* diffusion.py:167  x0 = (x_t - n*eps)/s */
+int pcd_remove_noise(const float* x_t, const float* eps, const float* n, const float* s, int stride,
+                     int64_t total, int64_t per_shape, float* x0, void* stream);
+/* diffusion.py:283-287 (DDIM):  x0 = (x-n*eps)/s ; x_next = s2*x0 + n2*eps.  x_next may be NULL. */
+int pcd_ddim_update(const float* x, const float* eps, const float* n, const float* s,
+                    const float* n2, const float* s2, int stride,
+                    int64_t total, int64_t per_shape, float* x0, float* x_next, void* stream);
+/* diffusion.py:246-255 (DDPM):  x0 as above ; x_next = s2*x0 + coef*n*z */
+int pcd_ddpm_update(const float* x, const float* eps, const float* z, const float* n, const float* s,
+                    const float* coef, const float* s2, int stride,
+                    int64_t total, int64_t per_shape, float* x0, float* x_next, void* stream);
+/* standard normal fill (Philox4x32-10 + Box-Muller), for perf runs (diffusion.py:239,254,275) */
+int pcd_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+
+/* output head: eps[m][j] = sum_k h[m][k]*w[j][k] + b[j], j<3  (networks.py:770 `output.3`),
+ * h fp16 [M][k], w fp32 [3][k]; eps fp32 [M][3]. */
+int pcd_head3(const void* h, int64_t m, int k, const float* w, const float* b, float* eps, void* stream);
+
+/* ------------------------------------------------ whole point denoiser (a7)
+ * UNetPointNetLarge.forward (networks.py:779-818) as one enqueue of ~30 kernels.
+ * The descriptor holds device pointers to host-folded weights (BN folded, refine_k folded
+ * into dec_k.conv1, time/global halves hoisted: SURVEY.md A.3).
+ */
+#define PCD_UNET_NLIN 26
+typedef struct {
+    const void* w; const float* b; int k; int c;
+} pcd_linear_desc_t;
+
+typedef struct {
+    int time_dim, dim;
+    const float* freqs;                       /* [time_dim/2] */
+    const float *tw0, *tb0, *tw2, *tb2;       /* time_mlp fp32 */
+    const float* e1w_xyz;                     /* [64][3]  */
+    const float* e1w_t;                       /* [64][dim] */
+    const float* e1b;                         /* [64] */
+    pcd_linear_desc_t lin[PCD_UNET_NLIN];     /* execution order, see csrc/unet.hip */
+    const void* wg; int wg_k, wg_c;           /* dec4.conv1 global-feature half fp16 [1024][4096] */
+    const float* head_w; const float* head_b; /* output.3 fp32 [3][64], [3] */
+} pcd_unet_desc_t;
+
+typedef struct pcd_unet pcd_unet_t;
+int pcd_unet_create(const pcd_unet_desc_t* desc, pcd_unet_t** out);
+void pcd_unet_destroy(pcd_unet_t* h);
+size_t pcd_unet_workspace_bytes(int batch, int n_points);
+/* eps = model(x, t):  x fp32 [B][N][3]; tbias fp32 [n_t][64] from pcd_time_embed with
+ * tbias_shape_stride 0 (one t for the batch) or 1 (one per shape); eps fp32 [B][N][3]. */
+int pcd_unet_forward(pcd_unet_t* h, const float* x, int batch, int n_points,
+                     const float* tbias, int tbias_shape_stride,
+                     float* eps, void* workspace, size_t workspace_bytes, void* stream);
+/* HIP-event timing of the dominant kernel (global_feat.3 GEMM + max) on the launch stream:
+ * enable, run forwards, then read the summed duration and launch count (bench.py roofline). */
+int pcd_unet_profile(pcd_unet_t* h, int enable);
+int pcd_unet_profile_read(pcd_unet_t* h, double* total_ms, int* launches);
+/* optional taps for parity tests: copies of x1..x4 (fp16), pooled (fp32), d4..d1 (fp16) */
+int pcd_unet_tap(pcd_unet_t* h, const char* name, int batch, int n_points,
+                 const void* workspace, void* dst, size_t dst_bytes, void* stream);
+
+/* -------------------------------------------------------- set attention (K6/K7)
+ * LayerNorm over C (eps 1e-5, biased var; networks.py:62,68) fp16 in -> fp16 out. */
+int pcd_layernorm_f16(const void* x, int64_t rows, int c, const float* gamma, const float* beta,
+                      void* out, void* stream);
+/* softmax(Q K^T) V per (shape, head), flash style, never materialising N x N
+ * (replaces the bmm/softmax/bmm path of nn.MultiheadAttention, networks.py:61,81).
+ * qkv fp16 [B*N][3C] = [q | k | v] as produced by in_proj; q is scaled by 1/sqrt(d)
+ * inside.  out fp16 [B*N][C] (heads concatenated, ready for out_proj).
+ * workspace holds V transposed per (shape, head): keys contiguous for the PV product. */
+size_t pcd_set_attention_workspace_bytes(int batch, int n_points, int c);
+int pcd_set_attention_f16(const void* qkv, int batch, int n_points, int c, int heads,
+                          void* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------- metrics (K10-K12)
+ * normalize_to_cube (metrics.py:7-21) for B clouds of N points, fp32 in/out. */
+int pcd_normalize_to_cube(const float* pts, int batch, int n, float* out, void* stream);
+/* Chamfer sums (metrics.py:41-46) on already-normalised clouds:
+ * sums[b][0] = sum_i min_j |x_i - y_j|, sums[b][1] = sum_j min_i |x_i - y_j| (unsquared L2),
+ * direct differences in fp32 (no matmul cancellation).  sums fp32 [B][2]. */
+int pcd_chamfer_sums(const float* x, const float* y, int batch, int n1, int n2, float* sums, void* stream);
+/* voxelize (utils.py:488-509): occupancy fp32 [B][R][R][R] indexed [x][y][z]; caller zeroes out. */
+int pcd_voxelize(const float* pts, int batch, int n, int res, float* vox, void* stream);
+/* voxel_tensor_to_point_clouds (utils.py:511-539): for each grid (D,H,W) emit the points with
+ * v > threshold in row-major (z,y,x) order as [x,y,z] mapped to [-1,1].
+ * counts int32 [B]; points fp32 [B][D*H*W][3] (first counts[b] rows valid). */
+int pcd_voxels_to_points(const float* vox, int batch, int d, int h, int w, float threshold,
+                         int32_t* counts, float* points, void* stream);
+/* mean BCE(x, target) with torch's log clamp at -100 (metrics.py:181); out fp32 [1]. */
+int pcd_binary_bce_mean(const float* x, const float* target, int64_t n, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCD_HIP_H */
