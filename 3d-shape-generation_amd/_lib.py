@@ -42,6 +42,25 @@ class UnetDesc(C.Structure):
                 ("head_w", vp), ("head_b", vp)]
 
 
+PCD_LATENT_NLIN = 12
+
+
+class LatentDesc(C.Structure):
+    _fields_ = [("lin", LinearDesc * PCD_LATENT_NLIN),
+                ("gn_gamma", vp * PCD_LATENT_NLIN), ("gn_beta", vp * PCD_LATENT_NLIN)]
+
+
+class Conv3dDesc(C.Structure):
+    _fields_ = [("inp", vp), ("batch", i32), ("in_d", i32), ("in_h", i32), ("in_w", i32), ("cin", i32),
+                ("rows_d", i32), ("rows_h", i32), ("rows_w", i32), ("stride", i32),
+                ("taps", vp), ("ntaps", i32), ("kpad", i32),
+                ("w", vp), ("bias", vp), ("resid", vp), ("relu", i32),
+                ("out", vp), ("cout", i32),
+                ("out_d", i32), ("out_h", i32), ("out_w", i32), ("out_scale", i32),
+                ("out_off_z", i32), ("out_off_y", i32), ("out_off_x", i32),
+                ("zero_page", vp)]
+
+
 # name -> (restype, argtypes).  Kept in the order of include/pcd_hip.h.
 _SIGS = {
     "pcd_last_error": (C.c_char_p, []),
@@ -70,9 +89,20 @@ _SIGS = {
     "pcd_unet_profile": (i32, [vp, i32]),
     "pcd_unet_profile_read": (i32, [vp, C.POINTER(C.c_double), C.POINTER(i32)]),
     "pcd_unet_tap": (i32, [vp, C.c_char_p, i32, i32, vp, vp, sz, vp]),
+    "pcd_groupnorm_relu_f16": (i32, [vp, i32, i32, i32, vp, vp, vp, vp]),
+    "pcd_latent_create": (i32, [C.POINTER(LatentDesc), C.POINTER(vp)]),
+    "pcd_latent_destroy": (None, [vp]),
+    "pcd_latent_workspace_bytes": (sz, [i32]),
+    "pcd_latent_forward": (i32, [vp, vp, i32, vp, i32, vp, vp, sz, vp]),
+    "pcd_conv3d_f16": (i32, [C.POINTER(Conv3dDesc), vp]),
+    "pcd_conv3d_first": (i32, [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp]),
+    "pcd_conv3d_last_sigmoid": (i32, [vp, i32, i32, i32, i32, i32, vp, f32, vp, vp]),
+    "pcd_reparameterize": (i32, [vp, vp, vp, vp, i64, vp]),
     "pcd_layernorm_f16": (i32, [vp, i64, i32, vp, vp, vp, vp]),
     "pcd_set_attention_workspace_bytes": (sz, [i32, i32, i32]),
     "pcd_set_attention_f16": (i32, [vp, i32, i32, i32, i32, vp, vp, sz, vp]),
+    "pcd_add_shape_bias_f16": (i32, [vp, i64, i32, i32, vp, vp, vp]),
+    "pcd_tail3": (i32, [vp, i32, vp, i32, i64, vp, vp, vp, vp, vp, vp]),
     "pcd_normalize_to_cube": (i32, [vp, i32, i32, vp, vp]),
     "pcd_chamfer_sums": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "pcd_voxelize": (i32, [vp, i32, i32, i32, vp, vp]),

@@ -123,31 +123,33 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmParams p) {
     // ------------------------------------------------------------------ epilogue
     // accumulator element (i, j, r): row = wm*WM + i*16 + q*4 + r, col = wn*WN + j*16 + (lane&15)
     const int colq = lane & 15;
+    // when a whole tile lies inside one shape the per-shape bias is just another per-column bias
+    const bool tile_one_shape = p.shape_bias != nullptr && (p.rows_per_shape % BM == 0);
+    const float* sb_generic = tile_one_shape ? nullptr : p.shape_bias;
     float bcol[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int col = n0 + wn * WN + j * 16 + colq;
-        bcol[j] = (p.bias != nullptr && col < p.c) ? p.bias[col] : 0.f;
+        float v = (p.bias != nullptr && col < p.c) ? p.bias[col] : 0.f;
+        if (tile_one_shape && col < p.c) v += p.shape_bias[(int64_t)(m0 / p.rows_per_shape) * p.c + col];
+        bcol[j] = v;
     }
 
     if constexpr (EPI == EPI_COLMAX) {
         // values are post-ReLU (>= 0): float bits order like unsigned ints, colmax pre-zeroed
         unsigned* cm = reinterpret_cast<unsigned*>(p.colmax);
         const int wrow0 = m0 + wm * WM;
-        const bool fast = (p.cm_rps % WM == 0) && (wrow0 + WM <= p.m);
+        const bool fast = (p.cm_rps % WM == 0) && (wrow0 + WM <= p.m) && sb_generic == nullptr;
         if (fast) {
             const int shape = wrow0 / p.cm_rps;
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 const int col = n0 + wn * WN + j * 16 + colq;
-                float sb = 0.f;
-                if (p.shape_bias != nullptr && col < p.c)
-                    sb = p.shape_bias[(int64_t)(wrow0 / p.rows_per_shape) * p.c + col];
                 float mx = 0.f;
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[i][j][r] + bcol[j] + sb);
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[i][j][r] + bcol[j]);
                 mx = fmaxf(mx, __shfl_xor(mx, 16));
                 mx = fmaxf(mx, __shfl_xor(mx, 32));
                 if (q == 0 && col < p.c) atomicMax(cm + (int64_t)shape * p.c + col, __float_as_uint(mx));
@@ -163,8 +165,8 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmParams p) {
                         const int col = n0 + wn * WN + j * 16 + colq;
                         if (row < p.m && col < p.c) {
                             float v = acc[i][j][r] + bcol[j];
-                            if (p.shape_bias != nullptr)
-                                v += p.shape_bias[(int64_t)(row / p.rows_per_shape) * p.c + col];
+                            if (sb_generic != nullptr)
+                                v += sb_generic[(int64_t)(row / p.rows_per_shape) * p.c + col];
                             v = fmaxf(v, 0.f);
                             atomicMax(cm + (int64_t)(row / p.cm_rps) * p.c + col, __float_as_uint(v));
                         }
@@ -182,8 +184,8 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmParams p) {
                     const int col = n0 + wn * WN + j * 16 + colq;
                     if (row < p.m && col < p.c) {
                         float v = acc[i][j][r] + bcol[j];
-                        if (p.shape_bias != nullptr)
-                            v += p.shape_bias[(int64_t)(row / p.rows_per_shape) * p.c + col];
+                        if (sb_generic != nullptr)
+                            v += sb_generic[(int64_t)(row / p.rows_per_shape) * p.c + col];
                         if (p.relu) v = fmaxf(v, 0.f);
                         p.out32[(int64_t)row * p.ldo + col] = v;
                     }
@@ -199,8 +201,8 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmParams p) {
                 const int lrow = wm * WM + i * 16 + q * 4 + r;
                 const int row = m0 + lrow;
                 const float* sbrow = nullptr;
-                if (p.shape_bias != nullptr && row < p.m)
-                    sbrow = p.shape_bias + (int64_t)(row / p.rows_per_shape) * p.c;
+                if (sb_generic != nullptr && row < p.m)
+                    sbrow = sb_generic + (int64_t)(row / p.rows_per_shape) * p.c;
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
                     const int lcol = wn * WN + j * 16 + colq;

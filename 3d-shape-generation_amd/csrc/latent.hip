@@ -1,0 +1,158 @@
+// a11: SimpleLatentUNetPointNet.forward (reference networks.py:1051-1086) on (B, C) vectors.
+//
+// Linear + GroupNorm(8, C, eps=1e-5) + ReLU U-net.  Weight-streaming bound (38 MB fp16 per
+// step, B <= 256 rows).  Algebra applied by the host packer: refine_k folded into the skip half
+// of dec_k (linear into linear); the time half of enc1 hoisted into a per-t bias (pcd_time_embed).
+//
+// lin[] execution order (K -> C):  0 enc1 256->128 (+tbias)   1 enc2 128->256   2 enc3 256->512
+//   3 enc4 512->1024   4 global_feat.0 1024->2048   5 global_feat.3 2048->4096
+//   6 dec4 [4096 | z4 1024]->1024   7 dec3 [1024 | z3 512]->512   8 dec2 [512 | z2 256]->256
+//   9 dec1 [256 | z1 128]->128     10 output.0 128->128 (ReLU)   11 output.2 128->256 (fp32 out)
+#include <new>
+#include "common.h"
+
+struct pcd_latent {
+    pcd_latent_desc_t d;
+};
+
+namespace pcd {
+
+// GroupNorm over C/groups consecutive channels of each row (biased variance), affine, ReLU.
+// One block per row, one wave per pair of groups; x fp32 [rows][c] -> out fp16.
+__global__ __launch_bounds__(256) void groupnorm_relu_kernel(const float* __restrict__ x, int c, int groups,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, half_t* __restrict__ out) {
+    const int row = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gsz = c / groups;
+    const float* xr = x + (int64_t)row * c;
+    half_t* orow = out + (int64_t)row * c;
+    for (int g = wave; g < groups; g += 4) {
+        const float* xg = xr + g * gsz;
+        float s = 0.f;
+        for (int i = lane; i < gsz; i += 64) s += xg[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / (float)gsz;
+        float v = 0.f;
+        for (int i = lane; i < gsz; i += 64) { const float dlt = xg[i] - mean; v += dlt * dlt; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        const float rstd = rsqrtf(v / (float)gsz + 1e-5f);
+        for (int i = lane; i < gsz; i += 64) {
+            const int ch = g * gsz + i;
+            orow[ch] = to_half_sat(fmaxf((xg[i] - mean) * rstd * gamma[ch] + beta[ch], 0.f));
+        }
+    }
+}
+
+static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+struct LatWs { size_t z16, z1, z2, z3, z4, g0, g1, d, tmp32, total; };
+
+static LatWs carve(int64_t b) {
+    LatWs w{};
+    size_t o = 0;
+    w.z16 = o; o += align_up(b * 256 * 2);
+    w.z1 = o; o += align_up(b * 128 * 2);
+    w.z2 = o; o += align_up(b * 256 * 2);
+    w.z3 = o; o += align_up(b * 512 * 2);
+    w.z4 = o; o += align_up(b * 1024 * 2);
+    w.g0 = o; o += align_up(b * 2048 * 2);
+    w.g1 = o; o += align_up(b * 4096 * 2);
+    w.d = o; o += align_up(b * 1024 * 2) * 2;   // two ping-pong decoder buffers
+    w.tmp32 = o; o += align_up(b * 4096 * 4);
+    w.total = o;
+    return w;
+}
+
+}  // namespace pcd
+
+using namespace pcd;
+
+static const int kLatK[PCD_LATENT_NLIN] = {256, 128, 256, 512, 1024, 2048, 5120, 1536, 768, 384, 128, 128};
+static const int kLatC[PCD_LATENT_NLIN] = {128, 256, 512, 1024, 2048, 4096, 1024, 512, 256, 128, 128, 256};
+
+extern "C" int pcd_groupnorm_relu_f16(const float* x, int rows, int c, int groups, const float* gamma,
+                                      const float* beta, void* out, void* stream) {
+    PCD_CHECK_ARG(x && gamma && beta && out && rows > 0 && c > 0 && groups > 0 && c % groups == 0);
+    hipLaunchKernelGGL(groupnorm_relu_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, c, groups, gamma, beta,
+                       (half_t*)out);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_latent_create(const pcd_latent_desc_t* desc, pcd_latent_t** out) {
+    PCD_CHECK_ARG(desc != nullptr && out != nullptr);
+    for (int i = 0; i < PCD_LATENT_NLIN; ++i) {
+        const bool has_gn = i < 10;
+        if (!desc->lin[i].w || !desc->lin[i].b || desc->lin[i].k != kLatK[i] || desc->lin[i].c != kLatC[i] ||
+            (has_gn && (!desc->gn_gamma[i] || !desc->gn_beta[i]))) {
+            set_error("pcd_latent_create: layer %d expects %d->%d (dim=512, latent=256, time=256 build)", i, kLatK[i],
+                      kLatC[i]);
+            return PCD_ERR_ARG;
+        }
+    }
+    pcd_latent* h = new (std::nothrow) pcd_latent;
+    PCD_CHECK_ARG(h != nullptr);
+    h->d = *desc;
+    *out = h;
+    return PCD_OK;
+}
+
+extern "C" void pcd_latent_destroy(pcd_latent_t* h) { delete h; }
+
+extern "C" size_t pcd_latent_workspace_bytes(int batch) { return batch > 0 ? carve(batch).total : 0; }
+
+extern "C" int pcd_latent_forward(pcd_latent_t* h, const float* z, int batch, const float* tbias,
+                                  int tbias_shape_stride, float* eps, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    PCD_CHECK_ARG(h && z && tbias && eps && workspace && batch > 0);
+    PCD_CHECK_ARG(tbias_shape_stride == 0 || tbias_shape_stride == 1);
+    const LatWs w = carve(batch);
+    if (workspace_bytes < w.total) {
+        set_error("pcd_latent_forward: workspace %zu < required %zu", workspace_bytes, w.total);
+        return PCD_ERR_WORKSPACE;
+    }
+    char* ws = (char*)workspace;
+    void *z16 = ws + w.z16, *z1 = ws + w.z1, *z2 = ws + w.z2, *z3 = ws + w.z3, *z4 = ws + w.z4, *g0 = ws + w.g0,
+         *g1 = ws + w.g1, *da = ws + w.d, *db = ws + w.d + align_up((size_t)batch * 1024 * 2);
+    float* t32 = (float*)(ws + w.tmp32);
+    const pcd_latent_desc_t& d = h->d;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+#define RUN(expr) do { rc = (expr); if (rc) return rc; } while (0)
+    auto lin_gn = [&](int idx, const void* a1, const void* a2, int k2, const float* bias, const float* sbias,
+                      void* out) -> int {
+        pcd_gemm_desc_t g{};
+        const pcd_linear_desc_t& L = d.lin[idx];
+        g.a1 = a1; g.k1 = L.k - k2; g.lda1 = g.k1;
+        g.a2 = a2; g.k2 = k2; g.lda2 = k2;
+        g.w = L.w; g.ldw = L.k; g.bias = bias; g.shape_bias = sbias; g.rows_per_shape = 1;
+        g.relu = 0; g.m = batch; g.c = L.c;
+        int r = pcd_gemm_f16_out32(&g, t32, L.c, s);
+        if (r) return r;
+        return pcd_groupnorm_relu_f16(t32, batch, L.c, 8, d.gn_gamma[idx], d.gn_beta[idx], out, s);
+    };
+    RUN(pcd_f32_to_f16(z, z16, (int64_t)batch * 256, s));
+    // enc1: time half hoisted into tbias (one row, or one row per sample)
+    RUN(lin_gn(0, z16, nullptr, 0, tbias_shape_stride ? nullptr : tbias, tbias_shape_stride ? tbias : nullptr, z1));
+    RUN(lin_gn(1, z1, nullptr, 0, d.lin[1].b, nullptr, z2));
+    RUN(lin_gn(2, z2, nullptr, 0, d.lin[2].b, nullptr, z3));
+    RUN(lin_gn(3, z3, nullptr, 0, d.lin[3].b, nullptr, z4));
+    RUN(lin_gn(4, z4, nullptr, 0, d.lin[4].b, nullptr, g0));
+    RUN(lin_gn(5, g0, nullptr, 0, d.lin[5].b, nullptr, g1));
+    RUN(lin_gn(6, g1, z4, 1024, d.lin[6].b, nullptr, da));
+    RUN(lin_gn(7, da, z3, 512, d.lin[7].b, nullptr, db));
+    RUN(lin_gn(8, db, z2, 256, d.lin[8].b, nullptr, da));
+    RUN(lin_gn(9, da, z1, 128, d.lin[9].b, nullptr, db));
+    {
+        pcd_gemm_desc_t g{};
+        g.a1 = db; g.k1 = 128; g.lda1 = 128; g.w = d.lin[10].w; g.ldw = 128; g.bias = d.lin[10].b;
+        g.relu = 1; g.m = batch; g.c = 128;
+        RUN(pcd_gemm_f16(&g, da, 128, s));
+        g.a1 = da; g.w = d.lin[11].w; g.bias = d.lin[11].b; g.relu = 0; g.c = 256;
+        RUN(pcd_gemm_f16_out32(&g, eps, 256, s));
+    }
+#undef RUN
+    return PCD_OK;
+}

@@ -235,6 +235,83 @@ __global__ __launch_bounds__(256) void f16_to_f32_kernel(const half_t* __restric
     if (i < n) d[i] = (float)s[i];
 }
 
+// x[m][c] += e[m / rows_per_shape][c]   (additive per-level time embeddings, networks.py:669-698)
+__global__ __launch_bounds__(256) void add_shape_bias_kernel(const half_t* __restrict__ x, int64_t m, int c,
+                                                              int rows_per_shape, const float* __restrict__ e,
+                                                              half_t* __restrict__ out) {
+    const int chunks = c / 8;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m * chunks) return;
+    const int64_t row = idx / chunks;
+    const int ch = (int)(idx - row * chunks);
+    const float* er = e + (row / rows_per_shape) * c + ch * 8;
+    half8 v = *(const half8*)(x + row * c + ch * 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = to_half_sat((float)v[i] + er[i]);
+    *(half8*)(out + row * c + ch * 8) = v;
+}
+
+// Tail of UNetAttentionPointExperimental (networks.py:647-650,700-702): dec1 = PointNetLayer(128,3,3)
+// on cat[a (ka ch) | b (kb ch)] followed by output = Conv1d(3,3).  BN folded; fp32 math per point.
+// w1 [3][ka+kb], w2/w3/w4 [3][3], biases [3].
+__global__ __launch_bounds__(256) void tail3_kernel(const half_t* __restrict__ a, int ka, const half_t* __restrict__ b,
+                                                     int kb, int64_t m, const float* __restrict__ w1,
+                                                     const float* __restrict__ b1, const float* __restrict__ w234,
+                                                     const float* __restrict__ b234, float* __restrict__ out) {
+    extern __shared__ float ws[];   // w1 [3][ka+kb]
+    const int k = ka + kb;
+    for (int i = threadIdx.x; i < 3 * k; i += blockDim.x) ws[i] = w1[i];
+    __syncthreads();
+    const int64_t pt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pt >= m) return;
+    float h[3] = {b1[0], b1[1], b1[2]};
+    for (int cidx = 0; cidx < ka / 8; ++cidx) {
+        const half8 v = *(const half8*)(a + pt * ka + cidx * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = (float)v[e];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) h[j] = fmaf(ws[j * k + cidx * 8 + e], f, h[j]);
+        }
+    }
+    for (int cidx = 0; cidx < kb / 8; ++cidx) {
+        const half8 v = *(const half8*)(b + pt * kb + cidx * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = (float)v[e];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) h[j] = fmaf(ws[j * k + ka + cidx * 8 + e], f, h[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) h[j] = fmaxf(h[j], 0.f);
+#pragma unroll
+    for (int layer = 0; layer < 3; ++layer) {
+        float o[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float acc = b234[layer * 3 + j];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc = fmaf(w234[layer * 9 + j * 3 + i], h[i], acc);
+            o[j] = layer < 2 ? fmaxf(acc, 0.f) : acc;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) h[j] = o[j];
+    }
+    out[pt * 3 + 0] = h[0]; out[pt * 3 + 1] = h[1]; out[pt * 3 + 2] = h[2];
+}
+
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void reparam_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
+                                                       const float* __restrict__ eps, float* __restrict__ z, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float sd = expf(0.5f * lv[i]);
+    const float e = eps[i] * sd;
+    z[i] = mu[i] + e;
+}
+#pragma clang fp contract(fast)
+
 static inline unsigned nblk(int64_t n) { return (unsigned)ceil_div(n, 256); }
 
 }  // namespace pcd
@@ -352,6 +429,33 @@ extern "C" int pcd_f32_to_f16(const float* src, void* dst, int64_t n, void* stre
 extern "C" int pcd_f16_to_f32(const void* src, float* dst, int64_t n, void* stream) {
     PCD_CHECK_ARG(src && dst && n > 0);
     hipLaunchKernelGGL(f16_to_f32_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, (const half_t*)src, dst, n);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_add_shape_bias_f16(const void* x, int64_t m, int c, int rows_per_shape, const float* e, void* out,
+                                      void* stream) {
+    PCD_CHECK_ARG(x && e && out && m > 0 && c > 0 && c % 8 == 0 && rows_per_shape > 0);
+    hipLaunchKernelGGL(add_shape_bias_kernel, dim3(nblk(m * (c / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)x, m, c, rows_per_shape, e, (half_t*)out);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_tail3(const void* a, int ka, const void* b, int kb, int64_t m, const float* w1, const float* b1,
+                         const float* w234, const float* b234, float* out, void* stream) {
+    PCD_CHECK_ARG(a && b && w1 && b1 && w234 && b234 && out && m > 0);
+    PCD_CHECK_ARG(ka > 0 && kb > 0 && ka % 8 == 0 && kb % 8 == 0 && ka + kb <= 4096);
+    hipLaunchKernelGGL(tail3_kernel, dim3(nblk(m)), dim3(256), (size_t)3 * (ka + kb) * sizeof(float),
+                       (hipStream_t)stream, (const half_t*)a, ka, (const half_t*)b, kb, m, w1, b1, w234, b234, out);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_reparameterize(const float* mu, const float* logvar, const float* eps, float* z, int64_t n,
+                                  void* stream) {
+    PCD_CHECK_ARG(mu && logvar && eps && z && n > 0);
+    hipLaunchKernelGGL(reparam_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, mu, logvar, eps, z, n);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

@@ -301,3 +301,94 @@ class PointCloudDiffusion(_DiffusionBase):
                 start_t = torch.ones(num_samples)
         tab = self.from_state_table(start_t.reshape(-1)[0], num_steps)
         return self._run_ddim(x, tab, self._denoiser(tab), skip_last_update=True)
+
+
+class LatentDiffusion(_DiffusionBase):
+    """Drop-in for reference diffusion.py:361-734 (sampling surface) over the latents of a frozen VAE."""
+    _sample_dims = 1   # one sample is (latent_dim,)
+
+    def __init__(self, vae, latent_dim=256, dim=512, time_dim=256, lr=1e-4, noise_schedule="cosine",
+                 is_voxel_based=True):
+        super().__init__()
+        from .networks import SimpleLatentUNetPointNet
+        self.hparams = _HParams(latent_dim=latent_dim, dim=dim, time_dim=time_dim, lr=lr,
+                                noise_schedule=noise_schedule, is_voxel_based=is_voxel_based)
+        self.vae = vae
+        for p in self.vae.parameters():
+            p.requires_grad = False
+        self.model = SimpleLatentUNetPointNet(latent_dim, dim, time_dim)
+        self.lr = lr
+        self._init_schedule(noise_schedule)
+
+    @classmethod
+    def load_from_checkpoint(cls, path, vae=None, map_location="cpu", **kwargs):
+        """`vae=` is required: the reference saves hyper-parameters with ignore=['vae'] (diffusion.py:375)."""
+        from .checkpoint import load_lightning_checkpoint
+        if vae is None:
+            raise TypeError("LatentDiffusion.load_from_checkpoint needs vae=")
+        hp, sd = load_lightning_checkpoint(path, map_location)
+        hp.update(kwargs)
+        keys = ("latent_dim", "dim", "time_dim", "lr", "noise_schedule", "is_voxel_based")
+        obj = cls(vae, **{k: hp[k] for k in keys if k in hp})
+        obj.load_state_dict(sd, strict=True)
+        return obj
+
+    def _denoiser(self, tab: StepTable):
+        tb = self.model.time_bias(tab.t)
+        eps = [None]
+
+        def denoise(z, k):
+            if eps[0] is None:
+                eps[0] = torch.empty_like(z)
+            return self.model.forward_with_bias(z, tb[k], 0, out=eps[0])
+        return denoise
+
+    def _start(self, num_samples, z_T):
+        self.eval()
+        self._require_cuda(z_T)
+        if z_T is None:
+            return self._randn_like(torch.empty(num_samples, self.hparams.latent_dim, device=self.device))
+        return z_T.to(self.device, torch.float32).contiguous().clone()
+
+    def _finish(self, z_0, threshold):
+        from .utils import voxel_tensor_to_point_clouds
+        x_0 = self.vae.decode(z_0)
+        if self.hparams.is_voxel_based:
+            return voxel_tensor_to_point_clouds(x_0, threshold=threshold)
+        # the reference's sample()/sample3() leave `point_clouds` unbound here (diffusion.py:650-653)
+        raise UnboundLocalError("local variable 'point_clouds' referenced before assignment "
+                                "(is_voxel_based=False is not supported by the reference's samplers either)")
+
+    @torch.no_grad()
+    def sample(self, num_samples, num_steps=1000, threshold=0.4, z_T=None, return_latent=False):
+        """DDIM in latent space, VAE decode, voxel -> points (diffusion.py:619-653)."""
+        z = self._start(num_samples, z_T)
+        tab = self.ddim_table(num_steps, num_samples)
+        z0 = self._run_ddim(z, tab, self._denoiser(tab), skip_last_update=False)
+        pcs = self._finish(z0, threshold)
+        return (pcs, z0) if return_latent else pcs
+
+    @torch.no_grad()
+    def sample2(self, num_samples, num_steps=1000, threshold=0.4, z_T=None, noises=None, return_latent=False):
+        """DDPM in latent space (diffusion.py:575-616)."""
+        z = self._start(num_samples, z_T)
+        tab = self.ddpm_table(num_steps, num_samples)
+        z0 = self._run_ddpm(z, tab, self._denoiser(tab), noises)
+        pcs = self._finish(z0, threshold)
+        return (pcs, z0) if return_latent else pcs
+
+    @torch.no_grad()
+    def sample3(self, num_samples, z=None, start_t=None, num_steps=1000, threshold=0.4, return_latent=False):
+        """DDIM from a given latent/time (diffusion.py:655-707)."""
+        self.eval()
+        if z is None:
+            z = self._start(num_samples, None)
+            start_t = torch.ones(num_samples)
+        else:
+            z = z.to(self.device, torch.float32).contiguous().clone()
+            if start_t is None:
+                start_t = torch.ones(num_samples)
+        tab = self.from_state_table(start_t.reshape(-1)[0], num_steps)
+        z0 = self._run_ddim(z, tab, self._denoiser(tab), skip_last_update=True)
+        pcs = self._finish(z0, threshold)
+        return (pcs, z0) if return_latent else pcs

@@ -216,3 +216,243 @@ class UNetPointNetLarge(_HipModule):
         _lib.check(_lib.load().pcd_unet_tap(self._handle, name.encode(), batch, n_points, ws.data_ptr(),
                                             dst.data_ptr(), dst.numel() * dst.element_size(), _lib.stream_ptr()), "tap")
         return dst
+
+
+# ------------------------------------------------------------------ set attention
+class _PackedSAB:
+    """Device weights of one SetAttentionBlock (reference networks.py:51-68)."""
+
+    def __init__(self, sd, prefix: str, dim: int, dev):
+        g = lambda k: sd[prefix + k].detach().to("cpu", torch.float64).numpy()
+        self.dim = dim
+        self.w_in, self.b_in = _dev16(g("attention.in_proj_weight"), dev), _dev32(g("attention.in_proj_bias"), dev)
+        self.w_out, self.b_out = _dev16(g("attention.out_proj.weight"), dev), _dev32(g("attention.out_proj.bias"), dev)
+        self.ln1_g, self.ln1_b = _dev32(g("ln1.weight"), dev), _dev32(g("ln1.bias"), dev)
+        self.ln2_g, self.ln2_b = _dev32(g("ln2.weight"), dev), _dev32(g("ln2.bias"), dev)
+        self.w_ff1, self.b_ff1 = _dev16(g("ff.0.weight"), dev), _dev32(g("ff.0.bias"), dev)
+        self.w_ff2, self.b_ff2 = _dev16(g("ff.2.weight"), dev), _dev32(g("ff.2.bias"), dev)
+
+    def run(self, x16: torch.Tensor, batch: int, n: int, heads: int) -> torch.Tensor:
+        """x16 fp16 [B*N][C] -> fp16 [B*N][C]  (networks.py:80-83, without the two transposes)."""
+        from . import ops
+        h = ops.layernorm_f16(x16, self.ln1_g, self.ln1_b)                       # LN1 (q = k = v source)
+        qkv = ops.gemm_f16(h, self.w_in, self.b_in)                              # in_proj C -> 3C
+        att = ops.set_attention_f16(qkv, batch, n, self.dim, heads)              # softmax(QK^T/sqrt d) V
+        x16 = ops.gemm_f16_residual(att, self.w_out, self.b_out, x16)            # x + out_proj(.)
+        h = ops.layernorm_f16(x16, self.ln2_g, self.ln2_b)
+        h = ops.gemm_f16(h, self.w_ff1, self.b_ff1, relu=True)                   # Linear(C,4C)+ReLU
+        return ops.gemm_f16_residual(h, self.w_ff2, self.b_ff2, x16)             # x + Linear(4C,C)
+
+
+class SetAttentionBlock(_HipModule):
+    """Drop-in for reference networks.py:51-83: (B, N, C) -> (B, N, C), pre-LN MHA + FFN."""
+
+    def __init__(self, dim: int, num_heads: int):
+        super().__init__()
+        self.dim, self.num_heads = dim, num_heads
+        self._build_from_spec(specs.set_attention_spec(dim))
+
+    def _ensure_packed(self):
+        if self._packed is None:
+            dev = self._need_cuda()
+            _lib.require_gpu()
+            self._packed = _PackedSAB(self.state_dict(), "", self.dim, dev)
+        return self._packed
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        self._need_cuda(x)
+        b, n, c = x.shape
+        if c != self.dim:
+            raise ValueError(f"expected {self.dim} channels, got {c}")
+        pk = self._ensure_packed()
+        x16 = x.to(torch.float16).contiguous().reshape(b * n, c)
+        return pk.run(x16, b, n, self.num_heads).reshape(b, n, c).to(x.dtype)
+
+
+class _PackedPNL:
+    """PointNetLayer (networks.py:16-49) with BN folded: three (W fp16, b fp32) stages."""
+
+    def __init__(self, sd, prefix: str, dev):
+        self.stages = []
+        for i in (1, 2, 3):
+            w, b = packing.fold_conv_bn(sd, f"{prefix}.conv{i}", f"{prefix}.bn{i}")
+            self.stages.append((w, b))
+        self.dev = [( _dev16(w, dev), _dev32(b, dev)) for w, b in self.stages]
+
+
+class UNetAttentionPointExperimental(_HipModule):
+    """Drop-in for reference networks.py:597-722 (the carrier of the set-attention blocks)."""
+
+    def __init__(self, num_points, dim=256, num_heads=4, num_blocks=3, time_dim=256):
+        super().__init__()
+        self.num_points, self.dim, self.num_heads, self.time_dim = num_points, dim, num_heads, time_dim
+        self._build_from_spec(specs.unet_attention_spec(dim, time_dim))
+
+    def _ensure_packed(self):
+        if self._packed is not None:
+            return self._packed
+        if self.dim != self.time_dim:
+            raise RuntimeError("UNetAttentionPointExperimental needs dim == time_dim: emb* layers take time_dim "
+                               "inputs but receive time_mlp's dim outputs (reference networks.py:613-624,664-668)")
+        dev = self._need_cuda()
+        _lib.require_gpu()
+        sd = self.state_dict()
+        g = lambda k: sd[k].detach().to("cpu", torch.float64).numpy()
+        pk = {"freqs": packing.timestep_freqs(self.time_dim).to(dev)}
+        for k in ("time_mlp.0", "time_mlp.2") + tuple(n for n, _ in specs.ATTN_UNET_EMB):
+            pk[k + ".w"], pk[k + ".b"] = _dev32(g(k + ".weight"), dev), _dev32(g(k + ".bias"), dev)
+        # enc1 = PointNetLayer(3, 64): the K=3 first conv runs in the xyz kernel
+        w, b = packing.fold_conv_bn(sd, "enc1.conv1", "enc1.bn1")
+        pk["e1w"], pk["e1b"] = _dev32(w, dev), _dev32(b, dev)
+        pk["enc1"] = [(_dev16(w, dev), _dev32(b, dev)) for w, b in
+                      (packing.fold_conv_bn(sd, f"enc1.conv{i}", f"enc1.bn{i}") for i in (2, 3))]
+        for name in ("enc2", "enc3", "dec3", "dec2"):
+            pk[name] = _PackedPNL(sd, name, dev).dev
+        for name, c in (("att1", 64), ("att2", 128), ("att3", 256), ("bottleneck", 256), ("att_dec3", 256),
+                        ("att_dec2", 128), ("att_dec1", 64)):
+            pk[name] = _PackedSAB(sd, name + ".", c, dev)
+        # tail: dec1 = PointNetLayer(128, 3, 3) + output Conv1d(3,3)
+        w1, b1 = packing.fold_conv_bn(sd, "dec1.conv1", "dec1.bn1")
+        w2, b2 = packing.fold_conv_bn(sd, "dec1.conv2", "dec1.bn2")
+        w3, b3 = packing.fold_conv_bn(sd, "dec1.conv3", "dec1.bn3")
+        w4, b4 = packing.fold_conv_bn(sd, "output", None)
+        pk["t_w1"], pk["t_b1"] = _dev32(w1, dev), _dev32(b1, dev)
+        pk["t_w234"] = _dev32(np.stack([w2, w3, w4]), dev)
+        pk["t_b234"] = _dev32(np.stack([b2, b3, b4]), dev)
+        self._packed = pk
+        return pk
+
+    def forward(self, x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        from . import ops
+        self._need_cuda(x, t)
+        pk = self._ensure_packed()
+        lib = _lib.load()
+        b, n, _ = x.shape
+        m = b * n
+        dev = self.device
+        x = x.to(torch.float32).contiguous()
+        t = t.to(torch.float32).contiguous()
+        st = _lib.stream_ptr()
+        # time path (fp32): t_embed = time_mlp(sinusoidal(t)); per-level embeddings emb*(t_embed)
+        temb = torch.empty(b, self.dim, dtype=torch.float32, device=dev)
+        _lib.check(lib.pcd_time_embed(t.data_ptr(), b, pk["freqs"].data_ptr(), self.time_dim, self.dim,
+                                      pk["time_mlp.0.w"].data_ptr(), pk["time_mlp.0.b"].data_ptr(),
+                                      pk["time_mlp.2.w"].data_ptr(), pk["time_mlp.2.b"].data_ptr(),
+                                      temb.data_ptr(), 0, 0, 0, 0, st), "time_embed")
+        emb = {name: ops.linear_f32(temb, pk[name + ".w"], pk[name + ".b"]) for name, _ in specs.ATTN_UNET_EMB}
+
+        def add(h, e, c):
+            out = torch.empty_like(h)
+            _lib.check(lib.pcd_add_shape_bias_f16(h.data_ptr(), m, c, n, e.data_ptr(), out.data_ptr(), st), "add_bias")
+            return out
+
+        def pnl(stages, a1, a2=None):
+            h = ops.gemm_f16(a1, stages[0][0], stages[0][1], a2=a2, relu=True)
+            for w, bb in stages[1:]:
+                h = ops.gemm_f16(h, w, bb, relu=True)
+            return h
+
+        # enc1.conv1(x + e1) = W x + (W e1 + b): per-shape bias of the K=3 kernel
+        tb1 = ops.linear_f32(emb["emb1"], pk["e1w"], pk["e1b"])
+        h = torch.empty(m, 64, dtype=torch.float16, device=dev)
+        _lib.check(lib.pcd_enc1_xyz(x.data_ptr(), m, n, pk["e1w"].data_ptr(), 64, tb1.data_ptr(), 1, h.data_ptr(), st), "enc1")
+        x1 = pnl(pk["enc1"], h)
+        x1 = pk["att1"].run(x1, b, n, self.num_heads)
+        x1 = add(x1, emb["emb2"], 64)
+        x2 = pk["att2"].run(pnl(pk["enc2"], x1), b, n, self.num_heads)
+        x2 = add(x2, emb["emb3"], 128)
+        x3 = pk["att3"].run(pnl(pk["enc3"], x2), b, n, self.num_heads)
+        xb = pk["bottleneck"].run(x3, b, n, self.num_heads)
+        xb = pk["att_dec3"].run(add(xb, emb["emb_dec3"], 256), b, n, self.num_heads)
+        h = pnl(pk["dec3"], xb, x3)
+        h = pk["att_dec2"].run(add(h, emb["emb_dec2"], 128), b, n, self.num_heads)
+        h = pnl(pk["dec2"], h, x2)
+        h = pk["att_dec1"].run(add(h, emb["emb_dec1"], 64), b, n, self.num_heads)
+        out = torch.empty(b, n, 3, dtype=torch.float32, device=dev)
+        _lib.check(lib.pcd_tail3(h.data_ptr(), 64, x1.data_ptr(), 64, m, pk["t_w1"].data_ptr(), pk["t_b1"].data_ptr(),
+                                 pk["t_w234"].data_ptr(), pk["t_b234"].data_ptr(), out.data_ptr(), st), "tail3")
+        return out
+
+
+# ------------------------------------------------------------------ latent denoiser
+class SimpleLatentUNetPointNet(_HipModule):
+    """Drop-in for reference networks.py:962-1106: eps = model(z (B, latent), t (B,)).
+    Eval-mode only (Dropout(0.1) in dec1 is the identity, as in every sampler)."""
+
+    def __init__(self, latent_dim, dim=512, time_dim=256, dropout_rate=0.1):
+        super().__init__()
+        self.latent_dim, self.dim, self.time_dim = latent_dim, dim, time_dim
+        self._build_from_spec(specs.latent_unet_spec(latent_dim, dim, time_dim))
+        self._handle = None
+
+    def _release(self):
+        if getattr(self, "_handle", None):
+            _lib.load().pcd_latent_destroy(self._handle)
+        self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _ensure_packed(self):
+        if self._packed is not None:
+            return self._packed
+        if (self.latent_dim, self.dim, self.time_dim) != (256, 512, 256):
+            raise RuntimeError("the HIP latent denoiser is built for latent_dim=256, dim=512, time_dim=256 "
+                               "(the configuration diffusion.py:362,380 instantiates)")
+        dev = self._need_cuda()
+        _lib.require_gpu()
+        lin, gn, ex = packing.pack_latent_unet(self.state_dict(), "")
+        keep = {"freqs": packing.timestep_freqs(self.time_dim).to(dev)}
+        for k, v in ex.items():
+            keep[k] = _dev32(v, dev)
+        desc = _lib.LatentDesc()
+        for i, (w, b) in enumerate(lin):
+            keep[f"w{i}"], keep[f"b{i}"] = _dev16(w, dev), _dev32(b, dev)
+            desc.lin[i].w, desc.lin[i].b = keep[f"w{i}"].data_ptr(), keep[f"b{i}"].data_ptr()
+            desc.lin[i].c, desc.lin[i].k = w.shape
+        for i, (gm, bt) in enumerate(gn):
+            keep[f"g{i}"], keep[f"be{i}"] = _dev32(gm, dev), _dev32(bt, dev)
+            desc.gn_gamma[i], desc.gn_beta[i] = keep[f"g{i}"].data_ptr(), keep[f"be{i}"].data_ptr()
+        handle = C.c_void_p()
+        _lib.check(_lib.load().pcd_latent_create(C.byref(desc), C.byref(handle)), "latent_create")
+        self._handle, self._packed = handle, keep
+        return keep
+
+    def time_bias(self, t: torch.Tensor) -> torch.Tensor:
+        """Hoisted time half of enc1 for each value of t: (len(t), 128) fp32."""
+        pk = self._ensure_packed()
+        t = t.to(self.device, torch.float32).contiguous()
+        out = torch.empty(t.numel(), 128, dtype=torch.float32, device=self.device)
+        _lib.check(_lib.load().pcd_time_embed(
+            t.data_ptr(), t.numel(), pk["freqs"].data_ptr(), self.time_dim, self.time_dim,
+            pk["tw0"].data_ptr(), pk["tb0"].data_ptr(), pk["tw2"].data_ptr(), pk["tb2"].data_ptr(),
+            0, pk["e1w_t"].data_ptr(), pk["e1b"].data_ptr(), 128, out.data_ptr(), _lib.stream_ptr()), "time_embed")
+        return out
+
+    def forward_with_bias(self, z, tbias, shape_stride, out=None):
+        self._ensure_packed()
+        lib = _lib.load()
+        b = z.shape[0]
+        ws = self._workspace((b,), lib.pcd_latent_workspace_bytes(b))
+        if out is None:
+            out = torch.empty_like(z)
+        _lib.check(lib.pcd_latent_forward(self._handle, z.data_ptr(), b, tbias.data_ptr(), shape_stride,
+                                          out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "latent_forward")
+        return out
+
+    def forward(self, z: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        self._need_cuda(z, t)
+        if z.dim() != 2 or z.shape[1] != self.latent_dim:
+            raise ValueError(f"z must be (B, {self.latent_dim}), got {tuple(z.shape)}")
+        z = z.to(torch.float32).contiguous()
+        return self.forward_with_bias(z, self.time_bias(t), 1)
+
+
+def __getattr__(name):   # VAE3DLarge lives in vae.py; keep `networks.VAE3DLarge` importable like the reference
+    if name == "VAE3DLarge":
+        from .vae import VAE3DLarge
+        return VAE3DLarge
+    raise AttributeError(name)

@@ -84,3 +84,32 @@ def timestep_freqs(time_dim: int) -> torch.Tensor:
     half = time_dim // 2
     step = torch.log(torch.tensor(10000.0)) / (half - 1)
     return torch.exp(torch.arange(half) * -step).float()
+
+
+def pack_latent_unet(sd: Dict[str, torch.Tensor], prefix: str):
+    """SimpleLatentUNetPointNet (dim=512, latent=256, time=256): returns (lin, gn, extras) in the
+    execution order of csrc/latent.hip.  refine_k is folded into the skip half of dec_k; the time
+    half of enc1 becomes `e1w_t` (a per-t bias computed by pcd_time_embed)."""
+    p = prefix
+    g = lambda k: _np(sd, p + k)
+    ex = {"tw0": g("time_mlp.0.weight"), "tb0": g("time_mlp.0.bias"),
+          "tw2": g("time_mlp.2.weight"), "tb2": g("time_mlp.2.bias")}
+    lin, gn = [], []
+    w, b = g("enc1.0.weight"), g("enc1.0.bias")
+    latent = w.shape[1] - ex["tw2"].shape[0]
+    ex["e1w_t"], ex["e1b"] = w[:, latent:].copy(), b
+    lin.append((w[:, :latent].copy(), b)); gn.append((g("enc1.1.weight"), g("enc1.1.bias")))
+    for name in ("enc2", "enc3", "enc4"):
+        lin.append((g(name + ".0.weight"), g(name + ".0.bias"))); gn.append((g(name + ".1.weight"), g(name + ".1.bias")))
+    lin.append((g("global_feat.0.weight"), g("global_feat.0.bias"))); gn.append((g("global_feat.1.weight"), g("global_feat.1.bias")))
+    lin.append((g("global_feat.3.weight"), g("global_feat.3.bias"))); gn.append((g("global_feat.4.weight"), g("global_feat.4.bias")))
+    for name, k in (("dec4", 4), ("dec3", 3), ("dec2", 2), ("dec1", 1)):
+        w, b = g(name + ".0.weight"), g(name + ".0.bias")
+        r_w, r_b = g(f"refine{k}.weight"), g(f"refine{k}.bias")
+        split = w.shape[1] - r_w.shape[0]
+        b = b + w[:, split:] @ r_b
+        w = np.concatenate([w[:, :split], w[:, split:] @ r_w], axis=1)
+        lin.append((w, b)); gn.append((g(name + ".1.weight"), g(name + ".1.bias")))
+    lin.append((g("output.0.weight"), g("output.0.bias")))
+    lin.append((g("output.2.weight"), g("output.2.bias")))
+    return lin, gn, ex

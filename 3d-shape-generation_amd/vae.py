@@ -1,0 +1,256 @@
+"""VAE3DLarge (reference networks.py:2208-2489): voxel VAE with the reference's
+encode / reparameterize / decode / forward / sample API on HIP implicit-GEMM convolutions.
+
+Activations are NDHWC fp16 on the device; eval-mode BatchNorm3d is folded into the conv
+weights at pack time; ConvTranspose3d(k4,s2,p1) runs as 8 output-parity classes of 2x2x2 taps.
+Training (loss, KL annealing, optimizers) is out of scope.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib, packing, specs
+from .networks import _HipModule, _dev16, _dev32
+from .utils import voxel_tensor_to_point_clouds
+
+
+def _taps_regular(k: int, pad: int) -> np.ndarray:
+    t = []
+    for kz in range(k):
+        for ky in range(k):
+            for kx in range(k):
+                t.append(((kz - pad) & 0xff) | (((ky - pad) & 0xff) << 8) | (((kx - pad) & 0xff) << 16))
+    return np.asarray(t, np.int32)
+
+
+def _pack_conv(w: np.ndarray, b: np.ndarray) -> Tuple[np.ndarray, np.ndarray, int]:
+    """(cout, cin, k,k,k) -> [cout][tap*cin] zero-padded to a multiple of 64."""
+    cout, cin = w.shape[:2]
+    wk = np.transpose(w, (0, 2, 3, 4, 1)).reshape(cout, -1)
+    kpad = (wk.shape[1] + 63) // 64 * 64
+    out = np.zeros((cout, kpad))
+    out[:, :wk.shape[1]] = wk
+    return out, b, kpad
+
+
+# per dimension: output parity -> [(kernel index, input offset)]   (o = 2 i - 1 + k)
+_CT_TAPS = {0: [(1, 0), (3, -1)], 1: [(0, 1), (2, 0)]}
+
+
+def _pack_convT_class(w: np.ndarray, pz: int, py: int, px: int):
+    """ConvTranspose3d weight (cin, cout, 4,4,4) -> class matrix [cout][8*cin] + tap table."""
+    cin, cout = w.shape[:2]
+    cols, taps = [], []
+    for kz, dz in _CT_TAPS[pz]:
+        for ky, dy in _CT_TAPS[py]:
+            for kx, dx in _CT_TAPS[px]:
+                cols.append(w[:, :, kz, ky, kx].T)          # [cout][cin]
+                taps.append((dz & 0xff) | ((dy & 0xff) << 8) | ((dx & 0xff) << 16))
+    return np.ascontiguousarray(np.concatenate(cols, axis=1)), np.asarray(taps, np.int32)
+
+
+class VAE3DLarge(_HipModule):
+    """Drop-in for reference networks.py:2208-2489 (inference surface)."""
+
+    def __init__(self, input_shape=(32, 32, 32), latent_dim=256, lr=1e-4, kl_warmup_epochs=10,
+                 kl_warmup_max_beta=0.1, kl_annealing_epochs=100):
+        super().__init__()
+        from .diffusion import _HParams
+        self.hparams = _HParams(input_shape=input_shape, latent_dim=latent_dim, lr=lr,
+                                kl_warmup_epochs=kl_warmup_epochs, kl_warmup_max_beta=kl_warmup_max_beta,
+                                kl_annealing_epochs=kl_annealing_epochs)
+        if tuple(input_shape) != (32, 32, 32):
+            raise ValueError("VAE3DLarge's encoder reduces 32^3 to 1^3; other input shapes fail in the reference too")
+        self.latent_dim = latent_dim
+        self._build_from_spec(specs.vae3d_large_spec(latent_dim))
+        # reference init_weights (networks.py:2281-2283): xavier-normal(gain 0.01) for the latent heads
+        with torch.no_grad():
+            for name in ("fc_mu", "fc_logvar"):
+                w = self._modules[name].weight
+                w.normal_(0.0, 0.01 * (2.0 / (w.shape[0] + w.shape[1])) ** 0.5)
+
+    # ---------------------------------------------------------------- packing
+    def _ensure_packed(self):
+        if self._packed is not None:
+            return self._packed
+        dev = self._need_cuda()
+        _lib.require_gpu()
+        sd = self.state_dict()
+        g = lambda k: sd[k].detach().to("cpu", torch.float64).numpy()
+        pk: Dict[str, object] = {"zero": torch.zeros(64, dtype=torch.float16, device=dev)}
+        pk["taps3"] = torch.from_numpy(_taps_regular(3, 1)).to(dev)
+        pk["taps4s2"] = torch.from_numpy(_taps_regular(4, 1)).to(dev)
+        pk["taps4p0"] = torch.from_numpy(_taps_regular(4, 0)).to(dev)
+        pk["taps1"] = torch.from_numpy(_taps_regular(1, 0)).to(dev)
+
+        def conv(key, bn=None):
+            w, b = g(key + ".weight"), g(key + ".bias")
+            if bn is not None:
+                scale = g(bn + ".weight") / np.sqrt(g(bn + ".running_var") + packing.BN_EPS)
+                w = w * scale[:, None, None, None, None]
+                b = (b - g(bn + ".running_mean")) * scale + g(bn + ".bias")
+            wk, b, kpad = _pack_conv(w, b)
+            return {"w": _dev16(wk, dev), "b": _dev32(b, dev), "kpad": kpad, "cin": w.shape[1], "cout": w.shape[0],
+                    "k": w.shape[2]}
+
+        def res(key):
+            d = {"c1": conv(key + ".conv1", key + ".bn1"), "c2": conv(key + ".conv2", key + ".bn2")}
+            if (key + ".downsample.weight") in sd:
+                d["ds"] = conv(key + ".downsample")
+            return d
+
+        def convT(key):
+            w, b = g(key + ".weight"), g(key + ".bias")
+            classes = []
+            for pz in (0, 1):
+                for py in (0, 1):
+                    for px in (0, 1):
+                        wc, taps = _pack_convT_class(w, pz, py, px)
+                        classes.append({"w": _dev16(wc, dev), "taps": torch.from_numpy(taps).to(dev), "p": (pz, py, px)})
+            return {"classes": classes, "b": _dev32(b, dev), "cin": w.shape[0], "cout": w.shape[1]}
+
+        w0, b0 = g("encoder.0.weight"), g("encoder.0.bias")
+        pk["enc0_w"], pk["enc0_b"] = _dev32(w0.reshape(w0.shape[0], 27), dev), _dev32(b0, dev)
+        for idx, op, a in specs.VAE_ENC[1:]:
+            pk[f"enc{idx}"] = res(f"encoder.{idx}") if op == "res" else conv(f"encoder.{idx}")
+        wl = np.concatenate([g("fc_mu.weight"), g("fc_logvar.weight")], axis=0)
+        bl = np.concatenate([g("fc_mu.bias"), g("fc_logvar.bias")], axis=0)
+        pk["fc_w"], pk["fc_b"] = _dev16(wl, dev), _dev32(bl, dev)
+        # decoder_input: output (c, z, y, x) -> NDHWC order (z, y, x, c)
+        wd, bd = g("decoder_input.weight"), g("decoder_input.bias")
+        perm = np.arange(512 * 64).reshape(512, 64).T.reshape(-1)
+        pk["din_w"], pk["din_b"] = _dev16(wd[perm], dev), _dev32(bd[perm], dev)
+        for idx, op, a in specs.VAE_DEC[:-1]:
+            key = f"decoder.{idx}"
+            pk[f"dec{idx}"] = res(key) if op == "res" else (convT(key) if op == "convT" else conv(key))
+        wl_, bl_ = g("decoder.12.weight"), g("decoder.12.bias")
+        pk["last_w"] = _dev32(np.transpose(wl_[0], (1, 2, 3, 0)).reshape(27, -1), dev)
+        pk["last_b"] = float(bl_[0])
+        self._packed = pk
+        return pk
+
+    # ---------------------------------------------------------------- launches
+    def _conv(self, L, x, b, din, stride, taps, relu, resid=None, dout=None):
+        lib = _lib.load()
+        pk = self._packed
+        k = L["k"]
+        if dout is None:
+            dout = din if (k == 3 or k == 1) else (din // 2 if stride == 2 else 1)
+        out = torch.empty(b * dout ** 3, L["cout"], dtype=torch.float16, device=x.device)
+        d = _lib.Conv3dDesc()
+        d.inp, d.batch, d.in_d, d.in_h, d.in_w, d.cin = x.data_ptr(), b, din, din, din, L["cin"]
+        d.rows_d = d.rows_h = d.rows_w = dout
+        d.stride = stride
+        d.taps, d.ntaps, d.kpad = taps.data_ptr(), taps.numel(), L["kpad"]
+        d.w, d.bias, d.resid, d.relu = L["w"].data_ptr(), L["b"].data_ptr(), _lib.ptr(resid), 1 if relu else 0
+        d.out, d.cout = out.data_ptr(), L["cout"]
+        d.out_d = d.out_h = d.out_w = dout
+        d.out_scale, d.out_off_z, d.out_off_y, d.out_off_x = 1, 0, 0, 0
+        d.zero_page = pk["zero"].data_ptr()
+        _lib.check(lib.pcd_conv3d_f16(d, _lib.stream_ptr()), "conv3d")
+        return out
+
+    def _convT(self, L, x, b, din):
+        lib = _lib.load()
+        dout = 2 * din
+        out = torch.empty(b * dout ** 3, L["cout"], dtype=torch.float16, device=x.device)
+        for cls in L["classes"]:
+            d = _lib.Conv3dDesc()
+            d.inp, d.batch, d.in_d, d.in_h, d.in_w, d.cin = x.data_ptr(), b, din, din, din, L["cin"]
+            d.rows_d = d.rows_h = d.rows_w = din
+            d.stride = 1
+            d.taps, d.ntaps, d.kpad = cls["taps"].data_ptr(), 8, 8 * L["cin"]
+            d.w, d.bias, d.resid, d.relu = cls["w"].data_ptr(), L["b"].data_ptr(), 0, 1
+            d.out, d.cout = out.data_ptr(), L["cout"]
+            d.out_d = d.out_h = d.out_w = dout
+            d.out_scale = 2
+            d.out_off_z, d.out_off_y, d.out_off_x = cls["p"]
+            d.zero_page = self._packed["zero"].data_ptr()
+            _lib.check(lib.pcd_conv3d_f16(d, _lib.stream_ptr()), "conv3d(T)")
+        return out
+
+    def _res(self, R, x, b, dim):
+        pk = self._packed
+        h = self._conv(R["c1"], x, b, dim, 1, pk["taps3"], relu=True)
+        resid = self._conv(R["ds"], x, b, dim, 1, pk["taps1"], relu=False) if "ds" in R else x
+        return self._conv(R["c2"], h, b, dim, 1, pk["taps3"], relu=True, resid=resid)   # relu(bn2(conv2) + residual)
+
+    # ---------------------------------------------------------------- reference API
+    def encode(self, x: torch.Tensor):
+        """networks.py:2299-2310: (B,1,32,32,32) -> (mu, logvar), each (B, latent_dim)."""
+        from . import ops
+        self._need_cuda(x)
+        pk = self._ensure_packed()
+        lib = _lib.load()
+        b = x.shape[0]
+        x = x.to(torch.float32).contiguous()
+        h = torch.empty(b * 32768, 32, dtype=torch.float16, device=x.device)
+        _lib.check(lib.pcd_conv3d_first(x.data_ptr(), b, 32, 32, 32, pk["enc0_w"].data_ptr(), pk["enc0_b"].data_ptr(),
+                                        32, h.data_ptr(), _lib.stream_ptr()), "conv3d_first")
+        h = self._res(pk["enc2"], h, b, 32)
+        h = self._conv(pk["enc3"], h, b, 32, 2, pk["taps4s2"], relu=True)
+        h = self._res(pk["enc5"], h, b, 16)
+        h = self._conv(pk["enc6"], h, b, 16, 2, pk["taps4s2"], relu=True)
+        h = self._res(pk["enc8"], h, b, 8)
+        h = self._conv(pk["enc9"], h, b, 8, 2, pk["taps4s2"], relu=True)
+        h = self._res(pk["enc11"], h, b, 4)
+        h = self._conv(pk["enc12"], h, b, 4, 1, pk["taps4p0"], relu=True, dout=1)      # (B, 512)
+        out = ops.gemm_f16_out32(h, pk["fc_w"], pk["fc_b"])
+        return out[:, :self.latent_dim].contiguous(), out[:, self.latent_dim:].contiguous()
+
+    def reparameterize(self, mu, logvar, eps=None):
+        """networks.py:2312-2325; `eps` injects the normal draw (otherwise on-device Philox)."""
+        self._need_cuda(mu, logvar)
+        lib = _lib.load()
+        mu, logvar = mu.to(torch.float32).contiguous(), logvar.to(torch.float32).contiguous()
+        if eps is None:
+            eps = torch.empty_like(mu)
+            self._philox = getattr(self, "_philox", 0)
+            _lib.check(lib.pcd_randn(eps.data_ptr(), eps.numel(), int(torch.initial_seed()) & (2 ** 64 - 1),
+                                     (1 << 40) + self._philox, _lib.stream_ptr()), "randn")
+            self._philox += (eps.numel() + 3) // 4
+        eps = eps.to(mu.device, torch.float32).contiguous()
+        z = torch.empty_like(mu)
+        _lib.check(lib.pcd_reparameterize(mu.data_ptr(), logvar.data_ptr(), eps.data_ptr(), z.data_ptr(), z.numel(),
+                                          _lib.stream_ptr()), "reparameterize")
+        return z
+
+    def decode(self, z: torch.Tensor) -> torch.Tensor:
+        """networks.py:2327-2339: (B, latent_dim) -> occupancy probabilities (B,1,32,32,32) fp32."""
+        from . import ops
+        self._need_cuda(z)
+        pk = self._ensure_packed()
+        lib = _lib.load()
+        b = z.shape[0]
+        z16 = z.to(torch.float16).contiguous()
+        h = ops.gemm_f16(z16, pk["din_w"], pk["din_b"]).reshape(b * 64, 512)           # NDHWC (B,4,4,4,512)
+        h = self._convT(pk["dec0"], h, b, 4)
+        h = self._res(pk["dec2"], h, b, 8)
+        h = self._convT(pk["dec3"], h, b, 8)
+        h = self._res(pk["dec5"], h, b, 16)
+        h = self._convT(pk["dec6"], h, b, 16)
+        h = self._res(pk["dec8"], h, b, 32)
+        h = self._conv(pk["dec9"], h, b, 32, 1, pk["taps3"], relu=True)
+        h = self._res(pk["dec11"], h, b, 32)
+        out = torch.empty(b, 1, 32, 32, 32, dtype=torch.float32, device=z.device)
+        _lib.check(lib.pcd_conv3d_last_sigmoid(h.data_ptr(), b, 32, 32, 32, 32, pk["last_w"].data_ptr(), pk["last_b"],
+                                               out.data_ptr(), _lib.stream_ptr()), "conv3d_last")
+        return out
+
+    def forward(self, x, eps=None):
+        """networks.py:2341-2353 -> (reconstruction, mu, logvar)."""
+        mu, logvar = self.encode(x)
+        return self.decode(self.reparameterize(mu, logvar, eps)), mu, logvar
+
+    @torch.no_grad()
+    def sample(self, num_samples, threshold=0.4, z=None):
+        """networks.py:2446-2462 -> python list of (n_i, 3) point clouds."""
+        self.eval()
+        if z is None:
+            z = torch.empty(num_samples, self.latent_dim, device=self.device)
+            _lib.check(_lib.load().pcd_randn(z.data_ptr(), z.numel(), int(torch.initial_seed()) & (2 ** 64 - 1),
+                                             1 << 41, _lib.stream_ptr()), "randn")
+        return voxel_tensor_to_point_clouds(self.decode(z), threshold)

@@ -161,6 +161,60 @@ int pcd_unet_profile_read(pcd_unet_t* h, double* total_ms, int* launches);
 int pcd_unet_tap(pcd_unet_t* h, const char* name, int batch, int n_points,
                  const void* workspace, void* dst, size_t dst_bytes, void* stream);
 
+/* ------------------------------------------------ latent denoiser (a11, K8)
+ * GroupNorm(groups, C, eps 1e-5, biased var) + affine + ReLU on rows of x fp32 [rows][c] -> fp16
+ * (the Linear+GroupNorm(8)+ReLU stages of networks.py:984-1036; 2-D input = per-sample groups). */
+int pcd_groupnorm_relu_f16(const float* x, int rows, int c, int groups, const float* gamma,
+                           const float* beta, void* out, void* stream);
+/* SimpleLatentUNetPointNet.forward (networks.py:1051-1086), latent_dim=256, dim=512, time_dim=256.
+ * lin[] order documented in csrc/latent.hip; refine_k folded into dec_k, enc1's time half hoisted
+ * into tbias [n_t][128] (pcd_time_embed with c1=128). */
+#define PCD_LATENT_NLIN 12
+typedef struct {
+    pcd_linear_desc_t lin[PCD_LATENT_NLIN];
+    const float* gn_gamma[PCD_LATENT_NLIN];   /* entries 0..9 (GroupNorm layers), rest NULL */
+    const float* gn_beta[PCD_LATENT_NLIN];
+} pcd_latent_desc_t;
+typedef struct pcd_latent pcd_latent_t;
+int pcd_latent_create(const pcd_latent_desc_t* desc, pcd_latent_t** out);
+void pcd_latent_destroy(pcd_latent_t* h);
+size_t pcd_latent_workspace_bytes(int batch);
+/* eps = model(z, t): z fp32 [B][256] -> eps fp32 [B][256]; tbias stride 0 (one t) or 1 (per sample) */
+int pcd_latent_forward(pcd_latent_t* h, const float* z, int batch, const float* tbias,
+                       int tbias_shape_stride, float* eps, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* ------------------------------------------------------ 3-D convolution (a12, K9)
+ * Implicit-GEMM Conv3d on NDHWC fp16 activations (replaces nn.Conv3d / nn.ConvTranspose3d +
+ * BatchNorm3d(eval) + ReLU / residual add of networks.py:2225-2264, 471-504; BN folded on the host).
+ * Rows m enumerate (b, oz, oy, ox) over rows_d x rows_h x rows_w; tap t reads input voxel
+ * (oz*stride+dz_t, oy*stride+dy_t, ox*stride+dx_t) (zero outside the grid) and multiplies
+ * w[cout][t*cin .. t*cin+cin); K = ntaps*cin zero-padded to kpad (multiple of 64).
+ * Output voxel = (oz*out_scale+out_off_z, ...) of an out_d x out_h x out_w grid, so one
+ * output-parity class of ConvTranspose3d(k4,s2,p1) is a 2x2x2-tap call with out_scale 2.
+ * out = relu?( conv + bias (+ resid) ).  taps: device int32 [ntaps], bytes (dz, dy, dx, 0) signed.
+ */
+typedef struct {
+    const void* in; int batch, in_d, in_h, in_w, cin;      /* fp16 [B][D][H][W][cin], cin power of two >= 8 */
+    int rows_d, rows_h, rows_w, stride;
+    const int* taps; int ntaps, kpad;
+    const void* w; const float* bias;                      /* fp16 [cout][kpad], fp32 [cout] */
+    const void* resid; int relu;                           /* optional fp16 residual indexed like out */
+    void* out; int cout;                                   /* fp16 [B][out_d][out_h][out_w][cout], cout % 8 == 0 */
+    int out_d, out_h, out_w, out_scale, out_off_z, out_off_y, out_off_x;
+    const void* zero_page;                                 /* >= 128 bytes of zeros */
+} pcd_conv3d_desc_t;
+int pcd_conv3d_f16(const pcd_conv3d_desc_t* d, void* stream);
+/* encoder.0: Conv3d(1, cout, k3, p1) + ReLU straight from the fp32 occupancy grid x [B][D][H][W];
+ * w fp32 [cout][27], out fp16 NDHWC. */
+int pcd_conv3d_first(const float* x, int batch, int d, int h, int w, const float* wgt, const float* bias,
+                     int cout, void* out, void* stream);
+/* decoder.12 + decoder.13: Conv3d(32, 1, k3, p1) + Sigmoid -> fp32 [B][D][H][W]; w fp32 [27][cin]. */
+int pcd_conv3d_last_sigmoid(const void* in, int batch, int d, int h, int w, int cin, const float* wgt,
+                            float bias, float* out, void* stream);
+/* z = mu + eps * exp(0.5 * logvar)  (networks.py:2323-2325), fp32 */
+int pcd_reparameterize(const float* mu, const float* logvar, const float* eps, float* z, int64_t n, void* stream);
+
 /* -------------------------------------------------------- set attention (K6/K7)
  * LayerNorm over C (eps 1e-5, biased var; networks.py:62,68) fp16 in -> fp16 out. */
 int pcd_layernorm_f16(const void* x, int64_t rows, int c, const float* gamma, const float* beta,
@@ -173,6 +227,16 @@ int pcd_layernorm_f16(const void* x, int64_t rows, int c, const float* gamma, co
 size_t pcd_set_attention_workspace_bytes(int batch, int n_points, int c);
 int pcd_set_attention_f16(const void* qkv, int batch, int n_points, int c, int heads,
                           void* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* x[m][c] + e[m / rows_per_shape][c] -> out (fp16 in/out, e fp32): the additive per-level time
+ * embeddings of UNetAttentionPointExperimental (networks.py:669-698). */
+int pcd_add_shape_bias_f16(const void* x, int64_t m, int c, int rows_per_shape, const float* e,
+                           void* out, void* stream);
+/* tail of UNetAttentionPointExperimental (networks.py:647-650,700-702): dec1 = PointNetLayer(128,3,3)
+ * on cat[a | b] then Conv1d(3,3); BN folded.  w1 fp32 [3][ka+kb], w234 fp32 [3][3][3], b234 [3][3];
+ * out fp32 [M][3]. */
+int pcd_tail3(const void* a, int ka, const void* b, int kb, int64_t m, const float* w1, const float* b1,
+              const float* w234, const float* b234, float* out, void* stream);
 
 /* ------------------------------------------------------------- metrics (K10-K12)
  * normalize_to_cube (metrics.py:7-21) for B clouds of N points, fp32 in/out. */
