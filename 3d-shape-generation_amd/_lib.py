@@ -108,6 +108,9 @@ _SIGS = {
     "pcd_voxelize": (i32, [vp, i32, i32, i32, vp, vp]),
     "pcd_voxels_to_points": (i32, [vp, i32, i32, i32, i32, f32, vp, vp, vp]),
     "pcd_binary_bce_mean": (i32, [vp, vp, i64, vp, vp]),
+    "pcd_pairwise_max_dist": (i32, [vp, vp, i32, i32, i32, vp, vp]),
+    "pcd_sinkhorn_dual_update": (i32, [vp, vp, i32, i32, i32, vp, f32, f32, vp, vp, vp, vp]),
+    "pcd_sinkhorn_cost": (i32, [vp, vp, i32, i32, i32, vp, f32, vp, vp, vp, vp, vp]),
 }
 
 _lib: Optional[C.CDLL] = None

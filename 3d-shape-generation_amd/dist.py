@@ -1,0 +1,104 @@
+"""Multi-GPU layer: one process per GPU, batch-sharded sampling, RCCL all-gather of results.
+
+The reference is single-device; every shape is independent through the whole
+sampling loop (eval-mode BN, per-shape max-pool/attention, per-sample metrics), so ranks share
+nothing per step.  The only collective is one all-gather after the loop: fixed-size per-sample
+metric rows, and optionally the output clouds (ragged clouds travel padded + counts).
+`torch.distributed` backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used for CPU tests.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Initialise the default process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, local
+
+
+def world() -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_range(total: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of `total` samples for `rank`; remainders go to the first ranks."""
+    base, rem = divmod(total, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_gather_rows(rows: torch.Tensor, counts: Optional[Sequence[int]] = None) -> torch.Tensor:
+    """Concatenate per-rank row blocks (r_i, ...) in rank order.  Uneven blocks are padded to the
+    largest block for one `all_gather_into_tensor` and trimmed afterwards."""
+    rank, ws = world()
+    if ws == 1:
+        return rows
+    if counts is None:
+        c = torch.tensor([rows.shape[0]], device=rows.device, dtype=torch.int64)
+        cl = [torch.zeros_like(c) for _ in range(ws)]
+        dist.all_gather(cl, c)
+        counts = [int(v.item()) for v in cl]
+    mx = max(counts)
+    pad = torch.zeros((mx,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    pad[:rows.shape[0]] = rows
+    out = torch.empty((ws * mx,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    dist.all_gather_into_tensor(out, pad.contiguous())
+    return torch.cat([out[r * mx:r * mx + counts[r]] for r in range(ws)], dim=0)
+
+
+def all_gather_clouds(clouds: List[torch.Tensor]) -> List[torch.Tensor]:
+    """All-gather a ragged python list of (n_i, 3) clouds (LatentDiffusion outputs): sizes first,
+    then one padded payload; returns the global list in rank order."""
+    rank, ws = world()
+    if ws == 1:
+        return clouds
+    dev = clouds[0].device if clouds else torch.device("cpu")
+    sizes = torch.tensor([c.shape[0] for c in clouds], dtype=torch.int64, device=dev)
+    all_sizes = all_gather_rows(sizes.reshape(-1, 1)).reshape(-1)
+    nmax = int(all_sizes.max().item()) if all_sizes.numel() else 0
+    pad = torch.zeros(len(clouds), max(nmax, 1), 3, dtype=torch.float32, device=dev)
+    for i, c in enumerate(clouds):
+        pad[i, :c.shape[0]] = c
+    allp = all_gather_rows(pad)
+    return [allp[i, :int(all_sizes[i])].clone() for i in range(allp.shape[0])]
+
+
+def sample_sharded(model, global_batch: int, num_points: int, num_steps: int, x_T_global: Optional[torch.Tensor] = None,
+                   sampler: str = "sample", gather: bool = True) -> torch.Tensor:
+    """Each rank denoises its shard of the global batch (zero per-step traffic); the clouds are
+    all-gathered at the end when `gather`.  With `x_T_global` (host tensor, same on all ranks) the
+    result is independent of the number of ranks."""
+    rank, ws = world()
+    lo, hi = shard_range(global_batch, rank, ws)
+    xs = None if x_T_global is None else x_T_global[lo:hi].to(model.device)
+    out = getattr(model, sampler)(hi - lo, num_points, num_steps=num_steps, x_T=xs)
+    return all_gather_rows(out.contiguous()) if gather else out
+
+
+def evaluate_sharded(original: torch.Tensor, reconstructed: torch.Tensor, use_approximate_gpu_emd: bool = False):
+    """Per-sample (CD, EMD, voxel BCE) rows for this rank's samples (test_point_ddpm.py:85-92),
+    all-gathered; returns (rows (B_global, 3), their mean)."""
+    from .metrics import compute_metrics
+    rows = []
+    for o, r in zip(original, reconstructed):
+        cd, emd, rec = compute_metrics(o, r, use_approximate_gpu_emd)
+        rows.append(torch.stack([torch.as_tensor(v, dtype=torch.float32, device=original.device).reshape(()) for v in (cd, emd, rec)]))
+    rows = torch.stack(rows) if rows else torch.zeros(0, 3, device=original.device)
+    allrows = all_gather_rows(rows)
+    return allrows, allrows.mean(dim=0)

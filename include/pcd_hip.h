@@ -255,6 +255,20 @@ int pcd_voxels_to_points(const float* vox, int batch, int d, int h, int w, float
 /* mean BCE(x, target) with torch's log clamp at -100 (metrics.py:181); out fp32 [1]. */
 int pcd_binary_bce_mean(const float* x, const float* target, int64_t n, float* out, void* stream);
 
+/* ---- Sinkhorn EMD (metrics.py:94-158, `earth_mover_distance_gpu`), cost matrix never stored ----
+ * out_max[0] = max over (b,i,j) of |x_i - y_j|   (the global C.max() of metrics.py:123) */
+int pcd_pairwise_max_dist(const float* x, const float* y, int batch, int n, int m, float* out_max, void* stream);
+/* one half-iteration (metrics.py:141 / :144): for the rows of p against cloud q with dual dual_q,
+ * dual_p[i] <- epsilon * (log_marginal - logsumexp_j(-|p_i - q_j| / (cmax*epsilon) + dual_q[j]));
+ * err_max[0] = max_i |new - old| (metrics.py:147-148).  duals fp32 [B][n]. */
+int pcd_sinkhorn_dual_update(const float* p, const float* q, int batch, int np, int nq, const float* cmax,
+                             float epsilon, float log_marginal, const float* dual_q, float* dual_p,
+                             float* err_max, void* stream);
+/* cost[b] = sum_ij exp(-C/eps + alpha_i + beta_j) * C_ij (metrics.py:153-156); row_scratch fp32 [B][n] */
+int pcd_sinkhorn_cost(const float* x, const float* y, int batch, int n, int m, const float* cmax,
+                      float epsilon, const float* alpha, const float* beta, float* row_scratch,
+                      float* cost, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -168,3 +168,19 @@ def test_voxels_to_points(golden):
     odd = (torch.rand(2, 1, 5, 7, 9, generator=torch.Generator().manual_seed(3)))
     for p, q in zip(U.voxel_tensor_to_point_clouds(odd.cuda(), 0.5), O.voxel_tensor_to_point_clouds(odd, 0.5)):
         assert torch.equal(p.cpu(), q)
+
+
+def test_sinkhorn_emd(golden):
+    """K12 vs the reference's `earth_mover_distance_gpu` goldens (units.py inputs: 5.9952).
+    Tolerance 2e-3 relative: the reference's cost matrix comes from matmul-form cdist."""
+    from shapegen_amd import metrics as M
+    g = golden("metrics.npz")
+    x, y = torch.from_numpy(g["units_x"]).cuda(), torch.from_numpy(g["units_y"]).cuda()
+    got = float(M.earth_mover_distance_gpu(x, y))
+    assert abs(got - float(g["units_emd_sinkhorn"])) < 2e-3 * float(g["units_emd_sinkhorn"])
+    a, b = torch.from_numpy(g["m_a"]).cuda(), torch.from_numpy(g["m_b"]).cuda()
+    got = float(M.earth_mover_distance_gpu(a, b))
+    assert abs(got - float(g["m_emd_sinkhorn_batch"])) < 2e-3 * float(g["m_emd_sinkhorn_batch"])
+    cd, emd, rec = M.compute_metrics(a[0], b[0], use_approximate_gpu_emd=True)
+    w = g["m_triple_sinkhorn0"]
+    assert abs(float(emd) - w[1]) < 2e-3 * w[1] and float(rec) == w[2] and abs(float(cd) - w[0]) < 0.1
