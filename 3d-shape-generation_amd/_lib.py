@@ -70,6 +70,7 @@ _SIGS = {
     "pcd_gemm_f16_out32": (i32, [C.POINTER(GemmDesc), vp, i64, vp]),
     "pcd_gemm_f16_residual": (i32, [C.POINTER(GemmDesc), vp, i64, vp, i64, vp]),
     "pcd_gemm_f16_colmax": (i32, [C.POINTER(GemmDesc), vp, i32, vp]),
+    "pcd_gemm_set_config": (i32, [i32]),
     "pcd_fill_zero": (i32, [vp, sz, vp]),
     "pcd_f32_to_f16": (i32, [vp, vp, i64, vp]),
     "pcd_f16_to_f32": (i32, [vp, vp, i64, vp]),

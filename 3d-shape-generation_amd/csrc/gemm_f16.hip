@@ -37,35 +37,49 @@ __device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
 }
 
 // Stage ROWS x 64 halfs (row-major, ld elements per row) into a lane-linear LDS image whose
-// 16-B chunk j of row r holds logical chunk j ^ ((r>>1)&7).
-template <int ROWS>
+// 16-B chunk j of row r holds logical chunk j ^ ((r>>1)&7).  NT threads: each wave covers 8 rows
+// per round (64 lanes x 16 B = 8 rows of 128 B).
+template <int ROWS, int NT>
 __device__ __forceinline__ void stage_rows(const half_t* __restrict__ src, int64_t ld, int row0, int row_limit,
                                            int kofs, char* lds_tile, int wave, int lane) {
-    constexpr int ROUNDS = ROWS / 32;
+    constexpr int RPR = NT / 8;          // rows per round
+    constexpr int ROUNDS = ROWS / RPR;
+    static_assert(ROWS % RPR == 0, "tile rows must be a multiple of the rows staged per round");
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-        const int row = r * 32 + wave * 8 + (lane >> 3);
+        const int row = r * RPR + wave * 8 + (lane >> 3);
         const int logical = (lane & 7) ^ ((row >> 1) & 7);
         int grow = row0 + row;
         grow = grow < row_limit ? grow : row_limit - 1;   // clamp: rows past the edge are masked in the epilogue
         const half_t* g = src + (int64_t)grow * ld + kofs + logical * 8;
-        glds16(g, lds_tile + (r * 32 + wave * 8) * ROWB);
+        glds16(g, lds_tile + (r * RPR + wave * 8) * ROWB);
     }
 }
 
-template <int BM, int BN, int EPI>
-__global__ __launch_bounds__(256) void gemm_f16_kernel(GemmParams p) {
-    constexpr int WM = BM / 2, WN = BN / 2;
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// BM x BN x 64 tile, WGM x WGN waves (each wave (BM/WGM) x (BN/WGN)), STAGES LDS buffers.
+// STAGES == 2: one tile prefetched, plain barrier.  STAGES >= 3: STAGES-1 tiles prefetched, the
+// LDS-DMA of the younger ones stays in flight across the (raw) barrier behind a counted vmcnt.
+template <int BM, int BN, int WGM, int WGN, int STAGES, int EPI>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) {
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int MI = WM / 16, NI = WN / 16;
     constexpr int STAGE_BYTES = (BM + BN) * ROWB;
     constexpr int OUT_LD = BN * 2 + 16;  // bytes per staged output row (fp16), keeps 16-B alignment
-    constexpr int LDS_BYTES = (2 * STAGE_BYTES > BM * OUT_LD) ? 2 * STAGE_BYTES : BM * OUT_LD;
+    constexpr int LDS_BYTES = (STAGES * STAGE_BYTES > BM * OUT_LD) ? STAGES * STAGE_BYTES : BM * OUT_LD;
+    constexpr int LOADS_PER_TILE = (BM + BN) / (NT / 8);   // global_load_lds per thread per K tile
+    static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the 160 KB LDS");
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave - wm * WGN;
 
     // tile order: n fastest so neighbouring blocks share the activation row panel
     const int bid = blockIdx.x;
@@ -82,9 +96,9 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmParams p) {
 
     auto stage = [&](int kt, int buf) {
         char* base = smem + buf * STAGE_BYTES;
-        if (kt < nk1) stage_rows<BM>(p.a1, p.lda1, m0, p.m, kt * BK, base, wave, lane);
-        else          stage_rows<BM>(p.a2, p.lda2, m0, p.m, (kt - nk1) * BK, base, wave, lane);
-        stage_rows<BN>(p.w, p.ldw, n0, p.c, kt * BK, base + BM * ROWB, wave, lane);
+        if (kt < nk1) stage_rows<BM, NT>(p.a1, p.lda1, m0, p.m, kt * BK, base, wave, lane);
+        else          stage_rows<BM, NT>(p.a2, p.lda2, m0, p.m, (kt - nk1) * BK, base, wave, lane);
+        stage_rows<BN, NT>(p.w, p.ldw, n0, p.c, kt * BK, base + BM * ROWB, wave, lane);
     };
 
     // per-lane fragment read offsets (bytes) inside a staged tile
@@ -99,12 +113,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmParams p) {
         offb[ks] = BM * ROWB + rb * ROWB + (((ks * 4 + q) ^ swb) << 4);
     }
 
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-        const char* base = smem + (kt & 1) * STAGE_BYTES;
+    auto compute = [&](const char* base) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             half8 af[MI], bf[NI];
@@ -117,6 +126,37 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmParams p) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if constexpr (STAGES == 2) {
+        stage(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            wait_vmcnt<0>();
+            __syncthreads();
+            if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+            compute(smem + (kt & 1) * STAGE_BYTES);
+        }
+    } else {
+        // prologue: STAGES-1 tiles in flight
+#pragma unroll
+        for (int t = 0; t < STAGES - 1; ++t)
+            if (t < nk) stage(t, t);
+        int buf = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            // tiles issued so far: min(kt + STAGES - 1, nk); tile kt must have landed, younger ones may fly
+            const int younger = min(kt + STAGES - 1, nk) - (kt + 1);
+            if (younger >= STAGES - 2) wait_vmcnt<(STAGES - 2) * LOADS_PER_TILE>();
+            else if (STAGES > 3 && younger == 1) wait_vmcnt<LOADS_PER_TILE>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();        // every wave's share of tile kt landed; buffer of tile kt-1 is free
+            if (kt + STAGES - 1 < nk) {
+                int nb = buf + STAGES - 1;
+                nb = nb >= STAGES ? nb - STAGES : nb;
+                stage(kt + STAGES - 1, nb);
+            }
+            compute(smem + buf * STAGE_BYTES);
+            buf = buf + 1 == STAGES ? 0 : buf + 1;
         }
     }
 
@@ -215,9 +255,10 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmParams p) {
         __syncthreads();
         constexpr int CHUNKS_PER_ROW = BN / 8;
         constexpr int TOTAL = BM * CHUNKS_PER_ROW;
+        static_assert(TOTAL % NT == 0, "tile copy-out must divide evenly");
 #pragma unroll
-        for (int it = 0; it < TOTAL / 256; ++it) {
-            const int idx = it * 256 + tid;
+        for (int it = 0; it < TOTAL / NT; ++it) {
+            const int idx = it * NT + tid;
             const int lrow = idx / CHUNKS_PER_ROW, ch = idx - lrow * CHUNKS_PER_ROW;
             const int row = m0 + lrow, col = n0 + ch * 8;
             if (row < p.m && col < p.c) {
@@ -233,23 +274,41 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmParams p) {
     }
 }
 
-template <int BM, int BN, int EPI>
+template <int BM, int BN, int WGM, int WGN, int STAGES, int EPI>
 static int launch(const GemmParams& p0, hipStream_t s) {
     GemmParams p = p0;
     p.tiles_m = (int)ceil_div(p.m, BM);
     p.tiles_n = (int)ceil_div(p.c, BN);
     const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n;
     if (blocks <= 0 || blocks > 0x7fffffff) { set_error("gemm: grid out of range"); return PCD_ERR_ARG; }
-    hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, EPI>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WGM, WGN, STAGES, EPI>), dim3((unsigned)blocks),
+                       dim3(64 * WGM * WGN), 0, s, p);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }
 
+static int g_force_cfg = -1;   // tuning hook (pcd_gemm_set_config): -1 = heuristic
+
 template <int EPI>
 static int dispatch(const GemmParams& p, hipStream_t s) {
-    // narrow outputs (C <= 64) use a 128x64 tile so no MFMA work is spent on masked columns
-    if (p.c <= 64) return launch<128, 64, EPI>(p, s);
-    return launch<128, 128, EPI>(p, s);
+    int cfg = g_force_cfg;
+    if (cfg < 0) {
+        // narrow outputs (C <= 64): 128x64 tile so no MFMA work is spent on masked columns.
+        // large problems: 256x256 tile, 8 waves (2x4, 128x64 per wave): half the L2->LDS bytes per FLOP
+        // of the 128x128 tile; measured 1223 vs 1074 TFLOP/s on 131072x2048x4096 and faster for every
+        // layer with K, C >= 256 (tools/bench_gemm.py, profiles/r01_c_gemm_tile_sweep.txt).
+        if (p.c <= 64) cfg = 0;
+        else if (p.m >= 16384 && p.c >= 256 && (p.k1 + p.k2) >= 256) cfg = 3;
+        else cfg = 1;
+    }
+    switch (cfg) {
+        case 0: return launch<128, 64, 2, 2, 2, EPI>(p, s);
+        case 1: return launch<128, 128, 2, 2, 2, EPI>(p, s);
+        case 2: return launch<256, 128, 4, 2, 3, EPI>(p, s);
+        case 3: return launch<256, 256, 2, 4, 2, EPI>(p, s);
+        case 4: return launch<128, 128, 2, 2, 3, EPI>(p, s);
+        default: set_error("gemm: unknown config %d", cfg); return PCD_ERR_ARG;
+    }
 }
 
 static int fill(const pcd_gemm_desc_t* d, GemmParams& p) {
@@ -314,4 +373,10 @@ extern "C" int pcd_gemm_f16_colmax(const pcd_gemm_desc_t* d, float* colmax, int 
     PCD_CHECK_ARG(colmax != nullptr && rows_per_shape > 0 && d->relu == 1);
     p.colmax = colmax; p.cm_rps = rows_per_shape;
     return dispatch<EPI_COLMAX>(p, (hipStream_t)stream);
+}
+
+extern "C" int pcd_gemm_set_config(int cfg) {
+    PCD_CHECK_ARG(cfg >= -1 && cfg <= 4);
+    g_force_cfg = cfg;
+    return PCD_OK;
 }

@@ -70,6 +70,10 @@ int pcd_gemm_f16_residual(const pcd_gemm_desc_t* d, const void* resid, int64_t l
  * (pcd_fill_zero) before the call; requires d->relu == 1. */
 int pcd_gemm_f16_colmax(const pcd_gemm_desc_t* d, float* colmax, int rows_per_shape, void* stream);
 
+/* tuning/benchmark hook: force a tile configuration for every following GEMM launch of this
+ * process (-1 = shape heuristic; 0: 128x64, 1: 128x128, 2: 256x128 3-stage, 3: 256x256, 4: 128x128 3-stage) */
+int pcd_gemm_set_config(int cfg);
+
 int pcd_fill_zero(void* p, size_t bytes, void* stream);
 int pcd_f32_to_f16(const float* src, void* dst, int64_t n, void* stream);
 int pcd_f16_to_f32(const void* src, float* dst, int64_t n, void* stream);
