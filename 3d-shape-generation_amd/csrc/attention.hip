@@ -6,9 +6,11 @@
 //   S^T[key][query] = sum_d K[key][d] Q[query][d]       A = K rows,  B = Q rows
 //   O^T[dd][query]  = sum_key Vt[dd][key] P^T[key][query]  A = Vt rows, B = P^T straight from
 //                                                           the S^T accumulators (no LDS trip)
-// With queries on the MFMA lane index, the softmax row reduction is 15 in-lane max/adds plus
-// one exchange between lane l and l+32, and the O^T rescale is a per-lane scalar.
-// V is transposed once per call into Vt[b][h][dd][n] (keys contiguous) by a small kernel.
+// With queries on the MFMA lane index, the softmax row reduction is in-lane max3/adds plus one
+// exchange between lane l and l+32 (v_permlane32_swap), and the O^T rescale is a per-lane scalar.
+// V stays row-major [key][d] in LDS (staged like K, straight from qkv); the Vt fragments come from
+// the hardware transpose read ds_read_b64_tr_b16, so there is no transpose pass and no workspace.
+#include <type_traits>
 #include "common.h"
 
 namespace pcd {
@@ -36,161 +38,264 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
     for (int i = lane; i < c; i += 64) orow[i] = to_half_sat(((float)xr[i] - mean) * rstd * gamma[i] + beta[i]);
 }
 
-// ---------------------------------------------------------- V -> Vt transpose
-// qkv [B*N][3C]; Vt [B][H][d][Npad] with Npad = N rounded up to 64 (pad keys are zero).
-__global__ __launch_bounds__(256) void v_transpose_kernel(const half_t* __restrict__ qkv, int n, int npad, int c,
-                                                           half_t* __restrict__ vt) {
-    extern __shared__ __attribute__((aligned(16))) half_t tile[];   // [64 keys][c + 2]
-    const int b = blockIdx.y, k0 = blockIdx.x * 64;
-    const int ldt = c + 2;
-    for (int i = threadIdx.x; i < 64 * c; i += blockDim.x) {
-        const int kr = i / c, cc = i - kr * c;
-        const int key = k0 + kr;
-        tile[kr * ldt + cc] = key < n ? qkv[((int64_t)b * n + key) * (3 * c) + 2 * c + cc] : (half_t)0.f;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 64 * c; i += blockDim.x) {
-        const int cc = i >> 6, kr = i & 63;
-        vt[((int64_t)b * c + cc) * npad + k0 + kr] = tile[kr * ldt + cc];
+// ------------------------------------------------------------ flash attention
+// block = 4 waves, each wave owns QT x 32 queries of one (shape, head); K [64][D] and Vt [D][64]
+// tiles arrive by LDS-DMA (global_load_lds 16 B/lane) into a 2-deep ring, XOR-swizzled through the
+// source address so the ds_read_b128 fragment reads are bank-conflict free.
+constexpr int KT = 64;
+#ifdef ATT_THR0
+constexpr float RESCALE_THR = 0.0f;
+#else
+constexpr float RESCALE_THR = 8.0f;
+#endif
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// fmaxf pair -> one v_max3_f32 (attention.o is built with -fno-honor-nans, so no canonicalising
+// v_max is needed on MFMA outputs).  NOT inline asm: an asm VALU reading an MFMA result gets none of
+// the hazard wait states hipcc inserts for its own instructions (wrong maxima at d = 16).
+__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+// max of lane l and lane l^32 in every lane, via v_permlane32_swap (VALU, no LDS)
+__device__ __forceinline__ float xhalf_max(float v) {
+#ifdef ATT_SHFL
+    return fmaxf(v, __shfl_xor(v, 32));
+#endif
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+__device__ __forceinline__ void aglds16(const half_t* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+// Swizzles (applied to the LDS-DMA source address and again on the reads).  K tile (ds_read_b128
+// fragment reads, rows = lanes): chunk ^ f(row) makes the four 16-lane groups conflict free.
+// V tile (ds_read_b64_tr_b16: 4 rows x 4 chunks per 32-lane half): with 128-B rows, rows r and r+2
+// share a bank half, so bit 1 of the row flips the 64-B half of the row.
+template <int RB>
+__device__ __forceinline__ int k_swz(int row, int ch) {
+    constexpr int CPR = RB / 16, LPR = 128 / RB;
+    return ch ^ ((row / (2 * LPR)) & (CPR - 1));
+}
+template <int RB>
+__device__ __forceinline__ int v_swz(int row, int ch) {
+    return RB == 128 ? (ch ^ ((row & 2) << 1)) : ch;
+}
+
+// stage ROWS rows of RB bytes (global row stride ld halfs) with 4 waves; VSW selects the swizzle
+template <int ROWS, int RB, bool VSW>
+__device__ __forceinline__ void stage_tile(const half_t* __restrict__ src, int64_t ld, int row0, int row_limit,
+                                           char* lds, int wave, int lane) {
+    constexpr int CPR = RB / 16, LPR = 128 / RB;
+    constexpr int ROWS_PER_INSTR = 8 * LPR;                 // 64 lanes x 16 B = 1 KB
+    constexpr int INSTRS = ROWS / ROWS_PER_INSTR;
+    constexpr int PER_WAVE = (INSTRS + 3) / 4;
+#pragma unroll
+    for (int r = 0; r < PER_WAVE; ++r) {
+        const int ins = r * 4 + wave;
+        if (INSTRS % 4 != 0 && ins >= INSTRS) break;
+        const int row = ins * ROWS_PER_INSTR + lane / CPR;
+        const int logical = VSW ? v_swz<RB>(row, lane % CPR) : k_swz<RB>(row, lane % CPR);
+        int grow = row0 + row;
+        grow = grow < row_limit ? grow : row_limit - 1;
+        aglds16(src + (int64_t)grow * ld + logical * 8, lds + ins * 1024);
     }
 }
 
-// ------------------------------------------------------------ flash attention
-// block = 4 waves; each wave owns 32 queries of one (shape, head); the block shares K / Vt
-// tiles of KT keys through LDS.
-constexpr int KT = 64;
-
-template <int D>
-__global__ __launch_bounds__(256) void set_attention_kernel(const half_t* __restrict__ qkv,
-                                                             const half_t* __restrict__ vt, int n, int npad, int c,
-                                                             int heads, float scale_log2e, half_t* __restrict__ out) {
+template <int D, int QT>
+__global__ __launch_bounds__(256) void set_attention_kernel(const half_t* __restrict__ qkv, int n, int c, int heads,
+                                                             float scale_log2e, half_t* __restrict__ out) {
     constexpr int DP = (D < 32) ? 32 : D;        // O^T rows padded to the 32-row MFMA tile
     constexpr int KSTEPS = D / 16;               // MFMA k-steps of the S^T product
     constexpr int OT = DP / 32;                  // 32-row O^T tiles
-    constexpr int KLD = D + 8;                   // halfs per staged K row (pad breaks the power-of-2 stride)
-    constexpr int VLD = KT + 8;                  // halfs per staged Vt row
-    __shared__ __attribute__((aligned(16))) half_t ks[KT * KLD];
-    __shared__ __attribute__((aligned(16))) half_t vs[DP * VLD];
+    constexpr int KRB = D * 2;                   // bytes per K row
+    constexpr int KBYTES = KT * KRB, STAGE = 2 * KBYTES;   // K tile + V tile, both [64 keys][D]
+    constexpr int ZERO_OFF = 2 * STAGE;                      // 64 zero bytes: O^T rows >= D (d = 16 only)
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + 64];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qr = lane & 31, hh = lane >> 5;
     const int bh = blockIdx.y, b = bh / heads, head = bh - b * heads;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blockIdx.x * (128 * QT) + wave * (32 * QT);
     const int64_t row_base = (int64_t)b * n;
     const int ld = 3 * c;
 
     // Q fragments (B operand): lane (query qr, half hh) holds Q[query][16*s + 8*hh + j]
-    half8 qf[KSTEPS];
-    {
-        int qi = q0 + qr;
+    half8 qf[QT][KSTEPS];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        int qi = q0 + t * 32 + qr;
         qi = qi < n ? qi : n - 1;
         const half_t* qp = qkv + (row_base + qi) * ld + head * D;
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) qf[s] = *(const half8*)(qp + 16 * s + 8 * hh);
+        for (int s = 0; s < KSTEPS; ++s) qf[t][s] = *(const half8*)(qp + 16 * s + 8 * hh);
     }
 
-    f32x16 oacc[OT];
+    f32x16 oacc[QT][OT];
+    float m_run[QT];
+    f32x2 l_acc[QT];
 #pragma unroll
-    for (int t = 0; t < OT; ++t)
+    for (int t = 0; t < QT; ++t) {
+        m_run[t] = -INFINITY; l_acc[t] = (f32x2){0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-
-    if (D < 32) {  // zero the padded Vt rows once
-        for (int i = tid; i < (DP - D) * VLD; i += 256) vs[D * VLD + i] = (half_t)0.f;
+        for (int o = 0; o < OT; ++o)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[t][o][r] = 0.f;
     }
+
+    if (tid < 16) *(float*)(smem + ZERO_OFF + tid * 4) = 0.f;
 
     const half_t* kbase = qkv + row_base * ld + c + head * D;
-    const half_t* vbase = vt + ((int64_t)b * c + head * D) * npad;
+    const half_t* vbase = qkv + row_base * ld + 2 * c + head * D;
+    const int ntiles = (n + KT - 1) / KT;
 
-    for (int k0 = 0; k0 < n; k0 += KT) {
-        __syncthreads();
-        // stage K tile [KT][D] and Vt tile [D][KT] (16-B pieces)
-        for (int i = tid; i < KT * (D / 8); i += 256) {
-            const int kr = i / (D / 8), ch = i - kr * (D / 8);
-            int key = k0 + kr;
-            key = key < n ? key : n - 1;
-            *(half8*)(ks + kr * KLD + ch * 8) = *(const half8*)(kbase + (int64_t)key * ld + ch * 8);
-        }
-        for (int i = tid; i < D * (KT / 8); i += 256) {
-            const int dr = i / (KT / 8), ch = i - dr * (KT / 8);
-            *(half8*)(vs + dr * VLD + ch * 8) = *(const half8*)(vbase + (int64_t)dr * npad + k0 + ch * 8);
-        }
-        __syncthreads();
+    // transpose-read addressing (ds_read_b64_tr_b16): in each 16-lane group, lane 4q+p supplies the
+    // address of key row q, d columns 4p..4p+3 of the group's 4 x 16 block and receives column (lane&15).
+    // Group g = lane>>4 covers O^T rows dd0 = 16*(g&1) .. +16 of a 32-row tile for key half hh = g>>1.
+    const int tq = (lane >> 2) & 3, tp = lane & 3, tg = lane >> 4;
+    const int tr_dd0 = 16 * (tg & 1);
 
+    auto stage = [&](int kt, int buf) {
+        char* base = smem + buf * STAGE;
+        stage_tile<KT, KRB, false>(kbase, ld, kt * KT, n, base, wave, lane);
+        stage_tile<KT, KRB, true>(vbase, ld, kt * KT, n, base + KBYTES, wave, lane);
+    };
+
+    // one KV tile; MASK only for the last, partial tile (keys >= n get -inf) so full tiles carry no
+    // compare/select code at all
+    auto tile_body = [&](int kt, auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
+        const char* kb = smem + (kt & 1) * STAGE;
+        const char* vb = kb + KBYTES;
 #pragma unroll
         for (int sub = 0; sub < KT / 32; ++sub) {
-            // S^T tile: 32 keys x 32 queries
-            f32x16 sacc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            half8 kf[KSTEPS];
 #pragma unroll
             for (int s = 0; s < KSTEPS; ++s) {
-                const half8 kf = *(const half8*)(ks + (sub * 32 + qr) * KLD + 16 * s + 8 * hh);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc, 0, 0, 0);
+                const int row = sub * 32 + qr;
+                kf[s] = *(const half8*)(kb + row * KRB + (k_swz<KRB>(row, 2 * s + hh) << 4));
             }
-            // register r of lane (qr, hh) is key (r&3) + 8*(r>>2) + 4*hh of this sub-tile
-            float mx = -INFINITY;
+            // Vt fragments: element j of lane half hh must be key 16*s2 + 8*(j>>2) + 4*hh + (j&3) (the k order
+            // in which the S^T accumulators hand over P^T): two transposed 4-key reads per fragment.
+            half8 vf[2][OT];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = k0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                sacc[r] = key < n ? sacc[r] * scale_log2e : -INFINITY;
-                mx = fmaxf(mx, sacc[r]);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0
-            float psum = 0.f;
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                sacc[r] = exp2f(sacc[r] - m_new);
-                psum += sacc[r];
-            }
-            psum += __shfl_xor(psum, 32);
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
+                for (int o = 0; o < OT; ++o) {
+                    const int dd0 = o * 32 + tr_dd0;
+                    fp16x4 lo, hi;
+                    if (D >= 32 || dd0 < D) {
+                        const int key = sub * 32 + 16 * s2 + 4 * (tg >> 1) + tq;
+                        const int ch = (dd0 >> 3) + (tp >> 1);
+                        const char* a0 = vb + key * KRB + (v_swz<KRB>(key, ch) << 4) + (tp & 1) * 8;
+                        const char* a1 = vb + (key + 8) * KRB + (v_swz<KRB>(key + 8, ch) << 4) + (tp & 1) * 8;
+                        lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)a0);
+                        hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)a1);
+                    } else {   // d = 16: O^T rows 16..31 do not exist; every lane still issues the read (EXEC all ones)
+                        const char* z = smem + ZERO_OFF + (tp & 1) * 8;
+                        lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)z);
+                        hi = lo;
+                    }
 #pragma unroll
-            for (int t = 0; t < OT; ++t)
+                    for (int e = 0; e < 4; ++e) { vf[s2][o][e] = (half_t)lo[e]; vf[s2][o][4 + e] = (half_t)hi[e]; }
+                }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
-            // P^T as B operand: k-step s2 takes registers 8*s2 .. 8*s2+7; element j of lane half hh
-            // is key 16*s2 + 8*(j>>2) + 4*hh + (j&3), so the Vt fragment gathers the same keys.
+            for (int t = 0; t < QT; ++t) {
+                // S^T tile: 32 keys x 32 queries
+                f32x16 sacc;
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                half8 pf;
+                for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pf[j] = (half_t)sacc[8 * s2 + j];
+                for (int s = 0; s < KSTEPS; ++s)
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[s], qf[t][s], sacc, 0, 0, 0);
+                if constexpr (MASK) {   // register r of lane (qr, hh) is key (r&3) + 8*(r>>2) + 4*hh of this sub-tile
 #pragma unroll
-                for (int t = 0; t < OT; ++t) {
-                    const half_t* vrow = vs + (t * 32 + qr) * VLD + sub * 32 + 16 * s2 + 4 * hh;
-                    const half4 lo = *(const half4*)(vrow);
-                    const half4 hi = *(const half4*)(vrow + 8);
-                    half8 vf;
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kt * KT + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        if (key >= n) sacc[r] = -INFINITY;
+                    }
+                }
+                // row max: 8 single-instruction v_max3 + one half-wave exchange (no canonicalising
+                // v_max, no LDS round trip)
+                float mx = max3(sacc[0], sacc[1], sacc[2]);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
-                    oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[t], 0, 0, 0);
+                for (int r = 3; r < 15; r += 2) mx = max3(mx, sacc[r], sacc[r + 1]);
+                mx = max3(mx, sacc[15], sacc[15]);
+                mx = xhalf_max(mx) * scale_log2e;                  // scale > 0 commutes with max
+                // deferred max (log2 domain): rescale O and l only when some row's max grew by more than
+                // RESCALE_THR; until then P <= 2^THR, exact in fp16's exponent range (fp32 row sums).
+                if (__any(mx > m_run[t] + RESCALE_THR)) {          // wave-uniform, rare after the first tiles
+                    const float m_new = fmaxf(m_run[t], mx);
+                    const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);   // first tile: exp2(-inf) = 0
+                    m_run[t] = m_new;
+                    l_acc[t] *= (f32x2){alpha, alpha};
+#pragma unroll
+                    for (int o = 0; o < OT; ++o)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) oacc[t][o][r] *= alpha;
+                }
+                const float nm = -m_run[t];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    sacc[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], scale_log2e, nm));
+                // per-lane partial row sums, two at a time (v_pk_add_f32); halves combined in the epilogue
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) l_acc[t] += (f32x2){sacc[r], sacc[r + 1]};
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    half8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (half_t)sacc[8 * s2 + j];
+#pragma unroll
+                    for (int o = 0; o < OT; ++o)
+                        oacc[t][o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[s2][o], pf, oacc[t][o], 0, 0, 0);
                 }
             }
         }
+    };
+
+    const int full_tiles = n / KT;
+    stage(0, 0);
+    for (int kt = 0; kt < full_tiles; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < ntiles) stage(kt + 1, (kt + 1) & 1);
+        tile_body(kt, std::false_type{});
+    }
+    if (full_tiles < ntiles) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        tile_body(full_tiles, std::true_type{});
     }
 
-    // epilogue: lane (query qr, half hh) holds O^T rows dd = t*32 + (r&3) + 8*(r>>2) + 4*hh
-    const int qi = q0 + qr;
-    if (qi < n) {
-        const float inv = 1.f / l_run;
-        half_t* orow = out + (row_base + qi) * c + head * D;
+    // epilogue: lane (query qr, half hh) holds O^T rows dd = o*32 + (r&3) + 8*(r>>2) + 4*hh
 #pragma unroll
-        for (int t = 0; t < OT; ++t)
+    for (int t = 0; t < QT; ++t) {
+        const int qi = q0 + t * 32 + qr;
+        const float l_half = l_acc[t][0] + l_acc[t][1];
+        const float l_tot = l_half + __shfl_xor(l_half, 32);
+        if (qi < n) {
+            const float inv = 1.f / l_tot;
+            half_t* orow = out + (row_base + qi) * c + head * D;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int dd = t * 32 + 8 * g + 4 * hh;
-                if (dd < D) {
-                    half4 o;
+            for (int o = 0; o < OT; ++o)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = to_half_sat(oacc[t][4 * g + e] * inv);
-                    *(half4*)(orow + dd) = o;
+                for (int g = 0; g < 4; ++g) {
+                    const int dd = o * 32 + 8 * g + 4 * hh;
+                    if (dd < D) {
+                        half4 ov;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ov[e] = to_half_sat(oacc[t][o][4 * g + e] * inv);
+                        *(half4*)(orow + dd) = ov;
+                    }
                 }
-            }
+        }
     }
 }
 
@@ -208,39 +313,30 @@ extern "C" int pcd_layernorm_f16(const void* x, int64_t rows, int c, const float
 }
 
 extern "C" size_t pcd_set_attention_workspace_bytes(int batch, int n_points, int c) {
-    if (batch <= 0 || n_points <= 0 || c <= 0) return 0;
-    const size_t npad = (size_t)ceil_div(n_points, KT) * KT;
-    return (size_t)batch * c * npad * sizeof(half_t);
+    (void)batch; (void)n_points; (void)c;
+    return 0;   // V is transposed on the fly by ds_read_b64_tr_b16: no workspace needed any more
 }
 
 extern "C" int pcd_set_attention_f16(const void* qkv, int batch, int n_points, int c, int heads, void* out,
                                      void* workspace, size_t workspace_bytes, void* stream) {
-    PCD_CHECK_ARG(qkv && out && workspace && batch > 0 && n_points > 0 && heads > 0 && c % heads == 0);
+    (void)workspace; (void)workspace_bytes;
+    PCD_CHECK_ARG(qkv && out && batch > 0 && n_points > 0 && heads > 0 && c % heads == 0);
     const int d = c / heads;
     PCD_CHECK_ARG(d == 16 || d == 32 || d == 64);
     PCD_CHECK_ARG(c % 8 == 0);
-    const size_t need = pcd_set_attention_workspace_bytes(batch, n_points, c);
-    if (workspace_bytes < need) {
-        set_error("pcd_set_attention_f16: workspace %zu < required %zu", workspace_bytes, need);
-        return PCD_ERR_WORKSPACE;
-    }
     hipStream_t s = (hipStream_t)stream;
-    const int npad = (int)(ceil_div(n_points, KT) * KT);
-    half_t* vt = (half_t*)workspace;
-    hipLaunchKernelGGL(v_transpose_kernel, dim3(npad / 64, batch), dim3(256), (size_t)64 * (c + 2) * sizeof(half_t), s,
-                       (const half_t*)qkv, n_points, npad, c, vt);
-    PCD_CHECK_LAUNCH();
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)d);
-    dim3 grid((unsigned)ceil_div(n_points, 128), (unsigned)(batch * heads));
+    constexpr int QT = 2;   // 64 queries per wave, 256 per block
+    dim3 grid((unsigned)ceil_div(n_points, 128 * QT), (unsigned)(batch * heads));
     if (d == 16)
-        hipLaunchKernelGGL((set_attention_kernel<16>), grid, dim3(256), 0, s, (const half_t*)qkv, vt, n_points, npad, c,
-                           heads, scale_log2e, (half_t*)out);
+        hipLaunchKernelGGL((set_attention_kernel<16, QT>), grid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads,
+                           scale_log2e, (half_t*)out);
     else if (d == 32)
-        hipLaunchKernelGGL((set_attention_kernel<32>), grid, dim3(256), 0, s, (const half_t*)qkv, vt, n_points, npad, c,
-                           heads, scale_log2e, (half_t*)out);
+        hipLaunchKernelGGL((set_attention_kernel<32, QT>), grid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads,
+                           scale_log2e, (half_t*)out);
     else
-        hipLaunchKernelGGL((set_attention_kernel<64>), grid, dim3(256), 0, s, (const half_t*)qkv, vt, n_points, npad, c,
-                           heads, scale_log2e, (half_t*)out);
+        hipLaunchKernelGGL((set_attention_kernel<64, QT>), grid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads,
+                           scale_log2e, (half_t*)out);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

@@ -72,10 +72,11 @@ def layernorm_f16(x, gamma, beta) -> torch.Tensor:
 def set_attention_f16(qkv, batch: int, n_points: int, c: int, heads: int) -> torch.Tensor:
     assert qkv.dtype == torch.float16 and qkv.is_contiguous() and qkv.shape[-1] == 3 * c
     lib = _lib.load()
-    ws = torch.empty(lib.pcd_set_attention_workspace_bytes(batch, n_points, c), dtype=torch.uint8, device=qkv.device)
+    nws = lib.pcd_set_attention_workspace_bytes(batch, n_points, c)      # 0 since the transpose-read kernel
+    ws = torch.empty(nws, dtype=torch.uint8, device=qkv.device) if nws else None
     out = torch.empty(batch * n_points, c, dtype=torch.float16, device=qkv.device)
-    _lib.check(lib.pcd_set_attention_f16(qkv.data_ptr(), batch, n_points, c, heads, out.data_ptr(), ws.data_ptr(),
-                                         ws.numel(), _lib.stream_ptr()), "set_attention")
+    _lib.check(lib.pcd_set_attention_f16(qkv.data_ptr(), batch, n_points, c, heads, out.data_ptr(), _lib.ptr(ws),
+                                         nws, _lib.stream_ptr()), "set_attention")
     return out
 
 

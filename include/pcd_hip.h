@@ -227,7 +227,8 @@ int pcd_layernorm_f16(const void* x, int64_t rows, int c, const float* gamma, co
  * (replaces the bmm/softmax/bmm path of nn.MultiheadAttention, networks.py:61,81).
  * qkv fp16 [B*N][3C] = [q | k | v] as produced by in_proj; q is scaled by 1/sqrt(d)
  * inside.  out fp16 [B*N][C] (heads concatenated, ready for out_proj).
- * workspace holds V transposed per (shape, head): keys contiguous for the PV product. */
+ * V is transposed on the fly (ds_read_b64_tr_b16), so the workspace query returns 0 and
+ * workspace may be NULL; the parameters are kept for ABI stability. */
 size_t pcd_set_attention_workspace_bytes(int batch, int n_points, int c);
 int pcd_set_attention_f16(const void* qkv, int batch, int n_points, int c, int heads,
                           void* out, void* workspace, size_t workspace_bytes, void* stream);

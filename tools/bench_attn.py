@@ -9,7 +9,7 @@ B, N, H = 64, 2048, 4
 for C in (256, 128, 64):
     g = torch.Generator(device="cuda").manual_seed(0)
     qkv = (torch.randn(B * N, 3 * C, device="cuda", generator=g) * 0.7).half()
-    ws = torch.empty(lib.pcd_set_attention_workspace_bytes(B, N, C), dtype=torch.uint8, device="cuda")
+    ws = torch.empty(max(16, lib.pcd_set_attention_workspace_bytes(B, N, C)), dtype=torch.uint8, device="cuda")
     out = torch.empty(B * N, C, dtype=torch.float16, device="cuda")
     def fn():
         _lib.check(lib.pcd_set_attention_f16(qkv.data_ptr(), B, N, C, H, out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
