@@ -42,7 +42,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
 // block = 4 waves, each wave owns QT x 32 queries of one (shape, head); K [64][D] and Vt [D][64]
 // tiles arrive by LDS-DMA (global_load_lds 16 B/lane) into a 2-deep ring, XOR-swizzled through the
 // source address so the ds_read_b128 fragment reads are bank-conflict free.
-constexpr int KT = 64;
+#ifndef ATT_KT
+#define ATT_KT 64
+#endif
+constexpr int KT = ATT_KT;
 #ifdef ATT_THR0
 constexpr float RESCALE_THR = 0.0f;
 #else
@@ -134,15 +137,23 @@ __global__ __launch_bounds__(256) void set_attention_kernel(const half_t* __rest
         qi = qi < n ? qi : n - 1;
         const half_t* qp = qkv + (row_base + qi) * ld + head * D;
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) qf[t][s] = *(const half8*)(qp + 16 * s + 8 * hh);
+        for (int s = 0; s < KSTEPS; ++s) {
+            // pre-scaled by log2(e)/sqrt(d) (one fp16 rounding) so the MFMA output is already in the exp2 domain
+            const half8 raw = *(const half8*)(qp + 16 * s + 8 * hh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[t][s][e] = (half_t)((float)raw[e] * scale_log2e);
+        }
     }
 
-    f32x16 oacc[QT][OT];
-    float m_run[QT];
+    // negm[t]: 16 registers all holding -m (running row max of query qr, exp2 domain).  It is the C input of
+    // the first S^T MFMA of every tile (D != C), so the accumulator comes out as s*c - m with no VALU work.
+    f32x16 oacc[QT][OT], negm[QT];
     f32x2 l_acc[QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-        m_run[t] = -INFINITY; l_acc[t] = (f32x2){0.f, 0.f};
+        l_acc[t] = (f32x2){0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[t][r] = 0.f;
 #pragma unroll
         for (int o = 0; o < OT; ++o)
 #pragma unroll
@@ -207,13 +218,17 @@ __global__ __launch_bounds__(256) void set_attention_kernel(const half_t* __rest
                 }
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
-                // S^T tile: 32 keys x 32 queries
-                f32x16 sacc;
+                // S'^T tile: 32 keys x 32 queries, already relative to the running max
+#ifdef ATT_PRIO
+                __builtin_amdgcn_s_setprio(1);
+#endif
+                f32x16 sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[t][0], negm[t], 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-#pragma unroll
-                for (int s = 0; s < KSTEPS; ++s)
+                for (int s = 1; s < KSTEPS; ++s)
                     sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[s], qf[t][s], sacc, 0, 0, 0);
+#ifdef ATT_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
                 if constexpr (MASK) {   // register r of lane (qr, hh) is key (r&3) + 8*(r>>2) + 4*hh of this sub-tile
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -221,29 +236,37 @@ __global__ __launch_bounds__(256) void set_attention_kernel(const half_t* __rest
                         if (key >= n) sacc[r] = -INFINITY;
                     }
                 }
-                // row max: 8 single-instruction v_max3 + one half-wave exchange (no canonicalising
-                // v_max, no LDS round trip)
+                // row max of s' (7 v_max3 + one half-wave exchange)
                 float mx = max3(sacc[0], sacc[1], sacc[2]);
 #pragma unroll
                 for (int r = 3; r < 15; r += 2) mx = max3(mx, sacc[r], sacc[r + 1]);
-                mx = max3(mx, sacc[15], sacc[15]);
-                mx = xhalf_max(mx) * scale_log2e;                  // scale > 0 commutes with max
-                // deferred max (log2 domain): rescale O and l only when some row's max grew by more than
-                // RESCALE_THR; until then P <= 2^THR, exact in fp16's exponent range (fp32 row sums).
-                if (__any(mx > m_run[t] + RESCALE_THR)) {          // wave-uniform, rare after the first tiles
-                    const float m_new = fmaxf(m_run[t], mx);
-                    const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);   // first tile: exp2(-inf) = 0
-                    m_run[t] = m_new;
+                mx = xhalf_max(fmaxf(mx, sacc[15]));
+                // Deferred max: move m only when some row's scores exceed it by more than RESCALE_THR (then
+                // P <= 2^THR, exact in fp16's exponent range; row sums and O are fp32).  The very first tile
+                // always sets m to its true row max (which may be negative).
+                const bool first = (kt == 0) && (sub == 0);
+                if (first || __any(mx > RESCALE_THR)) {          // wave-uniform, rare after the first tiles
+                    const float delta = first ? mx : fmaxf(mx, 0.f);
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
                     l_acc[t] *= (f32x2){alpha, alpha};
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { negm[t][r] -= delta; sacc[r] -= delta; }
 #pragma unroll
                     for (int o = 0; o < OT; ++o)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) oacc[t][o][r] *= alpha;
                 }
-                const float nm = -m_run[t];
+#ifdef ATT_SGB
+                // ask the scheduler for an MFMA : VALU interleave (1 MFMA, 1 transcendental, 3 VALU) x 8
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    sacc[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], scale_log2e, nm));
+                for (int g = 0; g < 8; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                }
+#endif
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[r] = __builtin_amdgcn_exp2f(sacc[r]);
                 // per-lane partial row sums, two at a time (v_pk_add_f32); halves combined in the epilogue
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) l_acc[t] += (f32x2){sacc[r], sacc[r + 1]};
@@ -260,6 +283,11 @@ __global__ __launch_bounds__(256) void set_attention_kernel(const half_t* __rest
         }
     };
 
+#ifdef ATT_STAGGER
+    // de-phase co-resident workgroups that run the same instruction stream (they would otherwise hit
+    // their MFMA bursts and their exp bursts together on the shared SIMD)
+    if ((blockIdx.x + blockIdx.y) & 1) __builtin_amdgcn_s_sleep(ATT_STAGGER);
+#endif
     const int full_tiles = n / KT;
     stage(0, 0);
     for (int kt = 0; kt < full_tiles; ++kt) {
@@ -326,7 +354,12 @@ extern "C" int pcd_set_attention_f16(const void* qkv, int batch, int n_points, i
     PCD_CHECK_ARG(c % 8 == 0);
     hipStream_t s = (hipStream_t)stream;
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)d);
-    constexpr int QT = 2;   // 64 queries per wave, 256 per block
+#ifndef ATT_QT
+#define ATT_QT 1
+#endif
+    // 32*QT queries per wave.  QT = 1 measured fastest (836 vs 764 TFLOP/s at d = 64): at QT = 2 the kernel
+    // sits at 256 VGPRs (2 waves/SIMD) and the shared K/V fragments do not pay for the lost occupancy.
+    constexpr int QT = ATT_QT;
     dim3 grid((unsigned)ceil_div(n_points, 128 * QT), (unsigned)(batch * heads));
     if (d == 16)
         hipLaunchKernelGGL((set_attention_kernel<16, QT>), grid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads,
