@@ -82,6 +82,8 @@ _SIGS = {
     "pcd_ddim_update": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i64, vp, vp, vp]),
     "pcd_ddpm_update": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i64, i64, vp, vp, vp]),
     "pcd_randn": (i32, [vp, i64, u64, u64, vp]),
+    "pcd_step_select": (i32, [vp, i32, vp, i32, vp, vp, i32, vp, vp]),
+    "pcd_randn_step": (i32, [vp, i64, u64, u64, u64, vp, vp]),
     "pcd_head3": (i32, [vp, i64, i32, vp, vp, vp, vp]),
     "pcd_unet_create": (i32, [C.POINTER(UnetDesc), C.POINTER(vp)]),
     "pcd_unet_destroy": (None, [vp]),
@@ -91,6 +93,9 @@ _SIGS = {
     "pcd_unet_profile_read": (i32, [vp, C.POINTER(C.c_double), C.POINTER(i32)]),
     "pcd_unet_tap": (i32, [vp, C.c_char_p, i32, i32, vp, vp, sz, vp]),
     "pcd_groupnorm_relu_f16": (i32, [vp, i32, i32, i32, vp, vp, vp, vp]),
+    "pcd_skinny_slabs": (i32, [i32, i32]),
+    "pcd_skinny_gemm_f16": (i32, [vp, i32, vp, i32, vp, i64, i32, i32, vp, vp]),
+    "pcd_skinny_finish": (i32, [vp, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
     "pcd_latent_create": (i32, [C.POINTER(LatentDesc), C.POINTER(vp)]),
     "pcd_latent_destroy": (None, [vp]),
     "pcd_latent_workspace_bytes": (sz, [i32]),

@@ -60,7 +60,7 @@ static LatWs carve(int64_t b) {
     w.g0 = o; o += align_up(b * 2048 * 2);
     w.g1 = o; o += align_up(b * 4096 * 2);
     w.d = o; o += align_up(b * 1024 * 2) * 2;   // two ping-pong decoder buffers
-    w.tmp32 = o; o += align_up(b * 4096 * 4);
+    w.tmp32 = o; o += align_up(b * 4096 * 4 * 20);   // fp32 split-K slabs: at most 20 slices of [b][4096]
     w.total = o;
     return w;
 }
@@ -106,7 +106,7 @@ extern "C" size_t pcd_latent_workspace_bytes(int batch) { return batch > 0 ? car
 extern "C" int pcd_latent_forward(pcd_latent_t* h, const float* z, int batch, const float* tbias,
                                   int tbias_shape_stride, float* eps, void* workspace, size_t workspace_bytes,
                                   void* stream) {
-    PCD_CHECK_ARG(h && z && tbias && eps && workspace && batch > 0);
+    PCD_CHECK_ARG(h && z && tbias && eps && workspace && batch > 0 && batch <= 256);
     PCD_CHECK_ARG(tbias_shape_stride == 0 || tbias_shape_stride == 1);
     const LatWs w = carve(batch);
     if (workspace_bytes < w.total) {
@@ -121,18 +121,19 @@ extern "C" int pcd_latent_forward(pcd_latent_t* h, const float* z, int batch, co
     hipStream_t s = (hipStream_t)stream;
     int rc;
 #define RUN(expr) do { rc = (expr); if (rc) return rc; } while (0)
-    auto lin_gn = [&](int idx, const void* a1, const void* a2, int k2, const float* bias, const float* sbias,
-                      void* out) -> int {
-        pcd_gemm_desc_t g{};
+    // one Linear (+GroupNorm+ReLU): weight-streaming split-K GEMM into fp32 slabs, then the finishing
+    // kernel (fixed-order slab sum + bias + GroupNorm + ReLU).  mode as in pcd_skinny_finish.
+    auto lin = [&](int idx, const void* a1, const void* a2, int k2, const float* bias, const float* row_bias,
+                   int mode, void* out16, float* out32) -> int {
         const pcd_linear_desc_t& L = d.lin[idx];
-        g.a1 = a1; g.k1 = L.k - k2; g.lda1 = g.k1;
-        g.a2 = a2; g.k2 = k2; g.lda2 = k2;
-        g.w = L.w; g.ldw = L.k; g.bias = bias; g.shape_bias = sbias; g.rows_per_shape = 1;
-        g.relu = 0; g.m = batch; g.c = L.c;
-        int r = pcd_gemm_f16_out32(&g, t32, L.c, s);
+        int r = pcd_skinny_gemm_f16(a1, L.k - k2, a2, k2, L.w, L.k, batch, L.c, t32, s);
         if (r) return r;
-        return pcd_groupnorm_relu_f16(t32, batch, L.c, 8, d.gn_gamma[idx], d.gn_beta[idx], out, s);
+        return pcd_skinny_finish(t32, pcd_skinny_slabs(L.k, L.c), batch, L.c, bias, row_bias, mode, 8,
+                                 mode == 0 ? d.gn_gamma[idx] : nullptr, mode == 0 ? d.gn_beta[idx] : nullptr, out16,
+                                 out32, s);
     };
+    auto lin_gn = [&](int idx, const void* a1, const void* a2, int k2, const float* bias, const float* sbias,
+                      void* out) -> int { return lin(idx, a1, a2, k2, bias, sbias, 0, out, nullptr); };
     RUN(pcd_f32_to_f16(z, z16, (int64_t)batch * 256, s));
     // enc1: time half hoisted into tbias (one row, or one row per sample)
     RUN(lin_gn(0, z16, nullptr, 0, tbias_shape_stride ? nullptr : tbias, tbias_shape_stride ? tbias : nullptr, z1));
@@ -145,14 +146,8 @@ extern "C" int pcd_latent_forward(pcd_latent_t* h, const float* z, int batch, co
     RUN(lin_gn(7, da, z3, 512, d.lin[7].b, nullptr, db));
     RUN(lin_gn(8, db, z2, 256, d.lin[8].b, nullptr, da));
     RUN(lin_gn(9, da, z1, 128, d.lin[9].b, nullptr, db));
-    {
-        pcd_gemm_desc_t g{};
-        g.a1 = db; g.k1 = 128; g.lda1 = 128; g.w = d.lin[10].w; g.ldw = 128; g.bias = d.lin[10].b;
-        g.relu = 1; g.m = batch; g.c = 128;
-        RUN(pcd_gemm_f16(&g, da, 128, s));
-        g.a1 = da; g.w = d.lin[11].w; g.bias = d.lin[11].b; g.relu = 0; g.c = 256;
-        RUN(pcd_gemm_f16_out32(&g, eps, 256, s));
-    }
+    RUN(lin(10, db, nullptr, 0, d.lin[10].b, nullptr, 1, da, nullptr));     // output.0 + ReLU
+    RUN(lin(11, da, nullptr, 0, d.lin[11].b, nullptr, 2, nullptr, eps));    // output.2 -> eps fp32
 #undef RUN
     return PCD_OK;
 }

@@ -312,6 +312,54 @@ __global__ __launch_bounds__(256) void reparam_kernel(const float* __restrict__ 
 }
 #pragma clang fp contract(fast)
 
+// Device-side step selection so that ONE captured HIP graph can be replayed for every timestep:
+// k = counter[0]; copy row k of the time-bias table and column k of the four rate tables to fixed
+// buffers; counter[1] = k (for consumers later in the step); counter[0] = k + 1.
+__global__ __launch_bounds__(256) void step_select_kernel(int* __restrict__ counter, int n_steps,
+                                                           const float* __restrict__ tb_table, int tb_elems,
+                                                           float* __restrict__ tb_cur,
+                                                           const float* __restrict__ rate_tables, int width,
+                                                           float* __restrict__ rates_cur) {
+    int k = counter[0];
+    k = k < n_steps ? k : n_steps - 1;
+    for (int i = threadIdx.x; i < tb_elems; i += blockDim.x) tb_cur[i] = tb_table[(int64_t)k * tb_elems + i];
+    for (int i = threadIdx.x; i < 4 * width; i += blockDim.x) {
+        const int tbl = i / width, j = i - tbl * width;
+        rates_cur[i] = rate_tables[((int64_t)tbl * n_steps + k) * width + j];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { counter[1] = k; counter[0] = k + 1; }
+}
+
+__global__ __launch_bounds__(256) void randn_step_kernel(float* __restrict__ out, int64_t n, uint64_t seed,
+                                                          uint64_t base, uint64_t stride,
+                                                          const int* __restrict__ counter) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q * 4 >= n) return;
+    const uint64_t ctr = (uint64_t)q + base + stride * (uint64_t)counter[1];
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    float v[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float u2 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float r = sqrtf(-2.0f * logf(u1));
+        float sn, cs;
+        sincosf(6.28318530717958647692f * u2, &sn, &cs);
+        v[2 * h] = r * cs;
+        v[2 * h + 1] = r * sn;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (q * 4 + e < n) out[q * 4 + e] = v[e];
+}
+
 static inline unsigned nblk(int64_t n) { return (unsigned)ceil_div(n, 256); }
 
 }  // namespace pcd
@@ -456,6 +504,24 @@ extern "C" int pcd_reparameterize(const float* mu, const float* logvar, const fl
                                   void* stream) {
     PCD_CHECK_ARG(mu && logvar && eps && z && n > 0);
     hipLaunchKernelGGL(reparam_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, mu, logvar, eps, z, n);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_step_select(int* counter, int n_steps, const float* tb_table, int tb_elems, float* tb_cur,
+                               const float* rate_tables, int width, float* rates_cur, void* stream) {
+    PCD_CHECK_ARG(counter && tb_table && tb_cur && rate_tables && rates_cur && n_steps > 0 && tb_elems > 0 && width > 0);
+    hipLaunchKernelGGL(step_select_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, counter, n_steps, tb_table,
+                       tb_elems, tb_cur, rate_tables, width, rates_cur);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_randn_step(float* out, int64_t n, uint64_t seed, uint64_t base_offset, uint64_t per_step_stride,
+                              const int* counter, void* stream) {
+    PCD_CHECK_ARG(out && counter && n > 0);
+    hipLaunchKernelGGL(randn_step_kernel, dim3(nblk(ceil_div(n, 4))), dim3(256), 0, (hipStream_t)stream, out, n, seed,
+                       base_offset, per_step_stride, counter);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

@@ -1,0 +1,183 @@
+// K8: weight-streaming GEMM for few rows (M <= 256: the latent denoiser's (B, C) vectors).
+//
+// The dense tile GEMM leaves most of the chip idle here (C/128 blocks, each streaming a long K);
+// this kernel is shaped for HBM bandwidth instead: a block owns 32 output columns and a K slice of
+// KS, so a layer is (C/32) x (K/KS) blocks that each stream 32 x KS x 2 bytes of weights exactly once.
+// No LDS staging: every lane loads 64 contiguous bytes of its weight row per 64-deep chunk (two
+// lanes = one 128-B line) and the same 64 bytes of its activation row; the four 16-k MFMA steps of a
+// chunk use a permuted k order that is identical for both operands, so no shuffles are needed.
+// The four waves split the block's K slice and reduce through LDS; split-K partial sums go to fp32
+// slabs [S][M][C] that the finishing kernel (bias + GroupNorm + ReLU) adds in a fixed order, so the
+// result is bitwise reproducible (no float atomics).
+#include "common.h"
+
+namespace pcd {
+
+struct SkinnyParams {
+    const half_t* a1; int k1;
+    const half_t* a2; int k2;
+    const half_t* w; int ldw;
+    int m, c, ks;
+    float* slabs;          // [S][M][C]
+};
+
+template <int MT>   // number of 32-row tiles (M <= 32*MT)
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyParams p) {
+    __shared__ float red[4][32][33];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int n0 = blockIdx.x * 32;
+    const int slice = blockIdx.y;
+    const int kbeg = slice * p.ks;
+    const int chunks = p.ks / 64;                    // 64-deep chunks in this block's slice
+    f32x16 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    int wn = n0 + r;
+    wn = wn < p.c ? wn : p.c - 1;
+    const half_t* wrow = p.w + (int64_t)wn * p.ldw;
+    for (int ch = wave; ch < chunks; ch += 4) {
+        const int k = kbeg + ch * 64 + 32 * hh;      // this lane's 32 consecutive k
+        half8 wf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[j] = *(const half8*)(wrow + k + 8 * j);
+        const half_t* src = k < p.k1 ? p.a1 : p.a2;
+        const int lda = k < p.k1 ? p.k1 : p.k2;
+        const int ka = k < p.k1 ? k : k - p.k1;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            int row = t * 32 + r;
+            row = row < p.m ? row : p.m - 1;
+            const half_t* arow = src + (int64_t)row * lda + ka;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const half8 af = *(const half8*)(arow + 8 * j);
+                // D[row = x-row][col = weight-row]: A = activations, B = weights
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, wf[j], acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // cross-wave reduction, one 32x32 tile at a time; accumulator register e of lane (r, hh) is
+    // row (e&3) + 8*(e>>2) + 4*hh (x row), column r (weight row)
+    float* out = p.slabs + (int64_t)slice * p.m * p.c;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[wave][(e & 3) + 8 * (e >> 2) + 4 * hh][r] = acc[t][e];
+        __syncthreads();
+        for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+            const int row = i >> 5, col = i & 31;
+            const float v = (red[0][row][col] + red[1][row][col]) + (red[2][row][col] + red[3][row][col]);
+            const int gr = t * 32 + row, gc = n0 + col;
+            if (gr < p.m && gc < p.c) out[(int64_t)gr * p.c + gc] = v;
+        }
+    }
+}
+
+// out = act( sum_s slabs[s] + bias [+ per-row bias] ), act: 0 = GroupNorm(groups)+affine+ReLU -> fp16,
+// 1 = ReLU -> fp16, 2 = identity -> fp32.  One block per (row, channel group): GroupNorm statistics
+// are per (row, group), so the groups of a row are independent (modes 1/2 just use the same split).
+__global__ __launch_bounds__(256) void skinny_finish_kernel(const float* __restrict__ slabs, int nslabs, int m, int c,
+                                                             const float* __restrict__ bias,
+                                                             const float* __restrict__ row_bias, int mode, int groups,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, half_t* __restrict__ out16,
+                                                             float* __restrict__ out32) {
+    extern __shared__ float buf[];   // [c / groups]
+    __shared__ float red[8];
+    const int row = blockIdx.x, g = blockIdx.y;
+    const int gsz = c / groups, c0 = g * gsz;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < gsz; i += blockDim.x) {
+        const int ch = c0 + i;
+        float v = bias != nullptr ? bias[ch] : 0.f;
+        if (row_bias != nullptr) v += row_bias[(int64_t)row * c + ch];
+        for (int sl = 0; sl < nslabs; ++sl) v += slabs[((int64_t)sl * m + row) * c + ch];
+        buf[i] = v;
+        s += v;
+    }
+    if (mode == 2) {
+        for (int i = threadIdx.x; i < gsz; i += blockDim.x) out32[(int64_t)row * c + c0 + i] = buf[i];
+        return;
+    }
+    if (mode == 1) {
+        for (int i = threadIdx.x; i < gsz; i += blockDim.x)
+            out16[(int64_t)row * c + c0 + i] = to_half_sat(fmaxf(buf[i], 0.f));
+        return;
+    }
+    // two-pass mean / biased variance over the group (fixed reduction order: deterministic)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)gsz;
+    float v = 0.f;
+    for (int i = threadIdx.x; i < gsz; i += blockDim.x) { const float d = buf[i] - mean; v += d * d; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) red[4 + wave] = v;
+    __syncthreads();
+    const float rstd = rsqrtf(((red[4] + red[5]) + (red[6] + red[7])) / (float)gsz + 1e-5f);
+    for (int i = threadIdx.x; i < gsz; i += blockDim.x) {
+        const int ch = c0 + i;
+        out16[(int64_t)row * c + ch] = to_half_sat(fmaxf((buf[i] - mean) * rstd * gamma[ch] + beta[ch], 0.f));
+    }
+}
+
+}  // namespace pcd
+
+using namespace pcd;
+
+// K slice per block: aim for >= ~256 blocks per layer, slices of at least 256 (4 waves x one 64-chunk)
+static int pick_ks(int k, int c) {
+    int ks = 512;
+    while (ks > 256 && (int64_t)(c / 32) * (k / ks) < 256) ks >>= 1;
+    while (k % ks != 0) ks >>= 1;      // k is a multiple of 64
+    return ks;
+}
+
+extern "C" int pcd_skinny_slabs(int k, int c) {
+    if (k <= 0 || c <= 0 || k % 64 != 0) return 0;
+    return k / pick_ks(k, c);
+}
+
+extern "C" int pcd_skinny_gemm_f16(const void* a1, int k1, const void* a2, int k2, const void* w, int64_t ldw, int m,
+                                   int c, float* slabs, void* stream) {
+    PCD_CHECK_ARG(a1 && w && slabs && m > 0 && m <= 256 && c > 0);
+    PCD_CHECK_ARG(k1 > 0 && k1 % 64 == 0 && k2 >= 0 && k2 % 64 == 0 && (k2 == 0 || a2 != nullptr));
+    PCD_CHECK_ARG(ldw >= k1 + k2 && ldw % 8 == 0);
+    SkinnyParams p{};
+    p.a1 = (const half_t*)a1; p.k1 = k1; p.a2 = (const half_t*)a2; p.k2 = k2;
+    p.w = (const half_t*)w; p.ldw = (int)ldw; p.m = m; p.c = c;
+    p.ks = pick_ks(k1 + k2, c);
+    // a 64-chunk must not straddle the two sources: k1 is a multiple of 64 (checked above)
+    p.slabs = slabs;
+    dim3 grid((unsigned)ceil_div(c, 32), (unsigned)((k1 + k2) / p.ks));
+    hipStream_t s = (hipStream_t)stream;
+    const int mt = (int)ceil_div(m, 32);
+    if (mt <= 1) hipLaunchKernelGGL((skinny_gemm_kernel<1>), grid, dim3(256), 0, s, p);
+    else if (mt <= 2) hipLaunchKernelGGL((skinny_gemm_kernel<2>), grid, dim3(256), 0, s, p);
+    else if (mt <= 4) hipLaunchKernelGGL((skinny_gemm_kernel<4>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((skinny_gemm_kernel<8>), grid, dim3(256), 0, s, p);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_skinny_finish(const float* slabs, int nslabs, int m, int c, const float* bias,
+                                 const float* row_bias, int mode, int groups, const float* gamma, const float* beta,
+                                 void* out16, float* out32, void* stream) {
+    PCD_CHECK_ARG(slabs && nslabs > 0 && m > 0 && c > 0 && mode >= 0 && mode <= 2);
+    PCD_CHECK_ARG(mode == 2 ? out32 != nullptr : out16 != nullptr);
+    PCD_CHECK_ARG(mode != 0 || (groups > 0 && c % groups == 0 && gamma && beta));
+    const int split = mode == 0 ? groups : (c % 8 == 0 ? 8 : 1);
+    hipLaunchKernelGGL(skinny_finish_kernel, dim3(m, split), dim3(256), (size_t)(c / split) * sizeof(float),
+                       (hipStream_t)stream, slabs, nslabs, m, c, bias, row_bias, mode, split, gamma, beta,
+                       (half_t*)out16, out32);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}

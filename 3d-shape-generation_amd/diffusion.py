@@ -188,48 +188,95 @@ class _DiffusionBase(nn.Module):
                 n2.append(torch.zeros(())); s2.append(torch.zeros(()))
         return StepTable(ts, ns, ss, n2, s2, self.device)
 
-    # ------------------------------------------------------------------ step kernels
-    def _ddim_step(self, x, eps, tab: StepTable, k: int, last_no_update: bool, x0, x_next):
-        lib = _lib.load()
-        fl = tab.offset(k)
-        nxt = 0 if last_no_update else x_next.data_ptr()
-        _lib.check(lib.pcd_ddim_update(x.data_ptr(), eps.data_ptr(), tab.n.data_ptr() + fl, tab.s.data_ptr() + fl,
-                                       tab.a.data_ptr() + fl, tab.b.data_ptr() + fl, tab.stride, x.numel(),
-                                       x.numel() // x.shape[0], x0.data_ptr(), nxt, _lib.stream_ptr()), "ddim_update")
+    # ------------------------------------------------------------------ stepping
+    GRAPH_MIN_STEPS = 8
+    use_graphs = True
 
-    def _ddpm_step(self, x, eps, z, tab: StepTable, k: int, last: bool, x0, x_next):
-        lib = _lib.load()
-        fl = tab.offset(k)
-        _lib.check(lib.pcd_ddpm_update(x.data_ptr(), eps.data_ptr(), 0 if last else z.data_ptr(),
-                                       tab.n.data_ptr() + fl, tab.s.data_ptr() + fl, tab.a.data_ptr() + fl,
-                                       tab.b.data_ptr() + fl, tab.stride, x.numel(), x.numel() // x.shape[0],
-                                       x0.data_ptr(), 0 if last else x_next.data_ptr(), _lib.stream_ptr()), "ddpm_update")
+    def _run(self, x, tab: "StepTable", bias_table: torch.Tensor, forward, kind: str, noises=None,
+             skip_last_update: bool = False):
+        """kind 'ddim' | 'ddpm'.  forward(x, tb_cur, eps_out) enqueues the denoiser for the current step."""
+        stp = Stepper(self, x, tab, bias_table, forward, kind, noises)
+        T = tab.steps
+        last_updates = not (skip_last_update or kind == "ddpm")     # ddpm: x_t = x_0 at i = 0, no update
+        n_uniform = T if last_updates else T - 1                       # steps that all look the same
+        k = 0
+        if self.use_graphs and noises is None and n_uniform - 1 >= self.GRAPH_MIN_STEPS:
+            stp.step(0, True)                                          # eager warm-up (loads every kernel)
+            stp.capture()
+            for _ in range(1, n_uniform):
+                stp.replay()
+            k = n_uniform
+        else:
+            while k < n_uniform:
+                stp.step(k, True)
+                k += 1
+        if k < T:
+            stp.step(k, False)
+        if kind == "ddpm":
+            self._philox_offset = stp.philox_base + stp.philox_stride * T
+        return stp.x0
 
-    # generic loops; `denoise(x, k)` returns eps for step k
-    def _run_ddim(self, x, tab: StepTable, denoise, skip_last_update: bool):
-        x0 = torch.empty_like(x)
-        x_next = torch.empty_like(x)
-        for k in range(tab.steps):
-            eps = denoise(x, k)
-            last = skip_last_update and k == tab.steps - 1
-            self._ddim_step(x, eps, tab, k, last, x0, x_next)
-            if not last:
-                x, x_next = x_next, x
-        return x0
 
-    def _run_ddpm(self, x, tab: StepTable, denoise, noises):
-        x0 = torch.empty_like(x)
-        x_next = torch.empty_like(x)
-        for k in range(tab.steps):
-            eps = denoise(x, k)
-            last = k == tab.steps - 1
-            z = None
-            if not last:
-                z = noises[k].to(self.device, torch.float32).contiguous() if noises is not None else self._randn_like(x)
-            self._ddpm_step(x, eps, z, tab, k, last, x0, x_next)
-            if not last:
-                x, x_next = x_next, x
-        return x0   # at i == 0 the reference sets x_t = x_0 and returns it
+class Stepper:
+    """One timestep = select (device side: copy step k's time bias and rates to fixed buffers, k++) ->
+    denoiser forward -> fused update, all on fixed pointers and with the state updated in place, so the
+    same enqueue is valid for every k.  Long runs capture it once in a HIP graph and replay it (host
+    cost per step: one graph launch instead of ~30 kernel launches)."""
+
+    def __init__(self, owner, x, tab: StepTable, bias_table, forward, kind, noises=None):
+        self.lib = _lib.load()
+        self.x, self.tab, self.forward, self.kind, self.noises = x, tab, forward, kind, noises
+        dev = x.device
+        self.T, self.R = tab.steps, tab.width
+        self.rates = torch.stack([tab.n, tab.s, tab.a, tab.b]).contiguous()      # (4, T, R)
+        self.bias_table = bias_table.contiguous()
+        self.tb_elems = self.bias_table.shape[1]
+        self.counter = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.tb_cur = torch.empty(self.tb_elems, dtype=torch.float32, device=dev)
+        self.rates_cur = torch.empty(4 * self.R, dtype=torch.float32, device=dev)
+        self.eps = torch.empty_like(x)
+        self.x0 = torch.empty_like(x)
+        self.z = torch.empty_like(x) if kind == "ddpm" else None
+        self.per_shape = x.numel() // x.shape[0]
+        self.seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        self.philox_base = getattr(owner, "_philox_offset", 0)
+        self.philox_stride = (x.numel() + 3) // 4
+        self.graph = None
+
+    def step(self, k: int, update: bool = True):
+        lib, x, R = self.lib, self.x, self.R
+        st = _lib.stream_ptr()
+        rp = self.rates_cur.data_ptr()
+        _lib.check(lib.pcd_step_select(self.counter.data_ptr(), self.T, self.bias_table.data_ptr(), self.tb_elems,
+                                       self.tb_cur.data_ptr(), self.rates.data_ptr(), R, rp, st), "step_select")
+        self.forward(x, self.tb_cur, self.eps)
+        nxt = x.data_ptr() if update else 0               # in place: every element is read before it is written
+        if self.kind == "ddim":
+            _lib.check(lib.pcd_ddim_update(x.data_ptr(), self.eps.data_ptr(), rp, rp + 4 * R, rp + 8 * R, rp + 12 * R,
+                                           self.tab.stride, x.numel(), self.per_shape, self.x0.data_ptr(), nxt, st),
+                       "ddim_update")
+            return
+        zp = 0
+        if update:
+            if self.noises is not None:
+                self.z.copy_(self.noises[k].to(x.device, torch.float32).reshape(self.z.shape))
+            else:
+                _lib.check(lib.pcd_randn_step(self.z.data_ptr(), self.z.numel(), self.seed, self.philox_base,
+                                              self.philox_stride, self.counter.data_ptr(), st), "randn_step")
+            zp = self.z.data_ptr()
+        _lib.check(lib.pcd_ddpm_update(x.data_ptr(), self.eps.data_ptr(), zp, rp, rp + 4 * R, rp + 8 * R, rp + 12 * R,
+                                       self.tab.stride, x.numel(), self.per_shape, self.x0.data_ptr(), nxt, st),
+                   "ddpm_update")
+
+    def capture(self):
+        """Capture one generic step (must follow at least one eager step: kernels loaded, workspaces allocated)."""
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.step(-1, True)
+
+    def replay(self):
+        self.graph.replay()
 
 
 class PointCloudDiffusion(_DiffusionBase):
@@ -255,15 +302,8 @@ class PointCloudDiffusion(_DiffusionBase):
         obj.load_state_dict(sd, strict=True)
         return obj
 
-    def _denoiser(self, tab: StepTable):
-        tb = self.model.time_bias(tab.t)          # (T, 64): one launch for all steps (K3)
-        eps = [None]
-
-        def denoise(x, k):
-            if eps[0] is None:
-                eps[0] = torch.empty_like(x)
-            return self.model.forward_with_bias(x, tb[k], 0, out=eps[0])
-        return denoise
+    def _forward_fn(self):
+        return lambda x, tb_cur, eps: self.model.forward_with_bias(x, tb_cur, 0, out=eps)
 
     def _start(self, num_samples, num_points, x_T):
         self.eval()
@@ -279,14 +319,14 @@ class PointCloudDiffusion(_DiffusionBase):
         """DDIM (diffusion.py:261-289).  Returns the last x_0.  `x_T` injects the start noise."""
         x = self._start(num_samples, num_points, x_T)
         tab = self.ddim_table(num_steps, num_samples)
-        return self._run_ddim(x, tab, self._denoiser(tab), skip_last_update=False)
+        return self._run(x, tab, self.model.time_bias(tab.t), self._forward_fn(), "ddim")
 
     @torch.no_grad()
     def sample2(self, num_samples, num_points, num_steps=1000, x_T=None, noises=None):
         """DDPM ancestral sampling (diffusion.py:225-259).  `noises[j]` injects the j-th draw."""
         x = self._start(num_samples, num_points, x_T)
         tab = self.ddpm_table(num_steps, num_samples)
-        return self._run_ddpm(x, tab, self._denoiser(tab), noises)
+        return self._run(x, tab, self.model.time_bias(tab.t), self._forward_fn(), "ddpm", noises=noises)
 
     @torch.no_grad()
     def sample3(self, num_samples, num_points, x=None, start_t=None, num_steps=1000):
@@ -300,7 +340,7 @@ class PointCloudDiffusion(_DiffusionBase):
             if start_t is None:
                 start_t = torch.ones(num_samples)
         tab = self.from_state_table(start_t.reshape(-1)[0], num_steps)
-        return self._run_ddim(x, tab, self._denoiser(tab), skip_last_update=True)
+        return self._run(x, tab, self.model.time_bias(tab.t), self._forward_fn(), "ddim", skip_last_update=True)
 
 
 class LatentDiffusion(_DiffusionBase):
@@ -333,15 +373,8 @@ class LatentDiffusion(_DiffusionBase):
         obj.load_state_dict(sd, strict=True)
         return obj
 
-    def _denoiser(self, tab: StepTable):
-        tb = self.model.time_bias(tab.t)
-        eps = [None]
-
-        def denoise(z, k):
-            if eps[0] is None:
-                eps[0] = torch.empty_like(z)
-            return self.model.forward_with_bias(z, tb[k], 0, out=eps[0])
-        return denoise
+    def _forward_fn(self):
+        return lambda x, tb_cur, eps: self.model.forward_with_bias(x, tb_cur, 0, out=eps)
 
     def _start(self, num_samples, z_T):
         self.eval()
@@ -364,7 +397,7 @@ class LatentDiffusion(_DiffusionBase):
         """DDIM in latent space, VAE decode, voxel -> points (diffusion.py:619-653)."""
         z = self._start(num_samples, z_T)
         tab = self.ddim_table(num_steps, num_samples)
-        z0 = self._run_ddim(z, tab, self._denoiser(tab), skip_last_update=False)
+        z0 = self._run(z, tab, self.model.time_bias(tab.t), self._forward_fn(), "ddim")
         pcs = self._finish(z0, threshold)
         return (pcs, z0) if return_latent else pcs
 
@@ -373,7 +406,7 @@ class LatentDiffusion(_DiffusionBase):
         """DDPM in latent space (diffusion.py:575-616)."""
         z = self._start(num_samples, z_T)
         tab = self.ddpm_table(num_steps, num_samples)
-        z0 = self._run_ddpm(z, tab, self._denoiser(tab), noises)
+        z0 = self._run(z, tab, self.model.time_bias(tab.t), self._forward_fn(), "ddpm", noises=noises)
         pcs = self._finish(z0, threshold)
         return (pcs, z0) if return_latent else pcs
 
@@ -389,6 +422,6 @@ class LatentDiffusion(_DiffusionBase):
             if start_t is None:
                 start_t = torch.ones(num_samples)
         tab = self.from_state_table(start_t.reshape(-1)[0], num_steps)
-        z0 = self._run_ddim(z, tab, self._denoiser(tab), skip_last_update=True)
+        z0 = self._run(z, tab, self.model.time_bias(tab.t), self._forward_fn(), "ddim", skip_last_update=True)
         pcs = self._finish(z0, threshold)
         return (pcs, z0) if return_latent else pcs

@@ -122,6 +122,16 @@ int pcd_ddpm_update(const float* x, const float* eps, const float* z, const floa
 /* standard normal fill (Philox4x32-10 + Box-Muller), for perf runs (diffusion.py:239,254,275) */
 int pcd_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
 
+/* HIP-graph support: select the per-step constants ON THE DEVICE so one captured step can be
+ * replayed for every timestep.  k = counter[0] (clamped to n_steps-1); tb_cur[0..tb_elems) =
+ * tb_table[k][:]; rates_cur[t*width + j] = rate_tables[t][k][j] for the 4 tables t (n, s, a, b of
+ * the sampler); counter[1] = k; counter[0] = k+1.  counter: device int32[2]. */
+int pcd_step_select(int* counter, int n_steps, const float* tb_table, int tb_elems, float* tb_cur,
+                    const float* rate_tables, int width, float* rates_cur, void* stream);
+/* pcd_randn whose Philox offset is base_offset + per_step_stride * counter[1] (read on the device) */
+int pcd_randn_step(float* out, int64_t n, uint64_t seed, uint64_t base_offset, uint64_t per_step_stride,
+                   const int* counter, void* stream);
+
 /* output head: eps[m][j] = sum_k h[m][k]*w[j][k] + b[j], j<3  (networks.py:770 `output.3`),
  * h fp16 [M][k], w fp32 [3][k]; eps fp32 [M][3]. */
 int pcd_head3(const void* h, int64_t m, int k, const float* w, const float* b, float* eps, void* stream);
@@ -170,6 +180,16 @@ int pcd_unet_tap(pcd_unet_t* h, const char* name, int batch, int n_points,
  * (the Linear+GroupNorm(8)+ReLU stages of networks.py:984-1036; 2-D input = per-sample groups). */
 int pcd_groupnorm_relu_f16(const float* x, int rows, int c, int groups, const float* gamma,
                            const float* beta, void* out, void* stream);
+/* Weight-streaming GEMM for M <= 256 rows (the latent vectors): split-K partial sums
+ * slabs[s][m][c] = sum over the s-th K slice of [A1|A2][m][k] * W[c][k]; pcd_skinny_slabs gives S.
+ * pcd_skinny_finish adds the slabs in a fixed order (+bias, + optional per-row bias) and applies
+ * mode 0: GroupNorm(groups)+affine+ReLU -> fp16, 1: ReLU -> fp16, 2: identity -> fp32. */
+int pcd_skinny_slabs(int k, int c);
+int pcd_skinny_gemm_f16(const void* a1, int k1, const void* a2, int k2, const void* w, int64_t ldw,
+                        int m, int c, float* slabs, void* stream);
+int pcd_skinny_finish(const float* slabs, int nslabs, int m, int c, const float* bias, const float* row_bias,
+                      int mode, int groups, const float* gamma, const float* beta,
+                      void* out16, float* out32, void* stream);
 /* SimpleLatentUNetPointNet.forward (networks.py:1051-1086), latent_dim=256, dim=512, time_dim=256.
  * lin[] order documented in csrc/latent.hip; refine_k folded into dec_k, enc1's time half hoisted
  * into tbias [n_t][128] (pcd_time_embed with c1=128). */

@@ -11,15 +11,22 @@ torch.set_grad_enabled(False)
 m = LatentDiffusion(VAE3DLarge()); m.load_state_dict(latent_sd(), strict=True); m = m.to("cuda").eval()
 for B in (32, 256):
     z = torch.randn(B, 256, device="cuda")
-    tab = m.ddim_table(1000, B); den = m._denoiser(tab)
-    x0 = torch.empty_like(z); xn = torch.empty_like(z)
+    from shapegen_amd.diffusion import Stepper
+    tab = m.ddim_table(1000, B)
+    stp = Stepper(m, z, tab, m.model.time_bias(tab.t), m._forward_fn(), "ddim")
     for k in range(5):
-        eps = den(z, k); m._ddim_step(z, eps, tab, k, False, x0, xn)
+        stp.step(k, True)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     K = 200
     for k in range(K):
-        eps = den(z, k); m._ddim_step(z, eps, tab, k, False, x0, xn); z, xn = xn, z
+        stp.step(k, True)
+    torch.cuda.synchronize(); dt_e = (time.perf_counter() - t0) / K
+    stp.capture()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for k in range(K):
+        stp.replay()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
+    print(f"  eager {dt_e*1e6:.1f} us/step, graph {dt*1e6:.1f} us/step")
     print(f"latent step B={B}: {dt*1e6:.1f} us/step  -> {1/dt:.0f} steps/s ; weight-stream roofline 38.2MB/8TB/s = 4.8us", flush=True)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     zz = torch.randn(min(B, 32), 256, device="cuda")
