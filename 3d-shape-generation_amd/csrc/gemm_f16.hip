@@ -26,6 +26,7 @@ struct GemmParams {
     const half_t* resid; int64_t ldr;
     float* colmax; int cm_rps;
     int tiles_m; int tiles_n;
+    int stagger;   // >0: first-round blocks start de-phased (see kernel)
 };
 
 constexpr int BK = 64;          // halfs per K tile = 128 B per row
@@ -70,9 +71,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int MI = WM / 16, NI = WN / 16;
     constexpr int STAGE_BYTES = (BM + BN) * ROWB;
-    constexpr int OUT_LD = BN * 2 + 16;  // bytes per staged output row (fp16), keeps 16-B alignment
-    constexpr int LDS_BYTES = (STAGES * STAGE_BYTES > BM * OUT_LD) ? STAGES * STAGE_BYTES : BM * OUT_LD;
+    constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
     constexpr int LOADS_PER_TILE = (BM + BN) / (NT / 8);   // global_load_lds per thread per K tile
+    // Store epilogues compute the transposed product (weights as the MFMA A operand): an accumulator then
+    // holds 4 CONSECUTIVE CHANNELS of one point, i.e. an 8-byte piece of an output row, and goes straight to
+    // global memory (no LDS staging, no barriers).  Column-max / fp32 epilogues keep channels on the lanes.
+    constexpr bool SWAP = (EPI == EPI_F16 || EPI == EPI_RESID);
     static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the 160 KB LDS");
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
@@ -87,6 +91,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int nk1 = p.k1 / BK, nk = (p.k1 + p.k2) / BK;
+
+    // De-phase the CUs once: with one block per CU and equal tiles, every CU would compute in lockstep and
+    // then store in lockstep (HBM idle, then saturated).  The first round of blocks (one per CU) starts
+    // offset by (bid % 8) / 8 of a tile's duration; later blocks inherit the phase of the block they replace.
+    if (p.stagger > 0 && bid < p.stagger) {
+        const int units = (nk * 28 * (bid & 7)) >> 3;     // ~ nk * 1800 cycles per tile, in 64-cycle s_sleep units
+        for (int u = 0; u < units; u += 64) __builtin_amdgcn_s_sleep(64);
+    }
 
     f32x4 acc[MI][NI];
 #pragma unroll
@@ -125,7 +137,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0)
+                                     : __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
     };
 
@@ -161,7 +174,50 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
     }
 
     // ------------------------------------------------------------------ epilogue
-    // accumulator element (i, j, r): row = wm*WM + i*16 + q*4 + r, col = wn*WN + j*16 + (lane&15)
+    if constexpr (SWAP) {
+        // accumulator element (i, j, r): point row = wm*WM + i*16 + (lane&15), channel = wn*WN + j*16 + 4*(lane>>4) + r
+        const int q4 = (lane >> 4) * 4, pr = lane & 15;
+        const bool one_shape = p.shape_bias != nullptr && (p.rows_per_shape % BM == 0);
+        const float* sb_rows = (p.shape_bias != nullptr && !one_shape) ? p.shape_bias : nullptr;   // generic: per row
+        // per-channel constants loaded once (bias + the tile's shape bias when the tile lies in one shape)
+        f32x4 bv[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            int col = n0 + wn * WN + j * 16 + q4;
+            col = col < p.c ? col : 0;
+            bv[j] = p.bias != nullptr ? *(const f32x4*)(p.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (one_shape) bv[j] += *(const f32x4*)(p.shape_bias + (int64_t)(m0 / p.rows_per_shape) * p.c + col);
+        }
+        const float lo = p.relu ? 0.f : -65504.f;      // ReLU and the fp16 saturation are one v_med3
+        const bool full = (m0 + BM <= p.m) && (n0 + BN <= p.c) && sb_rows == nullptr;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int row = m0 + wm * WM + i * 16 + pr;
+            if (!full && row >= p.m) continue;
+            half_t* orow = p.out16 + (int64_t)row * p.ldo;
+            const float* sbrow = sb_rows != nullptr ? sb_rows + (int64_t)(row / p.rows_per_shape) * p.c : nullptr;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {      // the wave's NI stores complete whole 128-B lines of 16 rows
+                const int col = n0 + wn * WN + j * 16 + q4;
+                if (!full && col >= p.c) continue;
+                f32x4 v = acc[i][j] + bv[j];
+                if (sbrow != nullptr) v += *(const f32x4*)(sbrow + col);
+                half4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (half_t)__builtin_amdgcn_fmed3f(v[e], lo, 65504.f);
+                if constexpr (EPI == EPI_RESID) {
+                    const half4 rs = *(const half4*)(p.resid + (int64_t)row * p.ldr + col);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = to_half_sat((float)o[e] + (float)rs[e]);
+                }
+#ifdef PCD_EPI_PROBE
+                if (p.stagger == 777) { asm volatile("" ::"v"(o)); continue; }    // probe: all epilogue math, no store
+#endif
+                *(half4*)(orow + col) = o;
+            }
+        }
+        return;
+    }
     const int colq = lane & 15;
     // when a whole tile lies inside one shape the per-shape bias is just another per-column bias
     const bool tile_one_shape = p.shape_bias != nullptr && (p.rows_per_shape % BM == 0);
@@ -231,46 +287,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
                     }
                 }
         return;
-    } else {
-        // stage the fp16 tile through LDS so global stores are whole 16-B pieces of a row
-        __syncthreads();  // all waves done reading the last K tile
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int lrow = wm * WM + i * 16 + q * 4 + r;
-                const int row = m0 + lrow;
-                const float* sbrow = nullptr;
-                if (sb_generic != nullptr && row < p.m)
-                    sbrow = sb_generic + (int64_t)(row / p.rows_per_shape) * p.c;
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    const int lcol = wn * WN + j * 16 + colq;
-                    float v = acc[i][j][r] + bcol[j];
-                    if (sbrow != nullptr && n0 + lcol < p.c) v += sbrow[n0 + lcol];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    *(half_t*)(smem + lrow * OUT_LD + lcol * 2) = to_half_sat(v);
-                }
-            }
-        __syncthreads();
-        constexpr int CHUNKS_PER_ROW = BN / 8;
-        constexpr int TOTAL = BM * CHUNKS_PER_ROW;
-        static_assert(TOTAL % NT == 0, "tile copy-out must divide evenly");
-#pragma unroll
-        for (int it = 0; it < TOTAL / NT; ++it) {
-            const int idx = it * NT + tid;
-            const int lrow = idx / CHUNKS_PER_ROW, ch = idx - lrow * CHUNKS_PER_ROW;
-            const int row = m0 + lrow, col = n0 + ch * 8;
-            if (row < p.m && col < p.c) {
-                half8 v = *(const half8*)(smem + lrow * OUT_LD + ch * 16);
-                if constexpr (EPI == EPI_RESID) {
-                    const half8 rsd = *(const half8*)(p.resid + (int64_t)row * p.ldr + col);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = to_half_sat((float)v[e] + (float)rsd[e]);
-                }
-                *(half8*)(p.out16 + (int64_t)row * p.ldo + col) = v;
-            }
-        }
     }
 }
 
@@ -288,6 +304,7 @@ static int launch(const GemmParams& p0, hipStream_t s) {
 }
 
 static int g_force_cfg = -1;   // tuning hook (pcd_gemm_set_config): -1 = heuristic
+static int g_stagger = 0;
 
 template <int EPI>
 static int dispatch(const GemmParams& p, hipStream_t s) {
@@ -301,11 +318,16 @@ static int dispatch(const GemmParams& p, hipStream_t s) {
         else if (p.m >= 16384 && p.c >= 256 && (p.k1 + p.k2) >= 256) cfg = 3;
         else cfg = 1;
     }
+    GemmParams q = p;
+    q.stagger = (cfg == 3 && EPI != EPI_COLMAX) ? g_stagger : 0;
+#ifdef PCD_EPI_PROBE
+    q.stagger = g_stagger;
+#endif
     switch (cfg) {
         case 0: return launch<128, 64, 2, 2, 2, EPI>(p, s);
         case 1: return launch<128, 128, 2, 2, 2, EPI>(p, s);
         case 2: return launch<256, 128, 4, 2, 3, EPI>(p, s);
-        case 3: return launch<256, 256, 2, 4, 2, EPI>(p, s);
+        case 3: return launch<256, 256, 2, 4, 2, EPI>(q, s);
         case 4: return launch<128, 128, 2, 2, 3, EPI>(p, s);
         default: set_error("gemm: unknown config %d", cfg); return PCD_ERR_ARG;
     }
@@ -376,6 +398,7 @@ extern "C" int pcd_gemm_f16_colmax(const pcd_gemm_desc_t* d, float* colmax, int 
 }
 
 extern "C" int pcd_gemm_set_config(int cfg) {
+    if (cfg >= 1000) { g_stagger = cfg - 1000; return PCD_OK; }   // 1000 + n: stagger the first n blocks
     PCD_CHECK_ARG(cfg >= -1 && cfg <= 4);
     g_force_cfg = cfg;
     return PCD_OK;

@@ -188,12 +188,19 @@ extern "C" int pcd_unet_forward(pcd_unet_t* h, const float* x, int batch, int n_
         RUN(pcd_gemm_f16_colmax(&g, pooled, n_points, s));
         if (prof) { PCD_CHECK_HIP(hipEventRecord(h->ev1[h->prof_n], s)); ++h->prof_n; }
     }
-    {   // hoisted global half of dec4.conv1: per-shape bias [B][1024]
+    {   // hoisted global half of dec4.conv1: per-shape bias [B][1024] = pooled . Wg^T + folded bias
         RUN(pcd_f32_to_f16(pooled, pooled16, (int64_t)batch * 4096, s));
-        pcd_gemm_desc_t g{};
-        g.a1 = pooled16; g.k1 = 4096; g.lda1 = 4096; g.w = d.wg; g.ldw = 4096; g.bias = d.lin[13].b;
-        g.relu = 0; g.m = batch; g.c = 1024;
-        RUN(pcd_gemm_f16_out32(&g, gbias, 1024, s));
+        if (batch <= 256) {
+            // few rows: weight-streaming split-K kernel (csrc/skinny.hip), slabs live in the free s1 buffer
+            RUN(pcd_skinny_gemm_f16(pooled16, 4096, nullptr, 0, d.wg, 4096, batch, 1024, (float*)s1, s));
+            RUN(pcd_skinny_finish((const float*)s1, pcd_skinny_slabs(4096, 1024), batch, 1024, d.lin[13].b, nullptr, 2, 8,
+                                  nullptr, nullptr, nullptr, gbias, s));
+        } else {
+            pcd_gemm_desc_t g{};
+            g.a1 = pooled16; g.k1 = 4096; g.lda1 = 4096; g.w = d.wg; g.ldw = 4096; g.bias = d.lin[13].b;
+            g.relu = 0; g.m = batch; g.c = 1024;
+            RUN(pcd_gemm_f16_out32(&g, gbias, 1024, s));
+        }
     }
     RUN(run_lin(d, 13, m, x4, nullptr, 0, gbias, n_points, s1, s));
     RUN(run_lin(d, 14, m, s1, nullptr, 0, nullptr, 0, s0, s));
