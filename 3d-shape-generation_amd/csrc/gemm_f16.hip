@@ -26,7 +26,7 @@ struct GemmParams {
     const half_t* resid; int64_t ldr;
     float* colmax; int cm_rps;
     int tiles_m; int tiles_n;
-    int stagger;   // >0: first-round blocks start de-phased (see kernel)
+    int stagger;   // debug probe only (PCD_EPI_PROBE)
 };
 
 constexpr int BK = 64;          // halfs per K tile = 128 B per row
@@ -67,6 +67,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 // LDS-DMA of the younger ones stays in flight across the (raw) barrier behind a counted vmcnt.
 template <int BM, int BN, int WGM, int WGN, int STAGES, int EPI>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) {
+    // cross-tile prefetch (next tile's first K tile requested before this tile's epilogue): only where the
+    // registers allow it; the 256x256 store variant would spill (128 accumulators + epilogue temporaries)
+    constexpr bool XPREF = (STAGES == 2) && (BM * BN <= 128 * 128);
     constexpr int NT = 64 * WGM * WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int MI = WM / 16, NI = WN / 16;
@@ -85,28 +88,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave - wm * WGN;
 
-    // tile order: n fastest so neighbouring blocks share the activation row panel
-    const int bid = blockIdx.x;
-    const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-
+    // Persistent blocks: block b walks tiles b, b + gridDim.x, ... (n fastest, so neighbouring blocks share
+    // the activation row panel).  The first K tile of the NEXT output tile is requested before the epilogue
+    // of the current one, so its load latency and the store tail overlap.
+    const int ntiles = p.tiles_m * p.tiles_n;
     const int nk1 = p.k1 / BK, nk = (p.k1 + p.k2) / BK;
 
-    // De-phase the CUs once: with one block per CU and equal tiles, every CU would compute in lockstep and
-    // then store in lockstep (HBM idle, then saturated).  The first round of blocks (one per CU) starts
-    // offset by (bid % 8) / 8 of a tile's duration; later blocks inherit the phase of the block they replace.
-    if (p.stagger > 0 && bid < p.stagger) {
-        const int units = (nk * 28 * (bid & 7)) >> 3;     // ~ nk * 1800 cycles per tile, in 64-cycle s_sleep units
-        for (int u = 0; u < units; u += 64) __builtin_amdgcn_s_sleep(64);
-    }
-
     f32x4 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto stage = [&](int kt, int buf) {
+    auto stage = [&](int m0, int n0, int kt, int buf) {
         char* base = smem + buf * STAGE_BYTES;
         if (kt < nk1) stage_rows<BM, NT>(p.a1, p.lda1, m0, p.m, kt * BK, base, wave, lane);
         else          stage_rows<BM, NT>(p.a2, p.lda2, m0, p.m, (kt - nk1) * BK, base, wave, lane);
@@ -142,19 +132,46 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
         }
     };
 
+    int it = 0;                      // K tiles consumed so far by this block (LDS ring position)
+    bool counted_wait = false;       // previous epilogue issued exactly MI*NI/2 stores after the prefetch
+    {
+        const int t0 = blockIdx.x;
+        const int tm0 = t0 / p.tiles_n;
+        if constexpr (XPREF) stage(tm0 * BM, (t0 - tm0 * p.tiles_n) * BN, 0, 0);
+    }
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int next = tile + (int)gridDim.x;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
     if constexpr (STAGES == 2) {
-        stage(0, 0);
+        if constexpr (!XPREF) {
+            __builtin_amdgcn_s_barrier();      // every wave is done reading the previous tile's LDS stages
+            stage(m0, n0, 0, it & 1);
+        }
         for (int kt = 0; kt < nk; ++kt) {
-            wait_vmcnt<0>();
-            __syncthreads();
-            if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-            compute(smem + (kt & 1) * STAGE_BYTES);
+            // the loads of this K tile are OLDER than the previous tile's epilogue stores: a counted wait
+            // retires the loads and leaves the stores draining (vmcnt counts loads and stores in issue order)
+            if (kt == 0 && counted_wait) wait_vmcnt<MI * NI / 2>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();   // raw: __syncthreads() would add its own vmcnt(0) while an LDS-DMA is pending
+            if (kt + 1 < nk) stage(m0, n0, kt + 1, (it + 1) & 1);
+            else if (XPREF && next < ntiles) {
+                const int tm2 = next / p.tiles_n;
+                stage(tm2 * BM, (next - tm2 * p.tiles_n) * BN, 0, (it + 1) & 1);
+            }
+            compute(smem + (it & 1) * STAGE_BYTES);
+            ++it;
         }
     } else {
-        // prologue: STAGES-1 tiles in flight
+        // prologue: STAGES-1 tiles in flight (no cross-tile prefetch in the deep-ring variant)
+        __syncthreads();
 #pragma unroll
         for (int t = 0; t < STAGES - 1; ++t)
-            if (t < nk) stage(t, t);
+            if (t < nk) stage(m0, n0, t, t);
         int buf = 0;
         for (int kt = 0; kt < nk; ++kt) {
             // tiles issued so far: min(kt + STAGES - 1, nk); tile kt must have landed, younger ones may fly
@@ -166,7 +183,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
             if (kt + STAGES - 1 < nk) {
                 int nb = buf + STAGES - 1;
                 nb = nb >= STAGES ? nb - STAGES : nb;
-                stage(kt + STAGES - 1, nb);
+                stage(m0, n0, kt + STAGES - 1, nb);
             }
             compute(smem + buf * STAGE_BYTES);
             buf = buf + 1 == STAGES ? 0 : buf + 1;
@@ -239,7 +256,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
                 }
             }
         }
-        return;
+        counted_wait = XPREF && (EPI == EPI_F16) && full;
+        continue;
     }
     const int colq = lane & 15;
     // when a whole tile lies inside one shape the per-shape bias is just another per-column bias
@@ -291,7 +309,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
                         }
                     }
         }
-        return;
     } else if constexpr (EPI == EPI_F32) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -309,19 +326,32 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
                         p.out32[(int64_t)row * p.ldo + col] = v;
                     }
                 }
-        return;
     }
+    }   // tile loop
+}
+
+static int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
 }
 
 template <int BM, int BN, int WGM, int WGN, int STAGES, int EPI>
-static int launch(const GemmParams& p0, hipStream_t s) {
+static int launch(const GemmParams& p0, hipStream_t s, int blocks_per_cu) {
     GemmParams p = p0;
     p.tiles_m = (int)ceil_div(p.m, BM);
     p.tiles_n = (int)ceil_div(p.c, BN);
-    const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n;
-    if (blocks <= 0 || blocks > 0x7fffffff) { set_error("gemm: grid out of range"); return PCD_ERR_ARG; }
-    hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WGM, WGN, STAGES, EPI>), dim3((unsigned)blocks),
-                       dim3(64 * WGM * WGN), 0, s, p);
+    const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n;
+    if (tiles <= 0 || tiles > 0x7fffffff) { set_error("gemm: grid out of range"); return PCD_ERR_ARG; }
+    // persistent grid: as many blocks as are resident at once, each walking tiles b, b + grid, ...
+    const int64_t resident = (int64_t)num_cus() * blocks_per_cu;
+    const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
+    hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WGM, WGN, STAGES, EPI>), dim3(grid), dim3(64 * WGM * WGN), 0, s, p);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }
@@ -342,16 +372,13 @@ static int dispatch(const GemmParams& p, hipStream_t s) {
         else cfg = 1;
     }
     GemmParams q = p;
-    q.stagger = (cfg == 3 && EPI != EPI_COLMAX) ? g_stagger : 0;
-#ifdef PCD_EPI_PROBE
     q.stagger = g_stagger;
-#endif
     switch (cfg) {
-        case 0: return launch<128, 64, 2, 2, 2, EPI>(p, s);
-        case 1: return launch<128, 128, 2, 2, 2, EPI>(p, s);
-        case 2: return launch<256, 128, 4, 2, 3, EPI>(p, s);
-        case 3: return launch<256, 256, 2, 4, 2, EPI>(q, s);
-        case 4: return launch<128, 128, 2, 2, 3, EPI>(p, s);
+        case 0: return launch<128, 64, 2, 2, 2, EPI>(q, s, 3);      // 48 KB LDS
+        case 1: return launch<128, 128, 2, 2, 2, EPI>(q, s, 2);     // 64 KB LDS
+        case 2: return launch<256, 128, 4, 2, 3, EPI>(q, s, 1);     // 144 KB LDS
+        case 3: return launch<256, 256, 2, 4, 2, EPI>(q, s, 1);     // 128 KB LDS
+        case 4: return launch<128, 128, 2, 2, 3, EPI>(q, s, 1);     // 96 KB LDS
         default: set_error("gemm: unknown config %d", cfg); return PCD_ERR_ARG;
     }
 }
