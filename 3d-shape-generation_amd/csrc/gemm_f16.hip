@@ -27,6 +27,7 @@ struct GemmParams {
     float* colmax; int cm_rps;
     int tiles_m; int tiles_n;
     int stagger;   // debug probe only (PCD_EPI_PROBE)
+    int patch_pn, patch_xn;   // XCD patch mapping (0 = linear tile order)
 };
 
 constexpr int BK = 64;          // halfs per K tile = 128 B per row
@@ -123,24 +124,46 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
             for (int i = 0; i < MI; ++i) af[i] = *(const half8*)(base + offa[ks] + i * 16 * ROWB);
 #pragma unroll
             for (int j = 0; j < NI; ++j) bf[j] = *(const half8*)(base + offb[ks] + j * 16 * ROWB);
+            __builtin_amdgcn_s_setprio(1);   // keeps the MFMA cluster together (+2.8 % on the dominant GEMM)
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0)
                                      : __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+    };
+
+    // tile index -> (row panel, column tile).  Default: n fastest.  XCD-aware variant (T1; speed only): a
+    // persistent grid of 256 blocks is dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2);
+    // within each round of 256 tiles XCD x owns a pm x pn patch (pm*pn = 32), so its L2 streams pm + pn
+    // operand panels instead of up to 32 + 1.
+    auto tile_coords = [&](int tile, int& tm, int& tn) {
+        if (gridDim.x == 256 && p.patch_pn > 0) {
+            const int pn = p.patch_pn, pm = 32 / pn, xn = p.patch_xn, xm = 8 / xn;
+            const int round = tile >> 8, b = tile & 255;
+            const int xcd = b & 7, slot = b >> 3;
+            const int sbn = p.tiles_n / (xn * pn);                   // super-blocks per row of super-blocks
+            const int sb_m = round / sbn, sb_n = round - sb_m * sbn;
+            tm = (sb_m * xm + xcd / xn) * pm + slot / pn;
+            tn = (sb_n * xn + xcd % xn) * pn + slot % pn;
+        } else {
+            tm = tile / p.tiles_n;
+            tn = tile - tm * p.tiles_n;
         }
     };
 
     int it = 0;                      // K tiles consumed so far by this block (LDS ring position)
     bool counted_wait = false;       // previous epilogue issued exactly MI*NI/2 stores after the prefetch
-    {
-        const int t0 = blockIdx.x;
-        const int tm0 = t0 / p.tiles_n;
-        if constexpr (XPREF) stage(tm0 * BM, (t0 - tm0 * p.tiles_n) * BN, 0, 0);
+    if constexpr (XPREF) {
+        int tm0, tn0;
+        tile_coords(blockIdx.x, tm0, tn0);
+        stage(tm0 * BM, tn0 * BN, 0, 0);
     }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    int tm, tn;
+    tile_coords(tile, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int next = tile + (int)gridDim.x;
 #pragma unroll
@@ -160,8 +183,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
             __builtin_amdgcn_s_barrier();   // raw: __syncthreads() would add its own vmcnt(0) while an LDS-DMA is pending
             if (kt + 1 < nk) stage(m0, n0, kt + 1, (it + 1) & 1);
             else if (XPREF && next < ntiles) {
-                const int tm2 = next / p.tiles_n;
-                stage(tm2 * BM, (next - tm2 * p.tiles_n) * BN, 0, (it + 1) & 1);
+                int tm2, tn2;
+                tile_coords(next, tm2, tn2);
+                stage(tm2 * BM, tn2 * BN, 0, (it + 1) & 1);
             }
             compute(smem + (it & 1) * STAGE_BYTES);
             ++it;
@@ -351,6 +375,14 @@ static int launch(const GemmParams& p0, hipStream_t s, int blocks_per_cu) {
     // persistent grid: as many blocks as are resident at once, each walking tiles b, b + grid, ...
     const int64_t resident = (int64_t)num_cus() * blocks_per_cu;
     const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
+    p.patch_pn = p.patch_xn = 0;
+    if (grid == 256 && tiles % 256 == 0) {
+        const int pn = p.tiles_n >= 8 ? 8 : p.tiles_n;               // 8, 4, 2 or 1 column tiles per patch
+        const int xn = p.tiles_n >= 16 ? 2 : 1;
+        if ((pn & (pn - 1)) == 0 && p.tiles_n % (xn * pn) == 0 && p.tiles_m % ((8 / xn) * (32 / pn)) == 0) {
+            p.patch_pn = pn; p.patch_xn = xn;
+        }
+    }
     hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WGM, WGN, STAGES, EPI>), dim3(grid), dim3(64 * WGM * WGN), 0, s, p);
     PCD_CHECK_LAUNCH();
     return PCD_OK;

@@ -36,6 +36,24 @@ def test_gemm_exact_integers(ops, m, k, c):
     assert torch.equal(got16, want.clamp_min(0).half().double())
 
 
+@pytest.mark.parametrize("m,k,c", [(32768, 64, 512), (65536, 64, 256), (131072, 64, 512), (32768, 128, 4096),
+                                   (4096, 64, 1024), (16384 + 256, 256, 512)])
+def test_gemm_persistent_tile_mappings_exact(ops, m, k, c):
+    """Large-M shapes that take the persistent 256-block grid with the XCD patch mapping (1, 2, 4, 8, 16
+    column tiles; one and several rounds; a ragged last round): every output element must still be
+    produced exactly once and from the right operands."""
+    g = torch.Generator(device="cuda").manual_seed(m + c)
+    a = torch.randint(-3, 4, (m, k), generator=g, device="cuda").half()
+    w = torch.randint(-2, 3, (c, k), generator=g, device="cuda").half()
+    bias = torch.randint(-3, 4, (c,), generator=g, device="cuda").float()
+    want = (a.float() @ w.float().t() + bias).clamp_min(0)        # exact: small integers
+    got = ops.gemm_f16(a, w, bias, relu=True).float()
+    assert torch.equal(got, want)
+    cm = ops.gemm_f16_colmax(a, w, bias, 2048 if m % 2048 == 0 else m)
+    want_cm = want.reshape(-1, 2048 if m % 2048 == 0 else m, c).max(1)[0]
+    assert torch.equal(cm, want_cm)
+
+
 def test_gemm_dual_source_shape_bias_residual(ops):
     m, k1, k2, c, rps = 384, 128, 64, 136, 96
     a1, a2, w = _int_mat(m, k1, 4), _int_mat(m, k2, 5), _int_mat(c, k1 + k2, 6)
