@@ -195,7 +195,7 @@ def main():
                                    "1000-step cosine schedule, fp16 operands/fp32 accumulate, random-init synthetic weights",
                        "batch_per_gpu": B_PER_GPU, "points": N_POINTS, "sampler": "ddpm/sample2", "launch": "hipGraph replay" if args.graph else "eager",
                        "point_steps_per_sec": world * args.steps * B_PER_GPU * N_POINTS / elapsed},
-            "roofline": {"bound": "mfma", "kernel": "gemm_f16_kernel<256,256,2x4 waves,COLMAX> (global_feat.3 2048->4096 + max over N)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_f16_kernel<256,256,2,4,2,COLMAX> persistent (global_feat.3 2048->4096 + max over N)",
                          "achieved": achieved, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": traffic,
                          "avg_launch_ms": gf3_ms, "launches_timed": launches.value,
