@@ -101,7 +101,8 @@ _SIGS = {
     "pcd_latent_workspace_bytes": (sz, [i32]),
     "pcd_latent_forward": (i32, [vp, vp, i32, vp, i32, vp, vp, sz, vp]),
     "pcd_conv3d_f16": (i32, [C.POINTER(Conv3dDesc), vp]),
-    "pcd_conv3d_first": (i32, [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp]),
+    "pcd_conv3d_first": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp]),
+    "pcd_convt3d_last_sigmoid": (i32, [vp, i32, i32, i32, i32, i32, vp, f32, vp, vp]),
     "pcd_conv3d_last_sigmoid": (i32, [vp, i32, i32, i32, i32, i32, vp, f32, vp, vp]),
     "pcd_reparameterize": (i32, [vp, vp, vp, vp, i64, vp]),
     "pcd_layernorm_f16": (i32, [vp, i64, i32, vp, vp, vp, vp]),

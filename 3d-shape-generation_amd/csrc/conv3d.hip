@@ -180,20 +180,23 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
 // first layer: x fp32 [B][D][H][W] (Cin = 1), k3 s1 p1 -> fp16 NDHWC [..][cout], ReLU.
 // thread = (voxel, 8-channel chunk); w fp32 [cout][27], b fp32 [cout]
 __global__ __launch_bounds__(256) void conv3d_first_kernel(const float* __restrict__ x, int B, int D, int H, int W,
-                                                            const float* __restrict__ w, const float* __restrict__ b,
-                                                            int cout, half_t* __restrict__ out) {
+                                                            int stride, const float* __restrict__ w,
+                                                            const float* __restrict__ b, int cout,
+                                                            half_t* __restrict__ out) {
     extern __shared__ float ws[];   // [cout][27] + [cout]
     for (int i = threadIdx.x; i < cout * 28; i += blockDim.x) ws[i] = i < cout * 27 ? w[i] : b[i - cout * 27];
     __syncthreads();
     const int chunks = cout / 8;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t nvox = (int64_t)B * D * H * W;
+    const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;   // k3, pad 1
+    const int64_t nvox = (int64_t)B * Do * Ho * Wo;
     if (idx >= nvox * chunks) return;
     const int64_t vox = idx / chunks;
     const int ch = (int)(idx - vox * chunks);
-    const int xx = (int)(vox % W); int64_t t = vox / W;
-    const int yy = (int)(t % H); t /= H;
-    const int zz = (int)(t % D); const int bb = (int)(t / D);
+    int xx = (int)(vox % Wo); int64_t t = vox / Wo;
+    int yy = (int)(t % Ho); t /= Ho;
+    int zz = (int)(t % Do); const int bb = (int)(t / Do);
+    xx *= stride; yy *= stride; zz *= stride;
     float tap[27];
 #pragma unroll
     for (int kz = 0; kz < 3; ++kz)
@@ -249,6 +252,46 @@ __global__ __launch_bounds__(256) void conv3d_last_kernel(const half_t* __restri
     out[vox] = 1.f / (1.f + expf(-a));
 }
 
+// VAE3D's last layer (networks.py:2018-2019): ConvTranspose3d(CIN, 1, k3, s2, p1, output_padding 1) + Sigmoid.
+// o = 2 i - 1 + k per dimension: even o takes (k=1, i=o/2); odd o takes (k=0, i=(o+1)/2) and (k=2, i=(o-1)/2).
+// in fp16 NDHWC [B][D][H][W][CIN]; w fp32 [27][CIN] (tap-major); out fp32 [B][2D][2H][2W].
+template <int CIN>
+__global__ __launch_bounds__(256) void convT3d_last_kernel(const half_t* __restrict__ in, int B, int D, int H, int W,
+                                                            const float* __restrict__ w, float bias,
+                                                            float* __restrict__ out) {
+    __shared__ float ws[27 * CIN];
+    for (int i = threadIdx.x; i < 27 * CIN; i += blockDim.x) ws[i] = w[i];
+    __syncthreads();
+    const int OD = 2 * D, OH = 2 * H, OW = 2 * W;
+    const int64_t vox = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vox >= (int64_t)B * OD * OH * OW) return;
+    const int ox = (int)(vox % OW); int64_t t = vox / OW;
+    const int oy = (int)(t % OH); t /= OH;
+    const int oz = (int)(t % OD); const int bb = (int)(t / OD);
+    float a = bias;
+    for (int kz = (oz & 1) ? 0 : 1; kz < 3; kz += 2) {
+        const int iz = (oz + 1 - kz) >> 1;
+        if ((unsigned)iz >= (unsigned)D) continue;
+        for (int ky = (oy & 1) ? 0 : 1; ky < 3; ky += 2) {
+            const int iy = (oy + 1 - ky) >> 1;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            for (int kx = (ox & 1) ? 0 : 1; kx < 3; kx += 2) {
+                const int ix = (ox + 1 - kx) >> 1;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const half8* src = (const half8*)(in + ((((int64_t)bb * D + iz) * H + iy) * W + ix) * CIN);
+                const float* wk = ws + ((kz * 3 + ky) * 3 + kx) * CIN;
+#pragma unroll
+                for (int c8 = 0; c8 < CIN / 8; ++c8) {
+                    const half8 v = src[c8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a = fmaf(wk[c8 * 8 + e], (float)v[e], a);
+                }
+            }
+        }
+    }
+    out[vox] = 1.f / (1.f + expf(-a));
+}
+
 }  // namespace pcd
 
 using namespace pcd;
@@ -288,13 +331,15 @@ extern "C" int pcd_conv3d_f16(const pcd_conv3d_desc_t* d, void* stream) {
     return PCD_OK;
 }
 
-extern "C" int pcd_conv3d_first(const float* x, int batch, int d, int h, int w, const float* wgt, const float* bias,
-                                int cout, void* out, void* stream) {
+extern "C" int pcd_conv3d_first(const float* x, int batch, int d, int h, int w, int stride, const float* wgt,
+                                const float* bias, int cout, void* out, void* stream) {
     PCD_CHECK_ARG(x && wgt && bias && out && batch > 0 && d > 0 && h > 0 && w > 0 && cout > 0 && cout % 8 == 0);
-    const int64_t total = (int64_t)batch * d * h * w * (cout / 8);
+    PCD_CHECK_ARG(stride == 1 || stride == 2);
+    const int64_t ovox = (int64_t)((d - 1) / stride + 1) * ((h - 1) / stride + 1) * ((w - 1) / stride + 1);
+    const int64_t total = (int64_t)batch * ovox * (cout / 8);
     hipLaunchKernelGGL(conv3d_first_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256),
-                       (size_t)cout * 28 * sizeof(float), (hipStream_t)stream, x, batch, d, h, w, wgt, bias, cout,
-                       (half_t*)out);
+                       (size_t)cout * 28 * sizeof(float), (hipStream_t)stream, x, batch, d, h, w, stride, wgt, bias,
+                       cout, (half_t*)out);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }
@@ -306,6 +351,17 @@ extern "C" int pcd_conv3d_last_sigmoid(const void* in, int batch, int d, int h, 
     const int64_t total = (int64_t)batch * d * h * w;
     hipLaunchKernelGGL((conv3d_last_kernel<32>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const half_t*)in, batch, d, h, w, wgt, bias, out);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_convt3d_last_sigmoid(const void* in, int batch, int d, int h, int w, int cin, const float* wgt,
+                                        float bias, float* out, void* stream) {
+    PCD_CHECK_ARG(in && wgt && out && batch > 0 && d > 0 && h > 0 && w > 0);
+    PCD_CHECK_ARG(cin == 32);
+    const int64_t total = (int64_t)batch * d * h * w * 8;
+    hipLaunchKernelGGL((convT3d_last_kernel<32>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const half_t*)in, batch, d, h, w, wgt, bias, out);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

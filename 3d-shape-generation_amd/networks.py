@@ -452,7 +452,7 @@ class SimpleLatentUNetPointNet(_HipModule):
 
 
 def __getattr__(name):   # VAE3DLarge lives in vae.py; keep `networks.VAE3DLarge` importable like the reference
-    if name == "VAE3DLarge":
-        from .vae import VAE3DLarge
-        return VAE3DLarge
+    if name in ("VAE3DLarge", "VAE3D"):
+        from . import vae
+        return getattr(vae, name)
     raise AttributeError(name)

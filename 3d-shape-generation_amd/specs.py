@@ -168,6 +168,23 @@ def vae3d_large_spec(latent_dim: int = 256, prefix: str = "") -> Spec:
     return s
 
 
+def vae3d_small_spec(latent_dim: int = 256, prefix: str = "") -> Spec:
+    """VAE3D (reference networks.py:1984-2021): stride-2 Conv3DBlocks / Deconv3DBlocks (k3)."""
+    s: Spec = []
+    for i, (a, b) in enumerate([(1, 32), (32, 64), (64, 128), (128, 256)]):
+        _conv3d(s, f"{prefix}encoder.{i}.conv", a, b, 3)
+        _bn(s, f"{prefix}encoder.{i}.bn", b)
+    _linear(s, prefix + "encoder.5", 256 * 8, 512)
+    _linear(s, prefix + "fc_mu", 512, latent_dim)
+    _linear(s, prefix + "fc_logvar", 512, latent_dim)
+    _linear(s, prefix + "decoder_input", latent_dim, 256 * 8)
+    for i, (a, b) in enumerate([(256, 128), (128, 64), (64, 32)]):
+        _convT3d(s, f"{prefix}decoder.{i}.deconv", a, b, 3)
+        _bn(s, f"{prefix}decoder.{i}.bn", b)
+    _convT3d(s, prefix + "decoder.3", 32, 1, 3)
+    return s
+
+
 # ------------------------------------------------------------- set attention
 def set_attention_spec(dim: int, prefix: str = "") -> Spec:
     s: Spec = []

@@ -188,7 +188,7 @@ class VAE3DLarge(_HipModule):
         b = x.shape[0]
         x = x.to(torch.float32).contiguous()
         h = torch.empty(b * 32768, 32, dtype=torch.float16, device=x.device)
-        _lib.check(lib.pcd_conv3d_first(x.data_ptr(), b, 32, 32, 32, pk["enc0_w"].data_ptr(), pk["enc0_b"].data_ptr(),
+        _lib.check(lib.pcd_conv3d_first(x.data_ptr(), b, 32, 32, 32, 1, pk["enc0_w"].data_ptr(), pk["enc0_b"].data_ptr(),
                                         32, h.data_ptr(), _lib.stream_ptr()), "conv3d_first")
         h = self._res(pk["enc2"], h, b, 32)
         h = self._conv(pk["enc3"], h, b, 32, 2, pk["taps4s2"], relu=True)
@@ -254,3 +254,159 @@ class VAE3DLarge(_HipModule):
             _lib.check(_lib.load().pcd_randn(z.data_ptr(), z.numel(), int(torch.initial_seed()) & (2 ** 64 - 1),
                                              1 << 41, _lib.stream_ptr()), "randn")
         return voxel_tensor_to_point_clouds(self.decode(z), threshold)
+
+
+# per dimension for ConvTranspose3d(k3, s2, p1, output_padding 1): output parity -> [(kernel index, input offset)]
+_CT3_TAPS = {0: [(1, 0)], 1: [(0, 1), (2, 0)]}
+
+
+def _pack_convT3_class(w: np.ndarray, pz: int, py: int, px: int):
+    """ConvTranspose3d weight (cin, cout, 3,3,3) -> class matrix [cout][ntaps*cin] (K padded to 64) + taps."""
+    cols, taps = [], []
+    for kz, dz in _CT3_TAPS[pz]:
+        for ky, dy in _CT3_TAPS[py]:
+            for kx, dx in _CT3_TAPS[px]:
+                cols.append(w[:, :, kz, ky, kx].T)
+                taps.append((dz & 0xff) | ((dy & 0xff) << 8) | ((dx & 0xff) << 16))
+    wc = np.concatenate(cols, axis=1)
+    kpad = (wc.shape[1] + 63) // 64 * 64
+    out = np.zeros((wc.shape[0], kpad))
+    out[:, :wc.shape[1]] = wc
+    return out, np.asarray(taps, np.int32), kpad
+
+
+class VAE3D(_HipModule):
+    """Drop-in for the small voxel VAE, reference networks.py:1984-2206 (inference surface): stride-2
+    Conv3DBlocks down to 256 x 2^3, Linear(2048, 512), mirrored Deconv3DBlocks, on the same HIP
+    implicit-GEMM kernel as VAE3DLarge."""
+
+    def __init__(self, input_shape=(32, 32, 32), latent_dim=256, beta=1e-1):
+        super().__init__()
+        from .diffusion import _HParams
+        self.hparams = _HParams(input_shape=input_shape, latent_dim=latent_dim, beta=beta)
+        if tuple(input_shape) != (32, 32, 32):
+            raise ValueError("VAE3D flattens 256 x 2 x 2 x 2 features: only 32^3 grids fit its Linear(2048, 512)")
+        self.latent_dim = latent_dim
+        self._build_from_spec(specs.vae3d_small_spec(latent_dim))
+
+    def _ensure_packed(self):
+        if self._packed is not None:
+            return self._packed
+        dev = self._need_cuda()
+        _lib.require_gpu()
+        sd = self.state_dict()
+        g = lambda k: sd[k].detach().to("cpu", torch.float64).numpy()
+        pk = {"zero": torch.zeros(64, dtype=torch.float16, device=dev),
+              "taps3": torch.from_numpy(_taps_regular(3, 1)).to(dev)}
+
+        def bn_scale(bn):
+            scale = g(bn + ".weight") / np.sqrt(g(bn + ".running_var") + packing.BN_EPS)
+            return scale, g(bn + ".bias") - g(bn + ".running_mean") * scale
+
+        sc, sh = bn_scale("encoder.0.bn")
+        w0 = g("encoder.0.conv.weight").reshape(32, 27) * sc[:, None]
+        pk["enc0_w"], pk["enc0_b"] = _dev32(w0, dev), _dev32(g("encoder.0.conv.bias") * sc + sh, dev)
+        for i in (1, 2, 3):
+            sc, sh = bn_scale(f"encoder.{i}.bn")
+            w = g(f"encoder.{i}.conv.weight") * sc[:, None, None, None, None]
+            wk, _, kpad = _pack_conv(w, None)
+            pk[f"enc{i}"] = {"w": _dev16(wk, dev), "b": _dev32(g(f"encoder.{i}.conv.bias") * sc + sh, dev), "kpad": kpad,
+                             "cin": w.shape[1], "cout": w.shape[0], "k": 3}
+        # Linear(2048, 512) reads the (c, z, y, x) flatten; activations here are (z, y, x, c)
+        perm = np.arange(256 * 8).reshape(256, 8).T.reshape(-1)
+        pk["lin_w"], pk["lin_b"] = _dev16(g("encoder.5.weight")[:, perm], dev), _dev32(g("encoder.5.bias"), dev)
+        pk["fc_w"] = _dev16(np.concatenate([g("fc_mu.weight"), g("fc_logvar.weight")], 0), dev)
+        pk["fc_b"] = _dev32(np.concatenate([g("fc_mu.bias"), g("fc_logvar.bias")], 0), dev)
+        pk["din_w"], pk["din_b"] = _dev16(g("decoder_input.weight")[perm], dev), _dev32(g("decoder_input.bias")[perm], dev)
+        for i in (0, 1, 2):
+            sc, sh = bn_scale(f"decoder.{i}.bn")
+            w = g(f"decoder.{i}.deconv.weight") * sc[None, :, None, None, None]
+            classes = []
+            for pz in (0, 1):
+                for py in (0, 1):
+                    for px in (0, 1):
+                        wc, taps, kpad = _pack_convT3_class(w, pz, py, px)
+                        classes.append({"w": _dev16(wc, dev), "taps": torch.from_numpy(taps).to(dev), "kpad": kpad,
+                                        "p": (pz, py, px)})
+            pk[f"dec{i}"] = {"classes": classes, "b": _dev32(g(f"decoder.{i}.deconv.bias") * sc + sh, dev),
+                             "cin": w.shape[0], "cout": w.shape[1]}
+        wl = g("decoder.3.weight")                                   # (32, 1, 3, 3, 3)
+        pk["last_w"] = _dev32(np.transpose(wl[:, 0], (1, 2, 3, 0)).reshape(27, 32), dev)
+        pk["last_b"] = float(g("decoder.3.bias")[0])
+        self._packed = pk
+        return pk
+
+    def _conv_s2(self, L, x, b, din):
+        lib = _lib.load()
+        dout = din // 2
+        out = torch.empty(b * dout ** 3, L["cout"], dtype=torch.float16, device=x.device)
+        d = _lib.Conv3dDesc()
+        d.inp, d.batch, d.in_d, d.in_h, d.in_w, d.cin = x.data_ptr(), b, din, din, din, L["cin"]
+        d.rows_d = d.rows_h = d.rows_w = dout
+        d.stride = 2
+        taps = self._packed["taps3"]
+        d.taps, d.ntaps, d.kpad = taps.data_ptr(), 27, L["kpad"]
+        d.w, d.bias, d.resid, d.relu = L["w"].data_ptr(), L["b"].data_ptr(), 0, 1
+        d.out, d.cout = out.data_ptr(), L["cout"]
+        d.out_d = d.out_h = d.out_w = dout
+        d.out_scale = 1
+        d.zero_page = self._packed["zero"].data_ptr()
+        _lib.check(lib.pcd_conv3d_f16(d, _lib.stream_ptr()), "conv3d")
+        return out
+
+    def _deconv(self, L, x, b, din):
+        lib = _lib.load()
+        dout = 2 * din
+        out = torch.empty(b * dout ** 3, L["cout"], dtype=torch.float16, device=x.device)
+        for cls in L["classes"]:
+            d = _lib.Conv3dDesc()
+            d.inp, d.batch, d.in_d, d.in_h, d.in_w, d.cin = x.data_ptr(), b, din, din, din, L["cin"]
+            d.rows_d = d.rows_h = d.rows_w = din
+            d.stride = 1
+            d.taps, d.ntaps, d.kpad = cls["taps"].data_ptr(), cls["taps"].numel(), cls["kpad"]
+            d.w, d.bias, d.resid, d.relu = cls["w"].data_ptr(), L["b"].data_ptr(), 0, 1
+            d.out, d.cout = out.data_ptr(), L["cout"]
+            d.out_d = d.out_h = d.out_w = dout
+            d.out_scale = 2
+            d.out_off_z, d.out_off_y, d.out_off_x = cls["p"]
+            d.zero_page = self._packed["zero"].data_ptr()
+            _lib.check(lib.pcd_conv3d_f16(d, _lib.stream_ptr()), "conv3d(T)")
+        return out
+
+    def encode(self, x: torch.Tensor):
+        """networks.py:2044-2057."""
+        from . import ops
+        self._need_cuda(x)
+        pk = self._ensure_packed()
+        lib = _lib.load()
+        b = x.shape[0]
+        x = x.to(torch.float32).contiguous()
+        h = torch.empty(b * 16 ** 3, 32, dtype=torch.float16, device=x.device)
+        _lib.check(lib.pcd_conv3d_first(x.data_ptr(), b, 32, 32, 32, 2, pk["enc0_w"].data_ptr(), pk["enc0_b"].data_ptr(),
+                                        32, h.data_ptr(), _lib.stream_ptr()), "conv3d_first")
+        h = self._conv_s2(pk["enc1"], h, b, 16)
+        h = self._conv_s2(pk["enc2"], h, b, 8)
+        h = self._conv_s2(pk["enc3"], h, b, 4)                        # (B*8, 256) = (B, 2,2,2, 256)
+        h = ops.gemm_f16(h.reshape(b, 2048), pk["lin_w"], pk["lin_b"], relu=True)
+        out = ops.gemm_f16_out32(h, pk["fc_w"], pk["fc_b"])
+        return out[:, :self.latent_dim].contiguous(), out[:, self.latent_dim:].contiguous()
+
+    reparameterize = VAE3DLarge.reparameterize
+
+    def decode(self, z: torch.Tensor) -> torch.Tensor:
+        """networks.py:2077-2090."""
+        from . import ops
+        self._need_cuda(z)
+        pk = self._ensure_packed()
+        b = z.shape[0]
+        h = ops.gemm_f16(z.to(torch.float16).contiguous(), pk["din_w"], pk["din_b"]).reshape(b * 8, 256)
+        h = self._deconv(pk["dec0"], h, b, 2)
+        h = self._deconv(pk["dec1"], h, b, 4)
+        h = self._deconv(pk["dec2"], h, b, 8)                          # (B, 16,16,16, 32)
+        out = torch.empty(b, 1, 32, 32, 32, dtype=torch.float32, device=z.device)
+        _lib.check(_lib.load().pcd_convt3d_last_sigmoid(h.data_ptr(), b, 16, 16, 16, 32, pk["last_w"].data_ptr(),
+                                                        pk["last_b"], out.data_ptr(), _lib.stream_ptr()), "convT3d_last")
+        return out
+
+    forward = VAE3DLarge.forward
+    sample = VAE3DLarge.sample

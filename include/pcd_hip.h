@@ -229,13 +229,17 @@ typedef struct {
     const void* zero_page;                                 /* >= 128 bytes of zeros */
 } pcd_conv3d_desc_t;
 int pcd_conv3d_f16(const pcd_conv3d_desc_t* d, void* stream);
-/* encoder.0: Conv3d(1, cout, k3, p1) + ReLU straight from the fp32 occupancy grid x [B][D][H][W];
- * w fp32 [cout][27], out fp16 NDHWC. */
-int pcd_conv3d_first(const float* x, int batch, int d, int h, int w, const float* wgt, const float* bias,
-                     int cout, void* out, void* stream);
+/* encoder.0: Conv3d(1, cout, k3, stride 1|2, p1) (+ folded BN) + ReLU straight from the fp32 occupancy
+ * grid x [B][D][H][W]; w fp32 [cout][27], out fp16 NDHWC (VAE3DLarge networks.py:2226, VAE3D :1999). */
+int pcd_conv3d_first(const float* x, int batch, int d, int h, int w, int stride, const float* wgt,
+                     const float* bias, int cout, void* out, void* stream);
 /* decoder.12 + decoder.13: Conv3d(32, 1, k3, p1) + Sigmoid -> fp32 [B][D][H][W]; w fp32 [27][cin]. */
 int pcd_conv3d_last_sigmoid(const void* in, int batch, int d, int h, int w, int cin, const float* wgt,
                             float bias, float* out, void* stream);
+/* VAE3D's last layer (networks.py:2018-2019): ConvTranspose3d(32, 1, k3, s2, p1, output_padding 1) + Sigmoid;
+ * in fp16 NDHWC [B][d][h][w][32], w fp32 [27][32] tap-major, out fp32 [B][2d][2h][2w]. */
+int pcd_convt3d_last_sigmoid(const void* in, int batch, int d, int h, int w, int cin, const float* wgt,
+                             float bias, float* out, void* stream);
 /* z = mu + eps * exp(0.5 * logvar)  (networks.py:2323-2325), fp32 */
 int pcd_reparameterize(const float* mu, const float* logvar, const float* eps, float* z, int64_t n, void* stream);
 

@@ -67,11 +67,29 @@ def synth_voxels(b, seed):
     return v
 
 
+def capture_vae3d_small(rn):
+    """G11: the small voxel VAE `VAE3D` (networks.py:1984-2206) -> tests/golden/vae3d_small.npz."""
+    spec = specs.vae3d_small_spec()
+    vae = rn.VAE3D().eval()
+    assert [(k, tuple(v.shape)) for k, v in vae.state_dict().items()] == [(k, s) for k, s, _ in spec]
+    vae.load_state_dict(T(specs.synth_state_dict(spec, seed=3, gain=VAE_GAIN)), strict=True)
+    vox = torch.from_numpy(synth_voxels(2, 5))
+    mu, logvar = vae.encode(vox)
+    g = {"occ_idx0": np.flatnonzero(vox.numpy().reshape(2, -1)[0]).astype(np.int32),
+         "occ_idx1": np.flatnonzero(vox.numpy().reshape(2, -1)[1]).astype(np.int32),
+         "mu": mu.numpy(), "logvar": logvar.numpy(), "dec": vae.decode(mu).numpy().astype(np.float32)}
+    np.savez_compressed(os.path.join(OUT, "vae3d_small.npz"), **g)
+    print("vae3d_small done; occupancy", [(torch.from_numpy(g["dec"])[i] > 0.4).float().mean().item() for i in range(2)])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rd, rn, rm, ru = ref_shim.load_reference()
     torch.set_grad_enabled(False)
     t_start = time.time()
+    if "vae3d" in sys.argv[1:]:
+        capture_vae3d_small(rn)
+        return
 
     # ------------------------------------------------------------------ point model
     pspec = specs.unet_pointnet_large_spec(prefix="model.")
@@ -294,6 +312,7 @@ def main():
     tu = torch.tensor([0.8, 0.2])
     g["una_x"], g["una_t"], g["una_eps"] = xu.numpy(), tu.numpy(), una(xu, tu).numpy()
     np.savez_compressed(os.path.join(OUT, "attention.npz"), **g)
+    capture_vae3d_small(rn)
     print("all done", time.time() - t_start)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

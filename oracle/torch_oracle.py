@@ -246,6 +246,28 @@ def vae_decode(sd: SD, p: str, z: torch.Tensor, dec_prog: Sequence) -> torch.Ten
     return _run_vae_program(sd, p + "decoder", dec_prog, h, "sigmoid")
 
 
+def vae3d_small_encode(sd: SD, p: str, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """VAE3D.encode (networks.py:2044-2057; encoder :1998-2006): four stride-2 Conv3DBlocks, Linear, ReLU."""
+    h = x
+    for i in range(4):
+        h = F.conv3d(h, sd[f"{p}encoder.{i}.conv.weight"], sd[f"{p}encoder.{i}.conv.bias"], stride=2, padding=1)
+        h = F.relu(_bn_eval(sd, f"{p}encoder.{i}.bn", h))
+    h = F.relu(F.linear(h.flatten(1), sd[p + "encoder.5.weight"], sd[p + "encoder.5.bias"]))
+    return (F.linear(h, sd[p + "fc_mu.weight"], sd[p + "fc_mu.bias"]),
+            F.linear(h, sd[p + "fc_logvar.weight"], sd[p + "fc_logvar.bias"]))
+
+
+def vae3d_small_decode(sd: SD, p: str, z: torch.Tensor) -> torch.Tensor:
+    """VAE3D.decode (networks.py:2077-2090; decoder :2014-2020)."""
+    h = F.linear(z, sd[p + "decoder_input.weight"], sd[p + "decoder_input.bias"]).view(-1, 256, 2, 2, 2)
+    for i in range(3):
+        h = F.conv_transpose3d(h, sd[f"{p}decoder.{i}.deconv.weight"], sd[f"{p}decoder.{i}.deconv.bias"],
+                               stride=2, padding=1, output_padding=1)
+        h = F.relu(_bn_eval(sd, f"{p}decoder.{i}.bn", h))
+    h = F.conv_transpose3d(h, sd[p + "decoder.3.weight"], sd[p + "decoder.3.bias"], stride=2, padding=1, output_padding=1)
+    return torch.sigmoid(h)
+
+
 def vae_reparameterize(mu: torch.Tensor, logvar: torch.Tensor, eps: torch.Tensor) -> torch.Tensor:
     """networks.py:2312-2325 with the normal draw passed in."""
     return mu + eps * torch.exp(0.5 * logvar)

@@ -44,3 +44,7 @@ def voxels_from_idx(idx_list):
     for i, idx in enumerate(idx_list):
         v[i, idx] = 1
     return torch.from_numpy(v.reshape(len(idx_list), 1, 32, 32, 32))
+
+
+def vae3d_small_sd():
+    return as_torch(specs.synth_state_dict(specs.vae3d_small_spec(), seed=3, gain=VAE_GAIN))

@@ -166,3 +166,22 @@ def test_latent_sample2_sample3_and_errors(ldm):
     bad = LatentDiffusion(ldm.vae, is_voxel_based=False).to("cuda")
     with pytest.raises(UnboundLocalError):      # reference diffusion.py:650-653 behaviour
         bad.sample(1, num_steps=1)
+
+
+def test_vae3d_small(golden):
+    """the small VAE3D on the same implicit-GEMM kernel (stride-2 convs, k3 transposed
+    convs as parity classes with 1/2/4/8 taps, Cout=1 transposed last layer)."""
+    from helpers import vae3d_small_sd
+    from shapegen_amd.vae import VAE3D
+    g = golden("vae3d_small.npz")
+    vae = VAE3D()
+    vae.load_state_dict(vae3d_small_sd(), strict=True)
+    vae = vae.to("cuda").eval()
+    vox = voxels_from_idx([g["occ_idx0"], g["occ_idx1"]]).cuda()
+    mu, logvar = vae.encode(vox)
+    assert rel_l2(mu.cpu(), g["mu"]) < 1e-2 and rel_l2(logvar.cpu(), g["logvar"]) < 1e-2
+    dec = vae.decode(torch.from_numpy(g["mu"]).cuda())
+    err = (dec.cpu() - torch.from_numpy(g["dec"])).abs()
+    assert dec.shape == (2, 1, 32, 32, 32) and float(err.max()) < 2e-2 and float(err.mean()) < 2e-3
+    pcs = vae.sample(2, threshold=0.4, z=torch.from_numpy(g["mu"]).cuda())
+    assert len(pcs) == 2 and all(p.shape[1] == 3 for p in pcs)

@@ -167,3 +167,14 @@ def test_set_attention(golden):
         assert rel_l2(out, g[f"sab{C}_out"]) < 2e-6, C
     eps = O.unet_attention(una_sd(), "", torch.from_numpy(g["una_x"]), torch.from_numpy(g["una_t"]))
     assert rel_l2(eps, g["una_eps"]) < 1e-5
+
+
+def test_vae3d_small(golden):
+    """G11: the small VAE3D (reference networks.py:1984-2206)."""
+    from helpers import vae3d_small_sd
+    g = golden("vae3d_small.npz")
+    sd = vae3d_small_sd()
+    vox = voxels_from_idx([g["occ_idx0"], g["occ_idx1"]])
+    mu, logvar = O.vae3d_small_encode(sd, "", vox)
+    assert rel_l2(mu, g["mu"]) < 1e-5 and rel_l2(logvar, g["logvar"]) < 1e-5
+    assert rel_l2(O.vae3d_small_decode(sd, "", torch.from_numpy(g["mu"])), g["dec"]) < 1e-5
