@@ -30,31 +30,41 @@ struct GemmParams {
     int patch_pn, patch_xn;   // XCD patch mapping (0 = linear tile order)
 };
 
-constexpr int BK = 64;          // halfs per K tile = 128 B per row
-constexpr int ROWB = BK * 2;    // bytes per staged row
+constexpr int BK = 64;          // K granularity required by the API (k1, k2 multiples of 64)
 
 __device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// Stage ROWS x 64 halfs (row-major, ld elements per row) into a lane-linear LDS image whose
-// 16-B chunk j of row r holds logical chunk j ^ ((r>>1)&7).  NT threads: each wave covers 8 rows
-// per round (64 lanes x 16 B = 8 rows of 128 B).
-template <int ROWS, int NT>
+// XOR swizzle of the 16-B chunk index inside a staged row (applied to the LDS-DMA source address and
+// again on the fragment reads): makes the four 16-lane groups of a ds_read_b128 hit 16 distinct
+// 16-B bank slots for the 16x16x32 operand map (lane -> row lane&15, chunk lane>>4).
+//   128-B rows (K tile 64): chunk ^ ((row>>1) & 7)
+//    64-B rows (K tile 32): chunk ^ ((-(row>>2)) & 3)
+template <int BKT>
+__device__ __forceinline__ int swz(int row, int chunk) {
+    return BKT == 64 ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((-(row >> 2)) & 3));
+}
+
+// Stage ROWS x BKT halfs (row-major, ld elements per row) into a lane-linear LDS image.  NT threads;
+// one wave-instruction covers 1 KB = 1024 / (2*BKT) rows.
+template <int ROWS, int NT, int BKT>
 __device__ __forceinline__ void stage_rows(const half_t* __restrict__ src, int64_t ld, int row0, int row_limit,
                                            int kofs, char* lds_tile, int wave, int lane) {
-    constexpr int RPR = NT / 8;          // rows per round
+    constexpr int CPR = BKT / 8;                 // 16-B chunks per row
+    constexpr int RPI = 64 / CPR;                // rows per wave-instruction
+    constexpr int RPR = (NT / 64) * RPI;         // rows per round (all waves)
     constexpr int ROUNDS = ROWS / RPR;
     static_assert(ROWS % RPR == 0, "tile rows must be a multiple of the rows staged per round");
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-        const int row = r * RPR + wave * 8 + (lane >> 3);
-        const int logical = (lane & 7) ^ ((row >> 1) & 7);
+        const int row = r * RPR + wave * RPI + lane / CPR;
+        const int logical = swz<BKT>(row, lane % CPR);
         int grow = row0 + row;
         grow = grow < row_limit ? grow : row_limit - 1;   // clamp: rows past the edge are masked in the epilogue
         const half_t* g = src + (int64_t)grow * ld + kofs + logical * 8;
-        glds16(g, lds_tile + (r * RPR + wave * 8) * ROWB);
+        glds16(g, lds_tile + (r * RPR + wave * RPI) * (BKT * 2));
     }
 }
 
@@ -66,8 +76,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 // BM x BN x 64 tile, WGM x WGN waves (each wave (BM/WGM) x (BN/WGN)), STAGES LDS buffers.
 // STAGES == 2: one tile prefetched, plain barrier.  STAGES >= 3: STAGES-1 tiles prefetched, the
 // LDS-DMA of the younger ones stays in flight across the (raw) barrier behind a counted vmcnt.
-template <int BM, int BN, int WGM, int WGN, int STAGES, int EPI>
+template <int BM, int BN, int WGM, int WGN, int STAGES, int EPI, int BKT = 64>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) {
+    constexpr int ROWB = BKT * 2;                // bytes per staged row
+    constexpr int KS = BKT / 32;                 // 32-deep MFMA steps per K tile
     // cross-tile prefetch (next tile's first K tile requested before this tile's epilogue): only where the
     // registers allow it; the 256x256 store variant would spill (128 accumulators + epilogue temporaries)
     constexpr bool XPREF = (STAGES == 2) && (BM * BN <= 128 * 128);
@@ -76,7 +88,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
     constexpr int MI = WM / 16, NI = WN / 16;
     constexpr int STAGE_BYTES = (BM + BN) * ROWB;
     constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
-    constexpr int LOADS_PER_TILE = (BM + BN) / (NT / 8);   // global_load_lds per thread per K tile
+    constexpr int LOADS_PER_TILE = (BM + BN) / ((NT / 64) * (512 / BKT));   // global_load_lds per thread per K tile
     // Store epilogues compute the transposed product (weights as the MFMA A operand): an accumulator then
     // holds 4 CONSECUTIVE CHANNELS of one point, i.e. an 8-byte piece of an output row, and goes straight to
     // global memory (no LDS staging, no barriers).  Column-max / fp32 epilogues keep channels on the lanes.
@@ -93,32 +105,31 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
     // the activation row panel).  The first K tile of the NEXT output tile is requested before the epilogue
     // of the current one, so its load latency and the store tail overlap.
     const int ntiles = p.tiles_m * p.tiles_n;
-    const int nk1 = p.k1 / BK, nk = (p.k1 + p.k2) / BK;
+    const int nk1 = p.k1 / BKT, nk = (p.k1 + p.k2) / BKT;
 
     f32x4 acc[MI][NI];
 
     auto stage = [&](int m0, int n0, int kt, int buf) {
         char* base = smem + buf * STAGE_BYTES;
-        if (kt < nk1) stage_rows<BM, NT>(p.a1, p.lda1, m0, p.m, kt * BK, base, wave, lane);
-        else          stage_rows<BM, NT>(p.a2, p.lda2, m0, p.m, (kt - nk1) * BK, base, wave, lane);
-        stage_rows<BN, NT>(p.w, p.ldw, n0, p.c, kt * BK, base + BM * ROWB, wave, lane);
+        if (kt < nk1) stage_rows<BM, NT, BKT>(p.a1, p.lda1, m0, p.m, kt * BKT, base, wave, lane);
+        else          stage_rows<BM, NT, BKT>(p.a2, p.lda2, m0, p.m, (kt - nk1) * BKT, base, wave, lane);
+        stage_rows<BN, NT, BKT>(p.w, p.ldw, n0, p.c, kt * BKT, base + BM * ROWB, wave, lane);
     };
 
     // per-lane fragment read offsets (bytes) inside a staged tile
     const int ra = wm * WM + (lane & 15);
     const int rb = wn * WN + (lane & 15);
-    const int swa = (ra >> 1) & 7, swb = (rb >> 1) & 7;
     const int q = lane >> 4;
-    int offa[2], offb[2];
+    int offa[KS], offb[KS];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        offa[ks] = ra * ROWB + (((ks * 4 + q) ^ swa) << 4);
-        offb[ks] = BM * ROWB + rb * ROWB + (((ks * 4 + q) ^ swb) << 4);
+    for (int ks = 0; ks < KS; ++ks) {
+        offa[ks] = ra * ROWB + (swz<BKT>(ra, ks * 4 + q) << 4);
+        offb[ks] = BM * ROWB + rb * ROWB + (swz<BKT>(rb, ks * 4 + q) << 4);
     }
 
     auto compute = [&](const char* base) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             half8 af[MI], bf[NI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) af[i] = *(const half8*)(base + offa[ks] + i * 16 * ROWB);
@@ -365,7 +376,7 @@ static int num_cus() {
     return n;
 }
 
-template <int BM, int BN, int WGM, int WGN, int STAGES, int EPI>
+template <int BM, int BN, int WGM, int WGN, int STAGES, int EPI, int BKT = 64>
 static int launch(const GemmParams& p0, hipStream_t s, int blocks_per_cu) {
     GemmParams p = p0;
     p.tiles_m = (int)ceil_div(p.m, BM);
@@ -383,7 +394,7 @@ static int launch(const GemmParams& p0, hipStream_t s, int blocks_per_cu) {
             p.patch_pn = pn; p.patch_xn = xn;
         }
     }
-    hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WGM, WGN, STAGES, EPI>), dim3(grid), dim3(64 * WGM * WGN), 0, s, p);
+    hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WGM, WGN, STAGES, EPI, BKT>), dim3(grid), dim3(64 * WGM * WGN), 0, s, p);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }
@@ -411,6 +422,9 @@ static int dispatch(const GemmParams& p, hipStream_t s) {
         case 2: return launch<256, 128, 4, 2, 3, EPI>(q, s, 1);     // 144 KB LDS
         case 3: return launch<256, 256, 2, 4, 2, EPI>(q, s, 1);     // 128 KB LDS
         case 4: return launch<128, 128, 2, 2, 3, EPI>(q, s, 1);     // 96 KB LDS
+        // measured and rejected: K tile 32 with 256x128 / 128x256 tiles (48 KB LDS, two blocks per CU, so one
+        // block's store tail hides behind the other's MFMAs): 733-753 TFLOP/s on the dominant GEMM vs 1195-1260
+        // for the 256x256 tile, and slower on every mid-size layer (profiles/r01_c_gemm_tile_sweep.txt).
         default: set_error("gemm: unknown config %d", cfg); return PCD_ERR_ARG;
     }
 }
