@@ -91,8 +91,8 @@ def cpu_baseline(sd, sample_batch=2, reps=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)      # 50 x ~4 ms; the GPU reaches steady clocks after ~10 steps
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay a captured HIP graph per step (what sample2() does for long runs); the default launches "
