@@ -72,6 +72,17 @@ class VAE3DLarge(_HipModule):
                 w = self._modules[name].weight
                 w.normal_(0.0, 0.01 * (2.0 / (w.shape[0] + w.shape[1])) ** 0.5)
 
+    @classmethod
+    def load_from_checkpoint(cls, path, map_location="cpu", **kwargs):
+        """Lightning-free loader for the reference's `.ckpt` layout (test_point_ldm.py:156, train_point_ldm.py:191)."""
+        from .checkpoint import load_lightning_checkpoint
+        hp, sd = load_lightning_checkpoint(path, map_location)
+        hp.update(kwargs)
+        keys = ("input_shape", "latent_dim", "lr", "kl_warmup_epochs", "kl_warmup_max_beta", "kl_annealing_epochs")
+        obj = cls(**{k: hp[k] for k in keys if k in hp})
+        obj.load_state_dict(sd, strict=True)
+        return obj
+
     # ---------------------------------------------------------------- packing
     def _ensure_packed(self):
         if self._packed is not None:
@@ -288,6 +299,15 @@ class VAE3D(_HipModule):
             raise ValueError("VAE3D flattens 256 x 2 x 2 x 2 features: only 32^3 grids fit its Linear(2048, 512)")
         self.latent_dim = latent_dim
         self._build_from_spec(specs.vae3d_small_spec(latent_dim))
+
+    @classmethod
+    def load_from_checkpoint(cls, path, map_location="cpu", **kwargs):
+        from .checkpoint import load_lightning_checkpoint
+        hp, sd = load_lightning_checkpoint(path, map_location)
+        hp.update(kwargs)
+        obj = cls(**{k: hp[k] for k in ("input_shape", "latent_dim", "beta") if k in hp})
+        obj.load_state_dict(sd, strict=True)
+        return obj
 
     def _ensure_packed(self):
         if self._packed is not None:

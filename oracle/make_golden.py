@@ -10,7 +10,8 @@ is re-played from the same seed and stored next to the outputs, so the tests
 never depend on a torch RNG stream.
 
 Fixture map: G1 schedule.npz, G2-G4 point_unet.npz,
-G5-G7 point_samplers.npz, G8 latent.npz, G9 metrics.npz, G10 attention.npz.
+G5-G7 point_samplers.npz, G8 latent.npz, G9 metrics.npz, G10 attention.npz; beyond the survey's list:
+G11 vae3d_small.npz (`make_golden.py vae3d`), G12 data.npz (`make_golden.py data`).
 """
 from __future__ import annotations
 
@@ -82,8 +83,68 @@ def capture_vae3d_small(rn):
     print("vae3d_small done; occupancy", [(torch.from_numpy(g["dec"])[i] > 0.4).float().mean().item() for i in range(2)])
 
 
+def write_data_dir(root):
+    """The synthetic sample directory behind data.npz: voxel grids named like the reference's files (the ShapeNet
+    synset id is the 5th '_' field).  The test rebuilds the same directory from the same generator."""
+    import random as pyrandom  # noqa: F401
+    names = ["vox_32_res_model_04379243_000.dd", "vox_32_res_model_04379243_001.dd", "vox_32_res_model_03001627_002.dd",
+             "vox_32_res_model_02691156_003.dd", "vox_32_res_model_04379243_004.dd"]
+    vox = synth_voxels(len(names), 9)[:, 0]
+    vox[1] *= 3.0                       # exercises the min-max normalisation
+    vox[4][:] = 0.25                    # constant grid: min == max branch
+    os.makedirs(root, exist_ok=True)
+    for n, v in zip(names, vox):
+        with open(os.path.join(root, n), "wb") as f:
+            np.savez(f, data=v)
+    return names, vox
+
+
+def capture_data():
+    """G12: data layer (data.py:160-311) -> tests/golden/data.npz.  Random draws are replayed from seeds."""
+    import random as pyrandom
+    import tempfile
+    r_data = ref_shim.load_reference_data()
+    g = {}
+    with tempfile.TemporaryDirectory() as root:
+        names, vox = write_data_dir(root)
+        ds = r_data.PointCloudDataset(root, input_mode="voxels", output_mode="voxels", jitter=False, rotate=False)
+        order = sorted(range(len(ds)), key=lambda i: ds.file_list[i])
+        g["vv_files"] = np.array([ds.file_list[i] for i in order])
+        g["vv_out"] = np.stack([ds[i].numpy() for i in order])
+        tab = r_data.PointCloudDataset(root, input_mode="voxels", output_mode="voxels", jitter=False, rotate=False,
+                                       relevant_object_categories=["table"])
+        g["table_files"] = np.array(sorted(tab.file_list))
+        # voxels -> point clouds, exact-size path (deterministic) and resampled paths (seeded)
+        n0 = int((vox[0] > 0.5).sum())
+        dp = r_data.PointCloudDataset(root, num_points=n0, input_mode="voxels", output_mode="point_clouds",
+                                      jitter=False, rotate=False)
+        i0 = dp.file_list.index(names[0])
+        g["pc_exact"] = dp[i0].numpy()
+        for tag, npts in (("more", n0 // 3), ("fewer", n0 + 257)):
+            dq = r_data.PointCloudDataset(root, num_points=npts, input_mode="voxels", output_mode="point_clouds",
+                                          jitter=False, rotate=False)
+            pyrandom.seed(11); np.random.seed(11)
+            g[f"pc_{tag}"] = dq[dq.file_list.index(names[0])].numpy()
+        # augmentations on, voxel output (jitter + rotate, seeded)
+        da = r_data.PointCloudDataset(root, input_mode="voxels", output_mode="voxels", jitter=True, rotate=True)
+        pyrandom.seed(12); np.random.seed(12)
+        g["aug_voxels"] = da[da.file_list.index(names[0])].numpy()
+        # helpers
+        pts = (specs.hash_uniform("datapts", 300 * 3, 4).reshape(300, 3) * 5).astype(np.float64)
+        g["helper_pts"] = pts
+        g["helper_norm"] = ds.normalize_point_cloud(pts)
+        g["helper_vox"] = ds.point_cloud_to_voxel(ds.normalize_point_cloud(pts), 32)
+        np.random.seed(13)
+        g["helper_fps"] = ds.farthest_point_sample(pts, 64)
+    np.savez_compressed(os.path.join(OUT, "data.npz"), **g)
+    print("data done:", {k: v.shape for k, v in g.items()})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "data" in sys.argv[1:]:
+        capture_data()
+        return
     rd, rn, rm, ru = ref_shim.load_reference()
     torch.set_grad_enabled(False)
     t_start = time.time()

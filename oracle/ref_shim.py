@@ -8,7 +8,9 @@ used by `oracle/make_golden.py` (fixture capture) and by the optional
 The reference needs two modules that are not installed and carry no
 arithmetic: `pytorch_lightning` (base class + hparams capture) and `plyfile`
 (PLY writer).  They are replaced by the minimal stand-ins below, following the
-recipe recorded in SURVEY.md section 8(c).
+recipe recorded in SURVEY.md section 8(c).  `load_reference_data()` additionally
+stands in for `deepdish` (HDF5 file reader, no arithmetic either): `dd.io.load`
+returns the `data` array of an `.npz` written under the `.dd` name.
 """
 from __future__ import annotations
 
@@ -97,3 +99,35 @@ def load_reference():
             sys.modules.pop(k, None)
         sys.modules.update(saved)
     return r_diffusion, r_networks, r_metrics, r_utils
+
+
+def load_reference_data():
+    """The reference's data.py module, with `deepdish.io.load(path)` reading {'data': array} from an npz file."""
+    if not reference_available():
+        raise RuntimeError(f"reference not present at {REFERENCE_DIR}")
+    import numpy as np
+    sys.dont_write_bytecode = True
+    import matplotlib
+    matplotlib.use("Agg")
+    _install_stubs()
+    if "deepdish" not in sys.modules:
+        dd = types.ModuleType("deepdish")
+        dd.io = types.ModuleType("deepdish.io")
+
+        def _load(path):
+            with np.load(path) as f:
+                return {"data": f["data"]}
+
+        dd.io.load = _load
+        sys.modules["deepdish"] = dd
+        sys.modules["deepdish.io"] = dd.io
+    saved = sys.modules.pop("data", None)
+    sys.path.insert(0, REFERENCE_DIR)
+    try:
+        import data as r_data
+    finally:
+        sys.path.remove(REFERENCE_DIR)
+        sys.modules.pop("data", None)
+        if saved is not None:
+            sys.modules["data"] = saved
+    return r_data
