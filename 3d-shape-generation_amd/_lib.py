@@ -118,6 +118,21 @@ _SIGS = {
     "pcd_pairwise_max_dist": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "pcd_sinkhorn_dual_update": (i32, [vp, vp, i32, i32, i32, vp, f32, f32, vp, vp, vp, vp]),
     "pcd_sinkhorn_cost": (i32, [vp, vp, i32, i32, i32, vp, f32, vp, vp, vp, vp, vp]),
+    "pcd_colsum_f16": (i32, [vp, i64, i32, i32, vp, vp]),
+    "pcd_bn_batch_stats": (i32, [vp, i64, i32, f32, vp, vp, vp, vp, vp, vp]),
+    "pcd_bn_apply_f16": (i32, [vp, i64, i32, vp, vp, vp, vp, f32, i32, vp, vp]),
+    "pcd_bn_backward_f16": (i32, [vp, vp, i64, i32, vp, vp, vp, vp, f32, i32, vp, vp, vp, vp]),
+    "pcd_transpose_f16": (i32, [vp, i64, i32, vp, vp]),
+    "pcd_colmax_argmax_f16": (i32, [vp, i32, i32, i32, vp, vp, vp]),
+    "pcd_maxpool_backward_f16": (i32, [vp, vp, i32, i32, i32, vp, vp]),
+    "pcd_enc1_linear": (i32, [vp, i64, i32, vp, i32, vp, vp, vp]),
+    "pcd_vec3_outer": (i32, [vp, vp, i64, i32, vp, vp, vp]),
+    "pcd_vec3_expand_f16": (i32, [vp, vp, i64, i32, vp, vp]),
+    "pcd_l1_loss": (i32, [vp, vp, i64, f32, vp, vp, vp]),
+    "pcd_matmul_f32": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, vp, i32, vp, i64, vp]),
+    "pcd_silu_f32": (i32, [vp, i64, vp, vp]),
+    "pcd_silu_backward_f32": (i32, [vp, vp, i64, vp, vp]),
+    "pcd_adamw_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
 }
 
 _lib: Optional[C.CDLL] = None

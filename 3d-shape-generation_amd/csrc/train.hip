@@ -1,0 +1,544 @@
+// Training-step kernels of the point denoiser (reference diffusion.py:70-86,170-186:
+// add_noise -> model in train() mode -> L1 loss -> AdamW).  The dense contractions (forward, backward-data,
+// backward-weight) all go through the fp16 MFMA GEMM of gemm_f16.hip; this file holds what surrounds them:
+// BatchNorm1d with batch statistics (networks.py:31-48) forward and backward, the max-pool with its argmax,
+// the K=3 / C=3 edge layers, column reductions, transposes, the L1 loss and the AdamW update.
+// All of it is HBM-bound elementwise / reduction work: 16-byte loads, fp32 accumulation, one pass per tensor.
+//
+// Layout: activations and their gradients are point-major fp16 [M][C] like everywhere else in the library;
+// the pre-BatchNorm conv outputs z are kept in fp32 (x_hat = (z - mean) * rstd cancels: fp16 z costs ~1e-3
+// per layer when |mean| >> std); statistics, parameter gradients and optimizer state are fp32.  Gradients carry the caller's loss scale.
+#include "common.h"
+
+namespace pcd {
+
+constexpr int CR_COLS = 64;     // columns per block: 8 threads x 8 halfs
+constexpr int CR_LANES = 32;    // row lanes per block
+constexpr int CR_ROWS = 2048;   // rows per block (64 iterations per lane)
+
+// sum the 32 row lanes of acc[v][0..8) per column and add the block's partial to out[v][col] atomically
+template <int NV>
+__device__ __forceinline__ void cr_finish(float (&acc)[NV][8], float* const (&out)[NV], int col0, int c) {
+    __shared__ float red[NV][CR_LANES][CR_COLS + 1];
+    const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[v][rl][cg * 8 + e] = acc[v][e];
+    __syncthreads();
+    if (threadIdx.x < CR_COLS) {
+        const int col = col0 + threadIdx.x;
+        if (col < c) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                float s = 0.f;
+                for (int r = 0; r < CR_LANES; ++r) s += red[v][r][threadIdx.x];
+                atomicAdd(out[v] + col, s);
+            }
+        }
+    }
+}
+
+// rows [row0, row1) of this block; returns false if the block has nothing to do
+__device__ __forceinline__ bool cr_range(int64_t rows_per_group, int64_t& row0, int64_t& row1) {
+    const int64_t g0 = (int64_t)blockIdx.z * rows_per_group;
+    row0 = g0 + (int64_t)blockIdx.y * CR_ROWS;
+    row1 = row0 + CR_ROWS;
+    if (row1 > g0 + rows_per_group) row1 = g0 + rows_per_group;
+    return row0 < row1;
+}
+
+__device__ __forceinline__ half8 ld8(const half_t* p, int col, int c) {
+    if (col + 8 <= c) return *(const half8*)(p + col);
+    half8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = col + e < c ? p[col + e] : (half_t)0.f;
+    return v;
+}
+struct f8 { float v[8]; };
+__device__ __forceinline__ f8 ldf8(const half_t* p, int col, int c) {
+    const half8 h = ld8(p, col, c);
+    f8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r.v[e] = (float)h[e];
+    return r;
+}
+__device__ __forceinline__ f8 ldf8(const float* p, int col, int c) {   // col is a multiple of 8: 32-byte aligned rows of c % 8 == 0
+    f8 r;
+    if (col + 8 <= c) {
+        const f32x4 a = *(const f32x4*)(p + col), b = *(const f32x4*)(p + col + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { r.v[e] = a[e]; r.v[4 + e] = b[e]; }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r.v[e] = col + e < c ? p[col + e] : 0.f;
+    }
+    return r;
+}
+__device__ __forceinline__ void st8(half_t* p, int col, int c, const half8& v) {
+    if (col + 8 <= c) { *(half8*)(p + col) = v; return; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (col + e < c) p[col + e] = v[e];
+}
+
+// out[g][col] += sum over the rows of group g of x[row][col]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t rows_per_group, int c,
+                                                      float* __restrict__ out) {
+    int64_t row0, row1;
+    if (!cr_range(rows_per_group, row0, row1)) return;
+    const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int col0 = blockIdx.x * CR_COLS, col = col0 + cg * 8;
+    float acc[1][8] = {};
+    if (col < c)
+        for (int64_t r = row0 + rl; r < row1; r += CR_LANES) {
+            const f8 v = ldf8(x + r * c, col, c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[0][e] += v.v[e];
+        }
+    float* const outs[1] = {out + (int64_t)blockIdx.z * c};
+    cr_finish<1>(acc, outs, col0, c);
+}
+
+// sqdev[col] += sum over rows of (x - sum[col]/m)^2      (second pass of the batch variance)
+__global__ __launch_bounds__(256) void coldev_kernel(const float* __restrict__ x, int64_t m, int c,
+                                                      const float* __restrict__ sum, float* __restrict__ sqdev) {
+    int64_t row0, row1;
+    if (!cr_range(m, row0, row1)) return;
+    const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int col0 = blockIdx.x * CR_COLS, col = col0 + cg * 8;
+    float acc[1][8] = {};
+    if (col < c) {
+        float mean[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mean[e] = col + e < c ? sum[col + e] / (float)m : 0.f;
+        for (int64_t r = row0 + rl; r < row1; r += CR_LANES) {
+            const f8 v = ldf8(x + r * c, col, c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v.v[e] - mean[e]; acc[0][e] += d * d; }
+        }
+    }
+    float* const outs[1] = {sqdev};
+    cr_finish<1>(acc, outs, col0, c);
+}
+
+__global__ void bn_finalize_kernel(const float* sum, const float* sqdev, int64_t m, int c, float momentum,
+                                   float* mean, float* var, float* running_mean, float* running_var) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    const float mu = sum[i] / (float)m, v = sqdev[i] / (float)m;
+    mean[i] = mu;
+    var[i] = v;
+    if (running_mean != nullptr) {   // torch: running_var tracks the UNBIASED variance (m/(m-1))
+        running_mean[i] = (1.f - momentum) * running_mean[i] + momentum * mu;
+        const float unb = m > 1 ? sqdev[i] / (float)(m - 1) : v;
+        running_var[i] = (1.f - momentum) * running_var[i] + momentum * unb;
+    }
+}
+
+// a = act(gamma * (z - mean) * rstd + beta)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, int64_t m, int c,
+                                                        const float* __restrict__ mean, const float* __restrict__ var,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, int relu, half_t* __restrict__ out) {
+    const int cgroups = (c + 7) / 8;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m * cgroups) return;
+    const int64_t row = idx / cgroups;
+    const int col = (int)(idx - row * cgroups) * 8;
+    const f8 v = ldf8(z + row * c, col, c);
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int cc = col + e < c ? col + e : c - 1;
+        float y = (v.v[e] - mean[cc]) * rsqrtf(var[cc] + eps) * gamma[cc] + beta[cc];
+        if (relu) y = fmaxf(y, 0.f);
+        o[e] = to_half_sat(y);
+    }
+    st8(out + row * c, col, c, o);
+}
+
+// g = da * [bn(z) > 0];  dbeta[col] += sum g ;  dgamma[col] += sum g * xhat
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const half_t* __restrict__ da, const float* __restrict__ z,
+                                                             int64_t m, int c, const float* __restrict__ mean,
+                                                             const float* __restrict__ var, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, int relu,
+                                                             float* __restrict__ dbeta, float* __restrict__ dgamma) {
+    int64_t row0, row1;
+    if (!cr_range(m, row0, row1)) return;
+    const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int col0 = blockIdx.x * CR_COLS, col = col0 + cg * 8;
+    float acc[2][8] = {};
+    if (col < c) {
+        float mu[8], rs[8], ga[8], be[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int cc = col + e < c ? col + e : c - 1;
+            mu[e] = mean[cc]; rs[e] = rsqrtf(var[cc] + eps); ga[e] = gamma[cc]; be[e] = beta[cc];
+        }
+        for (int64_t r = row0 + rl; r < row1; r += CR_LANES) {
+            const f8 zv = ldf8(z + r * c, col, c);
+            const half8 gv = ld8(da + r * c, col, c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xh = (zv.v[e] - mu[e]) * rs[e];
+                const float g = (!relu || xh * ga[e] + be[e] > 0.f) ? (float)gv[e] : 0.f;
+                acc[0][e] += g;
+                acc[1][e] += g * xh;
+            }
+        }
+    }
+    float* const outs[2] = {dbeta, dgamma};
+    cr_finish<2>(acc, outs, col0, c);
+}
+
+// dz = gamma * rstd * (g - dbeta/m - xhat * dgamma/m)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* __restrict__ da, const float* __restrict__ z,
+                                                            int64_t m, int c, const float* __restrict__ mean,
+                                                            const float* __restrict__ var, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps, int relu,
+                                                            const float* __restrict__ dbeta, const float* __restrict__ dgamma,
+                                                            half_t* __restrict__ dz) {
+    const int cgroups = (c + 7) / 8;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m * cgroups) return;
+    const int64_t row = idx / cgroups;
+    const int col = (int)(idx - row * cgroups) * 8;
+    const f8 zv = ldf8(z + row * c, col, c);
+    const half8 gv = ld8(da + row * c, col, c);
+    const float inv_m = 1.f / (float)m;
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int cc = col + e < c ? col + e : c - 1;
+        const float rs = rsqrtf(var[cc] + eps);
+        const float xh = (zv.v[e] - mean[cc]) * rs;
+        const float g = (!relu || xh * gamma[cc] + beta[cc] > 0.f) ? (float)gv[e] : 0.f;
+        o[e] = to_half_sat(gamma[cc] * rs * (g - dbeta[cc] * inv_m - xh * dgamma[cc] * inv_m));
+    }
+    st8(dz + row * c, col, c, o);
+}
+
+// dst[col][row] = src[row][col]; 64 x 64 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_kernel(const half_t* __restrict__ src, int64_t rows, int cols,
+                                                         half_t* __restrict__ dst) {
+    __shared__ half_t tile[64][66];
+    const int64_t r0 = (int64_t)blockIdx.y * 64;
+    const int c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t r = r0 + i;
+        const int cc = c0 + tx;
+        tile[i][tx] = (r < rows && cc < cols) ? src[r * cols + cc] : (half_t)0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int cc = c0 + i;
+        const int64_t r = r0 + tx;
+        if (cc < cols && r < rows) dst[(int64_t)cc * rows + r] = tile[tx][i];
+    }
+}
+
+// per shape and column: max over the n_points rows and the FIRST row index attaining it (torch.max semantics)
+__global__ __launch_bounds__(256) void colmax_argmax_kernel(const half_t* __restrict__ a, int n_points, int c,
+                                                             float* __restrict__ mx, int* __restrict__ arg) {
+    __shared__ float smax[4][64];
+    __shared__ int sarg[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    float best = -INFINITY;
+    int bi = 0;
+    if (col < c) {
+        const half_t* p = a + (int64_t)b * n_points * c + col;
+        for (int n = part; n < n_points; n += 4) {
+            const float v = (float)p[(int64_t)n * c];
+            if (v > best) { best = v; bi = n; }
+        }
+    }
+    smax[part][threadIdx.x & 63] = best;
+    sarg[part][threadIdx.x & 63] = bi;
+    __syncthreads();
+    if (part == 0 && col < c) {
+        for (int q = 1; q < 4; ++q) {
+            const float v = smax[q][threadIdx.x];
+            const int i = sarg[q][threadIdx.x];
+            if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+        }
+        mx[(int64_t)b * c + col] = best;
+        arg[(int64_t)b * c + col] = bi;
+    }
+}
+
+// da[b*n + arg[b][col]][col] = dg[b][col]   (da zero-filled by the caller side of the ABI)
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dg, const int* __restrict__ arg, int n_points, int c,
+                                   int batch, half_t* __restrict__ da) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)batch * c) return;
+    const int b = (int)(i / c), col = (int)(i - (int64_t)b * c);
+    da[((int64_t)b * n_points + arg[i]) * c + col] = to_half_sat(dg[i]);
+}
+
+// z0[m][c] = sum_j x[m][j] w[c][j] + tbias[m / n_points][c]      (enc1.conv1 before its BatchNorm)
+__global__ void enc1_linear_kernel(const float* __restrict__ x, int64_t m, int n_points, const float* __restrict__ w,
+                                   int c, const float* __restrict__ tbias, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m * c) return;
+    const int64_t row = i / c;
+    const int col = (int)(i - row * c);
+    const float* xr = x + row * 3;
+    out[i] = xr[0] * w[col * 3] + xr[1] * w[col * 3 + 1] + xr[2] * w[col * 3 + 2] + tbias[(row / n_points) * c + col];
+}
+
+// out[j][k] += sum_m vec[m][j] * mat[m][k]  (j < 3)  and  vsum[j] += sum_m vec[m][j]
+__global__ __launch_bounds__(256) void vec3_outer_kernel(const half_t* __restrict__ mat, const float* __restrict__ vec,
+                                                          int64_t m, int k, float* __restrict__ out, float* __restrict__ vsum) {
+    int64_t row0, row1;
+    if (!cr_range(m, row0, row1)) return;
+    const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int col0 = blockIdx.x * CR_COLS, col = col0 + cg * 8;
+    float acc[3][8] = {};
+    float vs[3] = {0.f, 0.f, 0.f};
+    for (int64_t r = row0 + rl; r < row1; r += CR_LANES) {
+        const float v0 = vec[r * 3], v1 = vec[r * 3 + 1], v2 = vec[r * 3 + 2];
+        if (blockIdx.x == 0 && cg == 0) { vs[0] += v0; vs[1] += v1; vs[2] += v2; }
+        if (col < k) {
+            const half8 mv = ld8(mat + r * k, col, k);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = (float)mv[e];
+                acc[0][e] += v0 * f; acc[1][e] += v1 * f; acc[2][e] += v2 * f;
+            }
+        }
+    }
+    float* const outs[3] = {out, out + k, out + 2 * k};
+    cr_finish<3>(acc, outs, col0, k);
+    if (vsum != nullptr && blockIdx.x == 0 && cg == 0) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) atomicAdd(vsum + j, vs[j]);
+    }
+}
+
+// out[m][k] = sum_j vec[m][j] * w[j][k]
+__global__ void vec3_expand_kernel(const float* __restrict__ vec, const float* __restrict__ w, int64_t m, int k,
+                                   half_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m * k) return;
+    const int64_t row = i / k;
+    const int col = (int)(i - row * k);
+    out[i] = to_half_sat(vec[row * 3] * w[col] + vec[row * 3 + 1] * w[k + col] + vec[row * 3 + 2] * w[2 * k + col]);
+}
+
+// loss_sum += sum |pred - target| ; dpred = scale * sign(pred - target) / n
+__global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ pred, const float* __restrict__ target, int64_t n,
+                                                  float scale, float* __restrict__ loss_sum, float* __restrict__ dpred) {
+    __shared__ float red[256];
+    float s = 0.f;
+    const float gs = scale / (float)n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = pred[i] - target[i];
+        s += fabsf(d);
+        dpred[i] = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(loss_sum, red[0]);
+}
+
+// C[i][j] (+)= sum_k opA(i,k) * opB(k,j): small fp32 products (time MLP, per-shape bias paths); one thread per output
+__global__ void matmul_f32_kernel(const float* __restrict__ a, int64_t lda, int ta, const float* __restrict__ b, int64_t ldb,
+                                  int tb, int mm, int nn, int kk, const float* __restrict__ bias, int accumulate,
+                                  float* __restrict__ c, int64_t ldc) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)mm * nn) return;
+    const int i = (int)(idx / nn), j = (int)(idx - (int64_t)i * nn);
+    float s = bias != nullptr ? bias[j] : 0.f;
+    for (int k = 0; k < kk; ++k) {
+        const float av = ta ? a[(int64_t)k * lda + i] : a[(int64_t)i * lda + k];
+        const float bv = tb ? b[(int64_t)j * ldb + k] : b[(int64_t)k * ldb + j];
+        s += av * bv;
+    }
+    float* o = c + (int64_t)i * ldc + j;
+    *o = accumulate ? *o + s : s;
+}
+
+__global__ void silu_kernel(const float* x, int64_t n, float* y) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = x[i] / (1.f + expf(-x[i]));
+}
+__global__ void silu_bwd_kernel(const float* x, const float* dy, int64_t n, float* dx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float s = 1.f / (1.f + expf(-x[i]));
+    dx[i] = dy[i] * s * (1.f + x[i] * (1.f - s));
+}
+
+// torch.optim.AdamW (decoupled weight decay), one flat buffer
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2,
+                             int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
+                             float inv_scale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gr = g[i] * inv_scale;
+    float w = p[i];
+    w -= lr * wd * w;
+    const float m = b1 * m1[i] + (1.f - b1) * gr;
+    const float v = b2 * m2[i] + (1.f - b2) * gr * gr;
+    m1[i] = m; m2[i] = v;
+    w -= (lr / bc1) * m / (sqrtf(v) / sqrtf(bc2) + eps);
+    p[i] = w;
+}
+
+static inline dim3 cr_grid(int c, int64_t rows_per_group, int groups) {
+    return dim3((unsigned)ceil_div(c, CR_COLS), (unsigned)ceil_div(rows_per_group, CR_ROWS), (unsigned)groups);
+}
+static inline unsigned nblk256(int64_t n) { return (unsigned)ceil_div(n, 256); }
+
+}  // namespace pcd
+
+using namespace pcd;
+
+extern "C" int pcd_colsum_f16(const void* x, int64_t rows_per_group, int groups, int c, float* out, void* stream) {
+    PCD_CHECK_ARG(x && out && rows_per_group > 0 && groups > 0 && groups <= 65535 && c > 0);
+    hipStream_t s = (hipStream_t)stream;
+    PCD_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)groups * c, s));
+    hipLaunchKernelGGL(colsum_kernel<half_t>, cr_grid(c, rows_per_group, groups), dim3(256), 0, s, (const half_t*)x, rows_per_group, c, out);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_bn_batch_stats(const float* z, int64_t m, int c, float momentum, float* mean, float* var,
+                                  float* running_mean, float* running_var, float* scratch, void* stream) {
+    PCD_CHECK_ARG(z && mean && var && scratch && m > 0 && c > 0 && c % 8 == 0);
+    PCD_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
+    hipStream_t s = (hipStream_t)stream;
+    float *sum = scratch, *sqdev = scratch + c;
+    PCD_CHECK_HIP(hipMemsetAsync(scratch, 0, sizeof(float) * 2 * (size_t)c, s));
+    hipLaunchKernelGGL(colsum_kernel<float>, cr_grid(c, m, 1), dim3(256), 0, s, z, m, c, sum);
+    hipLaunchKernelGGL(coldev_kernel, cr_grid(c, m, 1), dim3(256), 0, s, z, m, c, sum, sqdev);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(nblk256(c)), dim3(256), 0, s, sum, sqdev, m, c, momentum, mean, var,
+                       running_mean, running_var);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_bn_apply_f16(const float* z, int64_t m, int c, const float* mean, const float* var, const float* gamma,
+                                const float* beta, float eps, int relu, void* out, void* stream) {
+    PCD_CHECK_ARG(z && mean && var && gamma && beta && out && m > 0 && c > 0);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk256(m * ceil_div(c, 8))), dim3(256), 0, (hipStream_t)stream, z, m, c,
+                       mean, var, gamma, beta, eps, relu, (half_t*)out);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_bn_backward_f16(const void* da, const float* z, int64_t m, int c, const float* mean, const float* var,
+                                   const float* gamma, const float* beta, float eps, int relu, float* dgamma, float* dbeta,
+                                   void* dz, void* stream) {
+    PCD_CHECK_ARG(da && z && mean && var && gamma && beta && dgamma && dbeta && dz && m > 0 && c > 0);
+    hipStream_t s = (hipStream_t)stream;
+    PCD_CHECK_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * (size_t)c, s));
+    PCD_CHECK_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * (size_t)c, s));
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, cr_grid(c, m, 1), dim3(256), 0, s, (const half_t*)da, z, m, c, mean, var,
+                       gamma, beta, eps, relu, dbeta, dgamma);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk256(m * ceil_div(c, 8))), dim3(256), 0, s, (const half_t*)da, z, m, c,
+                       mean, var, gamma, beta, eps, relu, dbeta, dgamma, (half_t*)dz);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_transpose_f16(const void* src, int64_t rows, int cols, void* dst, void* stream) {
+    PCD_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ceil_div(rows, 64) <= 65535);
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)ceil_div(cols, 64), (unsigned)ceil_div(rows, 64)), dim3(256), 0,
+                       (hipStream_t)stream, (const half_t*)src, rows, cols, (half_t*)dst);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_colmax_argmax_f16(const void* a, int batch, int n_points, int c, float* mx, int* arg, void* stream) {
+    PCD_CHECK_ARG(a && mx && arg && batch > 0 && batch <= 65535 && n_points > 0 && c > 0);
+    hipLaunchKernelGGL(colmax_argmax_kernel, dim3((unsigned)ceil_div(c, 64), (unsigned)batch), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)a, n_points, c, mx, arg);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_maxpool_backward_f16(const float* dg, const int* arg, int batch, int n_points, int c, void* da, void* stream) {
+    PCD_CHECK_ARG(dg && arg && da && batch > 0 && n_points > 0 && c > 0);
+    hipStream_t s = (hipStream_t)stream;
+    PCD_CHECK_HIP(hipMemsetAsync(da, 0, sizeof(half_t) * (size_t)batch * n_points * c, s));
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblk256((int64_t)batch * c)), dim3(256), 0, s, dg, arg, n_points, c, batch, (half_t*)da);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_enc1_linear(const float* x, int64_t m, int n_points, const float* w_xyz, int c1, const float* tbias,
+                               float* out, void* stream) {
+    PCD_CHECK_ARG(x && w_xyz && tbias && out && m > 0 && n_points > 0 && c1 > 0);
+    hipLaunchKernelGGL(enc1_linear_kernel, dim3(nblk256(m * c1)), dim3(256), 0, (hipStream_t)stream, x, m, n_points, w_xyz, c1, tbias, out);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_vec3_outer(const void* mat, const float* vec, int64_t m, int k, float* out, float* vsum, void* stream) {
+    PCD_CHECK_ARG(mat && vec && out && m > 0 && k > 0);
+    hipStream_t s = (hipStream_t)stream;
+    PCD_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float) * 3 * (size_t)k, s));
+    if (vsum != nullptr) PCD_CHECK_HIP(hipMemsetAsync(vsum, 0, sizeof(float) * 3, s));
+    hipLaunchKernelGGL(vec3_outer_kernel, cr_grid(k, m, 1), dim3(256), 0, s, (const half_t*)mat, vec, m, k, out, vsum);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_vec3_expand_f16(const float* vec, const float* w, int64_t m, int k, void* out, void* stream) {
+    PCD_CHECK_ARG(vec && w && out && m > 0 && k > 0);
+    hipLaunchKernelGGL(vec3_expand_kernel, dim3(nblk256(m * k)), dim3(256), 0, (hipStream_t)stream, vec, w, m, k, (half_t*)out);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_l1_loss(const float* pred, const float* target, int64_t n, float grad_scale, float* loss_sum, float* dpred,
+                           void* stream) {
+    PCD_CHECK_ARG(pred && target && loss_sum && dpred && n > 0);
+    hipStream_t s = (hipStream_t)stream;
+    PCD_CHECK_HIP(hipMemsetAsync(loss_sum, 0, sizeof(float), s));
+    const unsigned blocks = (unsigned)(ceil_div(n, 256) < 1024 ? ceil_div(n, 256) : 1024);
+    hipLaunchKernelGGL(l1_kernel, dim3(blocks), dim3(256), 0, s, pred, target, n, grad_scale, loss_sum, dpred);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_matmul_f32(const float* a, int64_t lda, int trans_a, const float* b, int64_t ldb, int trans_b, int m, int n,
+                              int k, const float* bias, int accumulate, float* c, int64_t ldc, void* stream) {
+    PCD_CHECK_ARG(a && b && c && m > 0 && n > 0 && k > 0);
+    hipLaunchKernelGGL(matmul_f32_kernel, dim3(nblk256((int64_t)m * n)), dim3(256), 0, (hipStream_t)stream, a, lda, trans_a, b, ldb,
+                       trans_b, m, n, k, bias, accumulate, c, ldc);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_silu_f32(const float* x, int64_t n, float* y, void* stream) {
+    PCD_CHECK_ARG(x && y && n > 0);
+    hipLaunchKernelGGL(silu_kernel, dim3(nblk256(n)), dim3(256), 0, (hipStream_t)stream, x, n, y);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_silu_backward_f32(const float* x, const float* dy, int64_t n, float* dx, void* stream) {
+    PCD_CHECK_ARG(x && dy && dx && n > 0);
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3(nblk256(n)), dim3(256), 0, (hipStream_t)stream, x, dy, n, dx);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+    PCD_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && n > 0 && step >= 1 && grad_scale > 0.f);
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(nblk256(n)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, lr,
+                       beta1, beta2, eps, weight_decay, bc1, bc2, 1.f / grad_scale);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}

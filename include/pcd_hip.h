@@ -298,6 +298,53 @@ int pcd_sinkhorn_cost(const float* x, const float* y, int batch, int n, int m, c
                       float epsilon, const float* alpha, const float* beta, float* row_scratch,
                       float* cost, void* stream);
 
+/* ------------------------------------------------ training step of the point denoiser
+ * diffusion.py:70-86,170-186 (add_noise -> model in train() mode -> F.l1_loss -> AdamW, diffusion.py:60).
+ * The dense products (forward, backward-data, backward-weight) are pcd_gemm_f16* calls; these entry points
+ * are the BatchNorm1d-with-batch-statistics forward/backward (networks.py:31-48), the max-pool with its
+ * argmax (networks.py:807), the K=3 / C=3 edge layers, reductions, transposes, loss and optimizer.
+ * Activations / activation gradients fp16 [M][C]; statistics, parameter gradients, optimizer state fp32.
+ * Gradients carry the caller's loss scale; pcd_adamw_step divides it out. */
+/* out[g][c] = sum over the rows_per_group rows of group g of x[row][c]   (bias gradients, per-shape sums) */
+int pcd_colsum_f16(const void* x, int64_t rows_per_group, int groups, int c, float* out, void* stream);
+/* BatchNorm1d training statistics over the M rows of the fp32 conv output z [M][c] (c % 8 == 0): mean[c], biased
+ * var[c] (two passes); if running_* are given they are updated as torch does (momentum, UNBIASED variance).
+ * scratch: fp32 [2*c]. */
+int pcd_bn_batch_stats(const float* z, int64_t m, int c, float momentum, float* mean, float* var,
+                       float* running_mean, float* running_var, float* scratch, void* stream);
+/* a = act(gamma * (z - mean) / sqrt(var + eps) + beta) -> fp16, act = ReLU if relu; z fp32 */
+int pcd_bn_apply_f16(const float* z, int64_t m, int c, const float* mean, const float* var, const float* gamma,
+                     const float* beta, float eps, int relu, void* out, void* stream);
+/* backward of pcd_bn_apply_f16 with batch statistics: da -> dz, dgamma[c], dbeta[c] */
+int pcd_bn_backward_f16(const void* da, const float* z, int64_t m, int c, const float* mean, const float* var,
+                        const float* gamma, const float* beta, float eps, int relu, float* dgamma, float* dbeta,
+                        void* dz, void* stream);
+/* dst[c][r] = src[r][c]  (operands of the backward-weight product dW = dz^T a) */
+int pcd_transpose_f16(const void* src, int64_t rows, int cols, void* dst, void* stream);
+/* torch.max(x, 2) of networks.py:807 on a [B*N][C]: per shape and channel the max and the FIRST index attaining it */
+int pcd_colmax_argmax_f16(const void* a, int batch, int n_points, int c, float* mx, int* arg, void* stream);
+/* its backward: da = 0 except da[b*N + arg[b][c]][c] = dg[b][c] */
+int pcd_maxpool_backward_f16(const float* dg, const int* arg, int batch, int n_points, int c, void* da, void* stream);
+/* enc1.conv1 before its BatchNorm: z[m][c] = sum_j x[m][j] w_xyz[c][j] + tbias[m / n_points][c]; x fp32 [M][3], z fp32 */
+int pcd_enc1_linear(const float* x, int64_t m, int n_points, const float* w_xyz, int c1, const float* tbias,
+                    float* out, void* stream);
+/* out[j][k] = sum_m vec[m][j] * mat[m][k], j < 3 (dW of the 64->3 head and of enc1's xyz columns); vsum[j] = sum_m vec[m][j] or NULL */
+int pcd_vec3_outer(const void* mat, const float* vec, int64_t m, int k, float* out, float* vsum, void* stream);
+/* out[m][k] = sum_j vec[m][j] * w[j][k]  (backward-data of the 64->3 head) */
+int pcd_vec3_expand_f16(const float* vec, const float* w, int64_t m, int k, void* out, void* stream);
+/* F.l1_loss(noise, pred) of diffusion.py:182: loss_sum[0] = sum |pred - target| (divide by n on the host),
+ * dpred = grad_scale * sign(pred - target) / n */
+int pcd_l1_loss(const float* pred, const float* target, int64_t n, float grad_scale, float* loss_sum, float* dpred,
+                void* stream);
+/* small fp32 product C[m][n] (+)= op(A)[m][k] op(B)[k][n] + bias[n]: time_mlp and the per-shape bias paths */
+int pcd_matmul_f32(const float* a, int64_t lda, int trans_a, const float* b, int64_t ldb, int trans_b, int m, int n,
+                   int k, const float* bias, int accumulate, float* c, int64_t ldc, void* stream);
+int pcd_silu_f32(const float* x, int64_t n, float* y, void* stream);
+int pcd_silu_backward_f32(const float* x, const float* dy, int64_t n, float* dx, void* stream);
+/* torch.optim.AdamW step on one flat fp32 buffer (diffusion.py:60: lr, weight_decay 1e-5); grads are divided by grad_scale */
+int pcd_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

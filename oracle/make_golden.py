@@ -11,7 +11,8 @@ never depend on a torch RNG stream.
 
 Fixture map: G1 schedule.npz, G2-G4 point_unet.npz,
 G5-G7 point_samplers.npz, G8 latent.npz, G9 metrics.npz, G10 attention.npz; beyond the survey's list:
-G11 vae3d_small.npz (`make_golden.py vae3d`), G12 data.npz (`make_golden.py data`).
+G11 vae3d_small.npz (`make_golden.py vae3d`), G12 data.npz (`make_golden.py data`), G13 train.npz
+(`make_golden.py train`).
 """
 from __future__ import annotations
 
@@ -140,10 +141,63 @@ def capture_data():
     print("data done:", {k: v.shape for k, v in g.items()})
 
 
+def grad_digest(name, g):
+    """Small fingerprint of one gradient tensor: L2 norm, sum, and 64 entries at hash-chosen flat indices."""
+    flat = g.reshape(-1).double()
+    idx = (np.abs(specs.hash_uniform("digest." + name, 64, 7)) * (flat.numel() - 1)).astype(np.int64)
+    return np.concatenate([[flat.norm().item(), flat.sum().item()], flat[torch.from_numpy(idx)].numpy()]), idx
+
+
+def capture_train(rd):
+    """G13: one training step of PointCloudDiffusion (diffusion.py:70-86,170-186 + AdamW of :60) ->
+    tests/golden/train.npz.  Gradients are stored as digests (norm, sum, 64 sampled entries per tensor)."""
+    pspec = specs.unet_pointnet_large_spec(prefix="model.")
+    pcd = rd.PointCloudDiffusion(num_points=128)
+    pcd.load_state_dict(T(specs.synth_state_dict(pspec, seed=0, gain=POINT_GAIN)), strict=True)
+    pcd.train()
+    x0 = torch.from_numpy(synth_cloud(2, 128, 21))
+    t = torch.tensor([0.35, 0.8])
+    torch.manual_seed(5)
+    noise_replay = torch.randn_like(x0)
+    torch.manual_seed(5)
+    with torch.enable_grad():
+        x_t, noise, _, _ = pcd.add_noise(x0, t)
+        assert torch.equal(noise, noise_replay)
+        pred = pcd.model(x_t, t)
+        loss = torch.nn.functional.l1_loss(noise, pred)
+        # the optimizer of configure_optimizers (diffusion.py:60) built directly: the scheduler line next to it
+        # passes verbose=True, which torch 2.10's ReduceLROnPlateau no longer accepts (version skew, SURVEY 8(c))
+        opt = torch.optim.AdamW(pcd.parameters(), lr=pcd.lr, weight_decay=1e-5)
+        opt.zero_grad()
+        loss.backward()
+    g = {"x0": x0.numpy(), "t": t.numpy(), "noise": noise.numpy(), "x_t": x_t.detach().numpy(), "loss": loss.item(),
+         "pred": pred.detach().numpy()}
+    names = []
+    for k, prm in pcd.named_parameters():
+        d, idx = grad_digest(k, prm.grad)
+        g["grad." + k] = d
+        names.append(k)
+    opt.step()
+    for k, prm in pcd.named_parameters():
+        flat = prm.detach().reshape(-1).double()
+        idx = (np.abs(specs.hash_uniform("digest." + k, 64, 7)) * (flat.numel() - 1)).astype(np.int64)
+        g["param1." + k] = flat[torch.from_numpy(idx)].numpy()
+    for k, v in pcd.state_dict().items():
+        if k.endswith(("running_mean", "running_var")):
+            g["buf1." + k] = v.numpy()
+    g["param_names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "train.npz"), **g)
+    print("train done: loss", loss.item(), "entries", len(g))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if "data" in sys.argv[1:]:
         capture_data()
+        return
+    if "train" in sys.argv[1:]:
+        rd, rn, rm, ru = ref_shim.load_reference()
+        capture_train(rd)
         return
     rd, rn, rm, ru = ref_shim.load_reference()
     torch.set_grad_enabled(False)

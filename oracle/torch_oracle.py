@@ -70,7 +70,14 @@ def time_mlp(sd: SD, p: str, emb: torch.Tensor) -> torch.Tensor:
 
 
 # -------------------------------------------------------------- point layers
+_BN_TRAIN = False   # set by unet_pointnet_large(train=True): nn.BatchNorm1d in train() mode
+
+
 def _bn_eval(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    if _BN_TRAIN:   # batch statistics; running estimates updated in place (momentum 0.1, unbiased variance)
+        sd[p + ".num_batches_tracked"] += 1
+        return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"],
+                            sd[p + ".weight"], sd[p + ".bias"], True, 0.1, 1e-5)
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"],
                         sd[p + ".weight"], sd[p + ".bias"], False, 0.0, 1e-5)
 
@@ -84,8 +91,16 @@ def pointnet_layer(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
 
 
 def unet_pointnet_large(sd: SD, p: str, x: torch.Tensor, t: torch.Tensor,
-                        time_dim: int = 256, taps: Optional[dict] = None) -> torch.Tensor:
-    """networks.py:779-818.  x (B,N,3), t (B,) -> predicted noise (B,N,3)."""
+                        time_dim: int = 256, taps: Optional[dict] = None, train: bool = False) -> torch.Tensor:
+    """networks.py:779-818.  x (B,N,3), t (B,) -> predicted noise (B,N,3).  train=True: the module in train()
+    mode (BatchNorm batch statistics; sd's running_* / num_batches_tracked entries are updated in place)."""
+    global _BN_TRAIN
+    if train != _BN_TRAIN:
+        _BN_TRAIN = train
+        try:
+            return unet_pointnet_large(sd, p, x, t, time_dim, taps, train)
+        finally:
+            _BN_TRAIN = False
     n = x.shape[1]
     temb = time_mlp(sd, p, timestep_embedding(t, time_dim))
     h = torch.cat([x.transpose(2, 1), temb.unsqueeze(2).expand(-1, -1, n)], dim=1)
@@ -454,3 +469,42 @@ def compute_metrics(gen, ref, use_approximate_gpu_emd=False):
     emd = (earth_mover_distance_sinkhorn if use_approximate_gpu_emd else earth_mover_distance_cpu)(gen, ref)
     rec = F.binary_cross_entropy(voxelize(gen), voxelize(ref))
     return cd, emd, rec
+
+
+# ------------------------------------------------------------------ training step (diffusion.py:56-86,170-186)
+def point_training_step(sd: SD, p: str, x_t: torch.Tensor, t: torch.Tensor, noise: torch.Tensor):
+    """diffusion_loss after add_noise: loss = F.l1_loss(noise, model(x_t, t)) with the model in train() mode, and
+    its gradients by autograd.  Returns (loss, {key: grad}); sd's BatchNorm running statistics are updated in
+    place like the reference's buffers.  Parameters = every floating entry that is not a running statistic."""
+    work = dict(sd)
+    leaves = {}
+    for k, v in sd.items():
+        if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+            leaves[k] = v.detach().clone().requires_grad_(True)
+            work[k] = leaves[k]
+    with torch.enable_grad():
+        pred = unet_pointnet_large(work, p, x_t, t, train=True)
+        loss = F.l1_loss(noise, pred)
+        loss.backward()
+    for k in sd:
+        if k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            sd[k] = work[k]
+    return loss.detach(), {k: v.grad for k, v in leaves.items()}
+
+
+def adamw_step(params: SD, grads: SD, state: dict, lr: float = 1e-4, weight_decay: float = 1e-5,
+               betas=(0.9, 0.999), eps: float = 1e-8) -> None:
+    """torch.optim.AdamW as configured at diffusion.py:60, restated: decoupled decay, bias-corrected moments."""
+    state["step"] = state.get("step", 0) + 1
+    b1, b2 = betas
+    bc1, bc2 = 1 - b1 ** state["step"], 1 - b2 ** state["step"]
+    for k, w in params.items():
+        if k not in grads:
+            continue
+        g = grads[k]
+        m = state.setdefault("m", {}).setdefault(k, torch.zeros_like(w))
+        v = state.setdefault("v", {}).setdefault(k, torch.zeros_like(w))
+        w.mul_(1 - lr * weight_decay)
+        m.lerp_(g, 1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        w.addcdiv_(m, (v.sqrt() / bc2 ** 0.5).add_(eps), value=-lr / bc1)

@@ -1,0 +1,46 @@
+"""Pins the training-step restatement in oracle/torch_oracle.py (`point_training_step`, `adamw_step`) against
+tests/golden/train.npz, captured from the reference's PointCloudDiffusion in train() mode with autograd and
+torch.optim.AdamW (`python oracle/make_golden.py train`).  Same ATen ops => tight tolerances."""
+import numpy as np
+import torch
+
+from helpers import point_sd
+from oracle import torch_oracle as O
+from shapegen_amd import specs
+
+
+def _digest_idx(name, numel):
+    return (np.abs(specs.hash_uniform("digest." + name, 64, 7)) * (numel - 1)).astype(np.int64)
+
+
+def test_training_step_matches_reference(golden):
+    g = golden("train.npz")
+    sd = point_sd()
+    nbt0 = {k: int(v) for k, v in sd.items() if k.endswith("num_batches_tracked")}
+    x_t, t, noise = (torch.from_numpy(g[k]) for k in ("x_t", "t", "noise"))
+    xt2 = O.add_noise(torch.from_numpy(g["x0"]), t, noise)[0]
+    assert torch.equal(xt2, x_t)
+    loss, grads = O.point_training_step(sd, "model.", x_t, t, noise)
+    assert abs(loss.item() - float(g["loss"])) <= 1e-6
+    names = [str(n) for n in g["param_names"]]
+    assert sorted(names) == sorted(grads.keys())
+    for k in names:
+        flat = grads[k].reshape(-1).double()
+        want = g["grad." + k]
+        got = np.concatenate([[flat.norm().item(), flat.sum().item()], flat[torch.from_numpy(_digest_idx(k, flat.numel()))].numpy()])
+        scale = max(want[0], 1e-12)
+        assert np.abs(got[0] - want[0]) <= 1e-4 * scale, k
+        assert np.abs(got[2:] - want[2:]).max() <= 1e-4 * max(np.abs(want[2:]).max(), 1e-3 * scale / flat.numel() ** 0.5) + 1e-9, k
+    # BatchNorm running statistics after the step
+    for k, v in sd.items():
+        if k.endswith(("running_mean", "running_var")):
+            assert np.allclose(v.numpy(), g["buf1." + k], rtol=1e-5, atol=1e-6), k
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == nbt0[k] + 1
+    # one AdamW update (diffusion.py:60)
+    params = {k: sd[k] for k in names}
+    O.adamw_step(params, grads, {}, lr=1e-4, weight_decay=1e-5)
+    for k in names:
+        flat = params[k].reshape(-1).double()
+        got = flat[torch.from_numpy(_digest_idx(k, flat.numel()))].numpy()
+        assert np.abs(got - g["param1." + k]).max() <= 2e-6, k
