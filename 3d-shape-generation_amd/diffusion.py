@@ -305,6 +305,45 @@ class PointCloudDiffusion(_DiffusionBase):
     def _forward_fn(self):
         return lambda x, tb_cur, eps: self.model.forward_with_bias(x, tb_cur, 0, out=eps)
 
+    # ------------------------------------------------------------------ training surface (diffusion.py:56-86, 170-186)
+    def configure_optimizers(self):
+        """AdamW(lr, weight_decay=1e-5) + ReduceLROnPlateau(min, factor 0.5, patience 5) on `val_loss`
+        (diffusion.py:60-68); the optimizer object is the HIP trainer, which also owns forward/backward."""
+        from .training import PointTrainer, ReduceLROnPlateau
+        if getattr(self, "_trainer", None) is None:
+            self._trainer = PointTrainer(self.model, lr=self.lr, weight_decay=1e-5)
+        return {"optimizer": self._trainer,
+                "lr_scheduler": {"scheduler": ReduceLROnPlateau(self._trainer, factor=0.5, patience=5), "monitor": "val_loss"}}
+
+    def diffusion_loss(self, x_0, t, noise=None):
+        """diffusion.py:170-186: L1 between the drawn noise and the prediction at x_t.  In train() mode the forward
+        uses batch statistics and the parameter gradients are left in the trainer (loss and backward are one pass:
+        there is no autograd graph to keep); in eval() mode it is the sampler's folded forward."""
+        x_t, noise, _, _ = self.add_noise(x_0, t, noise)
+        if self.training:
+            tr = self.configure_optimizers()["optimizer"]
+            tr.forward(x_t, t.to(self.device, torch.float32))
+            return tr.backward(noise)
+        pred = self.model(x_t, t.to(self.device, torch.float32))
+        lib = _lib.load()
+        out = torch.empty(1, dtype=torch.float32, device=self.device)
+        scratch = torch.empty_like(pred)
+        _lib.check(lib.pcd_l1_loss(pred.data_ptr(), noise.data_ptr(), pred.numel(), 1.0, out.data_ptr(), scratch.data_ptr(),
+                                   _lib.stream_ptr()), "l1_loss")
+        return out[0] / pred.numel()
+
+    def training_step(self, batch, batch_idx=0):
+        """diffusion.py:70-86: t ~ U(0,1) per shape; returns the loss (gradients are ready for `optimizer.step`)."""
+        x_0 = batch.to(self.device)
+        t = torch.rand(x_0.shape[0], device=self.device)
+        return self.diffusion_loss(x_0, t)
+
+    def validation_step(self, batch, batch_idx=0):
+        """diffusion.py:88-100 (loss part; the TensorBoard figures of :106-135 are not reproduced)."""
+        x_0 = batch.to(self.device)
+        t = torch.rand(x_0.shape[0], device=self.device)
+        return self.diffusion_loss(x_0, t)
+
     def _start(self, num_samples, num_points, x_T):
         self.eval()
         self._require_cuda(x_T)

@@ -424,3 +424,89 @@ class PointTrainer:
         loss = self.backward(noise)
         self.optimizer_step()
         return loss
+
+
+    # torch.optim-like aliases so the object can stand where the reference's optimizer does
+    def step(self):
+        self.optimizer_step()
+
+    def zero_grad(self):
+        pass                                # every backward overwrites the whole gradient buffer
+
+    def state_dict(self):
+        return {"step": self.step_count, "lr": self.lr, "exp_avg": self.M1, "exp_avg_sq": self.M2}
+
+
+class ReduceLROnPlateau:
+    """torch.optim.lr_scheduler.ReduceLROnPlateau(mode='min', factor, patience) as configured at diffusion.py:61,
+    restated for the trainer (threshold 1e-4 relative, cooldown 0, min_lr 0: torch's defaults)."""
+
+    def __init__(self, trainer: PointTrainer, factor: float = 0.5, patience: int = 5, threshold: float = 1e-4):
+        self.trainer, self.factor, self.patience, self.threshold = trainer, factor, patience, threshold
+        self.best, self.bad = float("inf"), 0
+
+    def step(self, metric: float) -> None:
+        if metric < self.best * (1.0 - self.threshold):
+            self.best, self.bad = metric, 0
+        else:
+            self.bad += 1
+        if self.bad > self.patience:
+            self.trainer.lr *= self.factor
+            self.bad = 0
+
+
+def save_checkpoint(model, path: str, epoch: int, extra: Optional[dict] = None) -> None:
+    """A `.ckpt` in the layout the reference's Lightning checkpoints have (`state_dict` + `hyper_parameters`),
+    which `PointCloudDiffusion.load_from_checkpoint` of either code base reads back."""
+    import os
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    payload = {"state_dict": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
+               "hyper_parameters": dict(model.hparams), "epoch": epoch}
+    payload.update(extra or {})
+    torch.save(payload, path)
+
+
+def fit(model, data_module, max_epochs: int = 500, ckpt_dir: Optional[str] = None, log=print, max_steps: Optional[int] = None,
+        save_top_k: int = 10):
+    """What `pl.Trainer(max_epochs=...).fit(model, data_module)` does for the reference's train_point_ddpm.py:78-87:
+    epochs of training_step + optimizer step, then validation_step over the validation loader in eval() mode, the
+    plateau scheduler on the mean `val_loss`, and the `save_top_k` best checkpoints by it (train_point_ddpm.py:60-66)."""
+    cfg = model.configure_optimizers()
+    opt, sched = cfg["optimizer"], cfg["lr_scheduler"]["scheduler"]
+    data_module.setup()
+    kept: List[Tuple[float, str]] = []
+    steps = 0
+    history = []
+    for epoch in range(max_epochs):
+        model.train()
+        tl = []
+        for i, batch in enumerate(data_module.train_dataloader()):
+            if batch.shape[0] * batch.shape[1] % 64:
+                continue                       # ragged last batch: the backward-weight GEMM reduces over B*N in 64s
+            loss = model.training_step(batch, i)
+            opt.step()
+            tl.append(loss)
+            steps += 1
+            if max_steps is not None and steps >= max_steps:
+                break
+        model.eval()
+        vl = [model.validation_step(b, i) for i, b in enumerate(data_module.val_dataloader())]
+        train_loss = float(torch.stack(tl).mean()) if tl else float("nan")
+        val_loss = float(torch.stack(vl).mean()) if vl else train_loss
+        sched.step(val_loss)
+        history.append((epoch, train_loss, val_loss, opt.lr))
+        log(f"epoch {epoch}: train_loss {train_loss:.4f} val_loss {val_loss:.4f} lr {opt.lr:.2e}")
+        if ckpt_dir is not None:
+            import os
+            path = os.path.join(ckpt_dir, f"point_cloud_diffusion-epoch={epoch:02d}-val_loss={val_loss:.2f}.ckpt")
+            if len(kept) < save_top_k or val_loss < max(kept)[0]:
+                save_checkpoint(model, path, epoch)
+                kept.append((val_loss, path))
+                kept.sort()
+                for _, old in kept[save_top_k:]:
+                    if os.path.exists(old) and old != path:
+                        os.remove(old)
+                kept = kept[:save_top_k]
+        if max_steps is not None and steps >= max_steps:
+            break
+    return history

@@ -41,6 +41,22 @@ def test_train_entry_scripts_sampling_tails(tmp_path):
     assert "Generated 10 VAE samples" in out and "Generated 10 diffusion denoised samples" in out
     z = np.load(tmp_path / "s" / "latent_diffusion_samples.npz")
     assert len(z.files) == 10 and all(z[k].shape[1] == 3 for k in z.files)
-    out = _run([os.path.join(ROOT, "train_point_ddpm.py"), "--num-points", "256", "--steps", "20", "--out", str(tmp_path / "p")],
-               str(tmp_path))
+
+
+def test_train_point_ddpm_trains_checkpoints_and_samples(tmp_path):
+    """train_point_ddpm.py end to end on synthetic clouds: two short epochs on the HIP trainer, top-k checkpoints in
+    the reference's layout, reload through the Lightning-free loader, then the sampling tail."""
+    import glob
+    import torch
+    _run([os.path.join(ROOT, "train_point_ddpm.py"), "--num-points", "256", "--batch-size", "8", "--synthetic-shapes", "40",
+          "--epochs", "2", "--sample-steps", "20", "--out", str(tmp_path / "p"), "--data-dir", str(tmp_path / "none")], str(tmp_path))
     assert np.load(tmp_path / "p" / "samples.npy").shape == (10, 256, 3)
+    log = open(glob.glob(str(tmp_path / "train" / "logs" / "*.log"))[0]).read()
+    assert "epoch 0: train_loss" in log and "epoch 1: train_loss" in log
+    ckpts = sorted(glob.glob(str(tmp_path / "checkpoints" / "point_ddpm" / "*" / "*.ckpt")))
+    assert len(ckpts) == 2
+    ck = torch.load(ckpts[-1], map_location="cpu", weights_only=False)
+    assert ck["hyper_parameters"]["num_points"] == 256 and len(ck["state_dict"]) == 203
+    from shapegen_amd.diffusion import PointCloudDiffusion
+    m = PointCloudDiffusion.load_from_checkpoint(ckpts[-1])
+    assert int(m.state_dict()["model.enc1.bn1.num_batches_tracked"]) == 8       # 2 epochs x 4 batches of 8
