@@ -68,6 +68,8 @@ _SIGS = {
     "pcd_device_check": (i32, []),
     "pcd_gemm_f16": (i32, [C.POINTER(GemmDesc), vp, i64, vp]),
     "pcd_gemm_f16_out32": (i32, [C.POINTER(GemmDesc), vp, i64, vp]),
+    "pcd_gemm_f16_splitk": (i32, [C.POINTER(GemmDesc), i32, vp, vp]),
+    "pcd_sum_slabs_f32": (i32, [vp, i32, i64, i32, vp, i64, vp]),
     "pcd_gemm_f16_residual": (i32, [C.POINTER(GemmDesc), vp, i64, vp, i64, vp]),
     "pcd_gemm_f16_colmax": (i32, [C.POINTER(GemmDesc), vp, i32, vp]),
     "pcd_gemm_set_config": (i32, [i32]),

@@ -28,6 +28,9 @@ struct GemmParams {
     int tiles_m; int tiles_n;
     int stagger;   // debug probe only (PCD_EPI_PROBE)
     int patch_pn, patch_xn;   // XCD patch mapping (0 = linear tile order)
+    // split-K (EPI_F32 only): `splits` independent products over consecutive k1-deep slices of the reduction;
+    // slice s reads A and W at column offset s*k1 and writes the fp32 slab out32 + s*split_out
+    int splits; int64_t split_out;
 };
 
 constexpr int BK = 64;          // K granularity required by the API (k1, k2 multiples of 64)
@@ -104,16 +107,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
     // Persistent blocks: block b walks tiles b, b + gridDim.x, ... (n fastest, so neighbouring blocks share
     // the activation row panel).  The first K tile of the NEXT output tile is requested before the epilogue
     // of the current one, so its load latency and the store tail overlap.
-    const int ntiles = p.tiles_m * p.tiles_n;
+    const int tiles_mn = p.tiles_m * p.tiles_n;
+    const int ntiles = tiles_mn * p.splits;
     const int nk1 = p.k1 / BKT, nk = (p.k1 + p.k2) / BKT;
 
     f32x4 acc[MI][NI];
 
-    auto stage = [&](int m0, int n0, int kt, int buf) {
+    auto stage = [&](int m0, int n0, int kt, int buf, int split = 0) {
         char* base = smem + buf * STAGE_BYTES;
-        if (kt < nk1) stage_rows<BM, NT, BKT>(p.a1, p.lda1, m0, p.m, kt * BKT, base, wave, lane);
+        const int64_t koff = (int64_t)split * p.k1;          // split-K: slice `split` of the reduction (k2 == 0 then)
+        if (kt < nk1) stage_rows<BM, NT, BKT>(p.a1 + koff, p.lda1, m0, p.m, kt * BKT, base, wave, lane);
         else          stage_rows<BM, NT, BKT>(p.a2, p.lda2, m0, p.m, (kt - nk1) * BKT, base, wave, lane);
-        stage_rows<BN, NT, BKT>(p.w, p.ldw, n0, p.c, kt * BKT, base + BM * ROWB, wave, lane);
+        stage_rows<BN, NT, BKT>(p.w + koff, p.ldw, n0, p.c, kt * BKT, base + BM * ROWB, wave, lane);
     };
 
     // per-lane fragment read offsets (bytes) inside a staged tile
@@ -150,7 +155,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
     // persistent grid of 256 blocks is dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2);
     // within each round of 256 tiles XCD x owns a pm x pn patch (pm*pn = 32), so its L2 streams pm + pn
     // operand panels instead of up to 32 + 1.
-    auto tile_coords = [&](int tile, int& tm, int& tn) {
+    auto tile_coords = [&](int tile, int& tm, int& tn, int& split) {
+        split = 0;
+        if (p.splits > 1) { split = tile / tiles_mn; tile -= split * tiles_mn; }
         if (gridDim.x == 256 && p.patch_pn > 0) {
             const int pn = p.patch_pn, pm = 32 / pn, xn = p.patch_xn, xm = 8 / xn;
             const int round = tile >> 8, b = tile & 255;
@@ -168,13 +175,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
     int it = 0;                      // K tiles consumed so far by this block (LDS ring position)
     bool counted_wait = false;       // previous epilogue issued exactly MI*NI/2 stores after the prefetch
     if constexpr (XPREF) {
-        int tm0, tn0;
-        tile_coords(blockIdx.x, tm0, tn0);
-        stage(tm0 * BM, tn0 * BN, 0, 0);
+        int tm0, tn0, sp0;
+        tile_coords(blockIdx.x, tm0, tn0, sp0);
+        stage(tm0 * BM, tn0 * BN, 0, 0, sp0);
     }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    int tm, tn;
-    tile_coords(tile, tm, tn);
+    int tm, tn, sp;
+    tile_coords(tile, tm, tn, sp);
     const int m0 = tm * BM, n0 = tn * BN;
     const int next = tile + (int)gridDim.x;
 #pragma unroll
@@ -185,18 +192,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
     if constexpr (STAGES == 2) {
         if constexpr (!XPREF) {
             __builtin_amdgcn_s_barrier();      // every wave is done reading the previous tile's LDS stages
-            stage(m0, n0, 0, it & 1);
+            stage(m0, n0, 0, it & 1, sp);
         }
         for (int kt = 0; kt < nk; ++kt) {
             // the loads of this K tile are OLDER than the previous tile's epilogue stores: a counted wait
             // retires the loads and leaves the stores draining (vmcnt counts loads and stores in issue order)
             if (kt == 0 && counted_wait) wait_vmcnt<MI * NI / 2>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();   // raw: __syncthreads() would add its own vmcnt(0) while an LDS-DMA is pending
-            if (kt + 1 < nk) stage(m0, n0, kt + 1, (it + 1) & 1);
+            if (kt + 1 < nk) stage(m0, n0, kt + 1, (it + 1) & 1, sp);
             else if (XPREF && next < ntiles) {
-                int tm2, tn2;
-                tile_coords(next, tm2, tn2);
-                stage(tm2 * BM, tn2 * BN, 0, (it + 1) & 1);
+                int tm2, tn2, sp2;
+                tile_coords(next, tm2, tn2, sp2);
+                stage(tm2 * BM, tn2 * BN, 0, (it + 1) & 1, sp2);
             }
             compute(smem + (it & 1) * STAGE_BYTES);
             ++it;
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < STAGES - 1; ++t)
-            if (t < nk) stage(m0, n0, t, t);
+            if (t < nk) stage(m0, n0, t, t, sp);
         int buf = 0;
         for (int kt = 0; kt < nk; ++kt) {
             // tiles issued so far: min(kt + STAGES - 1, nk); tile kt must have landed, younger ones may fly
@@ -218,7 +225,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
             if (kt + STAGES - 1 < nk) {
                 int nb = buf + STAGES - 1;
                 nb = nb >= STAGES ? nb - STAGES : nb;
-                stage(m0, n0, kt + STAGES - 1, nb);
+                stage(m0, n0, kt + STAGES - 1, nb, sp);
             }
             compute(smem + buf * STAGE_BYTES);
             buf = buf + 1 == STAGES ? 0 : buf + 1;
@@ -358,7 +365,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
                         if (sb_generic != nullptr)
                             v += sb_generic[(int64_t)(row / p.rows_per_shape) * p.c + col];
                         if (p.relu) v = fmaxf(v, 0.f);
-                        p.out32[(int64_t)row * p.ldo + col] = v;
+                        p.out32[(int64_t)sp * p.split_out + (int64_t)row * p.ldo + col] = v;
                     }
                 }
     }
@@ -381,13 +388,14 @@ static int launch(const GemmParams& p0, hipStream_t s, int blocks_per_cu) {
     GemmParams p = p0;
     p.tiles_m = (int)ceil_div(p.m, BM);
     p.tiles_n = (int)ceil_div(p.c, BN);
-    const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n;
+    if (p.splits < 1) p.splits = 1;
+    const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n * p.splits;
     if (tiles <= 0 || tiles > 0x7fffffff) { set_error("gemm: grid out of range"); return PCD_ERR_ARG; }
     // persistent grid: as many blocks as are resident at once, each walking tiles b, b + grid, ...
     const int64_t resident = (int64_t)num_cus() * blocks_per_cu;
     const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
     p.patch_pn = p.patch_xn = 0;
-    if (grid == 256 && tiles % 256 == 0) {
+    if (grid == 256 && tiles % 256 == 0 && p.splits == 1) {
         const int pn = p.tiles_n >= 8 ? 8 : p.tiles_n;               // 8, 4, 2 or 1 column tiles per patch
         const int xn = p.tiles_n >= 16 ? 2 : 1;
         if ((pn & (pn - 1)) == 0 && p.tiles_n % (xn * pn) == 0 && p.tiles_m % ((8 / xn) * (32 / pn)) == 0) {
@@ -471,6 +479,39 @@ extern "C" int pcd_gemm_f16_out32(const pcd_gemm_desc_t* d, float* out, int64_t 
     PCD_CHECK_ARG(out != nullptr && ldo >= d->c);
     p.out32 = out; p.ldo = ldo;
     return dispatch<EPI_F32>(p, (hipStream_t)stream);
+}
+
+// split-K: slabs[s][m][c] = A[:, s*K/S : (s+1)*K/S] W[:, same]^T ; pcd_sum_slabs_f32 adds them in a fixed order
+extern "C" int pcd_gemm_f16_splitk(const pcd_gemm_desc_t* d, int splits, float* slabs, void* stream) {
+    GemmParams p;
+    int rc = fill(d, p);
+    if (rc) return rc;
+    PCD_CHECK_ARG(slabs != nullptr && splits >= 1 && d->k2 == 0 && d->bias == nullptr && d->shape_bias == nullptr && d->relu == 0);
+    PCD_CHECK_ARG(d->k1 % splits == 0 && (d->k1 / splits) % BK == 0);
+    p.k1 = d->k1 / splits;
+    p.splits = splits;
+    p.out32 = slabs; p.ldo = d->c; p.split_out = (int64_t)d->m * d->c;
+    return dispatch<EPI_F32>(p, (hipStream_t)stream);
+}
+
+namespace pcd {
+__global__ void sum_slabs_kernel(const float* __restrict__ slabs, int nslabs, int64_t rows, int cols, float* __restrict__ out,
+                                 int64_t ldo) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    float s = 0.f;
+    for (int k = 0; k < nslabs; ++k) s += slabs[(int64_t)k * rows * cols + i];
+    const int64_t r = i / cols;
+    out[r * ldo + (i - r * cols)] = s;
+}
+}  // namespace pcd
+
+extern "C" int pcd_sum_slabs_f32(const float* slabs, int nslabs, int64_t rows, int cols, float* out, int64_t ldo, void* stream) {
+    PCD_CHECK_ARG(slabs && out && nslabs >= 1 && rows > 0 && cols > 0 && ldo >= cols);
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)ceil_div(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, slabs, nslabs,
+                       rows, cols, out, ldo);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
 }
 
 extern "C" int pcd_gemm_f16_residual(const pcd_gemm_desc_t* d, const void* resid, int64_t ldr,

@@ -284,7 +284,20 @@ class PointTrainer:
             # dW[:, col:col+k] = dz^T a_in : rows = C, reduction = M, columns = k
             self._chk(lib.pcd_transpose_f16(a_in.data_ptr(), m, k, aT.data_ptr(), st), "transpose")
             g = _gemm_desc(dzT.data_ptr(), m, m, None, 0, 0, aT.data_ptr(), m, None, None, 0, c, k)
-            self._chk(lib.pcd_gemm_f16_out32(C.byref(g), gw.data_ptr() + col * 4, ktot, st), "gemm_dW")
+            # a C x k output is a handful of tiles with an M-deep reduction: split the reduction so that one launch
+            # carries >= ~512 tiles, then add the fp32 slabs in a fixed order
+            tiles = -(-c // 128) * -(-k // 128)
+            splits = 1
+            while splits * tiles < 512 and (m // 64) % (splits * 2) == 0 and m // (splits * 2) >= 256:
+                splits *= 2
+            if splits == 1:
+                self._chk(lib.pcd_gemm_f16_out32(C.byref(g), gw.data_ptr() + col * 4, ktot, st), "gemm_dW")
+            else:
+                slabs = self._buf("bwd.slabs", (16 * 1024 * 1024,), torch.float32)
+                if splits * c * k > slabs.numel():
+                    slabs = self._buf("bwd.slabs", (splits * c * k,), torch.float32)
+                self._chk(lib.pcd_gemm_f16_splitk(C.byref(g), splits, slabs.data_ptr(), st), "gemm_dW_splitk")
+                self._chk(lib.pcd_sum_slabs_f32(slabs.data_ptr(), splits, c, k, gw.data_ptr() + col * 4, ktot, st), "sum_slabs")
             if tgt is not None:
                 mode, dst = tgt
                 # da_in = dz W[:, col:col+k] : the rows [row, row+k) of W^T

@@ -61,6 +61,12 @@ typedef struct {
 int pcd_gemm_f16(const pcd_gemm_desc_t* d, void* out, int64_t ldo, void* stream);
 /* epilogue: store fp32 out[m][ldo] */
 int pcd_gemm_f16_out32(const pcd_gemm_desc_t* d, float* out, int64_t ldo, void* stream);
+/* split-K form for short-and-wide products with a long reduction (the backward-weight products dW = dz^T a of the
+ * training step, reduction over the B*N points): slabs[s][m][c] = A[:, s*K/S:(s+1)*K/S] W[:, same]^T, fp32, all S
+ * slices in ONE launch (S * tiles of work instead of a handful).  k2 = 0, no bias/relu; K/S a multiple of 64.
+ * pcd_sum_slabs_f32 then adds the S slabs in a fixed order into out[rows][ldo] (deterministic, no float atomics). */
+int pcd_gemm_f16_splitk(const pcd_gemm_desc_t* d, int splits, float* slabs, void* stream);
+int pcd_sum_slabs_f32(const float* slabs, int nslabs, int64_t rows, int cols, float* out, int64_t ldo, void* stream);
 /* epilogue: residual add, out[m][c] = resid[m][c] + (A W^T + bias), fp16 in/out (networks.py:81-82) */
 int pcd_gemm_f16_residual(const pcd_gemm_desc_t* d, const void* resid, int64_t ldr,
                           void* out, int64_t ldo, void* stream);

@@ -202,3 +202,25 @@ def test_sinkhorn_emd(golden):
     cd, emd, rec = M.compute_metrics(a[0], b[0], use_approximate_gpu_emd=True)
     w = g["m_triple_sinkhorn0"]
     assert abs(float(emd) - w[1]) < 2e-3 * w[1] and float(rec) == w[2] and abs(float(cd) - w[0]) < 0.1
+
+
+def test_gemm_splitk_matches_single_pass():
+    """pcd_gemm_f16_splitk + pcd_sum_slabs_f32 (backward-weight products: few output tiles, long reduction)."""
+    import ctypes as C
+    from shapegen_amd import _lib
+    lib, st = _lib.load(), _lib.stream_ptr()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for m, c, k, splits in ((64, 72, 4096, 16), (300, 256, 2048, 4), (1024, 128, 8192, 8)):
+        a = torch.randint(-3, 4, (m, k), device="cuda", generator=g).half()
+        w = torch.randint(-3, 4, (c, k), device="cuda", generator=g).half()
+        d = _lib.GemmDesc()
+        d.a1, d.lda1, d.k1, d.w, d.ldw, d.m, d.c = a.data_ptr(), k, k, w.data_ptr(), k, m, c
+        slabs = torch.empty(splits, m, c, device="cuda")
+        _lib.check(lib.pcd_gemm_f16_splitk(C.byref(d), splits, slabs.data_ptr(), st))
+        out = torch.full((m, c + 5), -7.0, device="cuda")
+        _lib.check(lib.pcd_sum_slabs_f32(slabs.data_ptr(), splits, m, c, out.data_ptr(), c + 5, st))
+        want = a.float() @ w.float().t()                       # small integers: exact in fp32
+        assert torch.equal(out[:, :c], want) and bool((out[:, c:] == -7.0).all())
+        for s_ in range(splits):
+            ks = k // splits
+            assert torch.equal(slabs[s_], a[:, s_ * ks:(s_ + 1) * ks].float() @ w[:, s_ * ks:(s_ + 1) * ks].float().t())

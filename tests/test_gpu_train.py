@@ -23,6 +23,13 @@ from oracle import torch_oracle as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _autograd_on():
+    # other test modules switch autograd off process-wide; the torch references below need it
+    with torch.enable_grad():
+        yield
+
+
 def _lib():
     from shapegen_amd import _lib
     return _lib, _lib.load(), _lib.stream_ptr()
