@@ -117,6 +117,15 @@ def test_train_kernels_against_torch():
     At, Bt = A.t().contiguous(), Bm.t().contiguous()
     L.check(lib.pcd_matmul_f32(At.data_ptr(), 7, 1, Bt.data_ptr(), 33, 1, 7, 19, 33, None, 1, Cm.data_ptr(), 19, st))
     assert torch.allclose(Cm, 2 * (A @ Bm) + bias, rtol=1e-5, atol=1e-4)
+    for (mr, nr, kr) in ((16, 1024, 4096), (5, 70, 300), (32, 4096, 1024)):          # few-row fast paths, both B layouts
+        Af = torch.randn(mr, kr, device="cuda", generator=g)
+        Bn, bb = torch.randn(kr, nr + 3, device="cuda", generator=g), torch.randn(nr, device="cuda", generator=g)
+        Cf = torch.zeros(mr, nr, device="cuda")
+        L.check(lib.pcd_matmul_f32(Af.data_ptr(), kr, 0, Bn.data_ptr(), nr + 3, 0, mr, nr, kr, bb.data_ptr(), 0, Cf.data_ptr(), nr, st))
+        assert rel_l2(Cf, Af @ Bn[:, :nr] + bb) < 1e-5
+        Bt = Bn[:, :nr].t().contiguous()
+        L.check(lib.pcd_matmul_f32(Af.data_ptr(), kr, 0, Bt.data_ptr(), kr, 1, mr, nr, kr, None, 1, Cf.data_ptr(), nr, st))
+        assert rel_l2(Cf, 2 * (Af @ Bn[:, :nr]) + bb) < 1e-5
     xs = torch.randn(500, device="cuda", generator=g).requires_grad_(True)
     y, dy, dx = torch.empty(500, device="cuda"), torch.randn(500, device="cuda", generator=g), torch.empty(500, device="cuda")
     L.check(lib.pcd_silu_f32(xs.data_ptr(), 500, y.data_ptr(), st))
