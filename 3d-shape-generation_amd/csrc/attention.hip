@@ -42,15 +42,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
 // block = 4 waves, each wave owns QT x 32 queries of one (shape, head); K [64][D] and Vt [D][64]
 // tiles arrive by LDS-DMA (global_load_lds 16 B/lane) into a 2-deep ring, XOR-swizzled through the
 // source address so the ds_read_b128 fragment reads are bank-conflict free.
-#ifndef ATT_KT
-#define ATT_KT 64
-#endif
-constexpr int KT = ATT_KT;
-#ifdef ATT_THR0
-constexpr float RESCALE_THR = 0.0f;
-#else
+constexpr int KT = 64;              // keys per K/V tile (128 measured neutral: fewer barriers, but 2 workgroups/CU)
 constexpr float RESCALE_THR = 8.0f;
-#endif
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -61,9 +54,6 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(
 
 // max of lane l and lane l^32 in every lane, via v_permlane32_swap (VALU, no LDS)
 __device__ __forceinline__ float xhalf_max(float v) {
-#ifdef ATT_SHFL
-    return fmaxf(v, __shfl_xor(v, 32));
-#endif
     const unsigned u = __float_as_uint(v);
     const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
@@ -229,16 +219,10 @@ __global__ __launch_bounds__(256) void set_attention_kernel(const half_t* __rest
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
                 // S'^T tile: 32 keys x 32 queries, already relative to the running max
-#ifdef ATT_PRIO
-                __builtin_amdgcn_s_setprio(1);
-#endif
                 f32x16 sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[t][0], negm[t], 0, 0, 0);
 #pragma unroll
                 for (int s = 1; s < KSTEPS; ++s)
                     sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[s], qf[t][s], sacc, 0, 0, 0);
-#ifdef ATT_PRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
                 if constexpr (MASK) {   // register r of lane (qr, hh) is key (r&3) + 8*(r>>2) + 4*hh of this sub-tile
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -266,15 +250,6 @@ __global__ __launch_bounds__(256) void set_attention_kernel(const half_t* __rest
 #pragma unroll
                         for (int r = 0; r < 16; ++r) oacc[t][o][r] *= alpha;
                 }
-#ifdef ATT_SGB
-                // ask the scheduler for an MFMA : VALU interleave (1 MFMA, 1 transcendental, 3 VALU) x 8
-#pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                }
-#endif
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sacc[r] = __builtin_amdgcn_exp2f(sacc[r]);
                 // per-lane partial row sums, two at a time (v_pk_add_f32); halves combined in the epilogue
@@ -293,11 +268,6 @@ __global__ __launch_bounds__(256) void set_attention_kernel(const half_t* __rest
         }
     };
 
-#ifdef ATT_STAGGER
-    // de-phase co-resident workgroups that run the same instruction stream (they would otherwise hit
-    // their MFMA bursts and their exp bursts together on the shared SIMD)
-    if ((blockIdx.x + blockIdx.y) & 1) __builtin_amdgcn_s_sleep(ATT_STAGGER);
-#endif
     const int full_tiles = n / KT;
     stage(0, 0);
     for (int kt = 0; kt < full_tiles; ++kt) {
@@ -649,12 +619,9 @@ extern "C" int pcd_set_attention_f16(const void* qkv, int batch, int n_points, i
     PCD_CHECK_ARG(c % 8 == 0);
     hipStream_t s = (hipStream_t)stream;
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)d);
-#ifndef ATT_QT
-#define ATT_QT 1
-#endif
     // 32*QT queries per wave.  QT = 1 measured fastest (836 vs 764 TFLOP/s at d = 64): at QT = 2 the kernel
     // sits at 256 VGPRs (2 waves/SIMD) and the shared K/V fragments do not pay for the lost occupancy.
-    constexpr int QT = ATT_QT;
+    constexpr int QT = 1;
 #ifdef ATT_PINGPONG
     if (d == 64 && n_points >= 512) {   // experimental ping-pong variant: 512 queries per workgroup
         dim3 pgrid((unsigned)ceil_div(n_points, 512), (unsigned)(batch * heads));
