@@ -190,7 +190,8 @@ class _DiffusionBase(nn.Module):
 
     # ------------------------------------------------------------------ stepping
     GRAPH_MIN_STEPS = 8
-    use_graphs = True
+    GRAPH_STEPS = 8            # timesteps captured per HIP graph (one graph launch costs ~10 us of host time: the
+    use_graphs = True          # 100 us latent step was launch-bound at one step per graph)
 
     def _run(self, x, tab: "StepTable", bias_table: torch.Tensor, forward, kind: str, noises=None,
              skip_last_update: bool = False):
@@ -202,10 +203,15 @@ class _DiffusionBase(nn.Module):
         k = 0
         if self.use_graphs and noises is None and n_uniform - 1 >= self.GRAPH_MIN_STEPS:
             stp.step(0, True)                                          # eager warm-up (loads every kernel)
-            stp.capture()
-            for _ in range(1, n_uniform):
+            per = self.GRAPH_STEPS
+            stp.capture(per)
+            k = 1
+            while k + per <= n_uniform:
                 stp.replay()
-            k = n_uniform
+                k += per
+            while k < n_uniform:                                       # remainder: eager, same enqueue
+                stp.step(k, True)
+                k += 1
         else:
             while k < n_uniform:
                 stp.step(k, True)
@@ -268,12 +274,15 @@ class Stepper:
                                        self.tab.stride, x.numel(), self.per_shape, self.x0.data_ptr(), nxt, st),
                    "ddpm_update")
 
-    def capture(self):
-        """Capture one generic step (must follow at least one eager step: kernels loaded, workspaces allocated)."""
+    def capture(self, steps: int = 1):
+        """Capture `steps` consecutive generic steps in one graph (must follow at least one eager step: kernels
+        loaded, workspaces allocated).  Every step reads its constants through the device-side counter, so the same
+        graph is valid wherever it is replayed."""
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.step(-1, True)
+            for _ in range(steps):
+                self.step(-1, True)
 
     def replay(self):
         self.graph.replay()
