@@ -134,6 +134,11 @@ _SIGS = {
     "pcd_matmul_f32": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, vp, i32, vp, i64, vp]),
     "pcd_silu_f32": (i32, [vp, i64, vp, vp]),
     "pcd_silu_backward_f32": (i32, [vp, vp, i64, vp, vp]),
+    "pcd_groupnorm_f32": (i32, [vp, i32, i32, i32, vp, vp, f32, i32, vp, vp, vp, vp]),
+    "pcd_groupnorm_backward_f32": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
+    "pcd_mask_scale_f32": (i32, [vp, vp, f32, i64, vp, vp]),
+    "pcd_relu_f32": (i32, [vp, i64, vp, vp]),
+    "pcd_relu_backward_f32": (i32, [vp, vp, i64, vp, vp]),
     "pcd_adamw_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
 }
 

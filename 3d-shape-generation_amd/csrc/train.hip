@@ -451,6 +451,93 @@ __global__ void silu_bwd_kernel(const float* x, const float* dy, int64_t n, floa
     dx[i] = dy[i] * s * (1.f + x[i] * (1.f - s));
 }
 
+// ---- latent denoiser training (networks.py:977-1049 layers on (B, C) rows, all fp32: B is the batch, 16-32 rows)
+// y = act(gamma * (x - mean) * rstd + beta) per (row, group of c/groups channels); one wave per (row, group)
+__global__ __launch_bounds__(256) void gn_fwd_f32_kernel(const float* __restrict__ x, int rows, int c, int groups,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, int relu, float* __restrict__ y,
+                                                          float* __restrict__ mean, float* __restrict__ rstd) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= rows * groups) return;
+    const int row = item / groups, g = item - row * groups, gsz = c / groups;
+    const float* xg = x + (int64_t)row * c + g * gsz;
+    float s = 0.f;
+    for (int i = lane; i < gsz; i += 64) s += xg[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mu = s / (float)gsz;
+    float v = 0.f;
+    for (int i = lane; i < gsz; i += 64) { const float d = xg[i] - mu; v += d * d; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const float rs = rsqrtf(v / (float)gsz + eps);
+    if (lane == 0) { mean[item] = mu; rstd[item] = rs; }
+    for (int i = lane; i < gsz; i += 64) {
+        const int ch = g * gsz + i;
+        float o = (xg[i] - mu) * rs * gamma[ch] + beta[ch];
+        if (relu) o = fmaxf(o, 0.f);
+        y[(int64_t)row * c + ch] = o;
+    }
+}
+// dx of the above; g = dy * [y > 0]
+__global__ __launch_bounds__(256) void gn_bwd_dx_f32_kernel(const float* __restrict__ dy, const float* __restrict__ x, int rows,
+                                                             int c, int groups, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, int relu, float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= rows * groups) return;
+    const int row = item / groups, g = item - row * groups, gsz = c / groups;
+    const int64_t base = (int64_t)row * c + g * gsz;
+    const float mu = mean[item], rs = rstd[item];
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = lane; i < gsz; i += 64) {
+        const int ch = g * gsz + i;
+        const float xh = (x[base + i] - mu) * rs;
+        const float gg = (!relu || xh * gamma[ch] + beta[ch] > 0.f) ? dy[base + i] * gamma[ch] : 0.f;
+        s1 += gg; s2 += gg * xh;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    s1 /= (float)gsz; s2 /= (float)gsz;
+    for (int i = lane; i < gsz; i += 64) {
+        const int ch = g * gsz + i;
+        const float xh = (x[base + i] - mu) * rs;
+        const float gg = (!relu || xh * gamma[ch] + beta[ch] > 0.f) ? dy[base + i] * gamma[ch] : 0.f;
+        dx[base + i] = rs * (gg - s1 - xh * s2);
+    }
+}
+// dgamma[ch] = sum_rows g * xhat, dbeta[ch] = sum_rows g ; one thread per channel (few rows)
+__global__ void gn_bwd_affine_f32_kernel(const float* __restrict__ dy, const float* __restrict__ x, int rows, int c, int groups,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         const float* __restrict__ mean, const float* __restrict__ rstd, int relu,
+                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    const int g = ch / (c / groups);
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < rows; ++r) {
+        const float xh = (x[(int64_t)r * c + ch] - mean[r * groups + g]) * rstd[r * groups + g];
+        const float gg = (!relu || xh * gamma[ch] + beta[ch] > 0.f) ? dy[(int64_t)r * c + ch] : 0.f;
+        a += gg * xh; b += gg;
+    }
+    dgamma[ch] = a; dbeta[ch] = b;
+}
+// y = x * mask * scale (Dropout forward with a given keep mask, and its backward); y = max(x, 0); dx = dy * [x > 0]
+__global__ void mask_scale_kernel(const float* x, const float* mask, float scale, int64_t n, float* y) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = x[i] * mask[i] * scale;
+}
+__global__ void relu_f32_kernel(const float* x, int64_t n, float* y) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = fmaxf(x[i], 0.f);
+}
+__global__ void relu_bwd_f32_kernel(const float* x, const float* dy, int64_t n, float* dx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dx[i] = x[i] > 0.f ? dy[i] : 0.f;
+}
+
 // torch.optim.AdamW (decoupled weight decay), one flat buffer
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2,
                              int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
@@ -635,6 +722,49 @@ extern "C" int pcd_adamw_step(float* params, const float* grads, float* exp_avg,
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adamw_kernel, dim3(nblk256(n)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, lr,
                        beta1, beta2, eps, weight_decay, bc1, bc2, 1.f / grad_scale);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_groupnorm_f32(const float* x, int rows, int c, int groups, const float* gamma, const float* beta, float eps,
+                                 int relu, float* y, float* mean, float* rstd, void* stream) {
+    PCD_CHECK_ARG(x && gamma && beta && y && mean && rstd && rows > 0 && c > 0 && groups > 0 && c % groups == 0);
+    hipLaunchKernelGGL(gn_fwd_f32_kernel, dim3((unsigned)ceil_div((int64_t)rows * groups, 4)), dim3(256), 0, (hipStream_t)stream, x, rows,
+                       c, groups, gamma, beta, eps, relu, y, mean, rstd);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_groupnorm_backward_f32(const float* dy, const float* x, int rows, int c, int groups, const float* gamma,
+                                          const float* beta, const float* mean, const float* rstd, int relu, float* dx,
+                                          float* dgamma, float* dbeta, void* stream) {
+    PCD_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx && dgamma && dbeta && rows > 0 && c > 0 && groups > 0 && c % groups == 0);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_bwd_dx_f32_kernel, dim3((unsigned)ceil_div((int64_t)rows * groups, 4)), dim3(256), 0, s, dy, x, rows, c, groups,
+                       gamma, beta, mean, rstd, relu, dx);
+    hipLaunchKernelGGL(gn_bwd_affine_f32_kernel, dim3(nblk256(c)), dim3(256), 0, s, dy, x, rows, c, groups, gamma, beta, mean, rstd, relu,
+                       dgamma, dbeta);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_mask_scale_f32(const float* x, const float* mask, float scale, int64_t n, float* y, void* stream) {
+    PCD_CHECK_ARG(x && mask && y && n > 0);
+    hipLaunchKernelGGL(mask_scale_kernel, dim3(nblk256(n)), dim3(256), 0, (hipStream_t)stream, x, mask, scale, n, y);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_relu_f32(const float* x, int64_t n, float* y, void* stream) {
+    PCD_CHECK_ARG(x && y && n > 0);
+    hipLaunchKernelGGL(relu_f32_kernel, dim3(nblk256(n)), dim3(256), 0, (hipStream_t)stream, x, n, y);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_relu_backward_f32(const float* x, const float* dy, int64_t n, float* dx, void* stream) {
+    PCD_CHECK_ARG(x && dy && dx && n > 0);
+    hipLaunchKernelGGL(relu_bwd_f32_kernel, dim3(nblk256(n)), dim3(256), 0, (hipStream_t)stream, x, dy, n, dx);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

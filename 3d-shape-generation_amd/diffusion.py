@@ -424,6 +424,40 @@ class LatentDiffusion(_DiffusionBase):
     def _forward_fn(self):
         return lambda x, tb_cur, eps: self.model.forward_with_bias(x, tb_cur, 0, out=eps)
 
+    # ------------------------------------------------------------------ training surface (diffusion.py:410-443, 522-537)
+    def configure_optimizers(self, max_epochs: int = 100):
+        """AdamW(lr, weight_decay=1e-5) on the denoiser (the VAE is frozen, diffusion.py:377-378) +
+        CosineAnnealingLR(T_max=max_epochs, eta_min=1e-6) (diffusion.py:414-419); the optimizer is the HIP trainer."""
+        from .training import CosineAnnealingLR, LatentTrainer
+        if getattr(self, "_trainer", None) is None:
+            self._trainer = LatentTrainer(self.model, lr=self.lr, weight_decay=1e-5)
+            self._scheduler = CosineAnnealingLR(self._trainer, T_max=max_epochs, eta_min=1e-6)
+        return {"optimizer": self._trainer, "lr_scheduler": self._scheduler}
+
+    def diffusion_loss(self, z_0, t, noise=None, dropout_mask=None):
+        """diffusion.py:522-537.  train(): the denoiser runs with Dropout active and the gradients are left in the trainer."""
+        z_t, noise, _, _ = self.add_noise(z_0, t, noise)
+        if self.training:
+            tr = self.configure_optimizers()["optimizer"]
+            tr.forward(z_t, t.to(self.device, torch.float32), dropout_mask)
+            return tr.backward(noise)
+        pred = self.model(z_t, t.to(self.device, torch.float32))
+        out = torch.empty(1, dtype=torch.float32, device=self.device)
+        scratch = torch.empty_like(pred)
+        _lib.check(_lib.load().pcd_l1_loss(pred.data_ptr(), noise.data_ptr(), pred.numel(), 1.0, out.data_ptr(), scratch.data_ptr(),
+                                           _lib.stream_ptr()), "l1_loss")
+        return out[0] / pred.numel()
+
+    def training_step(self, batch, batch_idx=0):
+        """diffusion.py:424-443: z = reparameterize(encode(x)) through the frozen VAE, t ~ U(0,1), L1 loss."""
+        x = batch.to(self.device)
+        mu, logvar = self.vae.encode(x)
+        z = self.vae.reparameterize(mu, logvar)
+        t = torch.rand(z.shape[0], device=self.device)
+        return self.diffusion_loss(z, t)
+
+    validation_step = training_step        # diffusion.py:445-467: same computation under eval() (figures not reproduced)
+
     def _start(self, num_samples, z_T):
         self.eval()
         self._require_cuda(z_T)

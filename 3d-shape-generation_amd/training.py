@@ -41,6 +41,27 @@ def _gemm_desc(a1, k1, lda1, a2, k2, lda2, w, ldw, bias, shape_bias, rps, m, c):
     return g
 
 
+def _flatten_parameters(model, dev):
+    """Re-point every trainable `nn.Parameter` of `model` into one flat fp32 buffer (the optimizer is then a single
+    launch and `state_dict()` always shows the trained weights); returns (P, G, M1, M2, views, grad views)."""
+    named = [(n, q) for n, q in model.named_parameters() if q.requires_grad]
+    total = sum(q.numel() for _, q in named)
+    P = torch.empty(total, dtype=torch.float32, device=dev)
+    G, M1, M2 = torch.zeros_like(P), torch.zeros_like(P), torch.zeros_like(P)
+    views: Dict[str, torch.Tensor] = {}
+    grads: Dict[str, torch.Tensor] = {}
+    off = 0
+    for name, prm in named:
+        n = prm.numel()
+        view = P[off:off + n].view(prm.shape)
+        view.copy_(prm.data)
+        prm.data = view
+        views[name] = view
+        grads[name] = G[off:off + n].view(prm.shape)
+        off += n
+    return P, G, M1, M2, views, grads
+
+
 class _Conv:
     """One Conv1d(k=1) [+ BatchNorm1d + ReLU]: names of its parameters and its saved tensors."""
 
@@ -66,23 +87,7 @@ class PointTrainer:
             raise RuntimeError("PointTrainer needs the model on an MI355X (model.to('cuda'))")
         self.step_count = 0
         # ---- one flat fp32 buffer for parameters, one for gradients, two for the AdamW moments
-        named = list(model.named_parameters())
-        total = sum(p.numel() for _, p in named)
-        self.P = torch.empty(total, dtype=torch.float32, device=self.dev)
-        self.G = torch.zeros_like(self.P)
-        self.M1 = torch.zeros_like(self.P)
-        self.M2 = torch.zeros_like(self.P)
-        self.p: Dict[str, torch.Tensor] = {}
-        self.g: Dict[str, torch.Tensor] = {}
-        off = 0
-        for name, prm in named:
-            n = prm.numel()
-            view = self.P[off:off + n].view(prm.shape)
-            view.copy_(prm.data)
-            prm.data = view
-            self.p[name] = view
-            self.g[name] = self.G[off:off + n].view(prm.shape)
-            off += n
+        self.P, self.G, self.M1, self.M2, self.p, self.g = _flatten_parameters(model, self.dev)
         self.buf = dict(model.named_buffers())
         self.freqs = timestep_freqs(256)
         # ---- layer table in execution order
@@ -450,6 +455,203 @@ class PointTrainer:
         return {"step": self.step_count, "lr": self.lr, "exp_avg": self.M1, "exp_avg_sq": self.M2}
 
 
+class LatentTrainer:
+    """Forward + backward + AdamW for `SimpleLatentUNetPointNet` (networks.py:963-1086) in train() mode, as used by
+    `LatentDiffusion.training_step` (diffusion.py:424-443; the VAE stays frozen).  The batch is 16-32 latent vectors,
+    so every product is a few-row fp32 product (`pcd_matmul_f32`: weights read once) and everything stays fp32 -
+    GroupNorm is per sample, so unlike the point denoiser nothing here couples the batch.  Dropout(0.1) after `dec1`
+    (networks.py:1035) takes its keep mask from torch's generator, or from the caller (parity tests)."""
+
+    GROUPS = 8
+    DROPOUT = 0.1
+
+    def __init__(self, model, lr: float = 1e-4, weight_decay: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.model = model
+        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.dev = model.device
+        if self.dev.type != "cuda":
+            raise RuntimeError("LatentTrainer needs the model on an MI355X (model.to('cuda'))")
+        self.step_count = 0
+        self.P, self.G, self.M1, self.M2, self.p, self.g = _flatten_parameters(model, self.dev)
+        self.freqs = timestep_freqs(256)
+        self._ws: Dict[str, torch.Tensor] = {}
+        self.saved: Dict[str, tuple] = {}
+
+    _st = PointTrainer._st
+    _chk = PointTrainer._chk
+    _buf = PointTrainer._buf
+    _mm = PointTrainer._mm
+
+    # ------------------------------------------------------------------ layer helpers
+    def _lin(self, name: str, inputs) -> torch.Tensor:
+        """y = [inputs] W^T + b  (nn.Linear; the torch.cat of networks.py:1062,1074-1077 is a split product)."""
+        w, b = self.p[name + ".weight"], self.p[name + ".bias"]
+        c, ktot = w.shape
+        rows = inputs[0][0].shape[0]
+        y = self._buf(name + ".y", (rows, c), torch.float32)
+        off = 0
+        for i, (a, k) in enumerate(inputs):
+            self._mm(a.data_ptr(), k, 0, w.data_ptr() + off * 4, ktot, 1, rows, c, k, b.data_ptr() if i == 0 else None, 1 if i else 0,
+                     y.data_ptr(), c)
+            off += k
+        self.saved[name] = tuple(inputs)
+        return y
+
+    def _lin_backward(self, name: str, dy: torch.Tensor, targets) -> None:
+        """dW, db into the gradient views; input gradients into targets[i] = None | ('set'|'add', tensor)."""
+        w, gw, gb = self.p[name + ".weight"], self.g[name + ".weight"], self.g[name + ".bias"]
+        c, ktot = w.shape
+        rows = dy.shape[0]
+        ones = self._buf("ones", (1, rows), torch.float32)
+        ones.fill_(1.0)
+        self._mm(ones.data_ptr(), rows, 0, dy.data_ptr(), c, 0, 1, c, rows, None, 0, gb.data_ptr(), c)
+        off = 0
+        for (a, k), tgt in zip(self.saved[name], targets):
+            self._mm(dy.data_ptr(), c, 1, a.data_ptr(), k, 0, c, k, rows, None, 0, gw.data_ptr() + off * 4, ktot)      # dW = dy^T a
+            if tgt is not None:
+                mode, dst = tgt
+                self._mm(dy.data_ptr(), c, 0, w.data_ptr() + off * 4, ktot, 0, rows, k, c, None, 1 if mode == "add" else 0,
+                         dst.data_ptr(), k)                                                                          # da = dy W
+            off += k
+
+    def _gn(self, name: str, x: torch.Tensor) -> torch.Tensor:
+        rows, c = x.shape
+        y = self._buf(name + ".y", (rows, c), torch.float32)
+        mean = self._buf(name + ".mean", (rows, self.GROUPS), torch.float32)
+        rstd = self._buf(name + ".rstd", (rows, self.GROUPS), torch.float32)
+        self._chk(self.lib.pcd_groupnorm_f32(x.data_ptr(), rows, c, self.GROUPS, self.p[name + ".weight"].data_ptr(),
+                                             self.p[name + ".bias"].data_ptr(), 1e-5, 1, y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                             self._st()), "groupnorm")
+        self.saved[name] = (x, mean, rstd)
+        return y
+
+    def _gn_backward(self, name: str, dy: torch.Tensor) -> torch.Tensor:
+        x, mean, rstd = self.saved[name]
+        rows, c = x.shape
+        dx = self._buf(name + ".dx", (rows, c), torch.float32)
+        self._chk(self.lib.pcd_groupnorm_backward_f32(dy.data_ptr(), x.data_ptr(), rows, c, self.GROUPS, self.p[name + ".weight"].data_ptr(),
+                                                      self.p[name + ".bias"].data_ptr(), mean.data_ptr(), rstd.data_ptr(), 1, dx.data_ptr(),
+                                                      self.g[name + ".weight"].data_ptr(), self.g[name + ".bias"].data_ptr(), self._st()),
+                  "groupnorm_backward")
+        return dx
+
+    # ------------------------------------------------------------------ forward / backward
+    def forward(self, z_t: torch.Tensor, t: torch.Tensor, dropout_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        lib, st = self.lib, self._st()
+        b = z_t.shape[0]
+        self.z = z_t.to(torch.float32).contiguous()
+        tt = t.detach().to("cpu", torch.float32)
+        e = tt[:, None] * self.freqs[None, :]
+        self.emb = torch.cat((torch.sin(e), torch.cos(e)), dim=-1).to(self.dev)
+        h1 = self._lin("time_mlp.0", [(self.emb, 256)])
+        s1 = self._buf("t.s1", (b, 256), torch.float32)
+        self._chk(lib.pcd_silu_f32(h1.data_ptr(), h1.numel(), s1.data_ptr(), st), "silu")
+        te = self._lin("time_mlp.2", [(s1, 256)])
+        z1 = self._gn("enc1.1", self._lin("enc1.0", [(self.z, 256), (te, 256)]))
+        z2 = self._gn("enc2.1", self._lin("enc2.0", [(z1, 128)]))
+        z3 = self._gn("enc3.1", self._lin("enc3.0", [(z2, 256)]))
+        z4 = self._gn("enc4.1", self._lin("enc4.0", [(z3, 512)]))
+        g = self._gn("global_feat.1", self._lin("global_feat.0", [(z4, 1024)]))
+        g = self._gn("global_feat.4", self._lin("global_feat.3", [(g, 2048)]))
+        h = self._gn("dec4.1", self._lin("dec4.0", [(g, 4096), (self._lin("refine4", [(z4, 1024)]), 1024)]))
+        h = self._gn("dec3.1", self._lin("dec3.0", [(h, 1024), (self._lin("refine3", [(z3, 512)]), 512)]))
+        h = self._gn("dec2.1", self._lin("dec2.0", [(h, 512), (self._lin("refine2", [(z2, 256)]), 256)]))
+        h = self._gn("dec1.1", self._lin("dec1.0", [(h, 256), (self._lin("refine1", [(z1, 128)]), 128)]))
+        if dropout_mask is None:
+            dropout_mask = (torch.rand(b, 128, device=self.dev) >= self.DROPOUT).to(torch.float32)
+        self.mask = dropout_mask.to(self.dev, torch.float32).contiguous()
+        hd = self._buf("drop.y", (b, 128), torch.float32)
+        self._chk(lib.pcd_mask_scale_f32(h.data_ptr(), self.mask.data_ptr(), 1.0 / (1.0 - self.DROPOUT), h.numel(), hd.data_ptr(), st), "dropout")
+        self.o0 = self._lin("output.0", [(hd, 128)])
+        o0r = self._buf("o0.relu", (b, 128), torch.float32)
+        self._chk(lib.pcd_relu_f32(self.o0.data_ptr(), self.o0.numel(), o0r.data_ptr(), st), "relu")
+        self.pred = self._lin("output.2", [(o0r, 128)])
+        return self.pred
+
+    def backward(self, target: torch.Tensor) -> torch.Tensor:
+        lib, st = self.lib, self._st()
+        b = self.pred.shape[0]
+        n = self.pred.numel()
+        loss_sum = self._buf("loss", (1,), torch.float32)
+        d = self._buf("d.pred", (b, 256), torch.float32)
+        target = target.to(self.dev, torch.float32).contiguous()
+        self._chk(lib.pcd_l1_loss(self.pred.data_ptr(), target.data_ptr(), n, 1.0, loss_sum.data_ptr(), d.data_ptr(), st), "l1_loss")
+
+        def new(key, c):
+            return self._buf("d." + key, (b, c), torch.float32)
+
+        d_o0r = new("o0r", 128)
+        self._lin_backward("output.2", d, [("set", d_o0r)])
+        d_o0 = new("o0", 128)
+        self._chk(lib.pcd_relu_backward_f32(self.o0.data_ptr(), d_o0r.data_ptr(), d_o0.numel(), d_o0.data_ptr(), st), "relu_bwd")
+        d_hd = new("hd", 128)
+        self._lin_backward("output.0", d_o0, [("set", d_hd)])
+        d_h = new("h1", 128)
+        self._chk(lib.pcd_mask_scale_f32(d_hd.data_ptr(), self.mask.data_ptr(), 1.0 / (1.0 - self.DROPOUT), d_hd.numel(), d_h.data_ptr(), st), "dropout_bwd")
+        dz = {}
+        for name, kprev, kskip, refine in (("dec1", 256, 128, "refine1"), ("dec2", 512, 256, "refine2"),
+                                           ("dec3", 1024, 512, "refine3"), ("dec4", 4096, 1024, "refine4")):
+            dx = self._gn_backward(name + ".1", d_h)
+            d_prev, d_r = new(name + ".prev", kprev), new(name + ".r", kskip)
+            self._lin_backward(name + ".0", dx, [("set", d_prev), ("set", d_r)])
+            dz[kskip] = new(f"z{kskip}", kskip)
+            self._lin_backward(refine, d_r, [("set", dz[kskip])])
+            d_h = d_prev
+        dx = self._gn_backward("global_feat.4", d_h)
+        d_g0 = new("g0", 2048)
+        self._lin_backward("global_feat.3", dx, [("set", d_g0)])
+        dx = self._gn_backward("global_feat.1", d_g0)
+        self._lin_backward("global_feat.0", dx, [("add", dz[1024])])
+        for name, kin, kout in (("enc4", 512, 1024), ("enc3", 256, 512), ("enc2", 128, 256)):
+            dx = self._gn_backward(name + ".1", dz[kout])
+            self._lin_backward(name + ".0", dx, [("add", dz[kin])])
+        dx = self._gn_backward("enc1.1", dz[128])
+        d_te = new("te", 256)
+        self._lin_backward("enc1.0", dx, [None, ("set", d_te)])
+        d_s1 = new("s1", 256)
+        self._lin_backward("time_mlp.2", d_te, [("set", d_s1)])
+        d_h1 = new("th1", 256)
+        h1 = self._ws["time_mlp.0.y"]
+        self._chk(lib.pcd_silu_backward_f32(h1.data_ptr(), d_s1.data_ptr(), d_s1.numel(), d_h1.data_ptr(), st), "silu_bwd")
+        self._lin_backward("time_mlp.0", d_h1, [None])
+        return loss_sum[0] / float(n)
+
+    def grads(self) -> Dict[str, torch.Tensor]:
+        return {k: v.clone() for k, v in self.g.items()}
+
+    def optimizer_step(self):
+        self.step_count += 1
+        b1, b2 = self.betas
+        self._chk(self.lib.pcd_adamw_step(self.P.data_ptr(), self.G.data_ptr(), self.M1.data_ptr(), self.M2.data_ptr(), self.P.numel(),
+                                          self.lr, b1, b2, self.eps, self.wd, self.step_count, 1.0, self._st()), "adamw")
+        self.model.invalidate()        # the sampler's packed fp16 weights are stale now
+
+    step = optimizer_step
+
+    def zero_grad(self):
+        pass
+
+    def train_step(self, z_t, t, noise, dropout_mask=None) -> torch.Tensor:
+        self.forward(z_t, t, dropout_mask)
+        loss = self.backward(noise)
+        self.optimizer_step()
+        return loss
+
+
+class CosineAnnealingLR:
+    """torch.optim.lr_scheduler.CosineAnnealingLR(T_max, eta_min) in closed form (diffusion.py:415-419)."""
+
+    def __init__(self, trainer, T_max: int, eta_min: float = 1e-6):
+        self.trainer, self.T_max, self.eta_min, self.base, self.epoch = trainer, T_max, eta_min, trainer.lr, 0
+
+    def step(self, metric=None) -> None:
+        import math
+        self.epoch += 1
+        self.trainer.lr = self.eta_min + (self.base - self.eta_min) * (1 + math.cos(math.pi * self.epoch / self.T_max)) / 2
+
+
 class ReduceLROnPlateau:
     """torch.optim.lr_scheduler.ReduceLROnPlateau(mode='min', factor, patience) as configured at diffusion.py:61,
     restated for the trainer (threshold 1e-4 relative, cooldown 0, min_lr 0: torch's defaults)."""
@@ -480,12 +682,18 @@ def save_checkpoint(model, path: str, epoch: int, extra: Optional[dict] = None) 
 
 
 def fit(model, data_module, max_epochs: int = 500, ckpt_dir: Optional[str] = None, log=print, max_steps: Optional[int] = None,
-        save_top_k: int = 10):
-    """What `pl.Trainer(max_epochs=...).fit(model, data_module)` does for the reference's train_point_ddpm.py:78-87:
-    epochs of training_step + optimizer step, then validation_step over the validation loader in eval() mode, the
-    plateau scheduler on the mean `val_loss`, and the `save_top_k` best checkpoints by it (train_point_ddpm.py:60-66)."""
-    cfg = model.configure_optimizers()
-    opt, sched = cfg["optimizer"], cfg["lr_scheduler"]["scheduler"]
+        save_top_k: int = 10, ckpt_name: str = "point_cloud_diffusion"):
+    """What `pl.Trainer(max_epochs=...).fit(model, data_module)` does for the reference's train_point_ddpm.py:78-87 and
+    train_point_ldm.py:100-108: epochs of training_step + optimizer step, then validation_step over the validation
+    loader in eval() mode, the model's scheduler (plateau on `val_loss` / cosine per epoch), and the `save_top_k` best
+    checkpoints by val_loss (train_point_ddpm.py:60-66)."""
+    import inspect
+    if "max_epochs" in inspect.signature(model.configure_optimizers).parameters:
+        cfg = model.configure_optimizers(max_epochs=max_epochs)
+    else:
+        cfg = model.configure_optimizers()
+    opt = cfg["optimizer"]
+    sched = cfg["lr_scheduler"]["scheduler"] if isinstance(cfg["lr_scheduler"], dict) else cfg["lr_scheduler"]
     data_module.setup()
     kept: List[Tuple[float, str]] = []
     steps = 0
@@ -494,8 +702,8 @@ def fit(model, data_module, max_epochs: int = 500, ckpt_dir: Optional[str] = Non
         model.train()
         tl = []
         for i, batch in enumerate(data_module.train_dataloader()):
-            if batch.shape[0] * batch.shape[1] % 64:
-                continue                       # ragged last batch: the backward-weight GEMM reduces over B*N in 64s
+            if batch.dim() == 3 and batch.shape[0] * batch.shape[1] % 64:
+                continue                       # ragged last point-cloud batch: the backward-weight GEMM reduces over B*N in 64s
             loss = model.training_step(batch, i)
             opt.step()
             tl.append(loss)
@@ -511,7 +719,7 @@ def fit(model, data_module, max_epochs: int = 500, ckpt_dir: Optional[str] = Non
         log(f"epoch {epoch}: train_loss {train_loss:.4f} val_loss {val_loss:.4f} lr {opt.lr:.2e}")
         if ckpt_dir is not None:
             import os
-            path = os.path.join(ckpt_dir, f"point_cloud_diffusion-epoch={epoch:02d}-val_loss={val_loss:.2f}.ckpt")
+            path = os.path.join(ckpt_dir, f"{ckpt_name}-epoch={epoch:02d}-val_loss={val_loss:.2f}.ckpt")
             if len(kept) < save_top_k or val_loss < max(kept)[0]:
                 save_checkpoint(model, path, epoch)
                 kept.append((val_loss, path))

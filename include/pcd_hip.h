@@ -347,6 +347,17 @@ int pcd_matmul_f32(const float* a, int64_t lda, int trans_a, const float* b, int
                    int k, const float* bias, int accumulate, float* c, int64_t ldc, void* stream);
 int pcd_silu_f32(const float* x, int64_t n, float* y, void* stream);
 int pcd_silu_backward_f32(const float* x, const float* dy, int64_t n, float* dx, void* stream);
+/* latent denoiser training (networks.py:977-1049: Linear + GroupNorm(8) + ReLU on (B, C) rows; all fp32, B = batch):
+ * GroupNorm forward keeping (mean, rstd) [rows][groups], and its backward (dx, dgamma, dbeta), ReLU folded in if relu */
+int pcd_groupnorm_f32(const float* x, int rows, int c, int groups, const float* gamma, const float* beta, float eps,
+                      int relu, float* y, float* mean, float* rstd, void* stream);
+int pcd_groupnorm_backward_f32(const float* dy, const float* x, int rows, int c, int groups, const float* gamma,
+                               const float* beta, const float* mean, const float* rstd, int relu, float* dx,
+                               float* dgamma, float* dbeta, void* stream);
+/* y = x * mask * scale: nn.Dropout forward with a given keep mask (scale = 1/(1-p)) and, applied to dy, its backward */
+int pcd_mask_scale_f32(const float* x, const float* mask, float scale, int64_t n, float* y, void* stream);
+int pcd_relu_f32(const float* x, int64_t n, float* y, void* stream);
+int pcd_relu_backward_f32(const float* x, const float* dy, int64_t n, float* dx, void* stream);
 /* torch.optim.AdamW step on one flat fp32 buffer (diffusion.py:60: lr, weight_decay 1e-5); grads are divided by grad_scale */
 int pcd_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);

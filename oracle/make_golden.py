@@ -12,7 +12,7 @@ never depend on a torch RNG stream.
 Fixture map: G1 schedule.npz, G2-G4 point_unet.npz,
 G5-G7 point_samplers.npz, G8 latent.npz, G9 metrics.npz, G10 attention.npz; beyond the survey's list:
 G11 vae3d_small.npz (`make_golden.py vae3d`), G12 data.npz (`make_golden.py data`), G13 train.npz
-(`make_golden.py train`).
+(`make_golden.py train`), G14 train_latent.npz (`make_golden.py train_latent`).
 """
 from __future__ import annotations
 
@@ -190,8 +190,56 @@ def capture_train(rd):
     print("train done: loss", loss.item(), "entries", len(g))
 
 
+def capture_train_latent(rn):
+    """G14: one training step of the latent denoiser as LatentDiffusion.training_step runs it (diffusion.py:424-443,
+    522-537; the frozen VAE only supplies z_0, replaced here by a stored latent batch) -> tests/golden/train_latent.npz."""
+    spec = specs.latent_unet_spec(prefix="model.")       # same names (hence same hashed values) as LatentDiffusion's keys
+    net = rn.SimpleLatentUNetPointNet(latent_dim=256, dim=512)
+    assert [("model." + k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, s_) for k, s_, _ in spec]
+    net.load_state_dict({k[len("model."):]: v for k, v in T(specs.synth_state_dict(spec, seed=0, gain=LATENT_GAIN)).items()},
+                        strict=True)
+    net.train()
+    z0 = torch.from_numpy(specs.hash_uniform("z0", 4 * 256, 3).reshape(4, 256).astype(np.float32)) * 1.5
+    t = torch.tensor([0.15, 0.4, 0.7, 0.95])
+    torch.manual_seed(9)
+    noise = torch.randn_like(z0)
+    from oracle import torch_oracle as O
+    z_t = O.add_noise(z0, t, noise)[0]
+    drops = [m for m in net.modules() if isinstance(m, torch.nn.Dropout)]
+    assert len(drops) == 1 and abs(drops[0].p - 0.1) < 1e-12
+    rec = {}
+    drops[0].register_forward_hook(lambda mod, inp, out: rec.update(inp=inp[0].detach().clone(), out=out.detach().clone()))
+    torch.manual_seed(10)
+    with torch.enable_grad():
+        pred = net(z_t, t)
+        loss = torch.nn.functional.l1_loss(noise, pred)
+        opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-5)      # diffusion.py:414
+        opt.zero_grad()
+        loss.backward()
+    mask = ((rec["out"] != 0) | (rec["inp"] == 0)).float()        # keep mask (free where the input is 0 anyway)
+    assert torch.allclose(rec["out"], rec["inp"] * mask / 0.9)
+    g = {"z_t": z_t.numpy(), "t": t.numpy(), "noise": noise.numpy(), "mask": mask.numpy(), "loss": loss.item(),
+         "pred": pred.detach().numpy()}
+    names = []
+    for k, prm in net.named_parameters():
+        g["grad." + k] = grad_digest(k, prm.grad)[0]
+        names.append(k)
+    opt.step()
+    for k, prm in net.named_parameters():
+        flat = prm.detach().reshape(-1).double()
+        idx = (np.abs(specs.hash_uniform("digest." + k, 64, 7)) * (flat.numel() - 1)).astype(np.int64)
+        g["param1." + k] = flat[torch.from_numpy(idx)].numpy()
+    g["param_names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "train_latent.npz"), **g)
+    print("train_latent done: loss", loss.item(), "kept", mask.mean().item())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "train_latent" in sys.argv[1:]:
+        rd, rn, rm, ru = ref_shim.load_reference()
+        capture_train_latent(rn)
+        return
     if "data" in sys.argv[1:]:
         capture_data()
         return

@@ -198,8 +198,10 @@ def _lin_gn_relu(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
     return F.relu(F.group_norm(y, 8, sd[p + ".1.weight"], sd[p + ".1.bias"], 1e-5))
 
 
-def latent_unet(sd: SD, p: str, z: torch.Tensor, t: torch.Tensor, time_dim: int = 256) -> torch.Tensor:
-    """networks.py:1051-1086 (eval mode: Dropout is identity)."""
+def latent_unet(sd: SD, p: str, z: torch.Tensor, t: torch.Tensor, time_dim: int = 256,
+                dropout_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """networks.py:1051-1086.  dropout_mask None = eval mode (Dropout is identity); a (B, 128) keep mask = train()
+    mode with that draw of nn.Dropout(0.1) after dec1 (networks.py:1035)."""
     te = time_mlp(sd, p, timestep_embedding(t, time_dim))
     h = torch.cat([z, te], dim=1)
     z1 = _lin_gn_relu(sd, p + "enc1", h)
@@ -217,6 +219,8 @@ def latent_unet(sd: SD, p: str, z: torch.Tensor, t: torch.Tensor, time_dim: int 
     h = _lin_gn_relu(sd, p + "dec3", torch.cat([h, refine(3, z3)], dim=1))
     h = _lin_gn_relu(sd, p + "dec2", torch.cat([h, refine(2, z2)], dim=1))
     h = _lin_gn_relu(sd, p + "dec1", torch.cat([h, refine(1, z1)], dim=1))
+    if dropout_mask is not None:
+        h = h * dropout_mask / (1.0 - 0.1)
     h = F.relu(F.linear(h, sd[p + "output.0.weight"], sd[p + "output.0.bias"]))
     return F.linear(h, sd[p + "output.2.weight"], sd[p + "output.2.bias"])
 
@@ -508,3 +512,19 @@ def adamw_step(params: SD, grads: SD, state: dict, lr: float = 1e-4, weight_deca
         m.lerp_(g, 1 - b1)
         v.mul_(b2).addcmul_(g, g, value=1 - b2)
         w.addcdiv_(m, (v.sqrt() / bc2 ** 0.5).add_(eps), value=-lr / bc1)
+
+
+def latent_training_step(sd: SD, p: str, z_t: torch.Tensor, t: torch.Tensor, noise: torch.Tensor, dropout_mask: torch.Tensor):
+    """LatentDiffusion.diffusion_loss (diffusion.py:522-537) with the denoiser in train() mode and its gradients by
+    autograd; only the entries under prefix p (the denoiser; the VAE is frozen, diffusion.py:377-378) get gradients."""
+    work = dict(sd)
+    leaves = {}
+    for k, v in sd.items():
+        if k.startswith(p) and v.is_floating_point():
+            leaves[k] = v.detach().clone().requires_grad_(True)
+            work[k] = leaves[k]
+    with torch.enable_grad():
+        pred = latent_unet(work, p, z_t, t, dropout_mask=dropout_mask)
+        loss = F.l1_loss(noise, pred)
+        loss.backward()
+    return loss.detach(), pred.detach(), {k: v.grad for k, v in leaves.items()}

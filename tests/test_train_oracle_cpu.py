@@ -44,3 +44,27 @@ def test_training_step_matches_reference(golden):
         flat = params[k].reshape(-1).double()
         got = flat[torch.from_numpy(_digest_idx(k, flat.numel()))].numpy()
         assert np.abs(got - g["param1." + k]).max() <= 2e-6, k
+
+
+def test_latent_training_step_matches_reference(golden):
+    """oracle.latent_training_step (train() mode: the recorded Dropout keep mask) against tests/golden/train_latent.npz."""
+    from helpers import latent_sd
+    g = golden("train_latent.npz")
+    sd = {k: v for k, v in latent_sd().items() if k.startswith("model.")}
+    z_t, t, noise, mask = (torch.from_numpy(g[k]) for k in ("z_t", "t", "noise", "mask"))
+    loss, pred, grads = O.latent_training_step(sd, "model.", z_t, t, noise, mask)
+    assert abs(loss.item() - float(g["loss"])) <= 1e-6 and np.abs(pred.numpy() - g["pred"]).max() <= 1e-5
+    names = [str(n) for n in g["param_names"]]
+    assert sorted("model." + n for n in names) == sorted(grads.keys())
+    params = {}
+    for k in names:
+        flat = grads["model." + k].reshape(-1).double()
+        want = g["grad." + k]
+        got = np.concatenate([[flat.norm().item(), flat.sum().item()], flat[torch.from_numpy(_digest_idx(k, flat.numel()))].numpy()])
+        assert abs(got[0] - want[0]) <= 1e-4 * max(want[0], 1e-12), k
+        assert np.abs(got[2:] - want[2:]).max() <= 1e-4 * max(np.abs(want[2:]).max(), 1e-9) + 1e-9, k
+        params["model." + k] = sd["model." + k].clone()
+    O.adamw_step(params, grads, {}, lr=1e-4, weight_decay=1e-5)
+    for k in names:
+        flat = params["model." + k].reshape(-1).double()
+        assert np.abs(flat[torch.from_numpy(_digest_idx(k, flat.numel()))].numpy() - g["param1." + k]).max() <= 2e-6, k

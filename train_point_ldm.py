@@ -1,8 +1,10 @@
 """Entry point kept from the reference (reference train_point_ldm.py:150-234): VAE -> VAE samples -> latent
-diffusion -> latent-diffusion samples, on the HIP VAE3DLarge / latent denoiser.  `train_vae` / `train_diffusion`
-(Lightning `trainer.fit`) are outside this framework's scope: pass checkpoints.
+diffusion -> latent-diffusion samples, on the HIP VAE3DLarge / latent denoiser.  `train_diffusion`
+(train_point_ldm.py:81-110) runs on the HIP latent trainer (frozen VAE encode -> L1 loss -> AdamW + cosine
+schedule); `train_vae` (Conv3d backward) is not implemented: pass a VAE checkpoint trained with the reference.
 
-    python train_point_ldm.py [--vae-ckpt vae.ckpt] [--diffusion-ckpt ldm.ckpt] [--steps 1000]
+    python train_point_ldm.py [--vae-ckpt vae.ckpt] [--diffusion-ckpt ldm.ckpt] [--train-diffusion-epochs N]
+                              [--data-dir DIR] [--category table] [--steps 1000]
 """
 from __future__ import annotations
 
@@ -23,6 +25,11 @@ def main():
     ap.add_argument("--vae-ckpt", default=None)
     ap.add_argument("--diffusion-ckpt", default=None)
     ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--train-diffusion-epochs", type=int, default=0, help="0 = the reference default (perform_diffusion_training = False)")
+    ap.add_argument("--data-dir", default=os.path.join("data", "shape_net_voxel_data_v1"))
+    ap.add_argument("--category", default="table")
+    ap.add_argument("--batch-size", type=int, default=16)
+    ap.add_argument("--synthetic-shapes", type=int, default=160)
     ap.add_argument("--out", default=os.path.join("samples", "point_ldm"))
     args = ap.parse_args()
     torch.manual_seed(24)
@@ -48,10 +55,45 @@ def main():
         diffusion.load_state_dict({**{k: torch.from_numpy(np.asarray(v)) for k, v in lsd.items()},
                                    **{f"vae.{k}": v for k, v in vae.state_dict().items()}}, strict=True)
         print("no --diffusion-ckpt given: sampling the latent diffusion from synthetic weights")
-    diffusion = diffusion.to("cuda").eval()
+    diffusion = diffusion.to("cuda")
+    if args.train_diffusion_epochs > 0:                      # train_point_ldm.py:81-110 (`train_diffusion`)
+        from shapegen_amd.training import fit
+        if os.path.isdir(args.data_dir):
+            from shapegen_amd.data import PointCloudDataDirectoryModule
+            dm = PointCloudDataDirectoryModule(args.data_dir, num_points=2048, batch_size=args.batch_size, file_mode="voxels",
+                                               output_mode="voxels", augmentations=False, relevant_object_categories=[args.category])
+        else:
+            print(f"{args.data_dir} not found: training on {args.synthetic_shapes} synthetic occupancy grids")
+            dm = _SyntheticVoxels(args.synthetic_shapes, args.batch_size)
+        fit(diffusion, dm, max_epochs=args.train_diffusion_epochs, ckpt_dir=os.path.join("checkpoints", "point_ldm", "latent_diffusion"),
+            ckpt_name="latent_diffusion")
+    diffusion = diffusion.eval()
     samples = diffusion.sample(num_samples=num_samples, num_steps=args.steps)  # train_point_ldm.py:222
     np.savez_compressed(os.path.join(args.out, "latent_diffusion_samples.npz"), **{f"sample_{i}": c.cpu().numpy() for i, c in enumerate(samples)})
     print(f"Generated {num_samples} diffusion denoised samples ({[int(c.shape[0]) for c in samples]} points)")
+
+
+class _SyntheticVoxels:
+    """(B,1,32,32,32) occupancy batches of ellipsoid blobs, 80/20 train/val."""
+
+    def __init__(self, count: int, batch_size: int, seed: int = 24):
+        rng = np.random.default_rng(seed)
+        zz, yy, xx = np.meshgrid(*[np.arange(32)] * 3, indexing="ij")
+        v = np.zeros((count, 1, 32, 32, 32), np.float32)
+        for i in range(count):
+            c, r = rng.uniform(8, 24, (3, 3)), rng.uniform(3, 9, (3, 3))
+            for j in range(3):
+                v[i, 0][((zz - c[j, 0]) / r[j, 0]) ** 2 + ((yy - c[j, 1]) / r[j, 1]) ** 2 + ((xx - c[j, 2]) / r[j, 2]) ** 2 <= 1] = 1
+        self.v, self.bs = torch.from_numpy(v), batch_size
+
+    def setup(self):
+        self.n_train = int(0.8 * len(self.v))
+
+    def train_dataloader(self):
+        return (self.v[i:i + self.bs] for i in range(0, self.n_train, self.bs))
+
+    def val_dataloader(self):
+        return (self.v[i:i + self.bs] for i in range(self.n_train, len(self.v), self.bs))
 
 
 if __name__ == "__main__":
