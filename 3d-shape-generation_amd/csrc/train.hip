@@ -233,23 +233,44 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const half_t* __restr
     }
 }
 
-// dst[col][row] = src[row][col]; 64 x 64 tiles through LDS
+// dst[col][row] = src[row][col]; 64 x 64 tiles through LDS, 16-byte global accesses on both sides (the 2-byte version
+// ran at ~40 % of HBM speed and was 1.9 ms of the 12.7 ms training step)
 __global__ __launch_bounds__(256) void transpose_kernel(const half_t* __restrict__ src, int64_t rows, int cols,
                                                          half_t* __restrict__ dst) {
-    __shared__ half_t tile[64][66];
+    __shared__ half_t tile[64][72];                       // +8 halfs: 16-byte aligned rows, conflict-light column reads
     const int64_t r0 = (int64_t)blockIdx.y * 64;
     const int c0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int i = ty; i < 64; i += 4) {
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;          // 8 x 8-half chunks per row, 32 rows per pass
+    const bool vec = (cols % 8 == 0) && (rows % 8 == 0);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int i = pass * 32 + ty;
         const int64_t r = r0 + i;
-        const int cc = c0 + tx;
-        tile[i][tx] = (r < rows && cc < cols) ? src[r * cols + cc] : (half_t)0.f;
+        const int cc = c0 + tx * 8;
+        half8 v;
+        if (vec && r < rows && cc + 8 <= cols) v = *(const half8*)(src + r * cols + cc);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (r < rows && cc + e < cols) ? src[r * cols + cc + e] : (half_t)0.f;
+        }
+        *(half8*)(&tile[i][tx * 8]) = v;
     }
     __syncthreads();
-    for (int i = ty; i < 64; i += 4) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int i = pass * 32 + ty;                     // output row = source column c0 + i
         const int cc = c0 + i;
-        const int64_t r = r0 + tx;
-        if (cc < cols && r < rows) dst[(int64_t)cc * rows + r] = tile[tx][i];
+        const int64_t r = r0 + tx * 8;
+        half8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = tile[tx * 8 + e][i];
+        if (cc < cols) {
+            if (vec && r + 8 <= rows) *(half8*)(dst + (int64_t)cc * rows + r) = v;
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (r + e < rows) dst[(int64_t)cc * rows + r + e] = v[e];
+            }
+        }
     }
 }
 

@@ -74,6 +74,10 @@ def test_train_kernels_against_torch():
     xt = torch.empty(72, 3000, dtype=torch.float16, device="cuda")
     L.check(lib.pcd_transpose_f16(x.data_ptr(), 3000, 72, xt.data_ptr(), st))
     assert torch.equal(xt, x.t().contiguous())
+    xo = torch.randn(1001, 37, device="cuda", generator=g).half()                      # odd sizes: scalar edge path
+    xot = torch.empty(37, 1001, dtype=torch.float16, device="cuda")
+    L.check(lib.pcd_transpose_f16(xo.data_ptr(), 1001, 37, xot.data_ptr(), st))
+    assert torch.equal(xot, xo.t().contiguous())
     # max-pool with first-index argmax (ties included) and its scatter
     b, n, cc = 3, 257, 130
     act = torch.randint(0, 5, (b * n, cc), device="cuda", generator=g).half()          # many exact ties
