@@ -99,38 +99,40 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
     cr_finish<1>(acc, outs, col0, c);
 }
 
-// sqdev[col] += sum over rows of (x - sum[col]/m)^2      (second pass of the batch variance)
-__global__ __launch_bounds__(256) void coldev_kernel(const float* __restrict__ x, int64_t m, int c,
-                                                      const float* __restrict__ sum, float* __restrict__ sqdev, int rpb) {
+// One pass over z for the batch statistics: sums of (z - shift) and (z - shift)^2 with shift[col] = z[0][col].  The
+// shift keeps E[d^2] - E[d]^2 free of cancellation (|mean - shift| is a few sigma at most), so a second read of z
+// for sum (z - mean)^2 is not needed.
+__global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ x, int64_t m, int c, float* __restrict__ s1,
+                                                        float* __restrict__ s2, int rpb) {
     int64_t row0, row1;
     if (!cr_range(m, rpb, row0, row1)) return;
     const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
     const int col0 = blockIdx.x * CR_COLS, col = col0 + cg * 8;
-    float acc[1][8] = {};
+    float acc[2][8] = {};
     if (col < c) {
-        float mean[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) mean[e] = col + e < c ? sum[col + e] / (float)m : 0.f;
+        const f8 sh = ldf8(x, col, c);
         for (int64_t r = row0 + rl; r < row1; r += CR_LANES) {
             const f8 v = ldf8(x + r * c, col, c);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float d = v.v[e] - mean[e]; acc[0][e] += d * d; }
+            for (int e = 0; e < 8; ++e) { const float d = v.v[e] - sh.v[e]; acc[0][e] += d; acc[1][e] += d * d; }
         }
     }
-    float* const outs[1] = {sqdev};
-    cr_finish<1>(acc, outs, col0, c);
+    float* const outs[2] = {s1, s2};
+    cr_finish<2>(acc, outs, col0, c);
 }
 
-__global__ void bn_finalize_kernel(const float* sum, const float* sqdev, int64_t m, int c, float momentum,
+__global__ void bn_finalize_kernel(const float* x, const float* s1, const float* s2, int64_t m, int c, float momentum,
                                    float* mean, float* var, float* running_mean, float* running_var) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= c) return;
-    const float mu = sum[i] / (float)m, v = sqdev[i] / (float)m;
+    const float d1 = s1[i] / (float)m;
+    const float mu = x[i] + d1;                                        // shift = z[0][i]
+    const float v = fmaxf(s2[i] / (float)m - d1 * d1, 0.f);
     mean[i] = mu;
     var[i] = v;
     if (running_mean != nullptr) {   // torch: running_var tracks the UNBIASED variance (m/(m-1))
         running_mean[i] = (1.f - momentum) * running_mean[i] + momentum * mu;
-        const float unb = m > 1 ? sqdev[i] / (float)(m - 1) : v;
+        const float unb = m > 1 ? v * (float)m / (float)(m - 1) : v;
         running_var[i] = (1.f - momentum) * running_var[i] + momentum * unb;
     }
 }
@@ -606,13 +608,12 @@ extern "C" int pcd_bn_batch_stats(const float* z, int64_t m, int c, float moment
     PCD_CHECK_ARG(z && mean && var && scratch && m > 0 && c > 0 && c % 8 == 0);
     PCD_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
     hipStream_t s = (hipStream_t)stream;
-    float *sum = scratch, *sqdev = scratch + c;
+    float *s1 = scratch, *s2 = scratch + c;
     PCD_CHECK_HIP(hipMemsetAsync(scratch, 0, sizeof(float) * 2 * (size_t)c, s));
     const ColGrid g = cr_grid(c, m, 1);
-    hipLaunchKernelGGL(colsum_kernel<float>, g.grid, dim3(256), 0, s, z, m, c, sum, g.rpb);
-    hipLaunchKernelGGL(coldev_kernel, g.grid, dim3(256), 0, s, z, m, c, sum, sqdev, g.rpb);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(nblk256(c)), dim3(256), 0, s, sum, sqdev, m, c, momentum, mean, var,
-                       running_mean, running_var);
+    hipLaunchKernelGGL(colstats_kernel, g.grid, dim3(256), 0, s, z, m, c, s1, s2, g.rpb);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(nblk256(c)), dim3(256), 0, s, z, s1, s2, m, c, momentum, mean, var, running_mean,
+                       running_var);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

@@ -314,7 +314,7 @@ int pcd_sinkhorn_cost(const float* x, const float* y, int batch, int n, int m, c
 /* out[g][c] = sum over the rows_per_group rows of group g of x[row][c]   (bias gradients, per-shape sums) */
 int pcd_colsum_f16(const void* x, int64_t rows_per_group, int groups, int c, float* out, void* stream);
 /* BatchNorm1d training statistics over the M rows of the fp32 conv output z [M][c] (c % 8 == 0): mean[c], biased
- * var[c] (two passes); if running_* are given they are updated as torch does (momentum, UNBIASED variance).
+ * var[c] (one pass, sums shifted by row 0 so that E[d^2] - E[d]^2 does not cancel); if running_* are given they are updated as torch does (momentum, UNBIASED variance).
  * scratch: fp32 [2*c]. */
 int pcd_bn_batch_stats(const float* z, int64_t m, int c, float momentum, float* mean, float* var,
                        float* running_mean, float* running_var, float* scratch, void* stream);
