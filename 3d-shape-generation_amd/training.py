@@ -62,6 +62,22 @@ def _flatten_parameters(model, dev):
     return P, G, M1, M2, views, grads
 
 
+def _allreduce_gradients(G: torch.Tensor) -> int:
+    """Data-parallel training: SUM the flat gradient buffer over the ranks (one collective per step: RCCL all-reduce over
+    xGMI under the `nccl` backend; staged through the host under `gloo`, which the CPU-side tests use).  Returns the
+    world size; the caller folds the 1/world of the mean into the optimizer's gradient scale."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 1
+    if dist.get_backend() == "nccl":
+        dist.all_reduce(G)
+    else:
+        h = G.cpu()
+        dist.all_reduce(h)
+        G.copy_(h)
+    return dist.get_world_size()
+
+
 class _Conv:
     """One Conv1d(k=1) [+ BatchNorm1d + ReLU]: names of its parameters and its saved tensors."""
 
@@ -432,9 +448,10 @@ class PointTrainer:
     def optimizer_step(self):
         self.step_count += 1
         b1, b2 = self.betas
+        world = _allreduce_gradients(self.G)           # data parallel: mean gradient over the ranks (BatchNorm stays per rank)
         self._chk(self.lib.pcd_adamw_step(self.P.data_ptr(), self.G.data_ptr(), self.M1.data_ptr(), self.M2.data_ptr(),
-                                          self.P.numel(), self.lr, b1, b2, self.eps, self.wd, self.step_count, self.loss_scale,
-                                          self._st()), "adamw")
+                                          self.P.numel(), self.lr, b1, b2, self.eps, self.wd, self.step_count,
+                                          self.loss_scale * world, self._st()), "adamw")
         self.refresh_weights()
 
     def train_step(self, x_t: torch.Tensor, t: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
@@ -624,8 +641,9 @@ class LatentTrainer:
     def optimizer_step(self):
         self.step_count += 1
         b1, b2 = self.betas
+        world = _allreduce_gradients(self.G)
         self._chk(self.lib.pcd_adamw_step(self.P.data_ptr(), self.G.data_ptr(), self.M1.data_ptr(), self.M2.data_ptr(), self.P.numel(),
-                                          self.lr, b1, b2, self.eps, self.wd, self.step_count, 1.0, self._st()), "adamw")
+                                          self.lr, b1, b2, self.eps, self.wd, self.step_count, float(world), self._st()), "adamw")
         self.model.invalidate()        # the sampler's packed fp16 weights are stale now
 
     step = optimizer_step
@@ -695,6 +713,8 @@ def fit(model, data_module, max_epochs: int = 500, ckpt_dir: Optional[str] = Non
     opt = cfg["optimizer"]
     sched = cfg["lr_scheduler"]["scheduler"] if isinstance(cfg["lr_scheduler"], dict) else cfg["lr_scheduler"]
     data_module.setup()
+    import torch.distributed as dist
+    rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
     kept: List[Tuple[float, str]] = []
     steps = 0
     history = []
@@ -704,6 +724,8 @@ def fit(model, data_module, max_epochs: int = 500, ckpt_dir: Optional[str] = Non
         for i, batch in enumerate(data_module.train_dataloader()):
             if batch.dim() == 3 and batch.shape[0] * batch.shape[1] % 64:
                 continue                       # ragged last point-cloud batch: the backward-weight GEMM reduces over B*N in 64s
+            if world > 1 and i % world != rank:
+                continue                       # data parallel: rank r takes batches r, r + world, ... (same loader order on every rank)
             loss = model.training_step(batch, i)
             opt.step()
             tl.append(loss)
@@ -717,7 +739,7 @@ def fit(model, data_module, max_epochs: int = 500, ckpt_dir: Optional[str] = Non
         sched.step(val_loss)
         history.append((epoch, train_loss, val_loss, opt.lr))
         log(f"epoch {epoch}: train_loss {train_loss:.4f} val_loss {val_loss:.4f} lr {opt.lr:.2e}")
-        if ckpt_dir is not None:
+        if ckpt_dir is not None and rank == 0:
             import os
             path = os.path.join(ckpt_dir, f"{ckpt_name}-epoch={epoch:02d}-val_loss={val_loss:.2f}.ckpt")
             if len(kept) < save_top_k or val_loss < max(kept)[0]:
