@@ -561,6 +561,133 @@ __global__ void relu_bwd_f32_kernel(const float* x, const float* dy, int64_t n, 
     if (i < n) dx[i] = x[i] > 0.f ? dy[i] : 0.f;
 }
 
+// ---- voxel VAE training (networks.py:2225-2264): every Conv3d / ConvTranspose3d becomes "gather rows, then the GEMM".
+// Geometry of one layer: input grid (di,hi,wi), output grid (do,ho,wo), cubic kernel k, stride s, padding p.
+// transposed = 0 (Conv3d): output o reads input o*s - p + t.  transposed = 1 (ConvTranspose3d): output o reads input
+// (o + p - t)/s where that is an integer.  Channels-last fp16 rows [b*D*H*W][C].
+struct ConvGeom { int di, hi, wi, d_o, ho, wo, k, s, p, transposed; };
+
+__device__ __forceinline__ bool conv_src(const ConvGeom& g, int o, int t, int in_extent, int& i) {
+    if (!g.transposed) { i = o * g.s - g.p + t; return i >= 0 && i < in_extent; }
+    const int num = o + g.p - t;
+    if (num < 0 || num % g.s != 0) return false;
+    i = num / g.s;
+    return i < in_extent;
+}
+// the inverse relation: which output position reads input i at tap t
+__device__ __forceinline__ bool conv_dst(const ConvGeom& g, int i, int t, int out_extent, int& o) {
+    if (!g.transposed) {
+        const int num = i + g.p - t;
+        if (num < 0 || num % g.s != 0) return false;
+        o = num / g.s;
+        return o < out_extent;
+    }
+    o = i * g.s - g.p + t;
+    return o >= 0 && o < out_extent;
+}
+
+// col[r][t*cin + c] = x[src(r, t)][c] or 0; columns >= k^3*cin (padding up to kp) are zeroed.  One thread per (row, tap).
+__global__ __launch_bounds__(256) void im2col_kernel(const half_t* __restrict__ x, int batch, int cin, ConvGeom g, int kp,
+                                                      half_t* __restrict__ col) {
+    const int taps = g.k * g.k * g.k;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t rows = (int64_t)batch * g.d_o * g.ho * g.wo;
+    if (idx >= rows * (taps + 1)) return;
+    const int64_t r = idx / (taps + 1);
+    const int t = (int)(idx - r * (taps + 1));
+    half_t* dst = col + r * kp;
+    if (t == taps) {                                      // zero the padding columns of this row
+        for (int c = taps * cin; c < kp; ++c) dst[c] = (half_t)0.f;
+        return;
+    }
+    int ow = (int)(r % g.wo), oh = (int)((r / g.wo) % g.ho), od = (int)((r / ((int64_t)g.wo * g.ho)) % g.d_o);
+    const int b = (int)(r / ((int64_t)g.wo * g.ho * g.d_o));
+    const int tz = t / (g.k * g.k), ty = (t / g.k) % g.k, tx = t % g.k;
+    int iz, iy, ix;
+    const bool ok = conv_src(g, od, tz, g.di, iz) && conv_src(g, oh, ty, g.hi, iy) && conv_src(g, ow, tx, g.wi, ix);
+    dst += (int64_t)t * cin;
+    if (!ok) {
+        for (int c = 0; c < cin; ++c) dst[c] = (half_t)0.f;
+        return;
+    }
+    const half_t* src = x + ((((int64_t)b * g.di + iz) * g.hi + iy) * g.wi + ix) * cin;
+    if (cin % 8 == 0) {
+        for (int c = 0; c < cin; c += 8) *(half8*)(dst + c) = *(const half8*)(src + c);
+    } else {
+        for (int c = 0; c < cin; ++c) dst[c] = src[c];
+    }
+}
+
+// dx[i][c] = sum over taps of dcol[dst(i, t)][t*cin + c]   (fp32 accumulation, fixed tap order: deterministic)
+__global__ __launch_bounds__(256) void col2im_kernel(const half_t* __restrict__ dcol, int batch, int cin, ConvGeom g, int kp,
+                                                      half_t* __restrict__ dx) {
+    const int cchunks = (cin + 7) / 8;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t rows = (int64_t)batch * g.di * g.hi * g.wi;
+    if (idx >= rows * cchunks) return;
+    const int64_t i = idx / cchunks;
+    const int c0 = (int)(idx - i * cchunks) * 8;
+    const int iw = (int)(i % g.wi), ih = (int)((i / g.wi) % g.hi), id = (int)((i / ((int64_t)g.wi * g.hi)) % g.di);
+    const int b = (int)(i / ((int64_t)g.wi * g.hi * g.di));
+    float acc[8] = {};
+    for (int tz = 0; tz < g.k; ++tz) {
+        int od;
+        if (!conv_dst(g, id, tz, g.d_o, od)) continue;
+        for (int ty = 0; ty < g.k; ++ty) {
+            int oh;
+            if (!conv_dst(g, ih, ty, g.ho, oh)) continue;
+            for (int tx = 0; tx < g.k; ++tx) {
+                int ow;
+                if (!conv_dst(g, iw, tx, g.wo, ow)) continue;
+                const int t = (tz * g.k + ty) * g.k + tx;
+                const half_t* src = dcol + ((((int64_t)b * g.d_o + od) * g.ho + oh) * g.wo + ow) * kp + (int64_t)t * cin + c0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (c0 + e < cin) acc[e] += (float)src[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        if (c0 + e < cin) dx[i * cin + c0 + e] = to_half_sat(acc[e]);
+}
+
+// out = relu(a + b) (ResidualBlock3D tail, networks.py:502-504) and the shared mask of its backward: d = dout * [out > 0]
+__global__ void add_relu_f16_kernel(const half_t* a, const half_t* b, int64_t n, half_t* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = to_half_sat(fmaxf((float)a[i] + (float)b[i], 0.f));
+}
+__global__ void relu_mask_f16_kernel(const half_t* dout, const half_t* out, int64_t n, half_t* d) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = (float)out[i] > 0.f ? dout[i] : (half_t)0.f;
+}
+__global__ void add_f16_kernel(const half_t* a, const half_t* b, int64_t n, half_t* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = to_half_sat((float)a[i] + (float)b[i]);
+}
+// recon = sigmoid(logit) ; loss_sum += BCE(recon, x) with torch's log clamp at -100 ; dlogit = scale * (recon - x) / n
+__global__ __launch_bounds__(256) void sigmoid_bce_kernel(const half_t* __restrict__ logit, int64_t ld, const float* __restrict__ target,
+                                                           int64_t n, float scale, float* __restrict__ loss_sum,
+                                                           float* __restrict__ recon, half_t* __restrict__ dlogit) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float z = (float)logit[i * ld];
+        const float r = 1.f / (1.f + expf(-z));
+        const float x = target[i];
+        s -= x * fmaxf(logf(r), -100.f) + (1.f - x) * fmaxf(logf(1.f - r), -100.f);
+        recon[i] = r;
+        dlogit[i * ld] = to_half_sat(scale * (r - x) / (float)n);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(loss_sum, red[0]);
+}
+
 // torch.optim.AdamW (decoupled weight decay), one flat buffer
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2,
                              int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
@@ -787,6 +914,58 @@ extern "C" int pcd_relu_f32(const float* x, int64_t n, float* y, void* stream) {
 extern "C" int pcd_relu_backward_f32(const float* x, const float* dy, int64_t n, float* dx, void* stream) {
     PCD_CHECK_ARG(x && dy && dx && n > 0);
     hipLaunchKernelGGL(relu_bwd_f32_kernel, dim3(nblk256(n)), dim3(256), 0, (hipStream_t)stream, x, dy, n, dx);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_im2col_f16(const void* x, int batch, int cin, int di, int hi, int wi, int d_o, int ho, int wo, int k, int stride,
+                              int pad, int transposed, int kp, void* col, void* stream) {
+    PCD_CHECK_ARG(x && col && batch > 0 && cin > 0 && di > 0 && hi > 0 && wi > 0 && d_o > 0 && ho > 0 && wo > 0 && k > 0 && stride > 0);
+    PCD_CHECK_ARG(pad >= 0 && kp >= k * k * k * cin && kp % 8 == 0);
+    const ConvGeom g{di, hi, wi, d_o, ho, wo, k, stride, pad, transposed};
+    const int64_t items = (int64_t)batch * d_o * ho * wo * (k * k * k + 1);
+    hipLaunchKernelGGL(im2col_kernel, dim3(nblk256(items)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, batch, cin, g, kp,
+                       (half_t*)col);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_col2im_f16(const void* dcol, int batch, int cin, int di, int hi, int wi, int d_o, int ho, int wo, int k, int stride,
+                              int pad, int transposed, int kp, void* dx, void* stream) {
+    PCD_CHECK_ARG(dcol && dx && batch > 0 && cin > 0 && di > 0 && hi > 0 && wi > 0 && d_o > 0 && ho > 0 && wo > 0 && k > 0 && stride > 0);
+    PCD_CHECK_ARG(pad >= 0 && kp >= k * k * k * cin);
+    const ConvGeom g{di, hi, wi, d_o, ho, wo, k, stride, pad, transposed};
+    const int64_t items = (int64_t)batch * di * hi * wi * ceil_div(cin, 8);
+    hipLaunchKernelGGL(col2im_kernel, dim3(nblk256(items)), dim3(256), 0, (hipStream_t)stream, (const half_t*)dcol, batch, cin, g, kp,
+                       (half_t*)dx);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_add_relu_f16(const void* a, const void* b, int64_t n, int relu, void* out, void* stream) {
+    PCD_CHECK_ARG(a && b && out && n > 0);
+    if (relu) hipLaunchKernelGGL(add_relu_f16_kernel, dim3(nblk256(n)), dim3(256), 0, (hipStream_t)stream, (const half_t*)a, (const half_t*)b, n, (half_t*)out);
+    else hipLaunchKernelGGL(add_f16_kernel, dim3(nblk256(n)), dim3(256), 0, (hipStream_t)stream, (const half_t*)a, (const half_t*)b, n, (half_t*)out);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_relu_mask_f16(const void* dout, const void* out, int64_t n, void* d, void* stream) {
+    PCD_CHECK_ARG(dout && out && d && n > 0);
+    hipLaunchKernelGGL(relu_mask_f16_kernel, dim3(nblk256(n)), dim3(256), 0, (hipStream_t)stream, (const half_t*)dout, (const half_t*)out, n,
+                       (half_t*)d);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_sigmoid_bce(const void* logit, int64_t ld, const float* target, int64_t n, float grad_scale, float* loss_sum,
+                               float* recon, void* dlogit, void* stream) {
+    PCD_CHECK_ARG(logit && target && loss_sum && recon && dlogit && n > 0 && ld >= 1);
+    hipStream_t s = (hipStream_t)stream;
+    PCD_CHECK_HIP(hipMemsetAsync(loss_sum, 0, sizeof(float), s));
+    const unsigned blocks = (unsigned)(ceil_div(n, 256) < 2048 ? ceil_div(n, 256) : 2048);
+    hipLaunchKernelGGL(sigmoid_bce_kernel, dim3(blocks), dim3(256), 0, s, (const half_t*)logit, ld, target, n, grad_scale, loss_sum, recon,
+                       (half_t*)dlogit);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

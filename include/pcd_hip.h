@@ -358,6 +358,21 @@ int pcd_groupnorm_backward_f32(const float* dy, const float* x, int rows, int c,
 int pcd_mask_scale_f32(const float* x, const float* mask, float scale, int64_t n, float* y, void* stream);
 int pcd_relu_f32(const float* x, int64_t n, float* y, void* stream);
 int pcd_relu_backward_f32(const float* x, const float* dy, int64_t n, float* dx, void* stream);
+/* voxel VAE training (networks.py:2225-2264, 471-504): a Conv3d / ConvTranspose3d layer as "gather rows, then the GEMM".
+ * Channels-last fp16 rows [b*D*H*W][C]; cubic kernel k, stride, pad; transposed = 1 for ConvTranspose3d indexing.
+ * col[r][t*cin + c] = x[source of output r at tap t][c] or 0, row length kp >= k^3*cin (extra columns zeroed);
+ * pcd_col2im_f16 is its adjoint as a gather: dx[i][c] = sum_t dcol[output that reads i at tap t][t*cin + c]. */
+int pcd_im2col_f16(const void* x, int batch, int cin, int di, int hi, int wi, int d_o, int ho, int wo, int k, int stride,
+                   int pad, int transposed, int kp, void* col, void* stream);
+int pcd_col2im_f16(const void* dcol, int batch, int cin, int di, int hi, int wi, int d_o, int ho, int wo, int k, int stride,
+                   int pad, int transposed, int kp, void* dx, void* stream);
+/* out = a + b, with ReLU if relu (ResidualBlock3D tail); d = dout * [out > 0] */
+int pcd_add_relu_f16(const void* a, const void* b, int64_t n, int relu, void* out, void* stream);
+int pcd_relu_mask_f16(const void* dout, const void* out, int64_t n, void* d, void* stream);
+/* recon = sigmoid(logit[i*ld]); loss_sum[0] = sum BCE(recon, target) with torch's -100 log clamp (networks.py:2387);
+ * dlogit[i*ld] = grad_scale * (recon - target) / n  (BCE and Sigmoid backward fused) */
+int pcd_sigmoid_bce(const void* logit, int64_t ld, const float* target, int64_t n, float grad_scale, float* loss_sum,
+                    float* recon, void* dlogit, void* stream);
 /* torch.optim.AdamW step on one flat fp32 buffer (diffusion.py:60: lr, weight_decay 1e-5); grads are divided by grad_scale */
 int pcd_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);

@@ -337,3 +337,58 @@ def test_latent_training_step_against_oracle(golden):
     m.eval()
     clouds = m.sample(num_samples=2, num_steps=3)
     assert len(clouds) == 2
+
+
+def _im2col(L, lib, st, x_cl, b, cin, din, dout, k, s, p, tr, kp):
+    col = torch.empty(b * dout ** 3, kp, dtype=torch.float16, device="cuda")
+    L.check(lib.pcd_im2col_f16(x_cl.data_ptr(), b, cin, din, din, din, dout, dout, dout, k, s, p, tr, kp, col.data_ptr(), st))
+    return col
+
+
+def test_im2col_col2im_against_torch_convs():
+    """Conv3d / ConvTranspose3d as gather + product, for every geometry VAE3DLarge uses (networks.py:2225-2264), and
+    col2im as the exact adjoint of im2col (that is what backward-data needs)."""
+    L, lib, st = _lib()
+    g = torch.Generator(device="cuda").manual_seed(4)
+    cases = [(0, 3, 1, 1, 8, 8, 1, 16), (0, 3, 1, 1, 8, 8, 16, 8), (0, 4, 2, 1, 8, 4, 8, 16), (0, 4, 1, 0, 4, 1, 16, 8),
+             (0, 1, 1, 0, 8, 8, 8, 16), (1, 4, 2, 1, 4, 8, 16, 8)]
+    for tr, k, s, p, din, dout, cin, cout in cases:
+        b = 2
+        x = torch.randint(-3, 4, (b, cin, din, din, din), device="cuda", generator=g).float()
+        w = (torch.randint(-2, 3, (cin, cout, k, k, k) if tr else (cout, cin, k, k, k), device="cuda", generator=g)).float()
+        want = F.conv_transpose3d(x, w, stride=s, padding=p) if tr else F.conv3d(x, w, stride=s, padding=p)
+        assert want.shape[-1] == dout
+        x_cl = x.permute(0, 2, 3, 4, 1).reshape(-1, cin).half().contiguous()
+        kk = k ** 3 * cin
+        kp = (kk + 63) // 64 * 64
+        col = _im2col(L, lib, st, x_cl, b, cin, din, dout, k, s, p, tr, kp)
+        assert bool((col[:, kk:] == 0).all())
+        wm = (w.permute(1, 2, 3, 4, 0) if tr else w.permute(0, 2, 3, 4, 1)).reshape(cout, kk)      # [cout][tap][cin]
+        got = col[:, :kk].float() @ wm.t()
+        assert torch.equal(got, want.permute(0, 2, 3, 4, 1).reshape(-1, cout)), (tr, k, s, p)       # small integers: exact
+        # adjoint: <im2col(x), y> == <x, col2im(y)>
+        y = torch.randint(-2, 3, (b * dout ** 3, kp), device="cuda", generator=g).half()
+        y[:, kk:] = 0
+        dx = torch.empty(b * din ** 3, cin, dtype=torch.float16, device="cuda")
+        L.check(lib.pcd_col2im_f16(y.data_ptr(), b, cin, din, din, din, dout, dout, dout, k, s, p, tr, kp, dx.data_ptr(), st))
+        lhs = (col.double() * y.double()).sum()
+        rhs = (x_cl.double() * dx.double()).sum()
+        assert lhs == rhs, (tr, k, s, p, float(lhs), float(rhs))
+    # residual tail and fused sigmoid + BCE
+    a, bb = torch.randn(1000, device="cuda", generator=g).half(), torch.randn(1000, device="cuda", generator=g).half()
+    o = torch.empty_like(a)
+    L.check(lib.pcd_add_relu_f16(a.data_ptr(), bb.data_ptr(), 1000, 1, o.data_ptr(), st))
+    assert torch.equal(o, (a.float() + bb.float()).clamp_min(0).half())
+    d = torch.empty_like(a)
+    L.check(lib.pcd_relu_mask_f16(bb.data_ptr(), o.data_ptr(), 1000, d.data_ptr(), st))
+    assert torch.equal(d, torch.where(o > 0, bb, torch.zeros_like(bb)))
+    logit = (torch.randn(777, 8, device="cuda", generator=g) * 4).half()
+    tgt = (torch.rand(777, device="cuda", generator=g) > 0.7).float()
+    ls, rec, dl = torch.empty(1, device="cuda"), torch.empty(777, device="cuda"), torch.zeros(777, 8, dtype=torch.float16, device="cuda")
+    L.check(lib.pcd_sigmoid_bce(logit.data_ptr(), 8, tgt.data_ptr(), 777, 64.0, ls.data_ptr(), rec.data_ptr(), dl.data_ptr(), st))
+    z = logit[:, 0].float().clone().requires_grad_(True)
+    r = torch.sigmoid(z)
+    loss = F.binary_cross_entropy(r, tgt)
+    loss.backward()
+    assert abs(ls.item() / 777 - loss.item()) < 1e-5 and torch.allclose(rec, r.detach(), atol=1e-6)
+    assert rel_l2(dl[:, 0].float() / 64.0, z.grad) < 2e-3
