@@ -144,6 +144,7 @@ _SIGS = {
     "pcd_add_relu_f16": (i32, [vp, vp, i64, i32, vp, vp]),
     "pcd_relu_mask_f16": (i32, [vp, vp, i64, vp, vp]),
     "pcd_sigmoid_bce": (i32, [vp, i64, vp, i64, f32, vp, vp, vp, vp]),
+    "pcd_vae_latent_backward": (i32, [vp, vp, vp, vp, i64, f32, vp, vp, vp, vp]),
     "pcd_adamw_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
 }
 

@@ -688,6 +688,18 @@ __global__ __launch_bounds__(256) void sigmoid_bce_kernel(const half_t* __restri
     if (threadIdx.x == 0) atomicAdd(loss_sum, red[0]);
 }
 
+// VAE latent head backward (networks.py:2323-2325, 2389-2396): z = mu + eps * exp(logvar / 2), KL = -0.5 mean(1 + lv - mu^2 - e^lv)
+//   dmu = dz + kl_scale * mu / n ; dlogvar = dz * eps * 0.5 * exp(lv / 2) + kl_scale * 0.5 * (e^lv - 1) / n ; kl_sum += 1 + lv - mu^2 - e^lv
+__global__ void vae_latent_bwd_kernel(const float* mu, const float* lv, const float* eps, const float* dz, int64_t n, float kl_scale,
+                                      float* dmu, float* dlv, float* kl_sum) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float e = expf(lv[i]);
+    dmu[i] = dz[i] + kl_scale * mu[i] / (float)n;
+    dlv[i] = dz[i] * eps[i] * 0.5f * expf(0.5f * lv[i]) + kl_scale * 0.5f * (e - 1.f) / (float)n;
+    atomicAdd(kl_sum, 1.f + lv[i] - mu[i] * mu[i] - e);
+}
+
 // torch.optim.AdamW (decoupled weight decay), one flat buffer
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2,
                              int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
@@ -966,6 +978,16 @@ extern "C" int pcd_sigmoid_bce(const void* logit, int64_t ld, const float* targe
     const unsigned blocks = (unsigned)(ceil_div(n, 256) < 2048 ? ceil_div(n, 256) : 2048);
     hipLaunchKernelGGL(sigmoid_bce_kernel, dim3(blocks), dim3(256), 0, s, (const half_t*)logit, ld, target, n, grad_scale, loss_sum, recon,
                        (half_t*)dlogit);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_vae_latent_backward(const float* mu, const float* logvar, const float* eps, const float* dz, int64_t n,
+                                       float kl_scale, float* dmu, float* dlogvar, float* kl_sum, void* stream) {
+    PCD_CHECK_ARG(mu && logvar && eps && dz && dmu && dlogvar && kl_sum && n > 0);
+    hipStream_t s = (hipStream_t)stream;
+    PCD_CHECK_HIP(hipMemsetAsync(kl_sum, 0, sizeof(float), s));
+    hipLaunchKernelGGL(vae_latent_bwd_kernel, dim3(nblk256(n)), dim3(256), 0, s, mu, logvar, eps, dz, n, kl_scale, dmu, dlogvar, kl_sum);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

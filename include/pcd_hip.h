@@ -373,6 +373,10 @@ int pcd_relu_mask_f16(const void* dout, const void* out, int64_t n, void* d, voi
  * dlogit[i*ld] = grad_scale * (recon - target) / n  (BCE and Sigmoid backward fused) */
 int pcd_sigmoid_bce(const void* logit, int64_t ld, const float* target, int64_t n, float grad_scale, float* loss_sum,
                     float* recon, void* dlogit, void* stream);
+/* backward of z = mu + eps * exp(logvar / 2) and of kl_scale * KL (networks.py:2323-2325, 2389-2396) over n = B * latent
+ * elements: dmu, dlogvar; kl_sum[0] = sum(1 + logvar - mu^2 - exp(logvar)) (KL = -0.5 * kl_sum / n) */
+int pcd_vae_latent_backward(const float* mu, const float* logvar, const float* eps, const float* dz, int64_t n,
+                            float kl_scale, float* dmu, float* dlogvar, float* kl_sum, void* stream);
 /* torch.optim.AdamW step on one flat fp32 buffer (diffusion.py:60: lr, weight_decay 1e-5); grads are divided by grad_scale */
 int pcd_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);

@@ -528,3 +528,43 @@ def latent_training_step(sd: SD, p: str, z_t: torch.Tensor, t: torch.Tensor, noi
         loss = F.l1_loss(noise, pred)
         loss.backward()
     return loss.detach(), pred.detach(), {k: v.grad for k, v in leaves.items()}
+
+
+# ------------------------------------------------------------------ VAE training step (networks.py:2341-2396)
+def vae_training_step(sd: SD, p: str, x: torch.Tensor, eps: torch.Tensor, kl_weight: float, enc_prog, dec_prog):
+    """VAE3DLarge.calculate_loss(mode='train') with the module in train() mode (BatchNorm3d batch statistics, running
+    estimates updated in sd) for a given reparameterisation draw eps and KL weight, and its gradients by autograd.
+    Returns (loss, recon_loss, kl_div, recon, mu, logvar, {key: grad})."""
+    global _BN_TRAIN
+    work = dict(sd)
+    leaves = {}
+    for k, v in sd.items():
+        if k.startswith(p) and v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+            leaves[k] = v.detach().clone().requires_grad_(True)
+            work[k] = leaves[k]
+    _BN_TRAIN = True
+    try:
+        with torch.enable_grad():
+            mu, logvar = vae_encode(work, p, x, enc_prog)
+            z = mu + eps * torch.exp(0.5 * logvar)
+            recon = vae_decode(work, p, z, dec_prog)
+            recon_loss = F.binary_cross_entropy(recon, x, reduction="mean")
+            kl = -0.5 * torch.mean(1 + logvar - mu.pow(2) - logvar.exp())
+            loss = recon_loss + kl_weight * kl
+            loss.backward()
+    finally:
+        _BN_TRAIN = False
+    for k in sd:
+        if k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            sd[k] = work[k]
+    return (loss.detach(), recon_loss.detach(), kl.detach(), recon.detach(), mu.detach(), logvar.detach(),
+            {k: v.grad for k, v in leaves.items()})
+
+
+def vae_kl_weight(epoch: int, max_epochs: int, kl_warmup_epochs: int = 10, kl_warmup_max_beta: float = 0.1,
+                  kl_annealing_epochs: int = 100) -> float:
+    """VAE3DLarge.get_kl_weight (networks.py:2355-2370), including its hard-coded `current_epoch < 10`."""
+    annealing = min(max_epochs, kl_annealing_epochs)
+    if epoch < 10:
+        return (epoch + 1) / kl_warmup_epochs * kl_warmup_max_beta
+    return min(kl_warmup_max_beta + (epoch - kl_warmup_epochs + 1) / (annealing - kl_warmup_epochs) * (1.0 - kl_warmup_max_beta), 1.0)
