@@ -719,6 +719,8 @@ def fit(model, data_module, max_epochs: int = 500, ckpt_dir: Optional[str] = Non
     steps = 0
     history = []
     for epoch in range(max_epochs):
+        if hasattr(model, "current_epoch"):
+            model.current_epoch, model._max_epochs = epoch, max_epochs      # VAE3DLarge.get_kl_weight reads these
         model.train()
         tl = []
         for i, batch in enumerate(data_module.train_dataloader()):

@@ -83,6 +83,56 @@ class VAE3DLarge(_HipModule):
         obj.load_state_dict(sd, strict=True)
         return obj
 
+    # ---------------------------------------------------------------- training surface (networks.py:2286-2416)
+    current_epoch = 0          # set by training.fit, like Lightning does
+    _max_epochs = 100
+
+    def get_kl_weight(self) -> float:
+        """networks.py:2355-2370: linear warm-up to kl_warmup_max_beta, then annealing to 1 (incl. the hard-coded `< 10`)."""
+        hp = self.hparams
+        annealing_epochs = min(self._max_epochs, hp.kl_annealing_epochs)
+        if self.current_epoch < 10:
+            return (self.current_epoch + 1) / hp.kl_warmup_epochs * hp.kl_warmup_max_beta
+        return min(hp.kl_warmup_max_beta + (self.current_epoch - hp.kl_warmup_epochs + 1) /
+                   (annealing_epochs - hp.kl_warmup_epochs) * (1.0 - hp.kl_warmup_max_beta), 1.0)
+
+    def configure_optimizers(self):
+        """torch.optim.Adam(lr) + ReduceLROnPlateau(min, 0.5, patience 5) on `val_loss` (networks.py:2286-2297);
+        the optimizer object is the HIP trainer (`training_vae.VAETrainer`), which also owns forward / backward."""
+        from .training import ReduceLROnPlateau
+        from .training_vae import VAETrainer
+        if getattr(self, "_trainer", None) is None:
+            self._trainer = VAETrainer(self, lr=self.hparams.lr)
+        return {"optimizer": self._trainer,
+                "lr_scheduler": {"scheduler": ReduceLROnPlateau(self._trainer, factor=0.5, patience=5), "monitor": "val_loss"}}
+
+    def calculate_loss(self, batch, mode):
+        """networks.py:2372-2402 -> (loss, reconstruction).  mode 'train' in train(): batch statistics, gradients left in
+        the trainer, KL weight from the schedule; otherwise the sampler's eval path and KL weight 1."""
+        x = batch.to(self.device, torch.float32)
+        lib = _lib.load()
+        if mode == "train" and self.training:
+            tr = self.configure_optimizers()["optimizer"]
+            tr.forward(x)
+            loss, _, _ = tr.backward(self.get_kl_weight())
+            return loss, tr.recon
+        recon, mu, logvar = self(x)
+        out = torch.empty(2, dtype=torch.float32, device=self.device)
+        _lib.check(lib.pcd_binary_bce_mean(recon.data_ptr(), x.contiguous().data_ptr(), recon.numel(), out.data_ptr(), _lib.stream_ptr()), "bce")
+        zero = torch.zeros_like(mu)
+        scratch = torch.empty_like(mu)
+        _lib.check(lib.pcd_vae_latent_backward(mu.data_ptr(), logvar.data_ptr(), zero.data_ptr(), zero.data_ptr(), mu.numel(), 0.0,
+                                               scratch.data_ptr(), scratch.data_ptr(), out[1:].data_ptr(), _lib.stream_ptr()), "kl")
+        kl = -0.5 * out[1] / mu.numel()
+        w = self.get_kl_weight() if mode == "train" else 1.0
+        return out[0] + w * kl, recon
+
+    def training_step(self, batch, batch_idx=0):
+        return self.calculate_loss(batch, mode="train")[0]
+
+    def validation_step(self, batch, batch_idx=0):
+        return self.calculate_loss(batch, mode="val")[0]       # networks.py:2416-2444 minus the TensorBoard figures
+
     # ---------------------------------------------------------------- packing
     def _ensure_packed(self):
         if self._packed is not None:

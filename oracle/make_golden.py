@@ -12,7 +12,7 @@ never depend on a torch RNG stream.
 Fixture map: G1 schedule.npz, G2-G4 point_unet.npz,
 G5-G7 point_samplers.npz, G8 latent.npz, G9 metrics.npz, G10 attention.npz; beyond the survey's list:
 G11 vae3d_small.npz (`make_golden.py vae3d`), G12 data.npz (`make_golden.py data`), G13 train.npz
-(`make_golden.py train`), G14 train_latent.npz (`make_golden.py train_latent`).
+(`make_golden.py train`), G14 train_latent.npz (`make_golden.py train_latent`), G15 train_vae.npz (`make_golden.py train_vae`).
 """
 from __future__ import annotations
 
@@ -234,8 +234,53 @@ def capture_train_latent(rn):
     print("train_latent done: loss", loss.item(), "kept", mask.mean().item())
 
 
+def capture_train_vae(rn):
+    """G15: VAE3DLarge.calculate_loss(mode='train') in train() mode + one Adam step (networks.py:2290, 2355-2416) ->
+    tests/golden/train_vae.npz (gradient digests; epoch 0 of 100 -> KL weight 0.01)."""
+    import types
+    spec = specs.vae3d_large_spec(prefix="vae.")
+    vae = rn.VAE3DLarge()
+    vae.load_state_dict({k[len("vae."):]: v for k, v in T(specs.synth_state_dict(spec, seed=0, gain=VAE_GAIN)).items()}, strict=True)
+    vae.train()
+    object.__setattr__(vae, "trainer", types.SimpleNamespace(max_epochs=100))
+    vae.current_epoch = 0
+    x = torch.from_numpy(synth_voxels(2, 5))
+    torch.manual_seed(11)
+    eps_replay = torch.randn(2, 256)
+    torch.manual_seed(11)
+    with torch.enable_grad():
+        opt = torch.optim.Adam(vae.parameters(), lr=1e-4)            # networks.py:2290 (scheduler line has the verbose= skew)
+        opt.zero_grad()
+        loss, recon = vae.calculate_loss(x, mode="train")
+        loss.backward()
+    g = {"loss": loss.item(), "kl_weight": vae.get_kl_weight(), "eps": eps_replay.numpy(), "recon_mean": recon.mean().item(),
+         "recon_sample": recon.detach().reshape(-1)[::997].numpy()}
+    names = []
+    for k, prm in vae.named_parameters():
+        g["grad." + k] = grad_digest(k, prm.grad)[0]
+        names.append(k)
+    opt.step()
+    for k, prm in vae.named_parameters():
+        flat = prm.detach().reshape(-1).double()
+        idx = (np.abs(specs.hash_uniform("digest." + k, 64, 7)) * (flat.numel() - 1)).astype(np.int64)
+        g["param1." + k] = flat[torch.from_numpy(idx)].numpy()
+    for k, v in vae.state_dict().items():
+        if k.endswith(("running_mean", "running_var")):
+            g["buf1." + k] = v.numpy()
+    g["param_names"] = np.array(names)
+    g["kl_weights"] = np.array([[e, 100, 0.0] for e in (0, 5, 9, 10, 50, 99)] + [[e, 20, 0.0] for e in (10, 19)], dtype=np.float64)
+    for row in g["kl_weights"]:
+        vae.current_epoch = int(row[0]); vae.trainer.max_epochs = int(row[1]); row[2] = vae.get_kl_weight()
+    np.savez_compressed(os.path.join(OUT, "train_vae.npz"), **g)
+    print("train_vae done: loss", loss.item(), "kl weight", g["kl_weight"])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "train_vae" in sys.argv[1:]:
+        rd, rn, rm, ru = ref_shim.load_reference()
+        capture_train_vae(rn)
+        return
     if "train_latent" in sys.argv[1:]:
         rd, rn, rm, ru = ref_shim.load_reference()
         capture_train_latent(rn)

@@ -37,12 +37,17 @@ def test_test_point_ldm_script(tmp_path):
 
 
 def test_train_entry_scripts_sampling_tails(tmp_path):
-    out = _run([os.path.join(ROOT, "train_point_ldm.py"), "--steps", "20", "--out", str(tmp_path / "s"), "--train-diffusion-epochs", "2",
-                "--synthetic-shapes", "40", "--batch-size", "8", "--data-dir", str(tmp_path / "none")], str(tmp_path))
+    out = _run([os.path.join(ROOT, "train_point_ldm.py"), "--steps", "20", "--out", str(tmp_path / "s"), "--train-vae-epochs", "1",
+                "--train-diffusion-epochs", "2", "--synthetic-shapes", "40", "--batch-size", "8", "--data-dir", str(tmp_path / "none")],
+               str(tmp_path))
     assert "Generated 10 VAE samples" in out and "Generated 10 diffusion denoised samples" in out
     assert "epoch 1: train_loss" in out                          # the latent-diffusion training loop ran
     import glob
     assert len(glob.glob(str(tmp_path / "checkpoints" / "point_ldm" / "latent_diffusion" / "latent_diffusion-epoch=*.ckpt"))) == 2
+    vae_ckpts = glob.glob(str(tmp_path / "checkpoints" / "point_ldm" / "vae" / "vae-epoch=*.ckpt"))
+    assert len(vae_ckpts) == 1
+    from shapegen_amd.vae import VAE3DLarge
+    assert VAE3DLarge.load_from_checkpoint(vae_ckpts[0]).latent_dim == 256
     z = np.load(tmp_path / "s" / "latent_diffusion_samples.npz")
     assert len(z.files) == 10 and all(z[k].shape[1] == 3 for k in z.files)
 

@@ -68,3 +68,39 @@ def test_latent_training_step_matches_reference(golden):
     for k in names:
         flat = params["model." + k].reshape(-1).double()
         assert np.abs(flat[torch.from_numpy(_digest_idx(k, flat.numel()))].numpy() - g["param1." + k]).max() <= 2e-6, k
+
+
+def test_vae_training_step_matches_reference(golden):
+    """oracle.vae_training_step / vae_kl_weight against tests/golden/train_vae.npz (VAE3DLarge.calculate_loss in train()
+    mode, autograd, one torch.optim.Adam step, the KL warm-up / annealing schedule)."""
+    from helpers import as_torch
+    from oracle import make_golden as MG
+    g = golden("train_vae.npz")
+    sd = as_torch(specs.synth_state_dict(specs.vae3d_large_spec(prefix="vae."), seed=0, gain=1.3))
+    x = torch.from_numpy(MG.synth_voxels(2, 5))
+    eps = torch.from_numpy(g["eps"])
+    for e, mx, want in g["kl_weights"]:
+        assert abs(O.vae_kl_weight(int(e), int(mx)) - want) < 1e-12
+    w = O.vae_kl_weight(0, 100)
+    loss, rl, kl, recon, mu, lv, grads = O.vae_training_step(sd, "vae.", x, eps, w, specs.VAE_ENC, specs.VAE_DEC)
+    assert abs(loss.item() - float(g["loss"])) <= 2e-6
+    assert np.abs(recon.reshape(-1)[::997].numpy() - g["recon_sample"]).max() <= 1e-5
+    names = [str(n) for n in g["param_names"]]
+    assert sorted("vae." + n for n in names) == sorted(grads.keys())
+    params = {}
+    for k in names:
+        flat = grads["vae." + k].reshape(-1).double()
+        want = g["grad." + k]
+        got = np.concatenate([[flat.norm().item(), flat.sum().item()], flat[torch.from_numpy(_digest_idx(k, flat.numel()))].numpy()])
+        assert abs(got[0] - want[0]) <= 2e-4 * max(want[0], 1e-12), k
+        assert np.abs(got[2:] - want[2:]).max() <= 2e-4 * max(np.abs(want[2:]).max(), 1e-3 * want[0] / flat.numel() ** 0.5) + 1e-10, k
+        params["vae." + k] = sd["vae." + k].clone()
+    for k, v in sd.items():
+        if k.endswith(("running_mean", "running_var")):
+            assert np.allclose(v.numpy(), g["buf1." + k[len("vae."):]], rtol=1e-4, atol=1e-6), k
+    O.adamw_step(params, grads, {}, lr=1e-4, weight_decay=0.0)             # Adam = AdamW without decay
+    for k in names:
+        flat = params["vae." + k].reshape(-1).double()
+        got = flat[torch.from_numpy(_digest_idx(k, flat.numel()))].numpy()
+        # the first Adam step is lr * g / (|g| + eps): elements with |g| ~ 1e-8 amplify last-bit gradient differences
+        assert np.abs(got - g["param1." + k]).max() <= 2e-5, k

@@ -1,9 +1,9 @@
 """Entry point kept from the reference (reference train_point_ldm.py:150-234): VAE -> VAE samples -> latent
-diffusion -> latent-diffusion samples, on the HIP VAE3DLarge / latent denoiser.  `train_diffusion`
-(train_point_ldm.py:81-110) runs on the HIP latent trainer (frozen VAE encode -> L1 loss -> AdamW + cosine
-schedule); `train_vae` (Conv3d backward) is not implemented: pass a VAE checkpoint trained with the reference.
+diffusion -> latent-diffusion samples, on the HIP VAE3DLarge / latent denoiser.  `train_vae` (train_point_ldm.py:24-79)
+runs on `training_vae.VAETrainer` (BCE + annealed KL, Adam, plateau scheduler), `train_diffusion` (:81-110) on the HIP
+latent trainer (frozen VAE encode -> L1 loss -> AdamW + cosine schedule).
 
-    python train_point_ldm.py [--vae-ckpt vae.ckpt] [--diffusion-ckpt ldm.ckpt] [--train-diffusion-epochs N]
+    python train_point_ldm.py [--vae-ckpt vae.ckpt | --train-vae-epochs N] [--diffusion-ckpt ldm.ckpt | --train-diffusion-epochs N]
                               [--data-dir DIR] [--category table] [--steps 1000]
 """
 from __future__ import annotations
@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--vae-ckpt", default=None)
     ap.add_argument("--diffusion-ckpt", default=None)
     ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--train-vae-epochs", type=int, default=0, help="train the voxel VAE first (train_point_ldm.py:24-79, `train_vae`)")
     ap.add_argument("--train-diffusion-epochs", type=int, default=0, help="0 = the reference default (perform_diffusion_training = False)")
     ap.add_argument("--data-dir", default=os.path.join("data", "shape_net_voxel_data_v1"))
     ap.add_argument("--category", default="table")
@@ -41,7 +42,11 @@ def main():
         sd = specs.synth_state_dict(specs.vae3d_large_spec(256), seed=2, gain=1.3)
         vae.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
         print("no --vae-ckpt given: training is out of scope here, using synthetic VAE weights")
-    vae = vae.to("cuda").eval()
+    vae = vae.to("cuda")
+    if args.train_vae_epochs > 0:                            # train_point_ldm.py:24-79 (`train_vae`)
+        from shapegen_amd.training import fit
+        fit(vae, _data_module(args), max_epochs=args.train_vae_epochs, ckpt_dir=os.path.join("checkpoints", "point_ldm", "vae"), ckpt_name="vae")
+    vae = vae.eval()
     os.makedirs(args.out, exist_ok=True)
     num_samples = 10
     samples_vae = vae.sample(num_samples=num_samples)                       # train_point_ldm.py:197
@@ -58,19 +63,22 @@ def main():
     diffusion = diffusion.to("cuda")
     if args.train_diffusion_epochs > 0:                      # train_point_ldm.py:81-110 (`train_diffusion`)
         from shapegen_amd.training import fit
-        if os.path.isdir(args.data_dir):
-            from shapegen_amd.data import PointCloudDataDirectoryModule
-            dm = PointCloudDataDirectoryModule(args.data_dir, num_points=2048, batch_size=args.batch_size, file_mode="voxels",
-                                               output_mode="voxels", augmentations=False, relevant_object_categories=[args.category])
-        else:
-            print(f"{args.data_dir} not found: training on {args.synthetic_shapes} synthetic occupancy grids")
-            dm = _SyntheticVoxels(args.synthetic_shapes, args.batch_size)
-        fit(diffusion, dm, max_epochs=args.train_diffusion_epochs, ckpt_dir=os.path.join("checkpoints", "point_ldm", "latent_diffusion"),
-            ckpt_name="latent_diffusion")
+        fit(diffusion, _data_module(args), max_epochs=args.train_diffusion_epochs,
+            ckpt_dir=os.path.join("checkpoints", "point_ldm", "latent_diffusion"), ckpt_name="latent_diffusion")
     diffusion = diffusion.eval()
     samples = diffusion.sample(num_samples=num_samples, num_steps=args.steps)  # train_point_ldm.py:222
     np.savez_compressed(os.path.join(args.out, "latent_diffusion_samples.npz"), **{f"sample_{i}": c.cpu().numpy() for i, c in enumerate(samples)})
     print(f"Generated {num_samples} diffusion denoised samples ({[int(c.shape[0]) for c in samples]} points)")
+
+
+def _data_module(args):
+    """Voxel batches: the reference's data module (train_point_ldm.py:166-168) or synthetic occupancy grids."""
+    if os.path.isdir(args.data_dir):
+        from shapegen_amd.data import PointCloudDataDirectoryModule
+        return PointCloudDataDirectoryModule(args.data_dir, num_points=2048, batch_size=args.batch_size, file_mode="voxels",
+                                             output_mode="voxels", augmentations=False, relevant_object_categories=[args.category])
+    print(f"{args.data_dir} not found: training on {args.synthetic_shapes} synthetic occupancy grids")
+    return _SyntheticVoxels(args.synthetic_shapes, args.batch_size)
 
 
 class _SyntheticVoxels:
