@@ -226,8 +226,9 @@ def test_training_step_against_oracle(golden):
         assert mine.shape == gr.shape and torch.isfinite(mine).all(), k
         if gr.dim() > 1 and gr.norm() > 0:
             cos[k] = F.cosine_similarity(mine.reshape(1, -1), gr.reshape(1, -1)).item()
-            assert 0.5 < mine.norm().item() / gr.norm().item() < 2.0, k
-    assert min(cos.values()) > 0.6 and np.median(list(cos.values())) > 0.85, sorted(cos.items(), key=lambda kv: kv[1])[:5]
+            assert 0.8 < mine.norm().item() / gr.norm().item() < 1.25, k
+    # measured: cosine min 0.94 / median 0.95, norm ratios 0.94..1.01, prediction 2.5e-2, loss 1e-3
+    assert min(cos.values()) > 0.85 and np.median(list(cos.values())) > 0.9, sorted(cos.items(), key=lambda kv: kv[1])[:5]
     for k, v in model.state_dict().items():
         if k.endswith(("running_mean", "running_var")):
             assert torch.allclose(v.cpu(), sd_ref[k], rtol=2e-2, atol=2e-2), k

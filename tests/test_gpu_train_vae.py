@@ -1,8 +1,8 @@
 """VAE3DLarge training step on the HIP kernels (shapegen_amd.training_vae.VAETrainer) against the oracle's autograd
-(oracle.torch_oracle.vae_training_step, pinned to the reference by tests/golden/train_vae.npz).  Like the point
-denoiser (BatchNorm batch statistics through ~16 normalised layers, fp16 operands) the end-to-end gradient comparison
-is a direction / magnitude check; the layer arithmetic is pinned exactly by the im2col / col2im / BatchNorm kernel tests
-in test_gpu_train.py."""
+(oracle.torch_oracle.vae_training_step, pinned to the reference by tests/golden/train_vae.npz).  With fp16 operands
+through ~30 conv layers the end-to-end gradient comparison is a direction / magnitude check (measured: cosine >= 0.99,
+norm ratio 0.99..1.02 on every weight tensor); the layer arithmetic is pinned exactly by the im2col / col2im / BatchNorm
+kernel tests in test_gpu_train.py."""
 import numpy as np
 import pytest
 import torch
@@ -40,10 +40,11 @@ def test_vae_training_step_against_oracle():
     loss, recon_loss, kl = tr.backward(0.01)
     sd_ref = {k: v.clone() for k, v in sd.items()}
     l_ref, r_ref, k_ref, recon_ref, mu_ref, lv_ref, grads_ref = O.vae_training_step(sd_ref, "vae.", x, eps, 0.01, specs.VAE_ENC, specs.VAE_DEC)
-    assert rel_l2(tr.mu.cpu(), mu_ref) < 3e-2 and rel_l2(tr.logvar.cpu(), lv_ref) < 3e-2
-    assert abs(kl.item() - k_ref.item()) < 3e-2 * abs(k_ref.item())
-    assert abs(recon_loss.item() - r_ref.item()) < 2e-2 * r_ref.item() and abs(loss.item() - l_ref.item()) < 2e-2 * l_ref.item()
-    assert rel_l2(tr.recon.cpu(), recon_ref) < 5e-2
+    # measured: mu / logvar 2e-3, loss 3e-4, reconstruction 1.5e-3, gradient cosines min 0.992 / median 0.997
+    assert rel_l2(tr.mu.cpu(), mu_ref) < 1e-2 and rel_l2(tr.logvar.cpu(), lv_ref) < 1e-2
+    assert abs(kl.item() - k_ref.item()) < 1e-2 * abs(k_ref.item())
+    assert abs(recon_loss.item() - r_ref.item()) < 5e-3 * r_ref.item() and abs(loss.item() - l_ref.item()) < 5e-3 * l_ref.item()
+    assert rel_l2(tr.recon.cpu(), recon_ref) < 1e-2
     grads = tr.grads()
     cos = {}
     for k, gr in grads_ref.items():
@@ -51,9 +52,9 @@ def test_vae_training_step_against_oracle():
         assert mine.shape == gr.shape and torch.isfinite(mine).all(), k
         if gr.dim() > 1 and gr.norm() > 0:
             cos[k] = F.cosine_similarity(mine.reshape(1, -1), gr.reshape(1, -1)).item()
-            assert 0.5 < mine.norm().item() / gr.norm().item() < 2.0, (k, mine.norm().item(), gr.norm().item())
+            assert 0.9 < mine.norm().item() / gr.norm().item() < 1.1, (k, mine.norm().item(), gr.norm().item())
     low = sorted(cos.items(), key=lambda kv: kv[1])[:5]
-    assert min(cos.values()) > 0.5 and np.median(list(cos.values())) > 0.9, low
+    assert min(cos.values()) > 0.95 and np.median(list(cos.values())) > 0.98, low
     for k, v in vae.state_dict().items():
         if k.endswith(("running_mean", "running_var")):
             assert torch.allclose(v.cpu(), sd_ref["vae." + k], rtol=3e-2, atol=3e-2), k
