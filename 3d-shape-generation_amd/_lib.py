@@ -141,6 +141,7 @@ _SIGS = {
     "pcd_relu_backward_f32": (i32, [vp, vp, i64, vp, vp]),
     "pcd_im2col_f16": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "pcd_col2im_f16": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "pcd_bias_act_f16": (i32, [vp, vp, i64, i32, i32, vp, vp]),
     "pcd_add_relu_f16": (i32, [vp, vp, i64, i32, vp, vp]),
     "pcd_relu_mask_f16": (i32, [vp, vp, i64, vp, vp]),
     "pcd_sigmoid_bce": (i32, [vp, i64, vp, i64, f32, vp, vp, vp, vp]),

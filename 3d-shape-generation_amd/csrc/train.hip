@@ -665,6 +665,14 @@ __global__ void add_f16_kernel(const half_t* a, const half_t* b, int64_t n, half
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = to_half_sat((float)a[i] + (float)b[i]);
 }
+// out[r][c] = act(x[r][c] + bias[c])   (bias + ReLU after a ConvTranspose3d computed as product-then-col2im)
+__global__ void bias_act_f16_kernel(const half_t* x, const float* bias, int64_t rows, int c, int relu, half_t* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * c) return;
+    float v = (float)x[i] + bias[i % c];
+    if (relu) v = fmaxf(v, 0.f);
+    out[i] = to_half_sat(v);
+}
 // recon = sigmoid(logit) ; loss_sum += BCE(recon, x) with torch's log clamp at -100 ; dlogit = scale * (recon - x) / n
 __global__ __launch_bounds__(256) void sigmoid_bce_kernel(const half_t* __restrict__ logit, int64_t ld, const float* __restrict__ target,
                                                            int64_t n, float scale, float* __restrict__ loss_sum,
@@ -988,6 +996,14 @@ extern "C" int pcd_vae_latent_backward(const float* mu, const float* logvar, con
     hipStream_t s = (hipStream_t)stream;
     PCD_CHECK_HIP(hipMemsetAsync(kl_sum, 0, sizeof(float), s));
     hipLaunchKernelGGL(vae_latent_bwd_kernel, dim3(nblk256(n)), dim3(256), 0, s, mu, logvar, eps, dz, n, kl_scale, dmu, dlogvar, kl_sum);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_bias_act_f16(const void* x, const float* bias, int64_t rows, int c, int relu, void* out, void* stream) {
+    PCD_CHECK_ARG(x && bias && out && rows > 0 && c > 0);
+    hipLaunchKernelGGL(bias_act_f16_kernel, dim3(nblk256(rows * c)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, bias, rows, c, relu,
+                       (half_t*)out);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

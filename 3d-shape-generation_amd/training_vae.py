@@ -1,16 +1,17 @@
 """Training step of the voxel VAE `VAE3DLarge` on the HIP kernels (reference networks.py:2209-2416: `calculate_loss`
 = BCE(reconstruction) + kl_weight * KL with the module in train() mode, `torch.optim.Adam(lr)`).
 
-Every Conv3d / ConvTranspose3d is run as "gather rows, then the GEMM": `pcd_im2col_f16` builds the row matrix
-col [B*Do*Ho*Wo][k^3*Cin] (ConvTranspose3d through its own index relation, so a stride-2 transposed layer is the same
-code with 7/8 of its columns zero), the fp16 MFMA GEMM does forward (z = col W^T), backward-weight (dW = dz^T col,
-split-K over the rows) and backward-data (dcol = dz W), and `pcd_col2im_f16` - the exact adjoint of the gather -
-turns dcol into the input gradient.  BatchNorm3d (inside the residual blocks only) is the same channels-last
+Every Conv3d is run as "gather rows, then the GEMM": `pcd_im2col_f16` builds the row matrix col
+[B*Do*Ho*Wo][k^3*Cin], the fp16 MFMA GEMM does forward (z = col W^T), backward-weight (dW = dz^T col, split-K over the
+rows) and backward-data (dcol = dz W), and `pcd_col2im_f16` - the exact adjoint of the gather, written as a gather -
+turns dcol into the input gradient.  A ConvTranspose3d(k, s, p) is the adjoint of a Conv3d(k, s, p) from its output
+grid to its input grid, so it runs the same three pieces in the other order (product P = x Wg^T, then col2im; backward:
+im2col of dz, then the two products) and carries no structural zeros.  BatchNorm3d (inside the residual blocks only) is the same channels-last
 batch-statistics kernel pair as the point denoiser's BatchNorm1d.  The 512-wide bottleneck (fc_mu / fc_logvar /
 decoder_input, reparameterisation, KL) is a handful of few-row fp32 products.
 
 This is the straightforward formulation, not a tuned one: the row matrices are materialised (tens of GB of traffic per
-step at batch 16) and the transposed layers carry their structural zeros.  It exists so that `train_point_ldm.py` can
+step at batch 16).  It exists so that `train_point_ldm.py` can
 run end to end on an MI355X; the sampler's implicit-GEMM convolutions (`csrc/conv3d.hip`) are the fast path.
 """
 from __future__ import annotations
@@ -38,6 +39,9 @@ class _VConv:
         self.kk = k ** 3 * cin
         self.kp = _up(self.kk, 64)
         self.cp = _up(cout, 64)          # the output width is the reduction length of backward-data: multiple of 64
+        if transposed:                   # run as the adjoint of Conv3d(k, s, p): product first, then col2im (no structural zeros)
+            self.np_ = _up(k ** 3 * cout, 64)
+            self.cp = cout
         self.col = self.z = self.a = self.mean = self.var = None
 
 
@@ -105,6 +109,14 @@ class VAETrainer:
         (Conv3d weight (Cout,Cin,k,k,k); ConvTranspose3d weight (Cin,Cout,k,k,k)), its transpose, padded bias / affine."""
         for L in self._layers():
             w = self.p[L.key + ".weight"]
+            if L.transposed:
+                # Wg [k^3*Cout (padded)][Cin], row t*Cout + co = W[:, co, t]: P = x Wg^T is what col2im scatters into the output
+                full = self._buf(L.key + ".wg32", (L.np_, L.cin), torch.float32, zero=True)
+                full[:L.k ** 3 * L.cout] = w.permute(2, 3, 4, 1, 0).reshape(L.k ** 3 * L.cout, L.cin)
+                self.wm[L.key] = full.to(torch.float16)
+                self.wmt[L.key] = full.t().contiguous().to(torch.float16)
+                self.bias[L.key] = self.p[L.key + ".bias"]
+                continue
             wm = (w.permute(1, 2, 3, 4, 0) if L.transposed else w.permute(0, 2, 3, 4, 1)).reshape(L.cout, L.kk)
             full = self._buf(L.key + ".wm32", (L.cp, L.kp), torch.float32, zero=True)
             full[:L.cout, :L.kk] = wm
@@ -122,7 +134,73 @@ class VAETrainer:
         self.vae.invalidate()
 
     # ------------------------------------------------------------------ one layer
+    def _convT_fwd(self, L: _VConv, a_in: torch.Tensor, b: int) -> torch.Tensor:
+        """ConvTranspose3d(k, s, p) = adjoint of Conv3d(k, s, p) from the output grid to the input grid:
+        P [M_in][k^3*Cout] = x Wg^T, y = col2im(P) + bias, ReLU."""
+        lib, st = self.lib, self._st()
+        m_in, m = b * L.din ** 3, b * L.dout ** 3
+        L.m, L.mp, L.m_in, L.mp_in, L.a_in = m, _up(m, 64), m_in, _up(m_in, 64), a_in
+        P = self._buf("convT.P", (L.mp_in * L.np_,), torch.float16) if L.mp_in * L.np_ > self._ws.get("convT.P", torch.empty(0)).numel() else self._ws["convT.P"]
+        g = _lib.GemmDesc()
+        g.a1, g.lda1, g.k1 = a_in.data_ptr(), L.cin, L.cin
+        g.w, g.ldw = self.wm[L.key].data_ptr(), L.cin
+        g.m, g.c = m_in, L.np_
+        self._chk(lib.pcd_gemm_f16(C.byref(g), P.data_ptr(), L.np_, st), "gemm_convT")
+        y = self._buf(L.key + ".y", (L.mp, L.cout), torch.float16, zero=True)
+        self._chk(lib.pcd_col2im_f16(P.data_ptr(), b, L.cout, L.dout, L.dout, L.dout, L.din, L.din, L.din, L.k, L.s, L.p, 0, L.np_, y.data_ptr(), st),
+                  "col2im_convT")
+        L.a = self._buf(L.key + ".a", (L.mp, L.cout), torch.float16, zero=True)
+        self._chk(lib.pcd_bias_act_f16(y.data_ptr(), self.bias[L.key].data_ptr(), m, L.cout, int(L.relu), L.a.data_ptr(), st), "bias_act")
+        return L.a
+
+    def _convT_bwd(self, L: _VConv, d_out: torch.Tensor, b: int) -> torch.Tensor:
+        lib, st = self.lib, self._st()
+        dz = self._buf(L.key + ".dz", (L.mp, L.cout), torch.float16, zero=True)
+        self._chk(lib.pcd_relu_mask_f16(d_out.data_ptr(), L.a.data_ptr(), L.m * L.cout, dz.data_ptr(), st), "relu_mask")
+        db = self._buf("bwd.db", (512,), torch.float32)
+        self._chk(lib.pcd_colsum_f16(dz.data_ptr(), L.m, 1, L.cout, db.data_ptr(), st), "colsum")
+        self.g[L.key + ".bias"].copy_(db[:L.cout])
+        n = L.mp_in * L.np_
+        dP = self._buf(L.key + ".dP", (L.mp_in, L.np_), torch.float16, zero=True)          # rows >= M_in stay zero
+        self._chk(lib.pcd_im2col_f16(dz.data_ptr(), b, L.cout, L.dout, L.dout, L.dout, L.din, L.din, L.din, L.k, L.s, L.p, 0, L.np_,
+                                     dP.data_ptr(), st), "im2col_convT")
+        # dWg [k^3*Cout][Cin] = dP^T x
+        dPT = self._buf("bwd.dzT", (n,), torch.float16) if n > self._ws.get("bwd.dzT", torch.empty(0)).numel() else self._ws["bwd.dzT"]
+        nx = L.cin * L.mp_in
+        xT = self._buf("bwd.colT", (nx,), torch.float16) if nx > self._ws.get("bwd.colT", torch.empty(0)).numel() else self._ws["bwd.colT"]
+        self._chk(lib.pcd_transpose_f16(dP.data_ptr(), L.mp_in, L.np_, dPT.data_ptr(), st), "transpose")
+        self._chk(lib.pcd_transpose_f16(L.a_in.data_ptr(), L.mp_in, L.cin, xT.data_ptr(), st), "transpose")
+        dwg = self._buf(L.key + ".dwg", (L.np_, L.cin), torch.float32)
+        g = _lib.GemmDesc()
+        g.a1, g.lda1, g.k1 = dPT.data_ptr(), L.mp_in, L.mp_in
+        g.w, g.ldw = xT.data_ptr(), L.mp_in
+        g.m, g.c = L.np_, L.cin
+        tiles = -(-L.np_ // 128) * -(-L.cin // 128)
+        splits = 1
+        while splits * tiles < 512 and (L.mp_in // 64) % (splits * 2) == 0 and L.mp_in // (splits * 2) >= 256:
+            splits *= 2
+        if splits == 1:
+            self._chk(lib.pcd_gemm_f16_out32(C.byref(g), dwg.data_ptr(), L.cin, st), "gemm_dWg")
+        else:
+            need = splits * L.np_ * L.cin
+            slabs = self._ws.get("bwd.slabs")
+            if slabs is None or slabs.numel() < need:
+                slabs = self._buf("bwd.slabs", (need,), torch.float32)
+            self._chk(lib.pcd_gemm_f16_splitk(C.byref(g), splits, slabs.data_ptr(), st), "gemm_dWg_splitk")
+            self._chk(lib.pcd_sum_slabs_f32(slabs.data_ptr(), splits, L.np_, L.cin, dwg.data_ptr(), L.cin, st), "sum_slabs")
+        self.g[L.key + ".weight"].copy_(dwg[:L.k ** 3 * L.cout].reshape(L.k, L.k, L.k, L.cout, L.cin).permute(4, 3, 0, 1, 2))
+        # dx = dP Wg
+        dx = self._buf(L.key + ".dx", (L.mp_in, L.cin), torch.float16, zero=True)
+        g2 = _lib.GemmDesc()
+        g2.a1, g2.lda1, g2.k1 = dP.data_ptr(), L.np_, L.np_
+        g2.w, g2.ldw = self.wmt[L.key].data_ptr(), L.np_
+        g2.m, g2.c = L.m_in, L.cin
+        self._chk(lib.pcd_gemm_f16(C.byref(g2), dx.data_ptr(), L.cin, st), "gemm_dx_convT")
+        return dx
+
     def _conv_fwd(self, L: _VConv, a_in: torch.Tensor, b: int, update_stats: bool) -> torch.Tensor:
+        if L.transposed:
+            return self._convT_fwd(L, a_in, b)
         lib, st = self.lib, self._st()
         m = b * L.dout ** 3
         mp = _up(m, 64)
@@ -165,6 +243,8 @@ class VAETrainer:
 
     def _conv_bwd(self, L: _VConv, d_out: torch.Tensor, b: int, need_dx: bool = True) -> Optional[torch.Tensor]:
         """d_out: gradient of the layer's output activation, fp16 [Mp][Cp] (rows >= M zero).  Returns dx [M_in][Cin]."""
+        if L.transposed:
+            return self._convT_bwd(L, d_out, b)
         lib, st = self.lib, self._st()
         m, mp = L.m, L.mp
         if L.bn:

@@ -366,6 +366,9 @@ int pcd_im2col_f16(const void* x, int batch, int cin, int di, int hi, int wi, in
                    int pad, int transposed, int kp, void* col, void* stream);
 int pcd_col2im_f16(const void* dcol, int batch, int cin, int di, int hi, int wi, int d_o, int ho, int wo, int k, int stride,
                    int pad, int transposed, int kp, void* dx, void* stream);
+/* out[r][c] = act(x[r][c] + bias[c]): a ConvTranspose3d is run as product-then-col2im (the adjoint of a Conv3d), its
+ * bias and ReLU applied afterwards */
+int pcd_bias_act_f16(const void* x, const float* bias, int64_t rows, int c, int relu, void* out, void* stream);
 /* out = a + b, with ReLU if relu (ResidualBlock3D tail); d = dout * [out > 0] */
 int pcd_add_relu_f16(const void* a, const void* b, int64_t n, int relu, void* out, void* stream);
 int pcd_relu_mask_f16(const void* dout, const void* out, int64_t n, void* d, void* stream);
