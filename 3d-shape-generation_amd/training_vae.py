@@ -78,6 +78,14 @@ class VAETrainer:
             self._ws[key] = t
         return t
 
+    def _scratch(self, key: str, numel: int, dtype=torch.float16) -> torch.Tensor:
+        """A flat scratch buffer that only ever grows (shared by the layers: transposes, dcol, P, slabs)."""
+        t = self._ws.get(key)
+        if t is None or t.numel() < numel or t.dtype != dtype:
+            t = torch.empty(numel, dtype=dtype, device=self.dev)
+            self._ws[key] = t
+        return t
+
     # ------------------------------------------------------------------ structure
     def _program(self, prefix: str, prog, d0: int):
         ops, d = [], d0
@@ -140,7 +148,7 @@ class VAETrainer:
         lib, st = self.lib, self._st()
         m_in, m = b * L.din ** 3, b * L.dout ** 3
         L.m, L.mp, L.m_in, L.mp_in, L.a_in = m, _up(m, 64), m_in, _up(m_in, 64), a_in
-        P = self._buf("convT.P", (L.mp_in * L.np_,), torch.float16) if L.mp_in * L.np_ > self._ws.get("convT.P", torch.empty(0)).numel() else self._ws["convT.P"]
+        P = self._scratch("convT.P", L.mp_in * L.np_)
         g = _lib.GemmDesc()
         g.a1, g.lda1, g.k1 = a_in.data_ptr(), L.cin, L.cin
         g.w, g.ldw = self.wm[L.key].data_ptr(), L.cin
@@ -165,9 +173,9 @@ class VAETrainer:
         self._chk(lib.pcd_im2col_f16(dz.data_ptr(), b, L.cout, L.dout, L.dout, L.dout, L.din, L.din, L.din, L.k, L.s, L.p, 0, L.np_,
                                      dP.data_ptr(), st), "im2col_convT")
         # dWg [k^3*Cout][Cin] = dP^T x
-        dPT = self._buf("bwd.dzT", (n,), torch.float16) if n > self._ws.get("bwd.dzT", torch.empty(0)).numel() else self._ws["bwd.dzT"]
+        dPT = self._scratch("bwd.dzT", n)
         nx = L.cin * L.mp_in
-        xT = self._buf("bwd.colT", (nx,), torch.float16) if nx > self._ws.get("bwd.colT", torch.empty(0)).numel() else self._ws["bwd.colT"]
+        xT = self._scratch("bwd.colT", nx)
         self._chk(lib.pcd_transpose_f16(dP.data_ptr(), L.mp_in, L.np_, dPT.data_ptr(), st), "transpose")
         self._chk(lib.pcd_transpose_f16(L.a_in.data_ptr(), L.mp_in, L.cin, xT.data_ptr(), st), "transpose")
         dwg = self._buf(L.key + ".dwg", (L.np_, L.cin), torch.float32)
@@ -182,10 +190,7 @@ class VAETrainer:
         if splits == 1:
             self._chk(lib.pcd_gemm_f16_out32(C.byref(g), dwg.data_ptr(), L.cin, st), "gemm_dWg")
         else:
-            need = splits * L.np_ * L.cin
-            slabs = self._ws.get("bwd.slabs")
-            if slabs is None or slabs.numel() < need:
-                slabs = self._buf("bwd.slabs", (need,), torch.float32)
+            slabs = self._scratch("bwd.slabs", splits * L.np_ * L.cin, torch.float32)
             self._chk(lib.pcd_gemm_f16_splitk(C.byref(g), splits, slabs.data_ptr(), st), "gemm_dWg_splitk")
             self._chk(lib.pcd_sum_slabs_f32(slabs.data_ptr(), splits, L.np_, L.cin, dwg.data_ptr(), L.cin, st), "sum_slabs")
         self.g[L.key + ".weight"].copy_(dwg[:L.k ** 3 * L.cout].reshape(L.k, L.k, L.k, L.cout, L.cin).permute(4, 3, 0, 1, 2))
@@ -265,8 +270,8 @@ class VAETrainer:
         self._chk(lib.pcd_colsum_f16(dz.data_ptr(), m, 1, L.cp, db.data_ptr(), st), "colsum")
         self.g[L.key + ".bias"].copy_(db[:L.cout])
         # dWm = dz^T col  (rows Cp, reduction Mp, columns Kp)
-        dzT = self._buf("bwd.dzT", (L.cp * mp,), torch.float16) if L.cp * mp > self._ws.get("bwd.dzT", torch.empty(0)).numel() else self._ws["bwd.dzT"]
-        colT = self._buf("bwd.colT", (L.kp * mp,), torch.float16) if L.kp * mp > self._ws.get("bwd.colT", torch.empty(0)).numel() else self._ws["bwd.colT"]
+        dzT = self._scratch("bwd.dzT", L.cp * mp)
+        colT = self._scratch("bwd.colT", L.kp * mp)
         self._chk(lib.pcd_transpose_f16(dz.data_ptr(), mp, L.cp, dzT.data_ptr(), st), "transpose")
         self._chk(lib.pcd_transpose_f16(L.col.data_ptr(), mp, L.kp, colT.data_ptr(), st), "transpose")
         dwm = self._buf(L.key + ".dwm", (L.cp, L.kp), torch.float32)
@@ -281,10 +286,7 @@ class VAETrainer:
         if splits == 1:
             self._chk(lib.pcd_gemm_f16_out32(C.byref(g), dwm.data_ptr(), L.kp, st), "gemm_dW")
         else:
-            need = splits * L.cp * L.kp
-            slabs = self._ws.get("bwd.slabs")
-            if slabs is None or slabs.numel() < need:
-                slabs = self._buf("bwd.slabs", (need,), torch.float32)
+            slabs = self._scratch("bwd.slabs", splits * L.cp * L.kp, torch.float32)
             self._chk(lib.pcd_gemm_f16_splitk(C.byref(g), splits, slabs.data_ptr(), st), "gemm_dW_splitk")
             self._chk(lib.pcd_sum_slabs_f32(slabs.data_ptr(), splits, L.cp, L.kp, dwm.data_ptr(), L.kp, st), "sum_slabs")
         gw = dwm[:L.cout, :L.kk].reshape(L.cout, L.k, L.k, L.k, L.cin)
@@ -292,7 +294,7 @@ class VAETrainer:
         if not need_dx:
             return None
         # dcol = dz Wm, then the adjoint of the gather
-        dcol = self._buf("bwd.dcol", (mp * L.kp,), torch.float16) if mp * L.kp > self._ws.get("bwd.dcol", torch.empty(0)).numel() else self._ws["bwd.dcol"]
+        dcol = self._scratch("bwd.dcol", mp * L.kp)
         g2 = _lib.GemmDesc()
         g2.a1, g2.lda1, g2.k1 = dz.data_ptr(), L.cp, L.cp
         g2.w, g2.ldw = self.wmt[L.key].data_ptr(), L.cp
