@@ -120,6 +120,8 @@ class PointTrainer:
         self._ws: Dict[str, torch.Tensor] = {}
         self.debug: Optional[Dict[str, torch.Tensor]] = None    # tests set a dict: per-layer da / dz copies are kept
         self.refresh_weights()
+        # load_state_dict copies into the flat buffer in place: the fp16 operand copies must follow
+        model.register_load_state_dict_post_hook(lambda module, incompatible: self.refresh_weights())
 
     # ------------------------------------------------------------------ helpers
     def _st(self):

@@ -66,6 +66,7 @@ class VAETrainer:
         self.wmt: Dict[str, torch.Tensor] = {}
         self.bias: Dict[str, torch.Tensor] = {}
         self.refresh_weights()
+        vae.register_load_state_dict_post_hook(lambda module, incompatible: self.refresh_weights())
 
     _st = PointTrainer._st
     _chk = PointTrainer._chk

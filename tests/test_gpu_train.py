@@ -251,6 +251,12 @@ def test_adamw_update_and_loss_decreases(golden):
         assert torch.allclose(v.detach().cpu(), params[k], rtol=0, atol=3e-7), k
     # the state_dict is the trained weights (parameters are views of the flat buffer) and the sampler sees them
     assert torch.allclose(model.state_dict()["model.output.3.weight"].cpu(), params["output.3.weight"], rtol=0, atol=3e-7)
+    # loading weights after the trainer exists refreshes its fp16 operand copies (the flat buffer is written in place)
+    w16_before = tr.w16["enc2.conv1"].clone()
+    model.load_state_dict(sd, strict=True)
+    assert torch.equal(model.state_dict()["model.enc2.conv1.weight"].cpu(), sd["model.enc2.conv1.weight"])
+    assert not torch.equal(tr.w16["enc2.conv1"], w16_before)
+    assert torch.equal(tr.w16["enc2.conv1"].cpu(), sd["model.enc2.conv1.weight"][:, :, 0].half())
     # a few more steps on the same batch: the L1 loss must go down
     tr2 = PointTrainer(model.model, lr=2e-3)
     losses = [tr2.train_step(x_t.cuda(), t.cuda(), noise.cuda()).item() for _ in range(12)]
