@@ -296,7 +296,10 @@ class PointTrainer:
         ktot = gw.shape[1]
         if self.debug is not None:
             self.debug[L.conv + ".dz"] = dz.clone()
-        self._chk(lib.pcd_colsum_f16(dz.data_ptr(), m, 1, c, self.g[L.conv + ".bias"].data_ptr(), st), "colsum")
+        if not L.bn:
+            self._chk(lib.pcd_colsum_f16(dz.data_ptr(), m, 1, c, self.g[L.conv + ".bias"].data_ptr(), st), "colsum")
+        # (a conv bias in front of a BatchNorm: dz is mean-free per channel by construction, its column sum is exactly the
+        #  analytic zero - the gradient view keeps the 0 it was allocated with; autograd leaves ~1e-9 rounding noise there)
         dzT = self._buf("bwd.dzT", (4096 * m,), torch.float16)
         self._chk(lib.pcd_transpose_f16(dz.data_ptr(), m, c, dzT.data_ptr(), st), "transpose")
         aT = self._buf("bwd.aT", (4096 * m,), torch.float16)

@@ -267,9 +267,10 @@ class VAETrainer:
             self._chk(lib.pcd_relu_mask_f16(d_out.data_ptr(), L.a.data_ptr(), m * L.cp, dz.data_ptr(), st), "relu_mask")
         else:
             dz = d_out
-        db = self._buf("bwd.db", (512,), torch.float32)
-        self._chk(lib.pcd_colsum_f16(dz.data_ptr(), m, 1, L.cp, db.data_ptr(), st), "colsum")
-        self.g[L.key + ".bias"].copy_(db[:L.cout])
+        if not L.bn:            # (in front of a BatchNorm the bias gradient is the analytic zero: dz is mean-free per channel)
+            db = self._buf("bwd.db", (512,), torch.float32)
+            self._chk(lib.pcd_colsum_f16(dz.data_ptr(), m, 1, L.cp, db.data_ptr(), st), "colsum")
+            self.g[L.key + ".bias"].copy_(db[:L.cout])
         # dWm = dz^T col  (rows Cp, reduction Mp, columns Kp)
         dzT = self._scratch("bwd.dzT", L.cp * mp)
         colT = self._scratch("bwd.colT", L.kp * mp)
