@@ -12,9 +12,13 @@ pytestmark = pytest.mark.gpu
 
 def test_two_rank_training_steps_stay_in_sync(tmp_path):
     out = str(tmp_path / "ddp.npy")
+    import socket
+    with socket.socket() as sock:                      # a free rendezvous port
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
     procs = []
     for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", DDP_OUT=out,
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port, DDP_OUT=out,
                    PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_train_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
