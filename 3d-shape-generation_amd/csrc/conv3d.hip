@@ -16,20 +16,32 @@ namespace pcd {
 constexpr int CBK = 64;
 constexpr int CROWB = CBK * 2;
 
+constexpr int MAX_VARIANTS = 8;      // the 2x2x2 output-parity classes of a stride-2 ConvTranspose3d
+constexpr int MAX_TAPS = 64;
+
+// what differs between the problems of one launch (blockIdx.y): tap table, weights, output parity
+struct ConvVariant {
+    const int* taps;                  // device [ntaps] packed (dz & 0xff) | (dy & 0xff) << 8 | (dx & 0xff) << 16
+    const half_t* w;                  // [Cout][kpad]
+    int pz, py, px, pad_;
+};
+
 struct ConvParams {
     const half_t* in; int D, H, W, Cin, cin_shift;
     int Do, Ho, Wo, stride;           // row space: m = ((b*Do+oz)*Ho+oy)*Wo+ox ; input coord = o*stride + d
     int ntaps, kpad;
-    const int* taps;                  // device [ntaps] packed (dz & 0xff) | (dy & 0xff) << 8 | (dx & 0xff) << 16
-    const half_t* w;                  // [Cout][kpad]
     const float* bias;
     const half_t* resid;              // optional, indexed like out
     half_t* out; int Cout;
-    int OD, OH, OW, os, pz, py, px;   // output voxel = (oz*os+pz, oy*os+py, ox*os+px) in an OD x OH x OW grid
+    int OD, OH, OW, os;               // output voxel = (oz*os+pz, oy*os+py, ox*os+px) in an OD x OH x OW grid
     int relu;
     int M;
     const half_t* zero;               // >= 128 B of zeros
     int tiles_n;
+    int splits;                       // split-K (blockIdx.z); > 1 -> fp32 partials into slabs, conv3d_finish_kernel
+    float* slabs;                     // [splits][nvar][M][Cout]
+    int nvar;
+    ConvVariant var[MAX_VARIANTS];
 };
 
 __device__ __forceinline__ void cglds16(const half_t* g, char* lds_wave_base) {
@@ -45,13 +57,22 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
     constexpr int LDS_BYTES = (2 * STAGE_BYTES > BM * OUT_LD) ? 2 * STAGE_BYTES : BM * OUT_LD;
     constexpr int AR = BM / 32, BR = BN / 32;
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+    __shared__ int taps_s[MAX_TAPS];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x - tm * p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int nk = p.kpad / CBK;
+    const int nk_all = p.kpad / CBK;
+    const int cls = blockIdx.y, sp = blockIdx.z;
+    const int kt0 = (int)((int64_t)sp * nk_all / p.splits), kt1 = (int)((int64_t)(sp + 1) * nk_all / p.splits);
+    const ConvVariant& cv = p.var[cls];
+    const half_t* __restrict__ wgt = cv.w;
+    // tap table -> LDS once: a global lookup inside stage() would put two dependent memory latencies
+    // on every K tile, which is what bounds the small-grid layers
+    if (tid < MAX_TAPS) taps_s[tid] = tid < p.ntaps ? cv.taps[tid] : 0;
+    __syncthreads();
 
     // the rows this thread stages (fixed for the whole K loop): decode the output voxel once
     const int srow = wave * 8 + (lane >> 3);                 // + r*32
@@ -75,7 +96,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
         const bool tap_ok = tap < p.ntaps;
         int dz = 0, dy = 0, dx = 0;
         if (tap_ok) {
-            const int pk = p.taps[tap];
+            const int pk = taps_s[tap];
             dz = (int)(signed char)(pk & 0xff); dy = (int)(signed char)((pk >> 8) & 0xff);
             dx = (int)(signed char)((pk >> 16) & 0xff);
         }
@@ -92,7 +113,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
         for (int r = 0; r < BR; ++r) {
             int n = n0 + r * 32 + srow;
             n = n < p.Cout ? n : p.Cout - 1;
-            cglds16(p.w + (int64_t)n * p.kpad + kidx, base + BM * CROWB + (r * 32 + wave * 8) * CROWB);
+            cglds16(wgt + (int64_t)n * p.kpad + kidx, base + BM * CROWB + (r * 32 + wave * 8) * CROWB);
         }
     };
 
@@ -111,12 +132,12 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
         offb[ks] = BM * CROWB + rbw * CROWB + (((ks * 4 + q) ^ swb) << 4);
     }
 
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
+    stage(kt0, 0);
+    for (int kt = kt0; kt < kt1; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-        const char* base = smem + (kt & 1) * STAGE_BYTES;
+        if (kt + 1 < kt1) stage(kt + 1, (kt + 1 - kt0) & 1);
+        const char* base = smem + ((kt - kt0) & 1) * STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             half8 af[MI], bf[NI];
@@ -134,6 +155,22 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
 
     // epilogue: bias -> LDS (fp16) -> row-contiguous 16-B stores (+ residual, ReLU) through the row map
     const int colq = lane & 15;
+    if (p.splits > 1) {
+        // split-K partial: raw fp32 accumulators to this split's slab; bias/residual/ReLU/row map in the finish
+        float* slab = p.slabs + ((int64_t)sp * p.nvar + cls) * p.M * p.Cout;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int col = n0 + wn * WN + j * 16 + colq;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * WM + i * 16 + q * 4 + r;
+                    if (m < p.M && col < p.Cout) slab[(int64_t)m * p.Cout + col] = acc[i][j][r];
+                }
+        }
+        return;
+    }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -160,8 +197,8 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
             const int ox = m % p.Wo; int t = m / p.Wo;
             const int oy = t % p.Ho; t /= p.Ho;
             const int oz = t % p.Do; const int b = t / p.Do;
-            const int64_t orow = (((int64_t)b * p.OD + oz * p.os + p.pz) * p.OH + oy * p.os + p.py) * p.OW +
-                                 ox * p.os + p.px;
+            const int64_t orow = (((int64_t)b * p.OD + oz * p.os + cv.pz) * p.OH + oy * p.os + cv.py) * p.OW +
+                                 ox * p.os + cv.px;
             half8 v = *(const half8*)(smem + lrow * OUT_LD + ch * 16);
             if (p.resid != nullptr) {
                 const half8 rs = *(const half8*)(p.resid + orow * p.Cout + col);
@@ -175,6 +212,51 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
             *(half8*)(p.out + orow * p.Cout + col) = v;
         }
     }
+}
+
+// split-K finish: sum the slabs in split order (deterministic), then the same epilogue as above.
+// thread = (variant, row, 8-column chunk)
+__global__ __launch_bounds__(256) void conv3d_finish_kernel(ConvParams p) {
+    const int cpr = p.Cout / 8;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per = (int64_t)p.M * cpr;
+    if (idx >= per * p.nvar) return;
+    const int cls = (int)(idx / per);
+    const int64_t rem = idx - cls * per;
+    const int m = (int)(rem / cpr), col = (int)(rem - (int64_t)m * cpr) * 8;
+    const ConvVariant& cv = p.var[cls];
+    float a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = 0.f;
+    for (int s = 0; s < p.splits; ++s) {
+        const float4* src = (const float4*)(p.slabs + (((int64_t)s * p.nvar + cls) * p.M + m) * p.Cout + col);
+        const float4 u = src[0], v = src[1];
+        a[0] += u.x; a[1] += u.y; a[2] += u.z; a[3] += u.w;
+        a[4] += v.x; a[5] += v.y; a[6] += v.z; a[7] += v.w;
+    }
+    const int ox = m % p.Wo; int t = m / p.Wo;
+    const int oy = t % p.Ho; t /= p.Ho;
+    const int oz = t % p.Do; const int b = t / p.Do;
+    const int64_t orow = (((int64_t)b * p.OD + oz * p.os + cv.pz) * p.OH + oy * p.os + cv.py) * p.OW + ox * p.os + cv.px;
+    half8 o;
+    if (p.resid != nullptr) {
+        const half8 rs = *(const half8*)(p.resid + orow * p.Cout + col);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            // same rounding points as the unsplit epilogue: fp16(acc + bias), then + residual in fp32
+            float f = (float)to_half_sat(a[e] + (p.bias ? p.bias[col + e] : 0.f)) + (float)rs[e];
+            if (p.relu) f = fmaxf(f, 0.f);
+            o[e] = to_half_sat(f);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float f = a[e] + (p.bias ? p.bias[col + e] : 0.f);
+            if (p.relu) f = fmaxf(f, 0.f);
+            o[e] = to_half_sat(f);
+        }
+    }
+    *(half8*)(p.out + orow * p.Cout + col) = o;
 }
 
 // first layer: x fp32 [B][D][H][W] (Cin = 1), k3 s1 p1 -> fp16 NDHWC [..][cout], ReLU.
@@ -296,39 +378,94 @@ __global__ __launch_bounds__(256) void convT3d_last_kernel(const half_t* __restr
 
 using namespace pcd;
 
-extern "C" int pcd_conv3d_f16(const pcd_conv3d_desc_t* d, void* stream) {
-    PCD_CHECK_ARG(d != nullptr);
+// split-K factor for a launch of `blocks` workgroups over `nk` K tiles: aim for ~2 workgroups per CU
+static int conv_splits(int64_t blocks, int nk) {
+    if (blocks >= 512 || nk < 8) return 1;
+    int s = (int)ceil_div((int64_t)512, blocks);
+    s = s < nk / 4 ? s : nk / 4;
+    s = s < 64 ? s : 64;
+    return s < 1 ? 1 : s;
+}
+
+static int conv_check(const pcd_conv3d_desc_t* d) {
     PCD_CHECK_ARG(d->in && d->w && d->out && d->taps && d->zero_page);
     PCD_CHECK_ARG(d->batch > 0 && d->in_d > 0 && d->in_h > 0 && d->in_w > 0);
     PCD_CHECK_ARG(d->cin >= 8 && (d->cin & (d->cin - 1)) == 0);
     PCD_CHECK_ARG(d->cout > 0 && d->cout % 8 == 0);
-    PCD_CHECK_ARG(d->ntaps > 0 && d->kpad % CBK == 0 && d->kpad >= d->ntaps * d->cin);
+    PCD_CHECK_ARG(d->ntaps > 0 && d->ntaps <= MAX_TAPS && d->kpad % CBK == 0 && d->kpad >= d->ntaps * d->cin);
     PCD_CHECK_ARG(d->rows_d > 0 && d->rows_h > 0 && d->rows_w > 0 && d->stride > 0);
     PCD_CHECK_ARG(d->out_scale > 0 && d->out_d > 0 && d->out_h > 0 && d->out_w > 0);
+    PCD_CHECK_ARG((int64_t)d->batch * d->rows_d * d->rows_h * d->rows_w <= 0x7fffffff);
+    return PCD_OK;
+}
+
+static void conv_shape(const pcd_conv3d_desc_t* d, int n, int64_t* m, int* tiles_n, int* splits) {
+    *m = (int64_t)d->batch * d->rows_d * d->rows_h * d->rows_w;
+    *tiles_n = (int)ceil_div(d->cout, d->cout <= 64 ? 64 : 128);
+    *splits = conv_splits(ceil_div(*m, 128) * *tiles_n * n, d->kpad / CBK);
+}
+
+extern "C" size_t pcd_conv3d_workspace_bytes(const pcd_conv3d_desc_t* d, int n) {
+    if (d == nullptr || n < 1 || n > MAX_VARIANTS || conv_check(d) != PCD_OK) return 0;
+    int64_t m; int tiles_n, splits;
+    conv_shape(d, n, &m, &tiles_n, &splits);
+    return splits > 1 ? (size_t)splits * n * m * d->cout * sizeof(float) : 0;
+}
+
+extern "C" int pcd_conv3d_f16_multi(const pcd_conv3d_desc_t* descs, int n, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+    PCD_CHECK_ARG(descs != nullptr && n >= 1 && n <= MAX_VARIANTS);
+    const pcd_conv3d_desc_t* d = descs;
+    for (int i = 0; i < n; ++i) {
+        const pcd_conv3d_desc_t* e = descs + i;
+        const int rc = conv_check(e);
+        if (rc != PCD_OK) return rc;
+        // one launch: everything except the tap table, the weights and the output parity is shared
+        PCD_CHECK_ARG(e->in == d->in && e->batch == d->batch && e->in_d == d->in_d && e->in_h == d->in_h &&
+                      e->in_w == d->in_w && e->cin == d->cin && e->rows_d == d->rows_d && e->rows_h == d->rows_h &&
+                      e->rows_w == d->rows_w && e->stride == d->stride && e->ntaps == d->ntaps && e->kpad == d->kpad &&
+                      e->bias == d->bias && e->resid == d->resid && e->relu == d->relu && e->out == d->out &&
+                      e->cout == d->cout && e->out_d == d->out_d && e->out_h == d->out_h && e->out_w == d->out_w &&
+                      e->out_scale == d->out_scale);
+    }
     ConvParams p{};
     p.in = (const half_t*)d->in; p.D = d->in_d; p.H = d->in_h; p.W = d->in_w; p.Cin = d->cin;
     p.cin_shift = __builtin_ctz((unsigned)d->cin);
     p.Do = d->rows_d; p.Ho = d->rows_h; p.Wo = d->rows_w; p.stride = d->stride;
-    p.ntaps = d->ntaps; p.kpad = d->kpad; p.taps = d->taps;
-    p.w = (const half_t*)d->w; p.bias = d->bias; p.resid = (const half_t*)d->resid;
+    p.ntaps = d->ntaps; p.kpad = d->kpad;
+    p.bias = d->bias; p.resid = (const half_t*)d->resid;
     p.out = (half_t*)d->out; p.Cout = d->cout;
     p.OD = d->out_d; p.OH = d->out_h; p.OW = d->out_w; p.os = d->out_scale;
-    p.pz = d->out_off_z; p.py = d->out_off_y; p.px = d->out_off_x;
     p.relu = d->relu;
-    const int64_t m = (int64_t)d->batch * d->rows_d * d->rows_h * d->rows_w;
-    PCD_CHECK_ARG(m <= 0x7fffffff);
-    p.M = (int)m;
     p.zero = (const half_t*)d->zero_page;
-    hipStream_t s = (hipStream_t)stream;
-    if (d->cout <= 64) {
-        p.tiles_n = (int)ceil_div(d->cout, 64);
-        hipLaunchKernelGGL((conv3d_igemm_kernel<128, 64>), dim3((unsigned)(ceil_div(m, 128) * p.tiles_n)), dim3(256), 0, s, p);
-    } else {
-        p.tiles_n = (int)ceil_div(d->cout, 128);
-        hipLaunchKernelGGL((conv3d_igemm_kernel<128, 128>), dim3((unsigned)(ceil_div(m, 128) * p.tiles_n)), dim3(256), 0, s, p);
+    p.nvar = n;
+    for (int i = 0; i < n; ++i) {
+        p.var[i].taps = descs[i].taps; p.var[i].w = (const half_t*)descs[i].w;
+        p.var[i].pz = descs[i].out_off_z; p.var[i].py = descs[i].out_off_y; p.var[i].px = descs[i].out_off_x;
     }
+    int64_t m; int splits;
+    conv_shape(d, n, &m, &p.tiles_n, &splits);
+    p.M = (int)m;
+    const size_t need = splits > 1 ? (size_t)splits * n * m * d->cout * sizeof(float) : 0;
+    if (need > 0 && (workspace == nullptr || workspace_bytes < need)) splits = 1;   // no scratch: unsplit launch
+    p.splits = splits;
+    p.slabs = splits > 1 ? (float*)workspace : nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)(ceil_div(m, 128) * p.tiles_n), (unsigned)n, (unsigned)splits);
+    if (d->cout <= 64) hipLaunchKernelGGL((conv3d_igemm_kernel<128, 64>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv3d_igemm_kernel<128, 128>), grid, dim3(256), 0, s, p);
     PCD_CHECK_LAUNCH();
+    if (splits > 1) {
+        const int64_t total = (int64_t)n * m * (d->cout / 8);
+        hipLaunchKernelGGL(conv3d_finish_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, p);
+        PCD_CHECK_LAUNCH();
+    }
     return PCD_OK;
+}
+
+extern "C" int pcd_conv3d_f16(const pcd_conv3d_desc_t* d, void* stream) {
+    PCD_CHECK_ARG(d != nullptr);
+    return pcd_conv3d_f16_multi(d, 1, nullptr, 0, stream);
 }
 
 extern "C" int pcd_conv3d_first(const float* x, int batch, int d, int h, int w, int stride, const float* wgt,

@@ -17,6 +17,16 @@ from .networks import _HipModule, _dev16, _dev32
 from .utils import voxel_tensor_to_point_clouds
 
 
+def _launch_convs(descs: List["_lib.Conv3dDesc"], device, what: str) -> None:
+    """One pcd_conv3d_f16_multi launch for `descs` (problems that differ only in taps / weights / output
+    parity), with the split-K scratch the library asks for."""
+    lib = _lib.load()
+    arr = (_lib.Conv3dDesc * len(descs))(*descs)
+    need = int(lib.pcd_conv3d_workspace_bytes(arr, len(descs)))
+    ws = torch.empty(need, dtype=torch.uint8, device=device) if need else None
+    _lib.check(lib.pcd_conv3d_f16_multi(arr, len(descs), _lib.ptr(ws), need, _lib.stream_ptr()), what)
+
+
 def _taps_regular(k: int, pad: int) -> np.ndarray:
     t = []
     for kz in range(k):
@@ -211,13 +221,13 @@ class VAE3DLarge(_HipModule):
         d.out_d = d.out_h = d.out_w = dout
         d.out_scale, d.out_off_z, d.out_off_y, d.out_off_x = 1, 0, 0, 0
         d.zero_page = pk["zero"].data_ptr()
-        _lib.check(lib.pcd_conv3d_f16(d, _lib.stream_ptr()), "conv3d")
+        _launch_convs([d], x.device, "conv3d")
         return out
 
     def _convT(self, L, x, b, din):
-        lib = _lib.load()
         dout = 2 * din
         out = torch.empty(b * dout ** 3, L["cout"], dtype=torch.float16, device=x.device)
+        descs = []
         for cls in L["classes"]:
             d = _lib.Conv3dDesc()
             d.inp, d.batch, d.in_d, d.in_h, d.in_w, d.cin = x.data_ptr(), b, din, din, din, L["cin"]
@@ -230,7 +240,8 @@ class VAE3DLarge(_HipModule):
             d.out_scale = 2
             d.out_off_z, d.out_off_y, d.out_off_x = cls["p"]
             d.zero_page = self._packed["zero"].data_ptr()
-            _lib.check(lib.pcd_conv3d_f16(d, _lib.stream_ptr()), "conv3d(T)")
+            descs.append(d)
+        _launch_convs(descs, x.device, "conv3d(T)")                 # the 8 parity classes in one launch
         return out
 
     def _res(self, R, x, b, dim):
@@ -421,13 +432,13 @@ class VAE3D(_HipModule):
         d.out_d = d.out_h = d.out_w = dout
         d.out_scale = 1
         d.zero_page = self._packed["zero"].data_ptr()
-        _lib.check(lib.pcd_conv3d_f16(d, _lib.stream_ptr()), "conv3d")
+        _launch_convs([d], x.device, "conv3d")
         return out
 
     def _deconv(self, L, x, b, din):
-        lib = _lib.load()
         dout = 2 * din
         out = torch.empty(b * dout ** 3, L["cout"], dtype=torch.float16, device=x.device)
+        groups: Dict[int, list] = {}                                # classes with the same tap count share a launch
         for cls in L["classes"]:
             d = _lib.Conv3dDesc()
             d.inp, d.batch, d.in_d, d.in_h, d.in_w, d.cin = x.data_ptr(), b, din, din, din, L["cin"]
@@ -440,7 +451,9 @@ class VAE3D(_HipModule):
             d.out_scale = 2
             d.out_off_z, d.out_off_y, d.out_off_x = cls["p"]
             d.zero_page = self._packed["zero"].data_ptr()
-            _lib.check(lib.pcd_conv3d_f16(d, _lib.stream_ptr()), "conv3d(T)")
+            groups.setdefault(cls["kpad"] * 64 + int(cls["taps"].numel()), []).append(d)
+        for descs in groups.values():
+            _launch_convs(descs, x.device, "conv3d(T)")
         return out
 
     def encode(self, x: torch.Tensor):

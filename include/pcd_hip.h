@@ -235,6 +235,15 @@ typedef struct {
     const void* zero_page;                                 /* >= 128 bytes of zeros */
 } pcd_conv3d_desc_t;
 int pcd_conv3d_f16(const pcd_conv3d_desc_t* d, void* stream);
+/* n (1..8) problems in ONE launch that share everything except taps, w and out_off_* -- the 2x2x2
+ * output-parity classes of ConvTranspose3d(k4, s2, p1) (networks.py:2243,2248,2253) -- and, when the
+ * launch would leave the chip mostly idle (few output rows, long K: encoder.9-12, decoder.0), split-K
+ * over blockIdx.z with fp32 partial slabs in `workspace`, summed in split order by a finish kernel that
+ * applies the same bias/residual/ReLU epilogue.  pcd_conv3d_workspace_bytes() returns the scratch that
+ * split needs (0 = the launch is not split); with a NULL/short workspace the launch runs unsplit. */
+size_t pcd_conv3d_workspace_bytes(const pcd_conv3d_desc_t* descs, int n);
+int pcd_conv3d_f16_multi(const pcd_conv3d_desc_t* descs, int n, void* workspace, size_t workspace_bytes,
+                         void* stream);
 /* encoder.0: Conv3d(1, cout, k3, stride 1|2, p1) (+ folded BN) + ReLU straight from the fp32 occupancy
  * grid x [B][D][H][W]; w fp32 [cout][27], out fp16 NDHWC (VAE3DLarge networks.py:2226, VAE3D :1999). */
 int pcd_conv3d_first(const float* x, int batch, int d, int h, int w, int stride, const float* wgt,

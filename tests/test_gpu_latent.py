@@ -26,7 +26,7 @@ def _int(shape, seed, lo=-2, hi=3):
     return torch.randint(lo, hi, shape, generator=torch.Generator().manual_seed(seed)).float()
 
 
-def _run_conv(x, w, bias, stride, pad, relu=False, resid=None):
+def _run_conv(x, w, bias, stride, pad, relu=False, resid=None, split=False):
     """x (B,Cin,D,D,D), w (Cout,Cin,k,k,k) integer valued -> NDHWC result through pcd_conv3d_f16."""
     from shapegen_amd import _lib
     from shapegen_amd.vae import _pack_conv, _taps_regular
@@ -54,7 +54,13 @@ def _run_conv(x, w, bias, stride, pad, relu=False, resid=None):
     d.out_d = d.out_h = d.out_w = dout
     d.out_scale = 1
     d.zero_page = zero.data_ptr()
-    _lib.check(lib.pcd_conv3d_f16(d, _lib.stream_ptr()))
+    if split:
+        need = int(lib.pcd_conv3d_workspace_bytes(d, 1))
+        assert need > 0, "this shape is expected to take the split-K path"
+        ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+        _lib.check(lib.pcd_conv3d_f16_multi(d, 1, ws.data_ptr(), need, _lib.stream_ptr()))
+    else:
+        _lib.check(lib.pcd_conv3d_f16(d, _lib.stream_ptr()))
     return out.float().cpu().reshape(b, dout, dout, dout, -1).permute(0, 4, 1, 2, 3)
 
 
@@ -63,11 +69,12 @@ def _run_conv(x, w, bias, stride, pad, relu=False, resid=None):
 def test_conv3d_exact_integers(cin, cout, k, stride, pad, din):
     x, w, bias = _int((2, cin, din, din, din), 1), _int((cout, cin, k, k, k), 2, -1, 2), _int((cout,), 3)
     want = F.conv3d(x.double(), w.double(), bias.double(), stride=stride, padding=pad)
-    got = _run_conv(x, w, bias, stride, pad).double()
-    assert torch.equal(got, want.half().double())
     resid = _int(tuple(want.shape), 4)
-    got = _run_conv(x, w, bias, stride, pad, relu=True, resid=resid).double()
-    assert torch.equal(got, (want.half().double() + resid.double()).clamp_min(0).half().double())
+    for split in ((False, True) if cin * k ** 3 >= 8 * 64 else (False,)):      # split-K needs >= 8 K tiles
+        got = _run_conv(x, w, bias, stride, pad, split=split).double()
+        assert torch.equal(got, want.half().double())
+        got = _run_conv(x, w, bias, stride, pad, relu=True, resid=resid, split=split).double()
+        assert torch.equal(got, (want.half().double() + resid.double()).clamp_min(0).half().double())
 
 
 def test_conv_transpose3d_classes_exact():
@@ -83,7 +90,7 @@ def test_conv_transpose3d_classes_exact():
     dout = 2 * din
     out = torch.empty(b * dout ** 3, cout, dtype=torch.float16, device="cuda")
     db = bias.cuda()
-    keep = []
+    keep, descs = [], []
     for pz in (0, 1):
         for py in (0, 1):
             for px in (0, 1):
@@ -100,8 +107,21 @@ def test_conv_transpose3d_classes_exact():
                 d.out_scale, d.out_off_z, d.out_off_y, d.out_off_x = 2, pz, py, px
                 d.zero_page = zero.data_ptr()
                 _lib.check(lib.pcd_conv3d_f16(d, _lib.stream_ptr()))
+                descs.append(d)
     got = out.float().cpu().reshape(b, dout, dout, dout, cout).permute(0, 4, 1, 2, 3).double()
     assert torch.equal(got, want.half().double())
+    # the same 8 classes as ONE launch (blockIdx.y = class), split-K with the finish kernel
+    out.zero_()
+    arr = (_lib.Conv3dDesc * 8)(*descs)
+    need = int(lib.pcd_conv3d_workspace_bytes(arr, 8))
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.pcd_conv3d_f16_multi(arr, 8, ws.data_ptr(), need, _lib.stream_ptr()))
+    got = out.float().cpu().reshape(b, dout, dout, dout, cout).permute(0, 4, 1, 2, 3).double()
+    assert torch.equal(got, want.half().double())
+    # classes that do not share a shape are refused, not silently mis-launched
+    arr[3].kpad += 64
+    assert lib.pcd_conv3d_f16_multi(arr, 8, ws.data_ptr(), need, _lib.stream_ptr()) != 0
 
 
 def test_latent_unet_forward(ldm, golden):
