@@ -103,6 +103,8 @@ _SIGS = {
     "pcd_latent_workspace_bytes": (sz, [i32]),
     "pcd_latent_forward": (i32, [vp, vp, i32, vp, i32, vp, vp, sz, vp]),
     "pcd_conv3d_f16": (i32, [C.POINTER(Conv3dDesc), vp]),
+    "pcd_conv3d_k3s1_supported": (i32, [C.POINTER(Conv3dDesc)]),
+    "pcd_conv3d_k3s1_f16": (i32, [C.POINTER(Conv3dDesc), vp]),
     "pcd_conv3d_workspace_bytes": (sz, [C.POINTER(Conv3dDesc), i32]),
     "pcd_conv3d_f16_multi": (i32, [C.POINTER(Conv3dDesc), i32, vp, sz, vp]),
     "pcd_conv3d_first": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp]),

@@ -214,6 +214,244 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k3 / stride 1 / pad 1 with an LDS-resident input halo.  The implicit GEMM above re-gathers every input
+// voxel once per tap (27x) from L2; at C_out <= 64 that gather traffic (24 KB per 1 MFLOP tile step) is
+// what bounds the 32^3 layers.  Here a workgroup owns a 4 x 4 x 8 block of output voxels (128 GEMM rows),
+// loads the 6 x 6 x 10 input halo ONCE into LDS (row pitch = C_in * 2 + 16 B: bank-conflict free up to one
+// 2-way overlap between the two y rows of a 16-row MFMA block) and reads the A fragments of all 27 taps
+// from it at compile-time offsets; only the weights stream (G taps per stage, LDS-DMA, double buffered).
+struct HaloParams {
+    const half_t* in; int B, D, H, W;
+    const half_t* w; int kpad;        // [Cout][kpad], k = tap * CIN + c, taps in (kz, ky, kx) order
+    const float* bias;
+    const half_t* resid;
+    half_t* out; int Cout;
+    int relu;
+    int tiles_n, tz, ty, tx;          // tiles per dimension
+    int nblocks;
+    int dbg;
+};
+
+constexpr int HTZ = 4, HTY = 4, HTX = 8, HHY = HTY + 2, HHX = HTX + 2, HROWS = (HTZ + 2) * HHY * HHX;
+
+// The same LDS-DMA from inline asm.  The compiler models the builtin as a FLAT access that may touch both
+// memory and LDS, and while one is pending it turns every later s_waitcnt into vmcnt(0) / lgkmcnt(0) -- which
+// drains the fragment prefetch of the halo kernel below.  Issued from asm, the DMA is invisible to that
+// bookkeeping; the caller owns the vmcnt wait and the barrier.
+__device__ __forceinline__ void cglds16_asm(const half_t* g, char* lds_wave_base) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m0v) : "memory", "m0");
+}
+
+template <int N>
+__device__ __forceinline__ void conv_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int CIN, int BN, int G, int NSTAGE>
+__global__ __launch_bounds__(256) void conv3d_halo_kernel(HaloParams p) {
+    constexpr int RB = CIN * 2, P = RB + 16, CPR = RB / 16, KS = CIN / 32;
+    constexpr int HALO_BYTES = HROWS * P;
+    constexpr int BST = G * BN * RB;                          // bytes per weight stage
+    constexpr int WAVES_N = BN / 32, WAVES_M = 4 / WAVES_N, WMR = 128 / WAVES_M, MI = WMR / 16, NI = 2;
+    constexpr int OUT_LD = BN * 2 + 16;
+    constexpr int NS = 27 / G;
+    constexpr int HIT = (HROWS * CPR + 255) / 256;           // halo chunks per thread
+    constexpr int RPI = 1024 / RB;                            // weight rows per wave-wide DMA instruction
+    constexpr int NINSTR = G * BN / RPI;
+    constexpr int U = (NINSTR + 3) / 4;                       // DMA instructions per wave and stage (uniform, so
+    constexpr int DUMP = (NINSTR % 4) ? 1024 : 0;             // the vmcnt arithmetic is: spare ones hit a dump KB)
+    static_assert(27 % G == 0 && 128 * OUT_LD <= HALO_BYTES && HALO_BYTES % 16 == 0 && NS >= NSTAGE, "layout");
+    __shared__ __attribute__((aligned(16))) char smem[HALO_BYTES + NSTAGE * BST + DUMP];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    // consecutive workgroups go round-robin over the 8 XCDs: give each XCD a contiguous run of tiles so that
+    // neighbouring tiles (which share halo voxels) meet in the same L2
+    int bid = blockIdx.x;
+    if ((p.nblocks & 7) == 0) bid = (bid & 7) * (p.nblocks >> 3) + (bid >> 3);
+    const int tn = bid % p.tiles_n; int t = bid / p.tiles_n;
+    const int tx = t % p.tx; t /= p.tx;
+    const int ty = t % p.ty; t /= p.ty;
+    const int tz = t % p.tz; const int b = t / p.tz;
+    const int z0 = tz * HTZ, y0 = ty * HTY, x0 = tx * HTX, n0 = tn * BN;
+
+    // ---- halo: global -> registers -> LDS (once)
+    // (loads are unconditional from a clamped address and zeroed afterwards: no divergent branches,
+    //  all HIT loads in flight together)
+    half8 hv[HIT];
+    unsigned okmask = 0;
+    if (!(p.dbg & 1))
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+        const int c = it * 256 + tid;
+        const int row = c / CPR, ch = c - row * CPR;
+        const int hx = row % HHX; const int r2 = row / HHX;
+        const int hy = r2 % HHY, hz = r2 / HHY;
+        const int iz = z0 - 1 + hz, iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const bool ok = row < HROWS && (unsigned)iz < (unsigned)p.D && (unsigned)iy < (unsigned)p.H &&
+                        (unsigned)ix < (unsigned)p.W;
+        okmask |= ok ? 1u << it : 0u;
+        const int cz = min(max(iz, 0), p.D - 1), cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
+        hv[it] = *(const half8*)(p.in + ((((int64_t)b * p.D + cz) * p.H + cy) * p.W + cx) * CIN + ch * 8);
+    }
+
+    auto stageB = [&](int s, int buf) {
+        char* base = smem + HALO_BYTES + buf * BST;
+        if (!(p.dbg & 4))
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int it = wave + 4 * u;
+            const bool real = it < NINSTR;
+            const int row = (real ? it : 0) * RPI + lane / CPR;
+            const int g = row / BN, n = row % BN;
+            const int lch = (lane % CPR) ^ (RB == 128 ? (n >> 1) & 7 : (n >> 2) & 3);
+            int nn = n0 + n;
+            nn = nn < p.Cout ? nn : p.Cout - 1;
+            cglds16_asm(p.w + (int64_t)nn * p.kpad + (s * G + g) * CIN + lch * 8,
+                        real ? base + it * 1024 : smem + HALO_BYTES + NSTAGE * BST);
+        }
+    };
+    stageB(0, 0);
+    if (NS > 1) stageB(1, 1);
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+        const int c = it * 256 + tid;
+        const int row = c / CPR, ch = c - row * CPR;
+        const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (row < HROWS) *(half8*)(smem + row * P + ch * 16) = (okmask >> it) & 1 ? hv[it] : zero8;
+    }
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int q = lane >> 4;
+    int abase[MI], boff[NI][KS];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = wm * WMR + i * 16 + (lane & 15);
+        const int x = m & 7, y = (m >> 3) & 3, z = m >> 5;
+        abase[i] = ((z * HHY + y) * HHX + x) * P + q * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = wn * 32 + j * 16 + (lane & 15);
+        const int sw = RB == 128 ? (n >> 1) & 7 : (n >> 2) & 3;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) boff[j][ks] = HALO_BYTES + n * RB + (((ks * 4 + q) ^ sw) << 4);
+    }
+
+    // Fragment registers are double buffered per 32-wide k step: while the MFMAs of step u run, the fragments
+    // of step u+1 are on their way from LDS (A from the halo, which never changes; B from the weight stage).
+    // One step ahead, not one tap: a wave can have at most 15 LDS reads outstanding (lgkmcnt is 4 bits).
+    half8 af[2][MI], bf[2][NI];
+    auto readA = [&](int par, int rowoff, int ks) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[par][i] = *(const half8*)(smem + abase[i] + rowoff * P + ks * 64);
+    };
+    auto readB = [&](int par, const char* bbuf, int g, int ks) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bf[par][j] = *(const half8*)(bbuf + boff[j][ks] + g * BN * RB);
+    };
+    // halo row offset of a stage's first tap and of a tap inside its stage
+    auto stage_off = [&](int s) {
+        return G == 1 ? ((s / 9) * HHY + (s / 3) % 3) * HHX + s % 3 : G == 3 ? ((s / 3) * HHY + s % 3) * HHX
+                                                                               : s * HHY * HHX;
+    };
+    auto tap_off = [&](int g) { return G == 1 ? 0 : G == 3 ? g : (g / 3) * HHX + g % 3; };
+
+    // Weight stages: buffer s % 3.  The barrier of stage s publishes stage s+1 (every wave waited for its own
+    // DMAs) and frees the buffer of stage s-1 for stage s+2, so the prefetch can always run one step ahead,
+    // also across a stage boundary.  Fully unrolled (27 taps): with a loop back-edge the compiler's waitcnt
+    // pass falls back to lgkmcnt(0) in front of the MFMAs, which drains the prefetch it is meant to overlap.
+    static_assert(NSTAGE == 3, "the prefetch protocol below is written for three weight buffers");
+    conv_wait_vmcnt<(NS > 1) ? U : 0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    readA(0, 0, 0);
+    readB(0, smem, 0, 0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (s + 1 < NS) {
+            conv_wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();   // raw: __syncthreads() adds its own waits
+            if (s + 2 < NS) stageB(s + 2, (s + 2) % 3);
+        }
+        const char* bcur = smem + (s % 3) * BST;
+        const char* bnxt = smem + ((s + 1) % 3) * BST;
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int par = ((s * G + g) * KS + ks) & 1;
+                if (ks + 1 < KS) {
+                    readA(par ^ 1, stage_off(s) + tap_off(g), ks + 1);
+                    readB(par ^ 1, bcur, g, ks + 1);
+                } else if (g + 1 < G) {
+                    readA(par ^ 1, stage_off(s) + tap_off(g + 1), 0);
+                    readB(par ^ 1, bcur, g + 1, 0);
+                } else if (s + 1 < NS) {
+                    readA(par ^ 1, stage_off(s + 1), 0);
+                    readB(par ^ 1, bnxt, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(p.dbg & 2))
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[par][i], bf[par][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    }
+
+    // epilogue (same rounding points as conv3d_igemm_kernel): bias -> fp16 in LDS -> 16-B row stores
+    const int colq = lane & 15;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int lcol = wn * 32 + j * 16 + colq;
+        const float bc = (p.bias != nullptr && n0 + lcol < p.Cout) ? p.bias[n0 + lcol] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lrow = wm * WMR + i * 16 + q * 4 + r;
+                float v = acc[i][j][r] + bc;
+                if (p.relu && p.resid == nullptr) v = fmaxf(v, 0.f);
+                *(half_t*)(smem + lrow * OUT_LD + lcol * 2) = to_half_sat(v);
+            }
+    }
+    __syncthreads();
+    constexpr int OCPR = BN / 8, TOTAL = 128 * OCPR;
+#pragma unroll
+    for (int it = 0; it < TOTAL / 256; ++it) {
+        const int idx = it * 256 + tid;
+        const int lrow = idx / OCPR, ch = idx - lrow * OCPR;
+        const int col = n0 + ch * 8;
+        if (col < p.Cout) {
+            const int x = lrow & 7, y = (lrow >> 3) & 3, z = lrow >> 5;
+            const int64_t orow = (((int64_t)b * p.D + z0 + z) * p.H + y0 + y) * p.W + x0 + x;
+            half8 v = *(const half8*)(smem + lrow * OUT_LD + ch * 16);
+            if (p.resid != nullptr) {
+                const half8 rs = *(const half8*)(p.resid + orow * p.Cout + col);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float f = (float)v[e] + (float)rs[e];
+                    if (p.relu) f = fmaxf(f, 0.f);
+                    v[e] = to_half_sat(f);
+                }
+            }
+            *(half8*)(p.out + orow * p.Cout + col) = v;
+        }
+    }
+}
+
 // split-K finish: sum the slabs in split order (deterministic), then the same epilogue as above.
 // thread = (variant, row, 8-column chunk)
 __global__ __launch_bounds__(256) void conv3d_finish_kernel(ConvParams p) {
@@ -466,6 +704,53 @@ extern "C" int pcd_conv3d_f16_multi(const pcd_conv3d_desc_t* descs, int n, void*
 extern "C" int pcd_conv3d_f16(const pcd_conv3d_desc_t* d, void* stream) {
     PCD_CHECK_ARG(d != nullptr);
     return pcd_conv3d_f16_multi(d, 1, nullptr, 0, stream);
+}
+
+static bool halo_supported(const pcd_conv3d_desc_t* d) {
+    return d->ntaps == 27 && d->stride == 1 && d->out_scale == 1 && (d->cin == 32 || d->cin == 64) &&
+           d->cout % 8 == 0 && d->kpad >= 27 * d->cin &&
+           d->rows_d == d->in_d && d->rows_h == d->in_h && d->rows_w == d->in_w && d->out_d == d->in_d &&
+           d->out_h == d->in_h && d->out_w == d->in_w && d->in_d % HTZ == 0 && d->in_h % HTY == 0 &&
+           d->in_w % HTX == 0 && d->out_off_z == 0 && d->out_off_y == 0 && d->out_off_x == 0;
+}
+
+extern "C" int pcd_conv3d_k3s1_supported(const pcd_conv3d_desc_t* d) {
+    return d != nullptr && conv_check(d) == PCD_OK && halo_supported(d) ? 1 : 0;
+}
+
+extern "C" int pcd_conv3d_k3s1_f16(const pcd_conv3d_desc_t* d, void* stream) {
+    PCD_CHECK_ARG(d != nullptr);
+    const int rc = conv_check(d);
+    if (rc != PCD_OK) return rc;
+    PCD_CHECK_ARG(halo_supported(d));
+    HaloParams p{};
+    p.in = (const half_t*)d->in; p.B = d->batch; p.D = d->in_d; p.H = d->in_h; p.W = d->in_w;
+    p.w = (const half_t*)d->w; p.kpad = d->kpad; p.bias = d->bias; p.resid = (const half_t*)d->resid;
+    p.out = (half_t*)d->out; p.Cout = d->cout; p.relu = d->relu;
+    const int bn = d->cout <= 32 ? 32 : 64;
+    p.tiles_n = (int)ceil_div(d->cout, bn);
+    p.tz = d->in_d / HTZ; p.ty = d->in_h / HTY; p.tx = d->in_w / HTX;
+    const int64_t blocks = (int64_t)d->batch * p.tz * p.ty * p.tx * p.tiles_n;
+    PCD_CHECK_ARG(blocks <= 0x7fffffff);
+    p.nblocks = (int)blocks;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)blocks), blk(256);
+    const char* ev = getenv("PCD_HALO_VARIANT");
+    const int var = 0;
+    p.dbg = ev ? atoi(ev) : 0;
+    if (d->cin == 64 && bn == 64) {
+        hipLaunchKernelGGL((conv3d_halo_kernel<64, 64, 1, 3>), grid, blk, 0, s, p);
+    } else if (d->cin == 64) {
+        hipLaunchKernelGGL((conv3d_halo_kernel<64, 32, 1, 3>), grid, blk, 0, s, p);
+    } else if (bn == 64) {
+        if (var == 1) hipLaunchKernelGGL((conv3d_halo_kernel<32, 64, 1, 3>), grid, blk, 0, s, p);
+        else hipLaunchKernelGGL((conv3d_halo_kernel<32, 64, 3, 3>), grid, blk, 0, s, p);
+    } else {
+        if (var == 1) hipLaunchKernelGGL((conv3d_halo_kernel<32, 32, 1, 3>), grid, blk, 0, s, p);
+        else hipLaunchKernelGGL((conv3d_halo_kernel<32, 32, 3, 3>), grid, blk, 0, s, p);
+    }
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
 }
 
 extern "C" int pcd_conv3d_first(const float* x, int batch, int d, int h, int w, int stride, const float* wgt,

@@ -221,7 +221,10 @@ class VAE3DLarge(_HipModule):
         d.out_d = d.out_h = d.out_w = dout
         d.out_scale, d.out_off_z, d.out_off_y, d.out_off_x = 1, 0, 0, 0
         d.zero_page = pk["zero"].data_ptr()
-        _launch_convs([d], x.device, "conv3d")
+        if k == 3 and stride == 1 and lib.pcd_conv3d_k3s1_supported(d):
+            _lib.check(lib.pcd_conv3d_k3s1_f16(d, _lib.stream_ptr()), "conv3d_k3s1")   # LDS-resident halo
+        else:
+            _launch_convs([d], x.device, "conv3d")
         return out
 
     def _convT(self, L, x, b, din):

@@ -244,6 +244,13 @@ int pcd_conv3d_f16(const pcd_conv3d_desc_t* d, void* stream);
 size_t pcd_conv3d_workspace_bytes(const pcd_conv3d_desc_t* descs, int n);
 int pcd_conv3d_f16_multi(const pcd_conv3d_desc_t* descs, int n, void* workspace, size_t workspace_bytes,
                          void* stream);
+/* Conv3d(k3, stride 1, pad 1) (+ folded BN, residual, ReLU) with the input halo of a 4x4x8 output block held in
+ * LDS and reused by all 27 taps -- the 32^3 layers of VAE3DLarge (encoder.2, decoder.8-11; networks.py:2227,
+ * 2256-2259), whose gather traffic bounds the generic kernel.  Same descriptor; the tap table is implied
+ * (regular 3x3x3, (kz, ky, kx) order, offsets -1..1) and d->taps is not read.  Supported: cin 32 or 64, spatial
+ * dims multiples of (4, 4, 8), out_scale 1; pcd_conv3d_k3s1_supported() tells (1/0), unsupported -> PCD_ERR_ARG. */
+int pcd_conv3d_k3s1_supported(const pcd_conv3d_desc_t* d);
+int pcd_conv3d_k3s1_f16(const pcd_conv3d_desc_t* d, void* stream);
 /* encoder.0: Conv3d(1, cout, k3, stride 1|2, p1) (+ folded BN) + ReLU straight from the fp32 occupancy
  * grid x [B][D][H][W]; w fp32 [cout][27], out fp16 NDHWC (VAE3DLarge networks.py:2226, VAE3D :1999). */
 int pcd_conv3d_first(const float* x, int batch, int d, int h, int w, int stride, const float* wgt,

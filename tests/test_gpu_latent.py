@@ -77,6 +77,49 @@ def test_conv3d_exact_integers(cin, cout, k, stride, pad, din):
         assert torch.equal(got, (want.half().double() + resid.double()).clamp_min(0).half().double())
 
 
+@pytest.mark.parametrize("cin,cout,dims", [(64, 64, (8, 8, 8)), (64, 32, (4, 8, 16)), (32, 64, (8, 4, 8)),
+                                           (32, 32, (4, 4, 8)), (64, 24, (4, 4, 8)), (32, 72, (4, 8, 8))])
+def test_conv3d_k3s1_halo_exact(cin, cout, dims):
+    """The LDS-halo kernel (32^3 layers of VAE3DLarge) against F.conv3d on exactly representable integers:
+    every border, partial / multiple C_out tiles, non-cubic volumes, residual + ReLU epilogue."""
+    from shapegen_amd import _lib
+    from shapegen_amd.vae import _pack_conv, _taps_regular
+    lib = _lib.load()
+    b = 3
+    x, w, bias = _int((b, cin) + dims, 11), _int((cout, cin, 3, 3, 3), 12, -1, 2), _int((cout,), 13)
+    want = F.conv3d(x.double(), w.double(), bias.double(), padding=1)
+    resid = _int(tuple(want.shape), 14)
+    wk, _, kpad = _pack_conv(w.double().numpy(), bias.double().numpy())
+    dx = x.permute(0, 2, 3, 4, 1).contiguous().half().cuda()
+    dw, db = torch.from_numpy(wk).half().cuda(), bias.cuda()
+    dr = resid.permute(0, 2, 3, 4, 1).contiguous().half().cuda()
+    taps = torch.from_numpy(_taps_regular(3, 1)).cuda()
+    zero = torch.zeros(64, dtype=torch.float16, device="cuda")
+    for use_resid in (False, True):
+        out = torch.empty(b * dims[0] * dims[1] * dims[2], cout, dtype=torch.float16, device="cuda")
+        d = _lib.Conv3dDesc()
+        d.inp, d.batch, d.in_d, d.in_h, d.in_w, d.cin = dx.data_ptr(), b, dims[0], dims[1], dims[2], cin
+        d.rows_d, d.rows_h, d.rows_w = dims
+        d.out_d, d.out_h, d.out_w = dims
+        d.stride, d.taps, d.ntaps, d.kpad = 1, taps.data_ptr(), 27, kpad
+        d.w, d.bias, d.relu = dw.data_ptr(), db.data_ptr(), 1
+        d.resid = dr.data_ptr() if use_resid else 0
+        d.out, d.cout, d.out_scale, d.zero_page = out.data_ptr(), cout, 1, zero.data_ptr()
+        assert lib.pcd_conv3d_k3s1_supported(d) == 1
+        _lib.check(lib.pcd_conv3d_k3s1_f16(d, _lib.stream_ptr()))
+        got = out.float().cpu().reshape((b,) + dims + (cout,)).permute(0, 4, 1, 2, 3).double()
+        ref = want.half().double()
+        ref = (ref + resid.double()).clamp_min(0).half().double() if use_resid else ref.clamp_min(0)
+        assert torch.equal(got, ref)
+        # and the generic implicit-GEMM kernel gives the same bits on the same descriptor
+        out2 = torch.empty_like(out)
+        d.out = out2.data_ptr()
+        _lib.check(lib.pcd_conv3d_f16(d, _lib.stream_ptr()))
+        assert torch.equal(out, out2)
+    d.in_w = d.rows_w = d.out_w = dims[2] + 4                  # not a multiple of 8: refused, never mis-tiled
+    assert lib.pcd_conv3d_k3s1_supported(d) == 0 and lib.pcd_conv3d_k3s1_f16(d, _lib.stream_ptr()) != 0
+
+
 def test_conv_transpose3d_classes_exact():
     """ConvTranspose3d(k4,s2,p1) as 8 parity classes of 2x2x2 taps."""
     from shapegen_amd import _lib

@@ -1,14 +1,12 @@
-"""Dev tool: print the kernels of the LAST pass in a rocprofv3 kernel-trace csv (argv[1]), argv[2] = passes."""
-import csv, sys
+"""Dev tool: aggregate a rocprofv3 kernel-trace csv (argv[1]) by (kernel, grid): calls, mean us."""
+import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
-passes = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-rows.sort(key=lambda r: int(r['Start_Timestamp']))
-n = len(rows) // passes
-last = rows[-n:]
-tot = 0
-for r in last:
-    t = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-    tot += t
-    if t > 15:
-        print(f"{r['Kernel_Name'][:58]:58s} {t:8.1f} us  grid {int(r['Grid_Size_X'])//int(r['Workgroup_Size_X'])}x{r['Grid_Size_Y']}x{r['Grid_Size_Z']}")
-print('kernels', n, 'total us', round(tot))
+agg = collections.OrderedDict()
+for r in sorted(rows, key=lambda r: int(r['Start_Timestamp'])):
+    key = (r['Kernel_Name'][:70], int(r['Grid_Size_X']) // int(r['Workgroup_Size_X']), r['Grid_Size_Y'], r['Grid_Size_Z'])
+    agg.setdefault(key, []).append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+for k, v in agg.items():
+    v2 = v[len(v) // 3:] if len(v) >= 3 else v
+    m = sum(v2) / len(v2)
+    if m * len(v) > 100:
+        print(f"{k[0]:70s} grid {k[1]}x{k[2]}x{k[3]:3s} calls {len(v):3d} mean {m:8.1f} us")
