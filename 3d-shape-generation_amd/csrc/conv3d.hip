@@ -230,7 +230,6 @@ struct HaloParams {
     int relu;
     int tiles_n, tz, ty, tx;          // tiles per dimension
     int nblocks;
-    int dbg;
 };
 
 constexpr int HTZ = 4, HTY = 4, HTX = 8, HHY = HTY + 2, HHX = HTX + 2, HROWS = (HTZ + 2) * HHY * HHX;
@@ -283,7 +282,6 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(HaloParams p) {
     //  all HIT loads in flight together)
     half8 hv[HIT];
     unsigned okmask = 0;
-    if (!(p.dbg & 1))
 #pragma unroll
     for (int it = 0; it < HIT; ++it) {
         const int c = it * 256 + tid;
@@ -300,7 +298,6 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(HaloParams p) {
 
     auto stageB = [&](int s, int buf) {
         char* base = smem + HALO_BYTES + buf * BST;
-        if (!(p.dbg & 4))
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int it = wave + 4 * u;
@@ -400,7 +397,6 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(HaloParams p) {
                     readB(par ^ 1, bnxt, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (!(p.dbg & 2))
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -540,6 +536,49 @@ __global__ __launch_bounds__(256) void conv3d_first_kernel(const float* __restri
     *(half8*)(out + vox * cout + ch * 8) = o;
 }
 
+// first layer, cout = 32 fast path: thread = voxel, all 32 output channels.  Weight indices are wave-uniform, so
+// they are scalar loads and the 864 FMAs per voxel take an SGPR operand (the generic kernel above reads one LDS
+// word per FMA, which is what bounds it).
+__global__ __launch_bounds__(256) void conv3d_first32_kernel(const float* __restrict__ x, int B, int D, int H, int W,
+                                                              int stride, const float* __restrict__ w,
+                                                              const float* __restrict__ b, half_t* __restrict__ out) {
+    constexpr int COUT = 32;
+    const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;   // k3, pad 1
+    const int64_t vox = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vox >= (int64_t)B * Do * Ho * Wo) return;
+    int xx = (int)(vox % Wo); int64_t t = vox / Wo;
+    int yy = (int)(t % Ho); t /= Ho;
+    int zz = (int)(t % Do); const int bb = (int)(t / Do);
+    xx *= stride; yy *= stride; zz *= stride;
+    float tap[27];
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iz = zz + kz - 1, iy = yy + ky - 1, ix = xx + kx - 1;
+                const bool ok = (unsigned)iz < (unsigned)D && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                const int cz = min(max(iz, 0), D - 1), cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+                const float v = x[(((int64_t)bb * D + cz) * H + cy) * W + cx];
+                tap[(kz * 3 + ky) * 3 + kx] = ok ? v : 0.f;
+            }
+    half_t* o = out + vox * COUT;
+#pragma unroll
+    for (int c8 = 0; c8 < COUT / 8; ++c8) {
+        half8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c8 * 8 + e;
+            float a = b[c];
+#pragma unroll
+            for (int k = 0; k < 27; ++k) a = fmaf(w[c * 27 + k], tap[k], a);
+            r[e] = to_half_sat(fmaxf(a, 0.f));
+        }
+        *(half8*)(o + c8 * 8) = r;
+    }
+}
+
 // last layer: fp16 NDHWC [..][CIN] -> fp32 [B][D][H][W], k3 s1 p1, Cout = 1, sigmoid.
 // w fp32 [27][CIN], one thread per output voxel.
 template <int CIN>
@@ -570,6 +609,60 @@ __global__ __launch_bounds__(256) void conv3d_last_kernel(const half_t* __restri
                 }
             }
     out[vox] = 1.f / (1.f + expf(-a));
+}
+
+// last layer with the halo in LDS: a workgroup owns 4 x 4 x 8 output voxels; thread = (voxel, half of the 27
+// taps); the direct kernel above re-reads every input voxel 27 times from L2 (1.8 GB at B = 32).
+// Requires D % 4 == H % 4 == W % 8 == 0.  Weights fp32 [27][32] are wave-uniform -> scalar loads.
+__global__ __launch_bounds__(256) void conv3d_last_halo_kernel(const half_t* __restrict__ in, int B, int D, int H, int W,
+                                                               const float* __restrict__ w, float bias,
+                                                               float* __restrict__ out, int ntz, int nty, int ntx) {
+    constexpr int CIN = 32, RB = CIN * 2, P = RB + 16, CPR = RB / 16;
+    constexpr int HIT = (HROWS * CPR + 255) / 256;
+    __shared__ __attribute__((aligned(16))) char smem[HROWS * P];
+    __shared__ float part[128];
+    const int tid = threadIdx.x;
+    int t = blockIdx.x;
+    const int tx = t % ntx; t /= ntx;
+    const int ty = t % nty; t /= nty;
+    const int tz = t % ntz; const int b = t / ntz;
+    const int z0 = tz * HTZ, y0 = ty * HTY, x0 = tx * HTX;
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+        const int c = it * 256 + tid;
+        const int row = c / CPR, ch = c - row * CPR;
+        const int hx = row % HHX; const int r2 = row / HHX;
+        const int hy = r2 % HHY, hz = r2 / HHY;
+        const int iz = z0 - 1 + hz, iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const bool ok = (unsigned)iz < (unsigned)D && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (row < HROWS) {
+            if (ok) v = *(const half8*)(in + ((((int64_t)b * D + iz) * H + iy) * W + ix) * CIN + ch * 8);
+            *(half8*)(smem + row * P + ch * 16) = v;
+        }
+    }
+    __syncthreads();
+    const int vox = tid & 127, half = __builtin_amdgcn_readfirstlane(tid >> 7);   // waves 0,1: taps 0-13; 2,3: 14-26
+    const int x = vox & 7, y = (vox >> 3) & 3, z = vox >> 5;
+    const char* base = smem + ((z * HHY + y) * HHX + x) * P;
+    float a = 0.f;
+    const int t0 = half * 14, t1 = half ? 27 : 14;
+    for (int tap = t0; tap < t1; ++tap) {
+        const int toff = ((tap / 9) * HHY + (tap / 3) % 3) * HHX + tap % 3;
+        const float* wk = w + tap * CIN;                          // uniform address: s_load
+#pragma unroll
+        for (int c8 = 0; c8 < CIN / 8; ++c8) {
+            const half8 v = *(const half8*)(base + toff * P + c8 * 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a = fmaf(wk[c8 * 8 + e], (float)v[e], a);
+        }
+    }
+    if (half) part[vox] = a;
+    __syncthreads();
+    if (!half) {
+        a += part[vox] + bias;
+        out[(((int64_t)b * D + z0 + z) * H + y0 + y) * W + x0 + x] = 1.f / (1.f + expf(-a));
+    }
 }
 
 // VAE3D's last layer (networks.py:2018-2019): ConvTranspose3d(CIN, 1, k3, s2, p1, output_padding 1) + Sigmoid.
@@ -735,20 +828,11 @@ extern "C" int pcd_conv3d_k3s1_f16(const pcd_conv3d_desc_t* d, void* stream) {
     p.nblocks = (int)blocks;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)blocks), blk(256);
-    const char* ev = getenv("PCD_HALO_VARIANT");
-    const int var = 0;
-    p.dbg = ev ? atoi(ev) : 0;
-    if (d->cin == 64 && bn == 64) {
-        hipLaunchKernelGGL((conv3d_halo_kernel<64, 64, 1, 3>), grid, blk, 0, s, p);
-    } else if (d->cin == 64) {
-        hipLaunchKernelGGL((conv3d_halo_kernel<64, 32, 1, 3>), grid, blk, 0, s, p);
-    } else if (bn == 64) {
-        if (var == 1) hipLaunchKernelGGL((conv3d_halo_kernel<32, 64, 1, 3>), grid, blk, 0, s, p);
-        else hipLaunchKernelGGL((conv3d_halo_kernel<32, 64, 3, 3>), grid, blk, 0, s, p);
-    } else {
-        if (var == 1) hipLaunchKernelGGL((conv3d_halo_kernel<32, 32, 1, 3>), grid, blk, 0, s, p);
-        else hipLaunchKernelGGL((conv3d_halo_kernel<32, 32, 3, 3>), grid, blk, 0, s, p);
-    }
+    // weight stage = one tap (three taps for 32 -> 32, where a tap is only 4 MFMAs per wave)
+    if (d->cin == 64 && bn == 64) hipLaunchKernelGGL((conv3d_halo_kernel<64, 64, 1, 3>), grid, blk, 0, s, p);
+    else if (d->cin == 64) hipLaunchKernelGGL((conv3d_halo_kernel<64, 32, 1, 3>), grid, blk, 0, s, p);
+    else if (bn == 64) hipLaunchKernelGGL((conv3d_halo_kernel<32, 64, 1, 3>), grid, blk, 0, s, p);
+    else hipLaunchKernelGGL((conv3d_halo_kernel<32, 32, 3, 3>), grid, blk, 0, s, p);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }
@@ -758,6 +842,12 @@ extern "C" int pcd_conv3d_first(const float* x, int batch, int d, int h, int w, 
     PCD_CHECK_ARG(x && wgt && bias && out && batch > 0 && d > 0 && h > 0 && w > 0 && cout > 0 && cout % 8 == 0);
     PCD_CHECK_ARG(stride == 1 || stride == 2);
     const int64_t ovox = (int64_t)((d - 1) / stride + 1) * ((h - 1) / stride + 1) * ((w - 1) / stride + 1);
+    if (cout == 32) {
+        hipLaunchKernelGGL(conv3d_first32_kernel, dim3((unsigned)ceil_div((int64_t)batch * ovox, 256)), dim3(256), 0,
+                           (hipStream_t)stream, x, batch, d, h, w, stride, wgt, bias, (half_t*)out);
+        PCD_CHECK_LAUNCH();
+        return PCD_OK;
+    }
     const int64_t total = (int64_t)batch * ovox * (cout / 8);
     hipLaunchKernelGGL(conv3d_first_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256),
                        (size_t)cout * 28 * sizeof(float), (hipStream_t)stream, x, batch, d, h, w, stride, wgt, bias,
@@ -771,8 +861,13 @@ extern "C" int pcd_conv3d_last_sigmoid(const void* in, int batch, int d, int h, 
     PCD_CHECK_ARG(in && wgt && out && batch > 0 && d > 0 && h > 0 && w > 0);
     PCD_CHECK_ARG(cin == 32);
     const int64_t total = (int64_t)batch * d * h * w;
-    hipLaunchKernelGGL((conv3d_last_kernel<32>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const half_t*)in, batch, d, h, w, wgt, bias, out);
+    if (d % HTZ == 0 && h % HTY == 0 && w % HTX == 0 && total / 128 <= 0x7fffffff) {
+        hipLaunchKernelGGL(conv3d_last_halo_kernel, dim3((unsigned)(total / 128)), dim3(256), 0, (hipStream_t)stream,
+                           (const half_t*)in, batch, d, h, w, wgt, bias, out, d / HTZ, h / HTY, w / HTX);
+    } else {
+        hipLaunchKernelGGL((conv3d_last_kernel<32>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0,
+                           (hipStream_t)stream, (const half_t*)in, batch, d, h, w, wgt, bias, out);
+    }
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

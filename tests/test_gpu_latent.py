@@ -120,6 +120,37 @@ def test_conv3d_k3s1_halo_exact(cin, cout, dims):
     assert lib.pcd_conv3d_k3s1_supported(d) == 0 and lib.pcd_conv3d_k3s1_f16(d, _lib.stream_ptr()) != 0
 
 
+@pytest.mark.parametrize("dims,stride", [((8, 8, 8), 1), ((4, 8, 16), 1), ((6, 5, 7), 1), ((8, 8, 8), 2)])
+def test_conv3d_first_and_last_layers(dims, stride):
+    """encoder.0 (Cin = 1, ReLU, fp16 NDHWC out) and decoder.12/13 (Cout = 1, sigmoid) against F.conv3d in fp64:
+    the LDS-halo last-layer path (dims multiples of 4, 4, 8), its direct fallback (6, 5, 7), and the cout = 32
+    first-layer path at both strides."""
+    from shapegen_amd import _lib
+    lib = _lib.load()
+    b = 2
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand((b, 1) + dims, generator=g)
+    w0, b0 = torch.randn(32, 1, 3, 3, 3, generator=g) * 0.3, torch.randn(32, generator=g) * 0.1
+    want = F.conv3d(x.double(), w0.double(), b0.double(), stride=stride, padding=1).clamp_min(0)
+    od = tuple((d - 1) // stride + 1 for d in dims)
+    out = torch.empty(b * od[0] * od[1] * od[2], 32, dtype=torch.float16, device="cuda")
+    dx, dw, db = x.cuda().contiguous(), w0.reshape(32, 27).contiguous().cuda(), b0.cuda()
+    _lib.check(lib.pcd_conv3d_first(dx.data_ptr(), b, dims[0], dims[1], dims[2], stride, dw.data_ptr(), db.data_ptr(), 32,
+                                    out.data_ptr(), _lib.stream_ptr()))
+    got = out.float().cpu().reshape((b,) + od + (32,)).permute(0, 4, 1, 2, 3).double()
+    assert (got - want).abs().max() <= 2e-3 * max(1.0, float(want.abs().max()))       # one fp16 rounding
+    if stride == 1:
+        h = out                                                                        # fp16 NDHWC, 32 channels
+        wl, bl = torch.randn(1, 32, 3, 3, 3, generator=g) * 0.1, 0.05
+        hin = h.float().cpu().reshape((b,) + dims + (32,)).permute(0, 4, 1, 2, 3).double()
+        want2 = torch.sigmoid(F.conv3d(hin, wl.double(), torch.tensor([bl]).double(), padding=1))
+        dwl = wl[0].permute(1, 2, 3, 0).reshape(27, 32).contiguous().cuda()
+        o2 = torch.empty((b, 1) + dims, dtype=torch.float32, device="cuda")
+        _lib.check(lib.pcd_conv3d_last_sigmoid(h.data_ptr(), b, dims[0], dims[1], dims[2], 32, dwl.data_ptr(), bl,
+                                               o2.data_ptr(), _lib.stream_ptr()))
+        assert (o2.cpu().double() - want2).abs().max() <= 2e-6
+
+
 def test_conv_transpose3d_classes_exact():
     """ConvTranspose3d(k4,s2,p1) as 8 parity classes of 2x2x2 taps."""
     from shapegen_amd import _lib
