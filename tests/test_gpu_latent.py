@@ -77,15 +77,15 @@ def test_conv3d_exact_integers(cin, cout, k, stride, pad, din):
         assert torch.equal(got, (want.half().double() + resid.double()).clamp_min(0).half().double())
 
 
-@pytest.mark.parametrize("cin,cout,dims", [(64, 64, (8, 8, 8)), (64, 32, (4, 8, 16)), (32, 64, (8, 4, 8)),
-                                           (32, 32, (4, 4, 8)), (64, 24, (4, 4, 8)), (32, 72, (4, 8, 8))])
-def test_conv3d_k3s1_halo_exact(cin, cout, dims):
+@pytest.mark.parametrize("cin,cout,dims,b", [(64, 64, (8, 8, 8), 4), (64, 32, (4, 8, 16), 3), (32, 64, (8, 4, 8), 3),
+                                             (32, 32, (4, 4, 8), 8), (64, 24, (4, 4, 8), 3), (32, 72, (4, 8, 8), 3)])
+def test_conv3d_k3s1_halo_exact(cin, cout, dims, b):
     """The LDS-halo kernel (32^3 layers of VAE3DLarge) against F.conv3d on exactly representable integers:
-    every border, partial / multiple C_out tiles, non-cubic volumes, residual + ReLU epilogue."""
+    every border, partial / multiple C_out tiles, non-cubic volumes, residual + ReLU epilogue; block counts that
+    are (b = 4, 8) and are not (b = 3) multiples of 8, i.e. with and without the XCD tile remap."""
     from shapegen_amd import _lib
     from shapegen_amd.vae import _pack_conv, _taps_regular
     lib = _lib.load()
-    b = 3
     x, w, bias = _int((b, cin) + dims, 11), _int((cout, cin, 3, 3, 3), 12, -1, 2), _int((cout,), 13)
     want = F.conv3d(x.double(), w.double(), bias.double(), padding=1)
     resid = _int(tuple(want.shape), 14)
