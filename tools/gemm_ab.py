@@ -1,4 +1,4 @@
-"""Dev tool: A/B of a run-time switch in the GEMM (pcd_gemm_set_config(1000 + v)) in one process, interleaved."""
+"""Dev tool: sweep of the run-time stagger value in the GEMM (pcd_gemm_set_config(1000 + v)) in one process."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -6,6 +6,7 @@ import shapegen_amd
 from shapegen_amd import _lib, ops
 lib = _lib.load()
 M = 64 * 2048
+vals = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "1"])]
 g = torch.Generator(device="cuda").manual_seed(0)
 for K, C, kind in [(2048, 4096, "colmax"), (1024, 2048, "f16"), (1024, 1024, "f16"), (512, 1024, "f16"), (512, 512, "f16"), (256, 512, "f16")]:
     a = torch.randn(M, K, device="cuda", generator=g).clamp_min(0).half()
@@ -13,9 +14,9 @@ for K, C, kind in [(2048, 4096, "colmax"), (1024, 2048, "f16"), (1024, 1024, "f1
     bias = torch.zeros(C, device="cuda")
     out = torch.empty(M, C, dtype=torch.float16, device="cuda") if kind == "f16" else None
     fn = (lambda: ops.gemm_f16(a, w, bias, relu=True, out=out)) if kind == "f16" else (lambda: ops.gemm_f16_colmax(a, w, bias, 2048))
-    res = {0: [], 1: []}
-    for rnd in range(6):
-        for v in (0, 1):
+    res = {v: [] for v in vals}
+    for rnd in range(5):
+        for v in vals:
             lib.pcd_gemm_set_config(1000 + v)
             fn(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -25,4 +26,4 @@ for K, C, kind in [(2048, 4096, "colmax"), (1024, 2048, "f16"), (1024, 1024, "f1
             e1.record(); torch.cuda.synchronize()
             res[v].append(e0.elapsed_time(e1) / 5 * 1e3)
     lib.pcd_gemm_set_config(1000)
-    print(f"K={K} C={C} {kind}: switch off(0) min {min(res[0]):.1f} med {sorted(res[0])[3]:.1f} us | on(1) min {min(res[1]):.1f} med {sorted(res[1])[3]:.1f} us", flush=True)
+    print(f"K={K} C={C} {kind}: " + " | ".join(f"[{v}] {min(res[v]):.1f}" for v in vals), flush=True)
