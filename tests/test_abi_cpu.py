@@ -38,6 +38,24 @@ def test_arg_validation_without_gpu():
     assert b"bad argument" in lib.pcd_last_error()
     assert lib.pcd_unet_workspace_bytes(64, 2048) == lib.pcd_unet_workspace_bytes(64, 2048) > 1 << 30
     assert lib.pcd_unet_workspace_bytes(0, 5) == 0
+    # conv3d: shape logic is host side -- the LDS-halo path is offered only for k3 / s1 / p1, C_in 32 or 64 and
+    # volumes that tile by (4, 4, 8); split-K scratch is asked for exactly when the launch would be small
+    c = _lib.Conv3dDesc()
+    assert lib.pcd_conv3d_k3s1_supported(c) == 0 and lib.pcd_conv3d_workspace_bytes(c, 1) == 0
+    assert lib.pcd_conv3d_f16(c, 0) == -1 and lib.pcd_conv3d_k3s1_f16(c, 0) == -1
+    c.inp = c.w = c.out = c.taps = c.zero_page = 64                       # never dereferenced on the host
+    c.batch, c.in_d, c.in_h, c.in_w, c.cin, c.cout = 32, 32, 32, 32, 64, 64
+    c.rows_d = c.rows_h = c.rows_w = c.out_d = c.out_h = c.out_w = 32
+    c.stride, c.out_scale, c.ntaps, c.kpad = 1, 1, 27, 27 * 64
+    assert lib.pcd_conv3d_k3s1_supported(c) == 1
+    assert lib.pcd_conv3d_workspace_bytes(c, 1) == 0                         # 8192 output tiles: no split
+    c.in_w = c.rows_w = c.out_w = 36
+    assert lib.pcd_conv3d_k3s1_supported(c) == 0
+    c.in_d = c.in_h = c.in_w = c.rows_d = c.rows_h = c.rows_w = c.out_d = c.out_h = c.out_w = 4
+    c.cin, c.cout, c.kpad = 512, 512, 27 * 512                               # encoder.11: 16 x 4 tiles, 216 K tiles
+    ws = lib.pcd_conv3d_workspace_bytes(c, 1)
+    assert ws > 0 and ws % (32 * 64 * 512 * 4) == 0                          # whole fp32 slabs [M][C_out]
+    assert lib.pcd_conv3d_workspace_bytes(c, 9) == 0                         # more than 8 variants: refused
 
 
 def test_packing_is_exact_algebra():
