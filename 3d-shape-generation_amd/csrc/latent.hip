@@ -4,6 +4,9 @@
 // step, B <= 256 rows).  Algebra applied by the host packer: refine_k folded into the skip half
 // of dec_k (linear into linear); the time half of enc1 hoisted into a per-t bias (pcd_time_embed).
 //
+// Layers 3-7 (>= 1 MB of weights) run as a weight-streaming split-K GEMM + finishing kernel; the other seven as one
+// fused launch each (csrc/skinny.hip).
+//
 // lin[] execution order (K -> C):  0 enc1 256->128 (+tbias)   1 enc2 128->256   2 enc3 256->512
 //   3 enc4 512->1024   4 global_feat.0 1024->2048   5 global_feat.3 2048->4096
 //   6 dec4 [4096 | z4 1024]->1024   7 dec3 [1024 | z3 512]->512   8 dec2 [512 | z2 256]->256
@@ -126,6 +129,11 @@ extern "C" int pcd_latent_forward(pcd_latent_t* h, const float* z, int batch, co
     auto lin = [&](int idx, const void* a1, const void* a2, int k2, const float* bias, const float* row_bias,
                    int mode, void* out16, float* out32) -> int {
         const pcd_linear_desc_t& L = d.lin[idx];
+        // small layers (enc1-3, dec1-2, output head): one launch instead of split-K + finish
+        if (pcd_skinny_fused_supported(L.k, L.c, mode, 8))
+            return pcd_skinny_fused(a1, L.k - k2, a2, k2, L.w, L.k, batch, L.c, bias, row_bias, mode, 8,
+                                    mode == 0 ? d.gn_gamma[idx] : nullptr, mode == 0 ? d.gn_beta[idx] : nullptr,
+                                    out16, out32, s);
         int r = pcd_skinny_gemm_f16(a1, L.k - k2, a2, k2, L.w, L.k, batch, L.c, t32, s);
         if (r) return r;
         return pcd_skinny_finish(t32, pcd_skinny_slabs(L.k, L.c), batch, L.c, bias, row_bias, mode, 8,

@@ -129,6 +129,109 @@ __global__ __launch_bounds__(256) void skinny_finish_kernel(const float* __restr
     }
 }
 
+// Small layers in ONE launch: Linear (+bias, + per-row bias) + GroupNorm + ReLU for weights of <= ~1.5 MB.  The
+// split-K + finish pair above pays two dependent launches (~3.7 us each inside a HIP graph), which is most of such
+// a layer's time in the latent denoiser step.  A workgroup owns BC = 32 * CT consecutive columns -- whole
+// GroupNorm groups -- and 32 rows over the FULL K; its 16 waves are CT column tiles x (16 / CT) K splits that are
+// summed through LDS in a fixed order; GroupNorm statistics are per (row, group), so nothing crosses workgroups.
+struct SkinnyFusedParams {
+    const half_t* a1; int k1;
+    const half_t* a2; int k2;
+    const half_t* w; int ldw;
+    int m, c;
+    const float* bias; const float* row_bias;
+    int mode, gsz;                                   // 0: GroupNorm(gsz channels)+ReLU -> fp16; 1: ReLU -> fp16; 2: fp32
+    const float* gamma; const float* beta;
+    half_t* out16; float* out32;
+};
+
+template <int CT>
+__global__ __launch_bounds__(1024) void skinny_fused_kernel(SkinnyFusedParams p) {
+    // 16 waves = CT column tiles x KSPLIT K splits: every wave has at most a few 64-deep chunks, all of whose loads
+    // are in flight together, so the layer costs about one memory latency
+    constexpr int BC = 32 * CT, KSPLIT = 16 / CT;
+    __shared__ float zt[KSPLIT][32][BC + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int ct = wave % CT, ksi = wave / CT;
+    const int n0 = blockIdx.x * BC + ct * 32;
+    const int row0 = blockIdx.y * 32;
+    const int chunks = (p.k1 + p.k2) / 64;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    int wn = n0 + r;
+    wn = wn < p.c ? wn : p.c - 1;
+    const half_t* wrow = p.w + (int64_t)wn * p.ldw;
+    int row = row0 + r;
+    row = row < p.m ? row : p.m - 1;
+#pragma unroll 3
+    for (int ch = ksi; ch < chunks; ch += KSPLIT) {
+        const int k = ch * 64 + 32 * hh;             // this lane's 32 consecutive k (same permuted order for both)
+        const half_t* src = k < p.k1 ? p.a1 : p.a2;
+        const int lda = k < p.k1 ? p.k1 : p.k2;
+        const int ka = k < p.k1 ? k : k - p.k1;
+        const half_t* arow = src + (int64_t)row * lda + ka;
+        half8 wf[4], af[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { wf[j] = *(const half8*)(wrow + k + 8 * j); af[j] = *(const half8*)(arow + 8 * j); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j], wf[j], acc, 0, 0, 0);
+    }
+    // accumulator e of lane (r, hh) is row (e&3) + 8*(e>>2) + 4*hh, column r; one LDS slab per K split
+#pragma unroll
+    for (int e = 0; e < 16; ++e) zt[ksi][(e & 3) + 8 * (e >> 2) + 4 * hh][ct * 32 + r] = acc[e];
+    __syncthreads();
+    // finish: 32 threads per row, CT consecutive columns each, K splits added in split order (deterministic);
+    // a GroupNorm group is gsz / CT neighbouring threads of the row
+    const int frow = threadIdx.x >> 5, part = threadIdx.x & 31;
+    const int grow = row0 + frow;
+    const int c0 = blockIdx.x * BC + part * CT;
+    float v[CT];
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+        const int ch = c0 + i;
+        float x = 0.f;
+#pragma unroll
+        for (int sidx = 0; sidx < KSPLIT; ++sidx) x += zt[sidx][frow][part * CT + i];
+        if (ch < p.c) {
+            if (p.bias != nullptr) x += p.bias[ch];
+            if (p.row_bias != nullptr && grow < p.m) x += p.row_bias[(int64_t)grow * p.c + ch];
+        }
+        v[i] = x;
+        s1 += x;
+    }
+    if (p.mode == 0) {
+        const int tpg = p.gsz / CT;                  // threads per group: 16 (gsz 16) or 32
+        for (int o = 1; o < tpg; o <<= 1) s1 += __shfl_xor(s1, o);
+        const float mean = s1 / (float)p.gsz;
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < CT; ++i) { const float dlt = v[i] - mean; s2 += dlt * dlt; }
+        for (int o = 1; o < tpg; o <<= 1) s2 += __shfl_xor(s2, o);
+        const float rstd = rsqrtf(s2 / (float)p.gsz + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            const int ch = c0 + i;
+            if (ch < p.c) v[i] = fmaxf((v[i] - mean) * rstd * p.gamma[ch] + p.beta[ch], 0.f);
+        }
+    } else if (p.mode == 1) {
+#pragma unroll
+        for (int i = 0; i < CT; ++i) v[i] = fmaxf(v[i], 0.f);
+    }
+    if (grow < p.m) {
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            const int ch = c0 + i;
+            if (ch < p.c) {
+                if (p.mode == 2) p.out32[(int64_t)grow * p.c + ch] = v[i];
+                else p.out16[(int64_t)grow * p.c + ch] = to_half_sat(v[i]);
+            }
+        }
+    }
+}
+
 }  // namespace pcd
 
 using namespace pcd;
@@ -178,6 +281,43 @@ extern "C" int pcd_skinny_finish(const float* slabs, int nslabs, int m, int c, c
     hipLaunchKernelGGL(skinny_finish_kernel, dim3(m, split), dim3(256), (size_t)(c / split) * sizeof(float),
                        (hipStream_t)stream, slabs, nslabs, m, c, bias, row_bias, mode, split, gamma, beta,
                        (half_t*)out16, out32);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+// One-launch Linear (+bias) + GroupNorm(groups) + ReLU (mode 0) / ReLU (1) / fp32 identity (2) for small layers:
+// whole GroupNorm groups per workgroup, full K.  Requires a group size of 16, 32, 64 or 128 channels for mode 0.
+extern "C" int pcd_skinny_fused_supported(int k, int c, int mode, int groups) {
+    if (k <= 0 || c <= 0 || k % 64 != 0 || mode < 0 || mode > 2) return 0;
+    if ((int64_t)k * c > 768 * 256) return 0;   // above ~400 KB of weights the split-K pair streams faster (8 CUs here)
+    if (mode == 0) {
+        if (groups <= 0 || c % groups != 0) return 0;
+        const int gsz = c / groups;
+        return gsz == 16 || gsz == 32 || gsz == 64 || gsz == 128;
+    }
+    return c % 32 == 0;
+}
+
+extern "C" int pcd_skinny_fused(const void* a1, int k1, const void* a2, int k2, const void* w, int64_t ldw, int m, int c,
+                                const float* bias, const float* row_bias, int mode, int groups, const float* gamma,
+                                const float* beta, void* out16, float* out32, void* stream) {
+    PCD_CHECK_ARG(a1 && w && m > 0 && m <= 256 && c > 0);
+    PCD_CHECK_ARG(k1 > 0 && k1 % 64 == 0 && k2 >= 0 && k2 % 64 == 0 && (k2 == 0 || a2 != nullptr));
+    PCD_CHECK_ARG(ldw >= k1 + k2 && ldw % 8 == 0);
+    PCD_CHECK_ARG(pcd_skinny_fused_supported(k1 + k2, c, mode, groups));
+    PCD_CHECK_ARG(mode == 2 ? out32 != nullptr : out16 != nullptr);
+    PCD_CHECK_ARG(mode != 0 || (gamma && beta));
+    SkinnyFusedParams p{};
+    p.a1 = (const half_t*)a1; p.k1 = k1; p.a2 = (const half_t*)a2; p.k2 = k2;
+    p.w = (const half_t*)w; p.ldw = (int)ldw; p.m = m; p.c = c;
+    p.bias = bias; p.row_bias = row_bias; p.mode = mode; p.gsz = mode == 0 ? c / groups : 0;
+    p.gamma = gamma; p.beta = beta; p.out16 = (half_t*)out16; p.out32 = out32;
+    const int bc = mode == 0 ? (p.gsz < 32 ? 32 : p.gsz) : 32;       // whole groups per workgroup
+    const dim3 grid((unsigned)ceil_div(c, bc), (unsigned)ceil_div(m, 32));
+    hipStream_t s = (hipStream_t)stream;
+    if (bc == 32) hipLaunchKernelGGL((skinny_fused_kernel<1>), grid, dim3(1024), 0, s, p);
+    else if (bc == 64) hipLaunchKernelGGL((skinny_fused_kernel<2>), grid, dim3(1024), 0, s, p);
+    else hipLaunchKernelGGL((skinny_fused_kernel<4>), grid, dim3(1024), 0, s, p);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

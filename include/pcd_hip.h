@@ -196,6 +196,14 @@ int pcd_skinny_gemm_f16(const void* a1, int k1, const void* a2, int k2, const vo
 int pcd_skinny_finish(const float* slabs, int nslabs, int m, int c, const float* bias, const float* row_bias,
                       int mode, int groups, const float* gamma, const float* beta,
                       void* out16, float* out32, void* stream);
+/* The same layer in ONE launch for small weights (k * c <= 768 * 256): a workgroup owns whole GroupNorm groups
+ * over the full K, so Linear + bias + GroupNorm + ReLU need no second kernel (enc1-3, dec1-2 and the output head of
+ * SimpleLatentUNetPointNet, networks.py:984-1049).  pcd_skinny_fused_supported() tells (1/0) whether a shape
+ * qualifies (mode 0: group size 16/32/64/128). */
+int pcd_skinny_fused_supported(int k, int c, int mode, int groups);
+int pcd_skinny_fused(const void* a1, int k1, const void* a2, int k2, const void* w, int64_t ldw, int m, int c,
+                     const float* bias, const float* row_bias, int mode, int groups, const float* gamma,
+                     const float* beta, void* out16, float* out32, void* stream);
 /* SimpleLatentUNetPointNet.forward (networks.py:1051-1086), latent_dim=256, dim=512, time_dim=256.
  * lin[] order documented in csrc/latent.hip; refine_k folded into dec_k, enc1's time half hoisted
  * into tbias [n_t][128] (pcd_time_embed with c1=128). */

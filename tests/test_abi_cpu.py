@@ -109,3 +109,21 @@ def test_linear_schedule_bug_for_bug():
     m = PointCloudDiffusion(num_points=8, noise_schedule="linear")
     n, s = m.diffusion_schedule(torch.tensor([0.5, 0.5, 0.5]))
     np.testing.assert_allclose(s.numpy(), [0.98995, 0.98000, 0.97015], atol=1e-5)   # SURVEY a2 probe
+
+
+@pytest.mark.parametrize("T", [1, 2, 7, 100, 1000])
+def test_vectorized_step_tables_equal_the_per_step_loop(T):
+    """The cosine-schedule step tables are built with one set of elementwise ops over all T steps; the literal
+    per-step transcription of the reference loops (diffusion.py:241-255, 277-286, 323-335) must give the same bits."""
+    from shapegen_amd.diffusion import PointCloudDiffusion
+    m = PointCloudDiffusion(num_points=8)
+    builders = [lambda: m.ddim_table(T, 4), lambda: m.ddpm_table(T, 4), lambda: m.from_state_table(torch.tensor(0.37), T),
+                lambda: m.from_state_table(1.0, T)]
+    for fn in builders:
+        m.vectorized_tables = True
+        a = fn()
+        m.vectorized_tables = False
+        b = fn()
+        assert a.steps == b.steps == T and a.width == b.width == 1 and a.stride == b.stride
+        for f in ("t", "n", "s", "a", "b"):
+            assert torch.equal(getattr(a, f), getattr(b, f)), f

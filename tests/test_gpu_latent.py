@@ -279,3 +279,48 @@ def test_vae3d_small(golden):
     assert dec.shape == (2, 1, 32, 32, 32) and float(err.max()) < 2e-2 and float(err.mean()) < 2e-3
     pcs = vae.sample(2, threshold=0.4, z=torch.from_numpy(g["mu"]).cuda())
     assert len(pcs) == 2 and all(p.shape[1] == 3 for p in pcs)
+
+
+@pytest.mark.parametrize("k1,k2,c,mode,m", [(256, 0, 128, 0, 32), (128, 0, 256, 0, 5), (256, 0, 512, 0, 70), (128, 0, 1024, 0, 32),
+                                            (512, 256, 256, 0, 33), (256, 128, 128, 0, 32), (128, 0, 128, 1, 32),
+                                            (128, 0, 256, 2, 256)])
+def test_skinny_fused_layer(k1, k2, c, mode, m):
+    """One-launch Linear + bias (+ per-row bias) + GroupNorm(8) + ReLU against torch in fp32 on the same fp16 inputs,
+    and against the split-K + finish pair it replaces (same inputs, same math, different summation order)."""
+    from shapegen_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(k1 + c + m)
+    a1 = torch.randn(m, k1, generator=g).half()
+    a2 = torch.randn(m, k2, generator=g).half() if k2 else None
+    w = (torch.randn(c, k1 + k2, generator=g) / (k1 + k2) ** 0.5).half()
+    bias, rb = torch.randn(c, generator=g) * 0.2, torch.randn(m, c, generator=g) * 0.2
+    gamma, beta = 1 + 0.3 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g)
+    assert lib.pcd_skinny_fused_supported(k1 + k2, c, mode, 8) == 1
+    a = torch.cat([a1, a2], 1) if k2 else a1
+    z = a.float() @ w.float().T + bias + rb
+    if mode == 0:
+        want = torch.relu(F.group_norm(z, 8, gamma, beta, eps=1e-5))
+    else:
+        want = torch.relu(z) if mode == 1 else z
+    d = lambda t: None if t is None else t.cuda().contiguous()
+    da1, da2, dw, db, drb, dg, dbt = d(a1), d(a2), d(w), d(bias), d(rb), d(gamma), d(beta)
+    o16 = torch.empty(m, c, dtype=torch.float16, device="cuda")
+    o32 = torch.empty(m, c, dtype=torch.float32, device="cuda")
+    _lib.check(lib.pcd_skinny_fused(da1.data_ptr(), k1, _lib.ptr(da2), k2, dw.data_ptr(), k1 + k2, m, c, db.data_ptr(),
+                                    drb.data_ptr(), mode, 8, dg.data_ptr(), dbt.data_ptr(), o16.data_ptr(), o32.data_ptr(),
+                                    _lib.stream_ptr()))
+    got = (o32 if mode == 2 else o16).float().cpu()
+    tol = 2e-6 * float(want.abs().max()) + 1e-5 if mode == 2 else 2e-3 * max(1.0, float(want.abs().max()))
+    assert (got - want).abs().max() <= tol
+    # the two-launch form on the same operands
+    ns = lib.pcd_skinny_slabs(k1 + k2, c)
+    slabs = torch.empty(ns, m, c, dtype=torch.float32, device="cuda")
+    p16, p32 = torch.empty_like(o16), torch.empty_like(o32)
+    _lib.check(lib.pcd_skinny_gemm_f16(da1.data_ptr(), k1, _lib.ptr(da2), k2, dw.data_ptr(), k1 + k2, m, c,
+                                       slabs.data_ptr(), _lib.stream_ptr()))
+    _lib.check(lib.pcd_skinny_finish(slabs.data_ptr(), ns, m, c, db.data_ptr(), drb.data_ptr(), mode, 8, dg.data_ptr(),
+                                     dbt.data_ptr(), p16.data_ptr(), p32.data_ptr(), _lib.stream_ptr()))
+    pair = (p32 if mode == 2 else p16).float().cpu()
+    assert (got - pair).abs().max() <= (1e-5 if mode == 2 else 2e-3) * max(1.0, float(want.abs().max()))
+    # shapes the fused form does not take
+    assert lib.pcd_skinny_fused_supported(2048, 4096, 0, 8) == 0 and lib.pcd_skinny_fused_supported(96, 128, 0, 8) == 0

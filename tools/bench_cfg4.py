@@ -17,6 +17,9 @@ vae = VAE3DLarge()
 m = LatentDiffusion(vae)
 m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
 m = m.to("cuda").eval()
+m.use_graphs = bool(int(os.environ.get("USE_GRAPHS", "1")))
+if "GRAPH_STEPS" in os.environ:
+    m.GRAPH_STEPS = int(os.environ["GRAPH_STEPS"])
 vox = (torch.rand(B, 1, 32, 32, 32, device="cuda") > 0.9).float()
 def run():
     torch.cuda.synchronize(); t0 = time.perf_counter()
