@@ -100,6 +100,7 @@ _SIGS = {
     "pcd_skinny_finish": (i32, [vp, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
     "pcd_skinny_fused_supported": (i32, [i32, i32, i32, i32]),
     "pcd_skinny_fused": (i32, [vp, i32, vp, i32, vp, i64, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
+    "pcd_skinny_fused_f32in": (i32, [vp, i32, vp, i64, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
     "pcd_latent_create": (i32, [C.POINTER(LatentDesc), C.POINTER(vp)]),
     "pcd_latent_destroy": (None, [vp]),
     "pcd_latent_workspace_bytes": (sz, [i32]),

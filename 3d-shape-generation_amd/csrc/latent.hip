@@ -142,9 +142,12 @@ extern "C" int pcd_latent_forward(pcd_latent_t* h, const float* z, int batch, co
     };
     auto lin_gn = [&](int idx, const void* a1, const void* a2, int k2, const float* bias, const float* sbias,
                       void* out) -> int { return lin(idx, a1, a2, k2, bias, sbias, 0, out, nullptr); };
-    RUN(pcd_f32_to_f16(z, z16, (int64_t)batch * 256, s));
-    // enc1: time half hoisted into tbias (one row, or one row per sample)
-    RUN(lin_gn(0, z16, nullptr, 0, tbias_shape_stride ? nullptr : tbias, tbias_shape_stride ? tbias : nullptr, z1));
+    // enc1: reads the fp32 state directly (rounded to fp16 on load); time half hoisted into tbias (one row, or one
+    // row per sample)
+    (void)z16;
+    RUN(pcd_skinny_fused_f32in(z, d.lin[0].k, d.lin[0].w, d.lin[0].k, batch, d.lin[0].c,
+                               tbias_shape_stride ? nullptr : tbias, tbias_shape_stride ? tbias : nullptr, 0, 8,
+                               d.gn_gamma[0], d.gn_beta[0], z1, nullptr, s));
     RUN(lin_gn(1, z1, nullptr, 0, d.lin[1].b, nullptr, z2));
     RUN(lin_gn(2, z2, nullptr, 0, d.lin[2].b, nullptr, z3));
     RUN(lin_gn(3, z3, nullptr, 0, d.lin[3].b, nullptr, z4));

@@ -143,6 +143,7 @@ struct SkinnyFusedParams {
     int mode, gsz;                                   // 0: GroupNorm(gsz channels)+ReLU -> fp16; 1: ReLU -> fp16; 2: fp32
     const float* gamma; const float* beta;
     half_t* out16; float* out32;
+    const float* a1_f32;                             // if set: the first source in fp32 (rounded to fp16 on load)
 };
 
 template <int CT>
@@ -174,7 +175,20 @@ __global__ __launch_bounds__(1024) void skinny_fused_kernel(SkinnyFusedParams p)
         const half_t* arow = src + (int64_t)row * lda + ka;
         half8 wf[4], af[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { wf[j] = *(const half8*)(wrow + k + 8 * j); af[j] = *(const half8*)(arow + 8 * j); }
+        for (int j = 0; j < 4; ++j) wf[j] = *(const half8*)(wrow + k + 8 * j);
+        if (p.a1_f32 != nullptr && k < p.k1) {
+            // same conversion as the separate fp32 -> fp16 pass this replaces (saturating, round to nearest even)
+            const float* frow = p.a1_f32 + (int64_t)row * p.k1 + k;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 lo = *(const float4*)(frow + 8 * j), hi = *(const float4*)(frow + 8 * j + 4);
+                af[j] = (half8){to_half_sat(lo.x), to_half_sat(lo.y), to_half_sat(lo.z), to_half_sat(lo.w),
+                                to_half_sat(hi.x), to_half_sat(hi.y), to_half_sat(hi.z), to_half_sat(hi.w)};
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) af[j] = *(const half8*)(arow + 8 * j);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j], wf[j], acc, 0, 0, 0);
     }
@@ -298,10 +312,10 @@ extern "C" int pcd_skinny_fused_supported(int k, int c, int mode, int groups) {
     return c % 32 == 0;
 }
 
-extern "C" int pcd_skinny_fused(const void* a1, int k1, const void* a2, int k2, const void* w, int64_t ldw, int m, int c,
-                                const float* bias, const float* row_bias, int mode, int groups, const float* gamma,
-                                const float* beta, void* out16, float* out32, void* stream) {
-    PCD_CHECK_ARG(a1 && w && m > 0 && m <= 256 && c > 0);
+static int skinny_fused_launch(const void* a1, const float* a1_f32, int k1, const void* a2, int k2, const void* w,
+                               int64_t ldw, int m, int c, const float* bias, const float* row_bias, int mode, int groups,
+                               const float* gamma, const float* beta, void* out16, float* out32, void* stream) {
+    PCD_CHECK_ARG((a1 || a1_f32) && w && m > 0 && m <= 256 && c > 0);
     PCD_CHECK_ARG(k1 > 0 && k1 % 64 == 0 && k2 >= 0 && k2 % 64 == 0 && (k2 == 0 || a2 != nullptr));
     PCD_CHECK_ARG(ldw >= k1 + k2 && ldw % 8 == 0);
     PCD_CHECK_ARG(pcd_skinny_fused_supported(k1 + k2, c, mode, groups));
@@ -312,6 +326,8 @@ extern "C" int pcd_skinny_fused(const void* a1, int k1, const void* a2, int k2, 
     p.w = (const half_t*)w; p.ldw = (int)ldw; p.m = m; p.c = c;
     p.bias = bias; p.row_bias = row_bias; p.mode = mode; p.gsz = mode == 0 ? c / groups : 0;
     p.gamma = gamma; p.beta = beta; p.out16 = (half_t*)out16; p.out32 = out32;
+    p.a1_f32 = a1_f32;
+    if (a1_f32 != nullptr) p.a1 = (const half_t*)a1_f32;             // never dereferenced as fp16 (k < k1 takes the fp32 branch)
     const int bc = mode == 0 ? (p.gsz < 32 ? 32 : p.gsz) : 32;       // whole groups per workgroup
     const dim3 grid((unsigned)ceil_div(c, bc), (unsigned)ceil_div(m, 32));
     hipStream_t s = (hipStream_t)stream;
@@ -320,4 +336,21 @@ extern "C" int pcd_skinny_fused(const void* a1, int k1, const void* a2, int k2, 
     else hipLaunchKernelGGL((skinny_fused_kernel<4>), grid, dim3(1024), 0, s, p);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
+}
+
+extern "C" int pcd_skinny_fused(const void* a1, int k1, const void* a2, int k2, const void* w, int64_t ldw, int m, int c,
+                                const float* bias, const float* row_bias, int mode, int groups, const float* gamma,
+                                const float* beta, void* out16, float* out32, void* stream) {
+    PCD_CHECK_ARG(a1 != nullptr);
+    return skinny_fused_launch(a1, nullptr, k1, a2, k2, w, ldw, m, c, bias, row_bias, mode, groups, gamma, beta, out16,
+                               out32, stream);
+}
+
+// the same with an fp32 activation matrix [m][k] (rounded to fp16 on load: the latent state z)
+extern "C" int pcd_skinny_fused_f32in(const float* a, int k, const void* w, int64_t ldw, int m, int c, const float* bias,
+                                      const float* row_bias, int mode, int groups, const float* gamma, const float* beta,
+                                      void* out16, float* out32, void* stream) {
+    PCD_CHECK_ARG(a != nullptr);
+    return skinny_fused_launch(nullptr, a, k, nullptr, 0, w, ldw, m, c, bias, row_bias, mode, groups, gamma, beta, out16,
+                               out32, stream);
 }

@@ -204,6 +204,11 @@ int pcd_skinny_fused_supported(int k, int c, int mode, int groups);
 int pcd_skinny_fused(const void* a1, int k1, const void* a2, int k2, const void* w, int64_t ldw, int m, int c,
                      const float* bias, const float* row_bias, int mode, int groups, const float* gamma,
                      const float* beta, void* out16, float* out32, void* stream);
+/* ... with the activations given in fp32 [m][k] and rounded to fp16 on load (enc1 reads the latent state z directly;
+ * saves the separate conversion launch). */
+int pcd_skinny_fused_f32in(const float* a, int k, const void* w, int64_t ldw, int m, int c, const float* bias,
+                           const float* row_bias, int mode, int groups, const float* gamma, const float* beta,
+                           void* out16, float* out32, void* stream);
 /* SimpleLatentUNetPointNet.forward (networks.py:1051-1086), latent_dim=256, dim=512, time_dim=256.
  * lin[] order documented in csrc/latent.hip; refine_k folded into dec_k, enc1's time half hoisted
  * into tbias [n_t][128] (pcd_time_embed with c1=128). */

@@ -324,3 +324,23 @@ def test_skinny_fused_layer(k1, k2, c, mode, m):
     assert (got - pair).abs().max() <= (1e-5 if mode == 2 else 2e-3) * max(1.0, float(want.abs().max()))
     # shapes the fused form does not take
     assert lib.pcd_skinny_fused_supported(2048, 4096, 0, 8) == 0 and lib.pcd_skinny_fused_supported(96, 128, 0, 8) == 0
+
+
+def test_skinny_fused_fp32_input_equals_converted_input():
+    """enc1 of the latent denoiser reads the fp32 state directly: same bits as converting to fp16 first."""
+    from shapegen_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    m, k, c = 37, 256, 128
+    a = (torch.randn(m, k, generator=g) * 3).cuda()
+    a[0, 0], a[1, 5] = 1e6, -1e6                                       # saturate, like pcd_f32_to_f16
+    w = (torch.randn(c, k, generator=g) / 16).half().cuda()
+    bias, gamma, beta = (torch.randn(c, generator=g).cuda() for _ in range(3))
+    a16 = torch.empty(m, k, dtype=torch.float16, device="cuda")
+    _lib.check(lib.pcd_f32_to_f16(a.data_ptr(), a16.data_ptr(), a.numel(), _lib.stream_ptr()))
+    o1, o2 = (torch.empty(m, c, dtype=torch.float16, device="cuda") for _ in range(2))
+    _lib.check(lib.pcd_skinny_fused(a16.data_ptr(), k, 0, 0, w.data_ptr(), k, m, c, bias.data_ptr(), 0, 0, 8,
+                                    gamma.data_ptr(), beta.data_ptr(), o1.data_ptr(), 0, _lib.stream_ptr()))
+    _lib.check(lib.pcd_skinny_fused_f32in(a.data_ptr(), k, w.data_ptr(), k, m, c, bias.data_ptr(), 0, 0, 8,
+                                          gamma.data_ptr(), beta.data_ptr(), o2.data_ptr(), 0, _lib.stream_ptr()))
+    assert torch.equal(o1, o2)
