@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
 // what bounds the 32^3 layers.  Here a workgroup owns a 4 x 4 x 8 block of output voxels (128 GEMM rows),
 // loads the 6 x 6 x 10 input halo ONCE into LDS (row pitch = C_in * 2 + 16 B: bank-conflict free up to one
 // 2-way overlap between the two y rows of a 16-row MFMA block) and reads the A fragments of all 27 taps
-// from it at compile-time offsets; only the weights stream (G taps per stage, LDS-DMA, double buffered).
+// from it at compile-time offsets; only the weights stream (G taps per stage, LDS-DMA, three buffers).
 struct HaloParams {
     const half_t* in; int B, D, H, W;
     const half_t* w; int kpad;        // [Cout][kpad], k = tap * CIN + c, taps in (kz, ky, kx) order
@@ -248,8 +248,9 @@ __device__ __forceinline__ void conv_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// NW waves per workgroup: 4 (2 x 2 or 4 x 1 wave grid, 64 x 32 / 32 x 32 wave tiles) or, for C_out = 64, 2 waves
-// of 64 x 64: 8 fragment reads per 16 MFMAs instead of 6 per 8, which takes the LDS array off the critical path.
+// NW waves per workgroup: 4 (2 x 2 or 4 x 1 wave grid, 64 x 32 / 32 x 32 wave tiles; what the launcher uses) or, for
+// C_out = 64, 2 waves of 64 x 64 (8 fragment reads per 16 MFMAs instead of 6 per 8, but one wave per SIMD: measured
+// slower, kept as a template parameter only).
 template <int CIN, int BN, int G, int NSTAGE, int NW>
 __global__ __launch_bounds__(64 * NW) void conv3d_halo_kernel(HaloParams p) {
     constexpr int NT = 64 * NW;
