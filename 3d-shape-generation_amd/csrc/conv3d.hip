@@ -467,11 +467,20 @@ __global__ __launch_bounds__(256) void conv3d_finish_kernel(ConvParams p) {
     float a[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) a[e] = 0.f;
-    for (int s = 0; s < p.splits; ++s) {
-        const float4* src = (const float4*)(p.slabs + (((int64_t)s * p.nvar + cls) * p.M + m) * p.Cout + col);
-        const float4 u = src[0], v = src[1];
-        a[0] += u.x; a[1] += u.y; a[2] += u.z; a[3] += u.w;
-        a[4] += v.x; a[5] += v.y; a[6] += v.z; a[7] += v.w;
+    // slabs added in split order, two splits' loads in flight together
+    const int64_t sstride = (int64_t)p.nvar * p.M * p.Cout;
+    const float* sp = p.slabs + ((int64_t)cls * p.M + m) * p.Cout + col;
+    for (int s = 0; s < p.splits; s += 2) {
+        const float4* s0 = (const float4*)(sp + (int64_t)s * sstride);
+        const bool two = s + 1 < p.splits;
+        const float4* s1 = (const float4*)(sp + (int64_t)(two ? s + 1 : s) * sstride);
+        const float4 u0 = s0[0], v0 = s0[1], u1 = s1[0], v1 = s1[1];
+        a[0] += u0.x; a[1] += u0.y; a[2] += u0.z; a[3] += u0.w;
+        a[4] += v0.x; a[5] += v0.y; a[6] += v0.z; a[7] += v0.w;
+        if (two) {
+            a[0] += u1.x; a[1] += u1.y; a[2] += u1.z; a[3] += u1.w;
+            a[4] += v1.x; a[5] += v1.y; a[6] += v1.z; a[7] += v1.w;
+        }
     }
     const int ox = m % p.Wo; int t = m / p.Wo;
     const int oy = t % p.Ho; t /= p.Ho;
