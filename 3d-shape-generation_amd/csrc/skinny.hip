@@ -92,6 +92,16 @@ __global__ __launch_bounds__(256) void skinny_finish_kernel(const float* __restr
     const int row = blockIdx.x, g = blockIdx.y;
     const int gsz = c / groups, c0 = g * gsz;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // GroupNorm affine of this thread's (first two) channels requested up front: their latency then overlaps the
+    // slab sums and the two block reductions instead of following them
+    float gpre[2] = {1.f, 1.f}, bpre[2] = {0.f, 0.f};
+    if (mode == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = threadIdx.x + j * (int)blockDim.x;
+            if (i < gsz) { gpre[j] = gamma[c0 + i]; bpre[j] = beta[c0 + i]; }
+        }
+    }
     float s = 0.f;
     for (int i = threadIdx.x; i < gsz; i += blockDim.x) {
         const int ch = c0 + i;
@@ -136,9 +146,10 @@ __global__ __launch_bounds__(256) void skinny_finish_kernel(const float* __restr
     if (lane == 0) red[4 + wave] = v;
     __syncthreads();
     const float rstd = rsqrtf(((red[4] + red[5]) + (red[6] + red[7])) / (float)gsz + 1e-5f);
-    for (int i = threadIdx.x; i < gsz; i += blockDim.x) {
+    for (int i = threadIdx.x, j = 0; i < gsz; i += blockDim.x, ++j) {
         const int ch = c0 + i;
-        out16[(int64_t)row * c + ch] = to_half_sat(fmaxf((buf[i] - mean) * rstd * gamma[ch] + beta[ch], 0.f));
+        const float ga = j < 2 ? gpre[j] : gamma[ch], be = j < 2 ? bpre[j] : beta[ch];
+        out16[(int64_t)row * c + ch] = to_half_sat(fmaxf((buf[i] - mean) * rstd * ga + be, 0.f));
     }
 }
 
@@ -171,6 +182,20 @@ __global__ __launch_bounds__(1024) void skinny_fused_kernel(SkinnyFusedParams p)
     const int n0 = blockIdx.x * BC + ct * 32;
     const int row0 = blockIdx.y * 32;
     const int chunks = (p.k1 + p.k2) / 64;
+    // the finish phase's per-column constants are requested now, so their latency overlaps the K loop's
+    const int frow = threadIdx.x >> 5, part = threadIdx.x & 31;
+    const int grow = row0 + frow;
+    const int c0 = blockIdx.x * BC + part * CT;
+    float cb[CT], cg[CT], cbt[CT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+        const int ch = c0 + i < p.c ? c0 + i : p.c - 1;
+        float x = p.bias != nullptr ? p.bias[ch] : 0.f;
+        if (p.row_bias != nullptr) x += p.row_bias[(int64_t)(grow < p.m ? grow : p.m - 1) * p.c + ch];
+        cb[i] = x;
+        cg[i] = p.mode == 0 ? p.gamma[ch] : 1.f;
+        cbt[i] = p.mode == 0 ? p.beta[ch] : 0.f;
+    }
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -211,21 +236,14 @@ __global__ __launch_bounds__(1024) void skinny_fused_kernel(SkinnyFusedParams p)
     __syncthreads();
     // finish: 32 threads per row, CT consecutive columns each, K splits added in split order (deterministic);
     // a GroupNorm group is gsz / CT neighbouring threads of the row
-    const int frow = threadIdx.x >> 5, part = threadIdx.x & 31;
-    const int grow = row0 + frow;
-    const int c0 = blockIdx.x * BC + part * CT;
     float v[CT];
     float s1 = 0.f;
 #pragma unroll
     for (int i = 0; i < CT; ++i) {
-        const int ch = c0 + i;
         float x = 0.f;
 #pragma unroll
         for (int sidx = 0; sidx < KSPLIT; ++sidx) x += zt[sidx][frow][part * CT + i];
-        if (ch < p.c) {
-            if (p.bias != nullptr) x += p.bias[ch];
-            if (p.row_bias != nullptr && grow < p.m) x += p.row_bias[(int64_t)grow * p.c + ch];
-        }
+        x += cb[i];
         v[i] = x;
         s1 += x;
     }
@@ -241,7 +259,7 @@ __global__ __launch_bounds__(1024) void skinny_fused_kernel(SkinnyFusedParams p)
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
             const int ch = c0 + i;
-            if (ch < p.c) v[i] = fmaxf((v[i] - mean) * rstd * p.gamma[ch] + p.beta[ch], 0.f);
+            if (ch < p.c) v[i] = fmaxf((v[i] - mean) * rstd * cg[i] + cbt[i], 0.f);
         }
     } else if (p.mode == 1) {
 #pragma unroll
