@@ -307,290 +307,6 @@ __global__ __launch_bounds__(256) void set_attention_kernel(const half_t* __rest
     }
 }
 
-#ifdef ATT_PINGPONG
-// ------------------------------------------------ ping-pong variant (experimental, -DATT_PINGPONG)
-// NOT the shipped path: at B=64, N=2048, d=64 it runs 398 us against 328 us for the kernel above
-// (profiles/r01_h_attention_pingpong.txt has the measurements and what they rule out).  Kept because it
-// is parity-green and is the starting point if the per-workgroup fixed cost can be removed.
-//
-// Idea: 8 waves per workgroup, two per SIMD, one workgroup per CU; the two waves of a SIMD run in
-// anti-phase, separated by one s_barrier per phase, so one is always on the matrix pipe while the other
-// is on the VALU:
-//     M segment (MFMA + LDS):  O^T += Vt_{j-1} P^T(j-1), the Vt reads of unit j, then S^T(j) = K_j Q^T - m with
-//                              each K fragment re-read for unit j+1 as soon as it has been consumed
-//     V segment (VALU):        row max / deferred rescale / exp2 / row sums / fp16 pack of S^T(j), plus ONE
-//                              1-KiB LDS-DMA piece of the K/V tile three tiles ahead
-// j counts 32-key units; each wave owns 64 queries (QT = 2), so a unit is 16 MFMAs against ~140 VALU.
-// K/V tiles of 64 keys live in a 4-slot ring: the 16 pieces of tile T are issued over phases 4T-9..4T-6
-// (one per wave per V phase), awaited (vmcnt(0) then the phase barrier) at the end of phase 4T-3, first
-// read in phase 4T-2 and last read in phase 4T+3.
-// Phase barrier of the ping-pong kernel.  The sched_barriers matter as much as the s_barrier: without them the
-// machine scheduler moves register-only work (the row-max chain, exps, even MFMAs) across the asm statement,
-// i.e. out of its phase, and the two wave groups stop alternating between the matrix pipe and the VALU.
-__device__ __forceinline__ void pp_barrier() {
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-template <int D, int QT>
-__global__ __launch_bounds__(512) void set_attention_pp_kernel(const half_t* __restrict__ qkv, int n, int c, int heads,
-                                                                float scale_log2e, half_t* __restrict__ out) {
-    static_assert(D == 64 || D == 32, "ping-pong variant: d = 32 or 64");
-    constexpr int NSLOT = 4, PKT = 64;
-    constexpr int KSTEPS = D / 16, OT = D / 32, KRB = D * 2;
-    constexpr int KBYTES = PKT * KRB, STAGE = 2 * KBYTES;
-    __shared__ __attribute__((aligned(16))) char smem[NSLOT * STAGE];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // Phase group: the two waves that share a SIMD must take opposite roles, and which waves share one is up
-    // to the dispatcher (w and w+4 on an idle CU, anything once workgroups replace each other).  So read the
-    // SIMD id and hand out 0 / 1 per SIMD in arrival order; at > 128 VGPRs a SIMD holds exactly two of the eight.
-    __shared__ int simd_rank[4];
-    if (tid < 4) simd_rank[tid] = 0;
-    __syncthreads();
-    int grp;
-    {
-        unsigned hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        int rank = 0;
-        if (lane == 0) rank = atomicAdd(&simd_rank[(hwid >> 4) & 3], 1);
-        grp = __builtin_amdgcn_readfirstlane(rank) & 1;   // 0: starts with an M segment, 1: one phase later
-    }
-    const int qr = lane & 31, hh = lane >> 5;
-    const int bh = blockIdx.y, b = bh / heads, head = bh - b * heads;
-    const int q0 = blockIdx.x * (256 * QT) + wave * (32 * QT);
-    const int64_t row_base = (int64_t)b * n;
-    const int ld = 3 * c;
-
-    const half_t* kbase = qkv + row_base * ld + c + head * D;
-    const half_t* vbase = qkv + row_base * ld + 2 * c + head * D;
-    const int ntiles = (n + PKT - 1) / PKT;
-    const int units = 2 * ntiles;
-    const bool partial = (n % PKT) != 0;
-
-    auto stage = [&](int kt) {
-        char* base = smem + (kt & (NSLOT - 1)) * STAGE;
-        stage_tile<PKT, KRB, false, 8, true>(kbase, ld, kt * PKT, n, base, wave, lane);
-        stage_tile<PKT, KRB, true, 8, true>(vbase, ld, kt * PKT, n, base + KBYTES, wave, lane);
-    };
-    // one 1-KiB piece (one wave instruction) of tile kt: pieces 0..NPIECE/2-1 are K rows, the rest V rows
-    constexpr int NPIECE = 2 * KBYTES / 1024, ROWS_PER_PIECE = 1024 / KRB, CPR = KRB / 16;
-    auto stage_piece = [&](int kt, int piece) {
-        const bool isv = piece >= NPIECE / 2;
-        const int ins = isv ? piece - NPIECE / 2 : piece;
-        const int row = ins * ROWS_PER_PIECE + lane / CPR;
-        const int logical = isv ? v_swz<KRB>(row, lane % CPR) : k_swz<KRB>(row, lane % CPR);
-        int grow = kt * PKT + row;
-        grow = grow < n ? grow : n - 1;
-        aglds16_asm((isv ? vbase : kbase) + (int64_t)grow * ld + logical * 8,
-                    smem + (kt & (NSLOT - 1)) * STAGE + (isv ? KBYTES : 0) + ins * 1024);
-    };
-    stage(0);
-    if (ntiles > 1) stage(1);
-    if (ntiles > 2) stage(2);
-
-    half8 qf[QT][KSTEPS];
-#pragma unroll
-    for (int t = 0; t < QT; ++t) {
-        int qi = q0 + t * 32 + qr;
-        qi = qi < n ? qi : n - 1;
-        const half_t* qp = qkv + (row_base + qi) * ld + head * D;
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            const half8 raw = *(const half8*)(qp + 16 * s + 8 * hh);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) qf[t][s][e] = (half_t)((float)raw[e] * scale_log2e);
-        }
-    }
-
-    f32x16 oacc[QT][OT], negm[QT], sacc[QT];
-    float l0[QT], l1[QT];
-    half8 pf[QT][2], kf[KSTEPS], vf[2][OT];
-#pragma unroll
-    for (int t = 0; t < QT; ++t) {
-        l0[t] = 0.f; l1[t] = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { negm[t][r] = 0.f; sacc[t][r] = 0.f; }
-#pragma unroll
-        for (int o = 0; o < OT; ++o)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[t][o][r] = 0.f;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) pf[t][s2][e] = (half_t)0.f;
-    }
-
-    const int tq = (lane >> 2) & 3, tp = lane & 3, tg = lane >> 4;
-    const int tr_dd0 = 16 * (tg & 1);
-
-    auto read_k = [&](int j) {        // K fragments of unit j (A operand of S^T)
-        const char* kb = smem + ((j >> 1) & (NSLOT - 1)) * STAGE;
-        const int row = (j & 1) * 32 + qr;
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) kf[s] = *(const half8*)(kb + row * KRB + (k_swz<KRB>(row, 2 * s + hh) << 4));
-    };
-    auto read_v = [&](int j) {        // Vt fragments of unit j (A operand of O^T), hardware-transposed
-        const char* vb = smem + ((j >> 1) & (NSLOT - 1)) * STAGE + KBYTES;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int o = 0; o < OT; ++o) {
-                const int dd0 = o * 32 + tr_dd0;
-                const int key = (j & 1) * 32 + 16 * s2 + 4 * (tg >> 1) + tq;
-                const int ch = (dd0 >> 3) + (tp >> 1);
-                const char* a0 = vb + key * KRB + (v_swz<KRB>(key, ch) << 4) + (tp & 1) * 8;
-                const char* a1 = vb + (key + 8) * KRB + (v_swz<KRB>(key + 8, ch) << 4) + (tp & 1) * 8;
-                const fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)a0);
-                const fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)a1);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { vf[s2][o][e] = (half_t)lo[e]; vf[s2][o][4 + e] = (half_t)hi[e]; }
-            }
-    };
-
-    // M segment of unit j (1 <= j < units), in issue order: the value product of unit j-1 (consumes vf, pf),
-    // the Vt reads of unit j (they complete under the score MFMAs), then the scores of unit j k-step by
-    // k-step, each K fragment re-read for unit j+1 as soon as both query tiles have consumed it.  An in-order
-    // wave issues nothing behind a queued MFMA, so LDS reads left to the end of the segment would add their
-    // whole latency to it (tools/ubench_pingpong2.hip: +170 cycles per phase).
-    auto seg_pv = [&]() {
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int t = 0; t < QT; ++t)
-#pragma unroll
-                for (int o = 0; o < OT; ++o)
-                    oacc[t][o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[s2][o], pf[t][s2], oacc[t][o], 0, 0, 0);
-    };
-    auto seg_s = [&](int jnext) {     // jnext: unit whose K fragments replace the consumed ones
-        const char* kb = smem + ((jnext >> 1) & (NSLOT - 1)) * STAGE;
-        const int row = (jnext & 1) * 32 + qr;
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-#pragma unroll
-            for (int t = 0; t < QT; ++t)
-                sacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[s], qf[t][s], s == 0 ? negm[t] : sacc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            kf[s] = *(const half8*)(kb + row * KRB + (k_swz<KRB>(row, 2 * s + hh) << 4));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    // V segment of unit j: softmax numerators of the scores left in sacc; FIRST sets m to the true row max
-    auto seg_v = [&](int j, auto mask_tag, auto first_tag) {
-        constexpr bool MASK = decltype(mask_tag)::value;
-        constexpr bool FIRST = decltype(first_tag)::value;
-#pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            if constexpr (MASK) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    if (key >= n) sacc[t][r] = -INFINITY;
-                }
-            }
-            float mx = max3(sacc[t][0], sacc[t][1], sacc[t][2]);
-#pragma unroll
-            for (int r = 3; r < 15; r += 2) mx = max3(mx, sacc[t][r], sacc[t][r + 1]);
-            mx = xhalf_max(fmaxf(mx, sacc[t][15]));
-            if (FIRST || __any(mx > RESCALE_THR)) {          // wave-uniform, rare after the first units
-                const float delta = FIRST ? mx : fmaxf(mx, 0.f);
-                const float alpha = __builtin_amdgcn_exp2f(-delta);
-                l0[t] *= alpha; l1[t] *= alpha;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { negm[t][r] -= delta; sacc[t][r] -= delta; }
-#pragma unroll
-                for (int o = 0; o < OT; ++o)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[t][o][r] *= alpha;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[t][r] = __builtin_amdgcn_exp2f(sacc[t][r]);
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) { l0[t] += sacc[t][r]; l1[t] += sacc[t][r + 1]; }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pf[t][s2][e] = (half_t)sacc[t][8 * s2 + e];
-        }
-    };
-
-    // phase bookkeeping (p = global phase index).  V phases carry ONE LDS-DMA piece of the tile three tiles ahead
-    // (an LDS-DMA piece costs the issuing wave 60-180 cycles, and the V segment is the shorter one).
-    auto dma_piece = [&](int p) {
-        const int kt = (p + 9) >> 2, piece = (((p + 9) & 3) >> 1) * 8 + wave;
-        if (kt >= 3 && kt < ntiles && piece < NPIECE) stage_piece(kt, piece);
-    };
-    auto phase_end = [&](int p) {
-        if ((p & 3) == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        pp_barrier();
-    };
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    read_k(0);
-    if (grp == 1) pp_barrier();     // group 1 runs one phase behind group 0
-
-    // unit 0: scores only, and the max is taken unconditionally
-    read_v(0);
-    seg_s(1);
-    phase_end(grp);
-    dma_piece(1 + grp);
-    seg_v(0, std::false_type{}, std::true_type{});
-    phase_end(1 + grp);
-    const int jm = partial ? units - 2 : units;                // units >= jm read keys >= n: masked variant
-    for (int j = 1; j < jm; ++j) {
-        const int p = 2 * j + grp;
-        seg_pv();
-        __builtin_amdgcn_sched_barrier(0);
-        read_v(j);
-        __builtin_amdgcn_sched_barrier(0);
-        seg_s(j + 1 < units ? j + 1 : j);
-        phase_end(p);
-        dma_piece(p + 1);
-        seg_v(j, std::false_type{}, std::false_type{});
-        phase_end(p + 1);
-    }
-    for (int j = jm > 1 ? jm : 1; j < units; ++j) {
-        const int p = 2 * j + grp;
-        seg_pv();
-        __builtin_amdgcn_sched_barrier(0);
-        read_v(j);
-        __builtin_amdgcn_sched_barrier(0);
-        seg_s(j + 1 < units ? j + 1 : j);
-        phase_end(p);
-        dma_piece(p + 1);
-        seg_v(j, std::true_type{}, std::false_type{});
-        phase_end(p + 1);
-    }
-    seg_pv();
-    if (grp == 0) pp_barrier();     // same barrier count in both groups
-
-#pragma unroll
-    for (int t = 0; t < QT; ++t) {
-        const int qi = q0 + t * 32 + qr;
-        const float l_half = l0[t] + l1[t];
-        const float l_tot = l_half + __shfl_xor(l_half, 32);
-        if (qi < n) {
-            const float inv = 1.f / l_tot;
-            half_t* orow = out + (row_base + qi) * c + head * D;
-#pragma unroll
-            for (int o = 0; o < OT; ++o)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int dd = o * 32 + 8 * g + 4 * hh;
-                    half4 ov;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) ov[e] = to_half_sat(oacc[t][o][4 * g + e] * inv);
-                    *(half4*)(orow + dd) = ov;
-                }
-        }
-    }
-}
-
-#endif  // ATT_PINGPONG
 
 }  // namespace pcd
 
@@ -622,15 +338,6 @@ extern "C" int pcd_set_attention_f16(const void* qkv, int batch, int n_points, i
     // 32*QT queries per wave.  QT = 1 measured fastest (836 vs 764 TFLOP/s at d = 64): at QT = 2 the kernel
     // sits at 256 VGPRs (2 waves/SIMD) and the shared K/V fragments do not pay for the lost occupancy.
     constexpr int QT = 1;
-#ifdef ATT_PINGPONG
-    if (d == 64 && n_points >= 512) {   // experimental ping-pong variant: 512 queries per workgroup
-        dim3 pgrid((unsigned)ceil_div(n_points, 512), (unsigned)(batch * heads));
-        hipLaunchKernelGGL((set_attention_pp_kernel<64, 2>), pgrid, dim3(512), 0, s, (const half_t*)qkv, n_points, c,
-                           heads, scale_log2e, (half_t*)out);
-        PCD_CHECK_LAUNCH();
-        return PCD_OK;
-    }
-#endif
     dim3 grid((unsigned)ceil_div(n_points, 128 * QT), (unsigned)(batch * heads));
     if (d == 16)
         hipLaunchKernelGGL((set_attention_kernel<16, QT>), grid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads,

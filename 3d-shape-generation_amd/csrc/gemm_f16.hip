@@ -26,7 +26,6 @@ struct GemmParams {
     const half_t* resid; int64_t ldr;
     float* colmax; int cm_rps;
     int tiles_m; int tiles_n;
-    int stagger;   // debug probe only (PCD_EPI_PROBE)
     int patch_pn, patch_xn;   // XCD patch mapping (0 = linear tile order)
     // split-K (EPI_F32 only): `splits` independent products over consecutive k1-deep slices of the reduction;
     // slice s reads A and W at column offset s*k1 and writes the fp32 slab out32 + s*split_out
@@ -291,9 +290,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
                         for (int e = 0; e < 8; ++e) ov[e] = to_half_sat((float)ov[e] + (float)rs[e]);
                         o = __builtin_bit_cast(u32x4, ov);
                     }
-#ifdef PCD_EPI_PROBE
-                    if (p.stagger == 777) { asm volatile("" ::"v"(o)); continue; }
-#endif
                     *(u32x4*)(orow + col) = o;
                 }
             }
@@ -408,7 +404,6 @@ static int launch(const GemmParams& p0, hipStream_t s, int blocks_per_cu) {
 }
 
 static int g_force_cfg = -1;   // tuning hook (pcd_gemm_set_config): -1 = heuristic
-static int g_stagger = 0;
 
 template <int EPI>
 static int dispatch(const GemmParams& p, hipStream_t s) {
@@ -423,7 +418,6 @@ static int dispatch(const GemmParams& p, hipStream_t s) {
         else cfg = 1;
     }
     GemmParams q = p;
-    q.stagger = g_stagger;
     switch (cfg) {
         case 0: return launch<128, 64, 2, 2, 2, EPI>(q, s, 3);      // 48 KB LDS
         case 1: return launch<128, 128, 2, 2, 2, EPI>(q, s, 2);     // 64 KB LDS
@@ -535,7 +529,6 @@ extern "C" int pcd_gemm_f16_colmax(const pcd_gemm_desc_t* d, float* colmax, int 
 }
 
 extern "C" int pcd_gemm_set_config(int cfg) {
-    if (cfg >= 1000) { g_stagger = cfg - 1000; return PCD_OK; }   // 1000 + n: stagger the first n blocks
     PCD_CHECK_ARG(cfg >= -1 && cfg <= 4);
     g_force_cfg = cfg;
     return PCD_OK;

@@ -4,7 +4,8 @@
 Host code only sequences the loop: the per-step constants (continuous-time t sequence,
 noise/signal rates) are computed on the host CPU with the reference's exact torch ops so
 that step indexing is bit-exact, uploaded once per call, and every
-per-timestep computation runs in HIP kernels (`_lib`).  Training hooks are out of scope.
+per-timestep computation runs in HIP kernels (`_lib`).  The training surface (`training_step`,
+`diffusion_loss`, `configure_optimizers`) forwards to the HIP trainers in `training.py`.
 """
 from __future__ import annotations
 
@@ -95,12 +96,27 @@ class _DiffusionBase(nn.Module):
             raise ValueError(f"rates have {v.numel()} entries for a batch of {batch}")
         return v, 1
 
+    # Philox stream layout.  One draw of a (batch, ...) tensor consumes `span` counters (4 normals each); a process
+    # that holds samples [lo, lo + b) of a global batch of `total` (set by dist.shard_context) reads the
+    # sub-block that starts `lo * per-sample counters` into the draw and advances by the GLOBAL span, so ranks
+    # never share counters and (per-sample size divisible by 4) sample i gets the same numbers whatever the
+    # number of ranks.
+    _shard = None
+
+    def _philox_span(self, numel: int, batch: int) -> Tuple[int, int]:
+        per4 = (numel // max(batch, 1) + 3) // 4
+        lo, total = self._shard if self._shard is not None else (0, batch)
+        return lo * per4, max(total, batch) * per4
+
     def _randn_like(self, x: torch.Tensor) -> torch.Tensor:
         out = torch.empty_like(x, dtype=torch.float32)
         seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
         self._philox_offset = getattr(self, "_philox_offset", 0)
-        _lib.check(_lib.load().pcd_randn(out.data_ptr(), out.numel(), seed, self._philox_offset, _lib.stream_ptr()), "randn")
-        self._philox_offset += (out.numel() + 3) // 4
+        batch = x.shape[0] if x.dim() > self._sample_dims else 1
+        shard_off, span = self._philox_span(out.numel(), batch)
+        _lib.check(_lib.load().pcd_randn(out.data_ptr(), out.numel(), seed, self._philox_offset + shard_off,
+                                         _lib.stream_ptr()), "randn")
+        self._philox_offset += span
         return out
 
     def add_noise(self, x_0: torch.Tensor, t: torch.Tensor, noise: Optional[torch.Tensor] = None):
@@ -248,7 +264,7 @@ class _DiffusionBase(nn.Module):
         if k < T:
             stp.step(k, False)
         if kind == "ddpm":
-            self._philox_offset = stp.philox_base + stp.philox_stride * T
+            self._philox_offset = stp.philox_start + stp.philox_stride * T
         return stp.x0
 
 
@@ -274,8 +290,10 @@ class Stepper:
         self.z = torch.empty_like(x) if kind == "ddpm" else None
         self.per_shape = x.numel() // x.shape[0]
         self.seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
-        self.philox_base = getattr(owner, "_philox_offset", 0)
-        self.philox_stride = (x.numel() + 3) // 4
+        shard_off, span = owner._philox_span(x.numel(), x.shape[0])
+        self.philox_start = getattr(owner, "_philox_offset", 0)        # the owner's stream position before this run
+        self.philox_base = self.philox_start + shard_off              # this process's sub-block of every draw
+        self.philox_stride = span                                     # counters one (global) draw consumes
         self.graph = None
 
     def step(self, k: int, update: bool = True):
@@ -436,6 +454,24 @@ class LatentDiffusion(_DiffusionBase):
         self.model = SimpleLatentUNetPointNet(latent_dim, dim, time_dim)
         self.lr = lr
         self._init_schedule(noise_schedule)
+        self.init_weights()
+
+    def init_weights(self):
+        """diffusion.py:392-408, quirk included: the reference's loop skips the child NAMED 'vae' but then
+        walks `self.modules()`, which contains the VAE's modules too, so every nn.Linear of the VAE (`fc_mu`,
+        `fc_logvar`, `decoder_input`, and VAE3D's `encoder.5`) is re-initialised in place with kaiming-normal
+        (fan_out, relu) weights and zero bias when a LatentDiffusion is constructed around it.  Conv3d / BatchNorm3d
+        are not in the reference's isinstance lists and stay.  Load VAE weights AFTER constructing LatentDiffusion
+        (a LatentDiffusion checkpoint carries the `vae.*` keys, so load_from_checkpoint does)."""
+        import math
+        sd = dict(self.vae.named_parameters())
+        with torch.no_grad():
+            for name, w in sd.items():
+                if name.endswith(".weight") and w.dim() == 2 and name[:-6] + "bias" in sd:      # an nn.Linear
+                    w.normal_(0.0, math.sqrt(2.0 / w.shape[0]))
+                    sd[name[:-6] + "bias"].zero_()
+        if hasattr(self.vae, "invalidate"):
+            self.vae.invalidate()
 
     @classmethod
     def load_from_checkpoint(cls, path, vae=None, map_location="cpu", **kwargs):

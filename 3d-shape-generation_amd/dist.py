@@ -43,23 +43,33 @@ def shard_range(total: int, rank: int, world_size: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _host_staged() -> bool:
+    """gloo moves host memory: device tensors are staged through the host (CPU-side tests, or the
+    one-GPU rehearsal of the multi-rank path); under nccl (RCCL) device buffers go over xGMI directly."""
+    return dist.get_backend() != "nccl"
+
+
 def all_gather_rows(rows: torch.Tensor, counts: Optional[Sequence[int]] = None) -> torch.Tensor:
     """Concatenate per-rank row blocks (r_i, ...) in rank order.  Uneven blocks are padded to the
     largest block for one `all_gather_into_tensor` and trimmed afterwards."""
     rank, ws = world()
     if ws == 1:
         return rows
+    dev = rows.device
+    staged = _host_staged() and dev.type != "cpu"
     if counts is None:
-        c = torch.tensor([rows.shape[0]], device=rows.device, dtype=torch.int64)
+        c = torch.tensor([rows.shape[0]], device="cpu" if staged else dev, dtype=torch.int64)
         cl = [torch.zeros_like(c) for _ in range(ws)]
         dist.all_gather(cl, c)
         counts = [int(v.item()) for v in cl]
     mx = max(counts)
-    pad = torch.zeros((mx,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
-    pad[:rows.shape[0]] = rows
-    out = torch.empty((ws * mx,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    work = rows.cpu() if staged else rows
+    pad = torch.zeros((mx,) + tuple(work.shape[1:]), dtype=work.dtype, device=work.device)
+    pad[:work.shape[0]] = work
+    out = torch.empty((ws * mx,) + tuple(work.shape[1:]), dtype=work.dtype, device=work.device)
     dist.all_gather_into_tensor(out, pad.contiguous())
-    return torch.cat([out[r * mx:r * mx + counts[r]] for r in range(ws)], dim=0)
+    out = torch.cat([out[r * mx:r * mx + counts[r]] for r in range(ws)], dim=0)
+    return out.to(dev) if staged else out
 
 
 def all_gather_clouds(clouds: List[torch.Tensor]) -> List[torch.Tensor]:
@@ -79,6 +89,23 @@ def all_gather_clouds(clouds: List[torch.Tensor]) -> List[torch.Tensor]:
     return [allp[i, :int(all_sizes[i])].clone() for i in range(allp.shape[0])]
 
 
+class shard_context:
+    """While active, `model` draws its on-device noise as samples [lo, lo + n) of a global batch of `total`
+    (diffusion._philox_span): ranks get disjoint Philox counter blocks instead of world copies of one stream."""
+
+    def __init__(self, model, lo: int, total: int):
+        self.model, self.shard = model, (lo, total)
+
+    def __enter__(self):
+        self.prev = getattr(self.model, "_shard", None)
+        self.model._shard = self.shard
+        return self.model
+
+    def __exit__(self, *exc):
+        self.model._shard = self.prev
+        return False
+
+
 def sample_sharded(model, global_batch: int, num_points: int, num_steps: int, x_T_global: Optional[torch.Tensor] = None,
                    sampler: str = "sample", gather: bool = True) -> torch.Tensor:
     """Each rank denoises its shard of the global batch (zero per-step traffic); the clouds are
@@ -87,18 +114,23 @@ def sample_sharded(model, global_batch: int, num_points: int, num_steps: int, x_
     rank, ws = world()
     lo, hi = shard_range(global_batch, rank, ws)
     xs = None if x_T_global is None else x_T_global[lo:hi].to(model.device)
-    out = getattr(model, sampler)(hi - lo, num_points, num_steps=num_steps, x_T=xs)
+    with shard_context(model, lo, global_batch):
+        out = getattr(model, sampler)(hi - lo, num_points, num_steps=num_steps, x_T=xs)
     return all_gather_rows(out.contiguous()) if gather else out
 
 
-def evaluate_sharded(original: torch.Tensor, reconstructed: torch.Tensor, use_approximate_gpu_emd: bool = False):
+def evaluate_sharded(original, reconstructed, use_approximate_gpu_emd: bool = False):
     """Per-sample (CD, EMD, voxel BCE) rows for this rank's samples (test_point_ddpm.py:85-92),
-    all-gathered; returns (rows (B_global, 3), their mean)."""
+    all-gathered; returns (rows (B_global, 3), their nan-mean).  `original` / `reconstructed` are (B, N, 3)
+    tensors or python lists of ragged (n_i, 3) clouds (the latent samplers' output); a pair with an empty
+    cloud has no metrics (the reference would raise) and gets a NaN row."""
     from .metrics import compute_metrics
-    rows = []
-    for o, r in zip(original, reconstructed):
+    dev = reconstructed[0].device if len(reconstructed) else torch.device("cpu")
+    rows = torch.full((len(reconstructed), 3), float("nan"), dtype=torch.float32, device=dev)
+    for i, (o, r) in enumerate(zip(original, reconstructed)):
+        if o.shape[0] == 0 or r.shape[0] == 0:
+            continue
         cd, emd, rec = compute_metrics(o, r, use_approximate_gpu_emd)
-        rows.append(torch.stack([torch.as_tensor(v, dtype=torch.float32, device=original.device).reshape(()) for v in (cd, emd, rec)]))
-    rows = torch.stack(rows) if rows else torch.zeros(0, 3, device=original.device)
+        rows[i] = torch.stack([torch.as_tensor(v, dtype=torch.float32, device=dev).reshape(()) for v in (cd, emd, rec)])
     allrows = all_gather_rows(rows)
-    return allrows, allrows.mean(dim=0)
+    return allrows, torch.nanmean(allrows, dim=0)

@@ -63,6 +63,9 @@ class _HipModule(ParamTree):
         super().__init__()
         self._packed = None
         self._ws: Dict[tuple, torch.Tensor] = {}
+        # a parent's load_state_dict recurses through _load_from_state_dict and never calls a child's
+        # load_state_dict override: the post hook fires for every module that received keys
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
 
     def invalidate(self) -> None:
         """Drop the packed device weights (call after mutating parameters in place)."""

@@ -78,6 +78,18 @@ def _allreduce_gradients(G: torch.Tensor) -> int:
     return dist.get_world_size()
 
 
+def _collective_inplace(fn, t: torch.Tensor, *args) -> None:
+    """Run an in-place collective (`dist.broadcast`, `dist.all_reduce`) on a device tensor: directly under `nccl` (RCCL),
+    staged through the host under `gloo`."""
+    import torch.distributed as dist
+    if dist.get_backend() == "nccl" or t.device.type == "cpu":
+        fn(t, *args)
+    else:
+        h = t.cpu()
+        fn(h, *args)
+        t.copy_(h)
+
+
 class _Conv:
     """One Conv1d(k=1) [+ BatchNorm1d + ReLU]: names of its parameters and its saved tensors."""
 
@@ -699,7 +711,8 @@ def save_checkpoint(model, path: str, epoch: int, extra: Optional[dict] = None) 
     import os
     os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
     payload = {"state_dict": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
-               "hyper_parameters": dict(model.hparams), "epoch": epoch}
+               "hyper_parameters": dict(model.hparams), "epoch": epoch,
+               "pytorch-lightning_version": "2.3.3"}       # the reference's pin; Lightning's loader looks for this key
     payload.update(extra or {})
     torch.save(payload, path)
 
@@ -720,6 +733,11 @@ def fit(model, data_module, max_epochs: int = 500, ckpt_dir: Optional[str] = Non
     data_module.setup()
     import torch.distributed as dist
     rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
+    if world > 1:                              # every rank starts from rank 0's parameters and BatchNorm buffers
+        for t in list(model.parameters()) + list(model.buffers()):
+            _collective_inplace(dist.broadcast, t.data, 0)
+        if hasattr(opt, "refresh_weights"):
+            opt.refresh_weights()
     kept: List[Tuple[float, str]] = []
     steps = 0
     history = []
@@ -728,11 +746,15 @@ def fit(model, data_module, max_epochs: int = 500, ckpt_dir: Optional[str] = Non
             model.current_epoch, model._max_epochs = epoch, max_epochs      # VAE3DLarge.get_kl_weight reads these
         model.train()
         tl = []
+        group = []                             # data parallel: consecutive usable batches are dealt out `world` at a time
         for i, batch in enumerate(data_module.train_dataloader()):
             if batch.dim() == 3 and batch.shape[0] * batch.shape[1] % 64:
                 continue                       # ragged last point-cloud batch: the backward-weight GEMM reduces over B*N in 64s
-            if world > 1 and i % world != rank:
-                continue                       # data parallel: rank r takes batches r, r + world, ... (same loader order on every rank)
+            group.append((i, batch))
+            if len(group) < world:
+                continue                       # an incomplete last group is dropped: every rank takes the same number of
+            i, batch = group[rank]             # steps, so each optimizer all-reduce pairs the same step on all ranks
+            group = []
             loss = model.training_step(batch, i)
             opt.step()
             tl.append(loss)
@@ -743,6 +765,10 @@ def fit(model, data_module, max_epochs: int = 500, ckpt_dir: Optional[str] = Non
         vl = [model.validation_step(b, i) for i, b in enumerate(data_module.val_dataloader())]
         train_loss = float(torch.stack(tl).mean()) if tl else float("nan")
         val_loss = float(torch.stack(vl).mean()) if vl else train_loss
+        if world > 1:                          # one val_loss for the scheduler and the top-k logic on every rank
+            v = torch.tensor([val_loss], dtype=torch.float64, device=model.device)
+            _collective_inplace(dist.all_reduce, v)
+            val_loss = float(v.item()) / world
         sched.step(val_loss)
         history.append((epoch, train_loss, val_loss, opt.lr))
         log(f"epoch {epoch}: train_loss {train_loss:.4f} val_loss {val_loss:.4f} lr {opt.lr:.2e}")

@@ -3,7 +3,7 @@ encode / reparameterize / decode / forward / sample API on HIP implicit-GEMM con
 
 Activations are NDHWC fp16 on the device; eval-mode BatchNorm3d is folded into the conv
 weights at pack time; ConvTranspose3d(k4,s2,p1) runs as 8 output-parity classes of 2x2x2 taps.
-Training (loss, KL annealing, optimizers) is out of scope.
+The training surface (`calculate_loss`, `training_step`, `configure_optimizers`) forwards to `training_vae.VAETrainer`.
 """
 from __future__ import annotations
 
@@ -60,6 +60,15 @@ def _pack_convT_class(w: np.ndarray, pz: int, py: int, px: int):
                 cols.append(w[:, :, kz, ky, kx].T)          # [cout][cin]
                 taps.append((dz & 0xff) | ((dy & 0xff) << 8) | ((dx & 0xff) << 16))
     return np.ascontiguousarray(np.concatenate(cols, axis=1)), np.asarray(taps, np.int32)
+
+
+def _shard_span(module, draw: torch.Tensor) -> Tuple[int, int]:
+    """(offset of this process's rows inside one global draw, Philox counters the global draw consumes): the
+    same layout as diffusion._philox_span; `module._shard = (lo, total)` is set by dist.shard_context."""
+    b = max(draw.shape[0], 1)
+    per4 = (draw.numel() // b + 3) // 4
+    lo, total = getattr(module, "_shard", None) or (0, b)
+    return lo * per4, max(total, b) * per4
 
 
 class VAE3DLarge(_HipModule):
@@ -284,9 +293,10 @@ class VAE3DLarge(_HipModule):
         if eps is None:
             eps = torch.empty_like(mu)
             self._philox = getattr(self, "_philox", 0)
+            off, span = _shard_span(self, eps)
             _lib.check(lib.pcd_randn(eps.data_ptr(), eps.numel(), int(torch.initial_seed()) & (2 ** 64 - 1),
-                                     (1 << 40) + self._philox, _lib.stream_ptr()), "randn")
-            self._philox += (eps.numel() + 3) // 4
+                                     (1 << 40) + self._philox + off, _lib.stream_ptr()), "randn")
+            self._philox += span
         eps = eps.to(mu.device, torch.float32).contiguous()
         z = torch.empty_like(mu)
         _lib.check(lib.pcd_reparameterize(mu.data_ptr(), logvar.data_ptr(), eps.data_ptr(), z.data_ptr(), z.numel(),
@@ -326,8 +336,11 @@ class VAE3DLarge(_HipModule):
         self.eval()
         if z is None:
             z = torch.empty(num_samples, self.latent_dim, device=self.device)
+            self._philox_sample = getattr(self, "_philox_sample", 0)      # advances like torch.randn's generator does
+            off, span = _shard_span(self, z)
             _lib.check(_lib.load().pcd_randn(z.data_ptr(), z.numel(), int(torch.initial_seed()) & (2 ** 64 - 1),
-                                             1 << 41, _lib.stream_ptr()), "randn")
+                                             (1 << 41) + self._philox_sample + off, _lib.stream_ptr()), "randn")
+            self._philox_sample += span
         return voxel_tensor_to_point_clouds(self.decode(z), threshold)
 
 

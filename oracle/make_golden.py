@@ -12,7 +12,8 @@ never depend on a torch RNG stream.
 Fixture map: G1 schedule.npz, G2-G4 point_unet.npz,
 G5-G7 point_samplers.npz, G8 latent.npz, G9 metrics.npz, G10 attention.npz; beyond the survey's list:
 G11 vae3d_small.npz (`make_golden.py vae3d`), G12 data.npz (`make_golden.py data`), G13 train.npz
-(`make_golden.py train`), G14 train_latent.npz (`make_golden.py train_latent`), G15 train_vae.npz (`make_golden.py train_vae`).
+(`make_golden.py train`), G14 train_latent.npz (`make_golden.py train_latent`), G15 train_vae.npz (`make_golden.py train_vae`),
+G16 linear.npz (`make_golden.py linear`: the linear schedule's per-shape rate tables and sampler outputs).
 """
 from __future__ import annotations
 
@@ -67,6 +68,57 @@ def synth_voxels(b, seed):
             m = ((zz - c[0]) / r[0]) ** 2 + ((yy - c[1]) / r[1]) ** 2 + ((xx - c[2]) / r[2]) ** 2 <= 1
             v[i, 0][m] = 1
     return v
+
+
+def capture_linear_schedule(rd):
+    """G16: the non-default `noise_schedule='linear'` through the reference's three samplers (diffusion.py:189-205:
+    `cumprod` runs over the BATCH axis, so shape b of a batch gets prod_{j<=b}(1-beta_j): per-shape rates) ->
+    tests/golden/linear.npz.  Per-step rate tables for a batch of 4 and the samplers' outputs at (4, 128, 3), T = 8,
+    with every normal draw replayed from its seed."""
+    B, N, Tn = 4, 128, 8
+    pspec = specs.unet_pointnet_large_spec(prefix="model.")
+    pcd = rd.PointCloudDiffusion(num_points=N, noise_schedule="linear").eval()
+    pcd.load_state_dict(T(specs.synth_state_dict(pspec, seed=0, gain=POINT_GAIN)), strict=True)
+    g = {}
+    # rate tables exactly as the loops form them (diffusion.py:277-286, 241-255, 323-335)
+    rows = []
+    for step in range(Tn):
+        t = torch.ones(B) - step * (1.0 / Tn)
+        n, s = pcd.diffusion_schedule(t)
+        nn_, sn = pcd.diffusion_schedule(t - 1.0 / Tn)
+        rows.append(torch.stack([n, s, nn_, sn]).numpy())
+    g["sample_rates"] = np.asarray(rows, np.float32)                 # (T, 4, B)
+    rows = []
+    for i in reversed(range(Tn)):
+        t = torch.ones(B) * i / Tn
+        n, s = pcd.diffusion_schedule(t)
+        if i > 0:
+            npv, sp = pcd.diffusion_schedule(torch.ones(B) * (i - 1) / Tn)
+            rows.append(torch.stack([n, s, torch.sqrt(npv / n), sp]).numpy())
+        else:
+            rows.append(torch.stack([n, s, torch.zeros(B), torch.zeros(B)]).numpy())
+    g["sample2_rates"] = np.asarray(rows, np.float32)
+    steps = torch.linspace(torch.tensor(0.3), torch.zeros(1)[0], Tn)
+    g["sample3_rates"] = np.asarray([[v.item() for v in pcd.diffusion_schedule(steps[i])] for i in range(Tn)], np.float32)  # (T, 2): 0-d t
+    torch.manual_seed(24)
+    out = pcd.sample(B, N, num_steps=Tn)
+    torch.manual_seed(24)
+    g["sample_xT"], g["sample_out"] = torch.randn(B, N, 3).numpy(), out.numpy()
+    torch.manual_seed(11)
+    out2 = pcd.sample2(B, N, num_steps=Tn)
+    torch.manual_seed(11)
+    g["s2_xT"] = torch.randn(B, N, 3).numpy()
+    g["s2_z"] = torch.stack([torch.randn(B, N, 3) for _ in range(Tn - 1)]).numpy()
+    g["s2_out"] = out2.numpy()
+    x0c = torch.from_numpy(synth_cloud(B, N, 9))
+    torch.manual_seed(5)
+    tt = torch.ones(B) * 0.3
+    noisy, noise, nr, sr = pcd.add_noise(x0c, tt)
+    g["s3_x0"], g["s3_noise"], g["s3_noisy"] = x0c.numpy(), noise.numpy(), noisy.numpy()
+    g["s3_add_rates"] = torch.stack([nr, sr]).numpy()
+    g["s3_out"] = pcd.sample3(B, N, x=noisy, start_t=tt, num_steps=Tn).numpy()
+    np.savez_compressed(os.path.join(OUT, "linear.npz"), **g)
+    print("linear done: |sample| max", float(out.abs().max()), "|sample2| max", float(out2.abs().max()))
 
 
 def capture_vae3d_small(rn):
@@ -297,6 +349,9 @@ def main():
     t_start = time.time()
     if "vae3d" in sys.argv[1:]:
         capture_vae3d_small(rn)
+        return
+    if "linear" in sys.argv[1:]:
+        capture_linear_schedule(rd)
         return
 
     # ------------------------------------------------------------------ point model

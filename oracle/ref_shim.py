@@ -2,8 +2,7 @@
 
 TEST TOOLING, container-only: the reference never travels to the GPU box, so
 nothing under `tests -m gpu`, `smoke()` or `bench.py` may call this.  It is
-used by `oracle/make_golden.py` (fixture capture) and by the optional
-`tests/test_oracle_vs_reference.py` (skipped when `/root/reference` is absent).
+used by `oracle/make_golden.py` (fixture capture) only.
 
 The reference needs two modules that are not installed and carry no
 arithmetic: `pytorch_lightning` (base class + hparams capture) and `plyfile`

@@ -49,9 +49,7 @@ def synthetic_clouds(batch: int, num_points: int, seed: int = 24) -> torch.Tenso
 def test_ddpm_generation(model, model_name, num_samples=10, num_points=2048, num_steps=1000):
     """reference test_point_ddpm.py:24-56 (DDIM `sample`); returns the generated clouds."""
     with torch.no_grad():
-        lo, hi = D.shard_range(num_samples, *D.world())
-        local = model.sample(num_samples=hi - lo, num_points=num_points, num_steps=num_steps)
-        generated = D.all_gather_rows(local.contiguous())
+        generated = D.sample_sharded(model, num_samples, num_points, num_steps)   # rank-disjoint start noise
     logging.getLogger(LOG).info(f"Generated {generated.shape[0]} samples for {model_name}.")
     return generated
 
@@ -63,7 +61,8 @@ def test_ddpm_reconstruction(model, model_name, original_samples, initial_t=0.01
     orig = original_samples[lo:hi].to(model.device)
     with torch.no_grad():
         t = torch.ones(orig.shape[0], device=model.device) * initial_t
-        noisy, _, _, _ = model.add_noise(orig, t)
+        with D.shard_context(model, lo, original_samples.shape[0]):
+            noisy, _, _, _ = model.add_noise(orig, t)
         recon = model.sample3(num_samples=orig.shape[0], num_points=orig.shape[1], x=noisy, start_t=t, num_steps=num_steps)
         rows, mean = D.evaluate_sharded(orig, recon)
     log = logging.getLogger(LOG)

@@ -45,7 +45,8 @@ def test_vae_generation(model, model_name, num_samples=10, threshold=0.5):
     """reference test_point_ldm.py:23-56: decode prior samples -> list of (n_i, 3) clouds."""
     with torch.no_grad():
         lo, hi = D.shard_range(num_samples, *D.world())
-        generated = D.all_gather_clouds(model.sample(num_samples=hi - lo, threshold=threshold))
+        with D.shard_context(model, lo, num_samples):                # rank-disjoint prior draws
+            generated = D.all_gather_clouds(model.sample(num_samples=hi - lo, threshold=threshold))
     logging.getLogger(LOG).info(f"Generated and saved {len(generated)} samples.")
     return generated
 
@@ -57,17 +58,11 @@ def test_vae_reconstruction(model, model_name, original_samples, num_samples=10,
     lo, hi = D.shard_range(original_samples.shape[0], rank, world)
     with torch.no_grad():
         vox = original_samples[lo:hi].to(model.device)
-        recon_vox, _, _ = model(vox)
+        with D.shard_context(model, lo, original_samples.shape[0]):  # rank-disjoint reparameterisation draws
+            recon_vox, _, _ = model(vox)
         orig = voxel_tensor_to_point_clouds(vox, threshold)
         recon = voxel_tensor_to_point_clouds(recon_vox, threshold)
-        rows = torch.zeros(len(orig), 3, device=model.device)
-        for i, (o, r) in enumerate(zip(orig, recon)):
-            if len(o) and len(r):                                    # an empty cloud has no metrics (reference would raise)
-                rows[i] = torch.stack([torch.as_tensor(v, dtype=torch.float32, device=model.device)
-                                       for v in compute_metrics(o, r)])
-            else:
-                rows[i] = float("nan")
-        rows = D.all_gather_rows(rows)
+        rows, _ = D.evaluate_sharded(orig, recon)                    # an empty cloud has no metrics: NaN row
     log = logging.getLogger(LOG)
     mean = torch.nanmean(rows, dim=0)
     log.info(f"Average Chamfer Distance: {float(mean[0]):.3f}")

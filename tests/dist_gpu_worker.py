@@ -1,0 +1,68 @@
+"""Worker for tests/test_gpu_dist.py: two ranks (both on cuda:0, gloo rendezvous on 127.0.0.1, collectives staged
+through the host) run the batch-sharded sampler and the sharded evaluation; rank 0 compares the gathered results with
+the single-process run of the same global batch."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import shapegen_amd  # noqa: E402,F401
+from helpers import point_sd  # noqa: E402
+from shapegen_amd import dist as D  # noqa: E402
+from shapegen_amd.diffusion import PointCloudDiffusion  # noqa: E402
+
+
+def main():
+    torch.set_grad_enabled(False)
+    rank, world, _ = D.init_from_env("gloo")
+    torch.cuda.set_device(0)
+    model = PointCloudDiffusion(num_points=128)
+    model.load_state_dict(point_sd(), strict=True)
+    model = model.to("cuda").eval()
+    B, N, T = 6, 128, 12
+    g = torch.Generator().manual_seed(24)
+    x_T = torch.randn(B, N, 3, generator=g)
+    res = {}
+    # (1) injected start noise: rank-order concat of the shards == the single-process result, bit for bit
+    sharded = D.sample_sharded(model, B, N, T, x_T_global=x_T)
+    # (2) on-device start noise: ranks draw disjoint Philox blocks, and sample i gets the same numbers as in one process
+    torch.manual_seed(7)
+    model._philox_offset = 0
+    drawn = D.sample_sharded(model, B, N, T)
+    # (3) DDPM per-step noise under sharding
+    torch.manual_seed(7)
+    model._philox_offset = 0
+    drawn2 = D.sample_sharded(model, B, N, T, sampler="sample2")
+    # (4) sharded evaluation rows (Chamfer, Sinkhorn EMD, voxel BCE per sample), all-gathered
+    lo, hi = D.shard_range(B, rank, world)
+    clouds = torch.tanh(x_T).cuda()
+    rows, mean = D.evaluate_sharded(clouds[lo:hi], sharded[lo:hi].cuda().contiguous(), use_approximate_gpu_emd=True)
+    if rank == 0:
+        import torch.distributed as dist
+        single = model.sample(B, N, num_steps=T, x_T=x_T.cuda())
+        torch.manual_seed(7)
+        model._philox_offset = 0
+        single_drawn = model.sample(B, N, num_steps=T)
+        torch.manual_seed(7)
+        model._philox_offset = 0
+        single_drawn2 = model.sample2(B, N, num_steps=T)
+        from shapegen_amd.metrics import compute_metrics
+        want_rows = torch.stack([torch.stack([torch.as_tensor(v, dtype=torch.float32).reshape(()).cpu() for v in
+                                              compute_metrics(clouds[i], single[i], True)]) for i in range(B)])
+        np.savez(os.environ["DIST_OUT"],
+                 sharded_equal=torch.equal(sharded.cpu(), single.cpu()),
+                 drawn_equal=torch.equal(drawn.cpu(), single_drawn.cpu()),
+                 drawn2_equal=torch.equal(drawn2.cpu(), single_drawn2.cpu()),
+                 halves_differ=not torch.equal(drawn[:B // 2].cpu(), drawn[B // 2:].cpu()),
+                 rows=rows.cpu().numpy(), want_rows=want_rows.numpy(), mean=mean.cpu().numpy(), world=world)
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -71,3 +71,41 @@ def test_latent_checkpoint_needs_vae(tmp_path):
     got = m.state_dict()
     assert set(got.keys()) == set(sd.keys()) and all(torch.equal(got[k], sd[k]) for k in sd)
     assert not any(p.requires_grad for p in m.vae.parameters())  # frozen VAE, diffusion.py:377-378
+
+
+def test_latent_diffusion_construction_reinitialises_vae_linear_heads():
+    """SURVEY a16 / reference diffusion.py:392-408: `init_weights` skips the child named 'vae' but walks
+    `self.modules()`, so constructing a LatentDiffusion re-initialises every nn.Linear of the VAE in place
+    (kaiming-normal fan_out weights, zero bias) and leaves Conv3d / BatchNorm3d alone.  Restated bug for bug."""
+    import numpy as np
+    from shapegen_amd import specs
+    from shapegen_amd.diffusion import LatentDiffusion
+    from shapegen_amd.vae import VAE3D, VAE3DLarge
+    for cls, spec, heads in ((VAE3DLarge, specs.vae3d_large_spec(), ("fc_mu", "fc_logvar", "decoder_input")),
+                             (VAE3D, specs.vae3d_small_spec(), ("encoder.5", "fc_mu", "fc_logvar", "decoder_input"))):
+        vae = cls()
+        sd = {k: torch.from_numpy(np.asarray(v)) for k, v in specs.synth_state_dict(spec, seed=3, gain=1.3).items()}
+        vae.load_state_dict(sd, strict=True)
+        torch.manual_seed(5)
+        LatentDiffusion(vae)
+        got = vae.state_dict()
+        for k, v in sd.items():
+            head = any(k.startswith(h + ".") for h in heads)
+            if not head:
+                assert torch.equal(got[k], v), k                       # convs, norms, running statistics untouched
+            elif k.endswith(".bias"):
+                assert torch.count_nonzero(got[k]) == 0, k
+            else:
+                assert not torch.equal(got[k], v), k
+                std = float(got[k].std())
+                assert abs(std / (2.0 / v.shape[0]) ** 0.5 - 1) < 0.05, (k, std)   # kaiming fan_out: std = sqrt(2 / out_features)
+        assert not any(p.requires_grad for p in vae.parameters())
+
+
+def test_parent_load_state_dict_invalidates_child_packed_weights():
+    """A parent's load_state_dict never calls a child's override; the post hook must drop the packed device weights."""
+    from shapegen_amd.diffusion import PointCloudDiffusion
+    m = PointCloudDiffusion(num_points=64)
+    m.model._packed = {"stale": True}
+    m.load_state_dict(m.state_dict(), strict=True)
+    assert m.model._packed is None

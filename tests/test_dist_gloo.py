@@ -65,3 +65,64 @@ def test_single_process_passthrough():
     t = torch.arange(6.).reshape(2, 3)
     assert D.all_gather_rows(t) is t
     assert D.shard_range(5, 0, 1) == (0, 5)
+
+
+def _eval_worker(rank, world, port, tmp):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import shapegen_amd  # noqa: F401
+    from shapegen_amd import dist as D
+    from shapegen_amd import metrics as M
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    D.init_from_env("gloo")
+    # the metric kernels need the GPU; the sharding / gathering layer around them is what runs here
+    M.compute_metrics = lambda o, r, approx=False: (o.sum() + r.sum(), o.shape[0] * 1.0, r.shape[0] * (2.0 if approx else 1.0))
+    total = 5
+    lo, hi = D.shard_range(total, rank, world)
+    orig = [torch.full((i + 1, 3), float(i)) for i in range(total)]
+    recon = [torch.full((2, 3), 0.5) if i != 3 else torch.zeros(0, 3) for i in range(total)]       # sample 3: empty cloud
+    rows, mean = D.evaluate_sharded(orig[lo:hi], recon[lo:hi], use_approximate_gpu_emd=True)
+    assert rows.shape == (total, 3)
+    for i in range(total):
+        if i == 3:
+            assert torch.isnan(rows[i]).all()
+        else:
+            assert torch.equal(rows[i], torch.tensor([3.0 * i * (i + 1) + 3.0, i + 1.0, 4.0]))
+    keep = [i for i in range(total) if i != 3]
+    assert torch.allclose(mean, rows[keep].mean(0))
+    # dense (B, N, 3) inputs take the same path
+    a = torch.arange(total * 6, dtype=torch.float32).reshape(total, 2, 3)
+    rows2, _ = D.evaluate_sharded(a[lo:hi], a[lo:hi] * 2)
+    assert torch.equal(rows2[:, 0], (a.sum((1, 2)) * 3))
+    # shard_context: ranks read disjoint sub-blocks of one global Philox draw
+    class _M:
+        _shard = None
+    from shapegen_amd.diffusion import _DiffusionBase
+    m = _M()
+    with D.shard_context(m, lo, total):
+        off, span = _DiffusionBase._philox_span(m, (hi - lo) * 64 * 3, hi - lo)
+    assert (off, span) == (lo * 48, total * 48) and m._shard is None
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(tmp, f"eval_ok{rank}"), "w").write("ok")
+
+
+def test_two_rank_evaluate_sharded(tmp_path):
+    port = _free_port()
+    mp.spawn(_eval_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "eval_ok0").exists() and (tmp_path / "eval_ok1").exists()
+
+
+def test_bench_parent_stays_gpu_free_and_reports_failed_ranks():
+    """`python bench.py --gpus 2` without WORLD_SIZE: the parent spawns the ranks before importing torch.  Here (no
+    GPU) every rank fails, so the parent must exit non-zero and say which ranks failed."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("the failure path needs a box without a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and "ranks failed" in p.stderr

@@ -257,7 +257,8 @@ def test_latent_sample2_sample3_and_errors(ldm):
     want = O.ddim_from_state(model, zT, torch.ones(3) * 0.3, 12)
     _, z0 = ldm.sample3(3, z=zT.cuda(), start_t=torch.ones(3) * 0.3, num_steps=12, return_latent=True)
     assert rel_l2(z0.cpu(), want) < 5e-3
-    bad = LatentDiffusion(ldm.vae, is_voxel_based=False).to("cuda")
+    from shapegen_amd.vae import VAE3DLarge
+    bad = LatentDiffusion(VAE3DLarge(), is_voxel_based=False).to("cuda")   # a fresh VAE: construction re-initialises its heads (a16)
     with pytest.raises(UnboundLocalError):      # reference diffusion.py:650-653 behaviour
         bad.sample(1, num_steps=1)
 

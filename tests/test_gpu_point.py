@@ -160,3 +160,91 @@ def test_cpu_module_fails_loudly():
         m.sample(1, 16, num_steps=1)
     with pytest.raises(RuntimeError):
         m.model(torch.zeros(1, 16, 3), torch.zeros(1))
+
+
+# ------------------------------------------------------------------ a2: the linear schedule on the GPU
+@pytest.fixture(scope="module")
+def linear_model():
+    from shapegen_amd.diffusion import PointCloudDiffusion
+    m = PointCloudDiffusion(num_points=128, noise_schedule="linear")
+    m.load_state_dict(point_sd(), strict=True)
+    return m.to("cuda").eval()
+
+
+def test_linear_schedule_samplers(linear_model, golden):
+    """`noise_schedule='linear'` (diffusion.py:189-205): the batch-axis cumprod gives every shape its own rates, so
+    the step tables are (T, batch) and the update kernels run with per-shape rate stride 1.  The three samplers at
+    (4, 128), T = 8 against the reference's outputs (G16) and the rate tables bit-exact on the device."""
+    g = golden("linear.npz")
+    m = linear_model
+    tab = m.ddim_table(8, 4)
+    assert tab.width == 4 and tab.stride == 1
+    assert np.array_equal(torch.stack([tab.n, tab.s, tab.a, tab.b], dim=1).cpu().numpy(), g["sample_rates"])
+    tab = m.ddpm_table(8, 4)
+    assert np.array_equal(torch.stack([tab.n, tab.s, tab.a, tab.b], dim=1).cpu().numpy(), g["sample2_rates"])
+    out = m.sample(4, 128, num_steps=8, x_T=torch.from_numpy(g["sample_xT"]).cuda())
+    assert rel_l2(out.cpu(), g["sample_out"]) < 5e-3
+    out = m.sample2(4, 128, num_steps=8, x_T=torch.from_numpy(g["s2_xT"]).cuda(), noises=torch.from_numpy(g["s2_z"]).cuda())
+    assert rel_l2(out.cpu(), g["s2_out"]) < 5e-3
+    x0 = torch.from_numpy(g["s3_x0"]).cuda()
+    t = torch.ones(4, device="cuda") * 0.3
+    noisy, _, nr, sr = m.add_noise(x0, t, noise=torch.from_numpy(g["s3_noise"]).cuda())
+    assert np.array_equal(torch.stack([nr, sr]).cpu().numpy(), g["s3_add_rates"])
+    assert torch.equal(noisy.cpu(), torch.from_numpy(g["s3_noisy"]))                  # per-shape rates, bit exact
+    out = m.sample3(4, 128, x=noisy, start_t=t, num_steps=8)
+    assert rel_l2(out.cpu(), g["s3_out"]) < 5e-3
+
+
+def test_linear_schedule_long_run_uses_graph_replay(linear_model):
+    """T = 20 > GRAPH_MIN_STEPS: the (T, batch) tables go through the device-side step select inside replayed HIP
+    graphs; against the oracle with `sched=linear_schedule`."""
+    from oracle import torch_oracle as O
+    sd = point_sd()
+    g = torch.Generator().manual_seed(8)
+    xT = torch.randn(3, 128, 3, generator=g)
+    want = O.ddim_sample(lambda x, t: O.unet_pointnet_large(sd, "model.", x, t), xT, 20, sched=O.linear_schedule)
+    assert linear_model.use_graphs and 20 - 1 >= linear_model.GRAPH_MIN_STEPS
+    got = linear_model.sample(3, 128, num_steps=20, x_T=xT.cuda())
+    assert rel_l2(got.cpu(), want) < 5e-3
+
+
+def test_philox_stream_positions_across_graph_replays(model):
+    """On-device noise of `sample2`: step k draws the counter block [base + k*stride, base + (k+1)*stride) whether it
+    runs eagerly or inside a replayed graph (the draw reads k from the device-side counter), no block is used twice,
+    and the owner's stream position advances by T*stride.  A zero-eps denoiser makes the final state a known function
+    of every draw, recomputed here from pcd_randn at the expected offsets."""
+    from shapegen_amd import _lib
+    lib = _lib.load()
+    B, N, T = 2, 64, 29                      # 1 eager + 3 graphs of 8 + 3 eager + the final no-update step
+    torch.manual_seed(99)
+    seed = int(torch.initial_seed())
+    model._philox_offset = 1000
+    g = torch.Generator().manual_seed(1)
+    xT = torch.randn(B, N, 3, generator=g).cuda()
+    tab = model.ddpm_table(T, B)
+    zero_eps = lambda x, tb, eps: eps.zero_()
+    assert model.use_graphs and T - 2 >= model.GRAPH_MIN_STEPS
+    out = model._run(xT.clone(), tab, torch.zeros(T, 64, device="cuda"), zero_eps, "ddpm")
+    stride = B * N * 3 // 4
+    assert model._philox_offset == 1000 + stride * T
+    x = xT.clone()
+    draws = []
+    for k in range(T):
+        n, s, a, b = (float(v[k, 0]) for v in (tab.n, tab.s, tab.a, tab.b))
+        x0 = x / torch.tensor(s)                                # remove_noise with eps = 0
+        if k < T - 1:
+            z = torch.empty_like(x)
+            _lib.check(lib.pcd_randn(z.data_ptr(), z.numel(), seed, 1000 + k * stride, _lib.stream_ptr()))
+            draws.append(z.clone())
+            x = b * x0 + (a * n) * z
+    assert rel_l2(out.cpu(), x0.cpu()) < 1e-5
+    flat = torch.stack(draws).reshape(len(draws), -1)
+    assert len({tuple(r[:8].tolist()) for r in flat.cpu()}) == len(draws)      # no counter block drawn twice
+    # a sharded run reads the sub-block of its samples out of the same global draw (dist.shard_context)
+    model._philox_offset = 1000
+    from shapegen_amd import dist as D
+    with D.shard_context(model, 1, B):
+        part = model._randn_like(torch.empty(1, N, 3, device="cuda"))
+    model._philox_offset = 1000
+    whole = model._randn_like(torch.empty(B, N, 3, device="cuda"))
+    assert torch.equal(part[0], whole[1])

@@ -178,3 +178,44 @@ def test_vae3d_small(golden):
     mu, logvar = O.vae3d_small_encode(sd, "", vox)
     assert rel_l2(mu, g["mu"]) < 1e-5 and rel_l2(logvar, g["logvar"]) < 1e-5
     assert rel_l2(O.vae3d_small_decode(sd, "", torch.from_numpy(g["mu"])), g["dec"]) < 1e-5
+
+
+def test_linear_schedule_samplers_vs_reference(golden):
+    """G16 (a2): the non-default linear schedule, whose batch-axis cumprod (diffusion.py:202) gives every
+    shape of the batch its own rates.  Oracle rate tables bit-exact, sampler outputs <= 1e-5."""
+    g = golden("linear.npz")
+    sd = point_sd()
+    model = lambda x, t: O.unet_pointnet_large(sd, "model.", x, t)
+    B, T = 4, 8
+    for k in range(T):
+        t = torch.ones(B) - k * (1.0 / T)
+        n, s = O.linear_schedule(t)
+        nn_, sn = O.linear_schedule(t - 1.0 / T)
+        assert np.array_equal(torch.stack([n, s, nn_, sn]).numpy(), g["sample_rates"][k])
+    assert len({float(v) for v in g["sample_rates"][3, 0]}) == B          # per-shape rates really differ
+    out = O.ddim_sample(model, torch.from_numpy(g["sample_xT"]), T, sched=O.linear_schedule)
+    assert rel_l2(out, g["sample_out"]) < 1e-5
+    out = O.ddpm_sample(model, torch.from_numpy(g["s2_xT"]), T, list(torch.from_numpy(g["s2_z"])), sched=O.linear_schedule)
+    assert rel_l2(out, g["s2_out"]) < 1e-5
+    noisy, nr, sr = O.add_noise(torch.from_numpy(g["s3_x0"]), torch.ones(B) * 0.3, torch.from_numpy(g["s3_noise"]),
+                                sched=O.linear_schedule)
+    assert np.array_equal(torch.stack([nr, sr]).numpy(), g["s3_add_rates"]) and np.array_equal(noisy.numpy(), g["s3_noisy"])
+    out = O.ddim_from_state(model, noisy, torch.ones(B) * 0.3, T, sched=O.linear_schedule)
+    assert rel_l2(out, g["s3_out"]) < 1e-5
+
+
+def test_linear_schedule_step_tables_bit_exact(golden):
+    """The product's host-side step tables (diffusion.StepTable, R = batch columns for the linear schedule)
+    against the rates the reference's loops form: bit exact."""
+    from shapegen_amd.diffusion import PointCloudDiffusion
+    g = golden("linear.npz")
+    m = PointCloudDiffusion(num_points=128, noise_schedule="linear")
+    tab = m.ddim_table(8, 4)
+    assert tab.width == 4 and tab.stride == 1
+    got = torch.stack([tab.n, tab.s, tab.a, tab.b], dim=1).numpy()               # (T, 4, B)
+    assert np.array_equal(got, g["sample_rates"])
+    tab = m.ddpm_table(8, 4)
+    assert np.array_equal(torch.stack([tab.n, tab.s, tab.a, tab.b], dim=1).numpy(), g["sample2_rates"])
+    tab = m.from_state_table(torch.tensor(0.3), 8)
+    assert tab.width == 1                                                          # 0-d t: shared by the batch
+    assert np.array_equal(torch.stack([tab.n[:, 0], tab.s[:, 0]], dim=1).numpy(), g["sample3_rates"])
