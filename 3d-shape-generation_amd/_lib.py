@@ -117,6 +117,7 @@ _SIGS = {
     "pcd_layernorm_f16": (i32, [vp, i64, i32, vp, vp, vp, vp]),
     "pcd_set_attention_workspace_bytes": (sz, [i32, i32, i32]),
     "pcd_set_attention_f16": (i32, [vp, i32, i32, i32, i32, vp, vp, sz, vp]),
+    "pcd_set_attention_config": (i32, [i32]),
     "pcd_add_shape_bias_f16": (i32, [vp, i64, i32, i32, vp, vp, vp]),
     "pcd_tail3": (i32, [vp, i32, vp, i32, i64, vp, vp, vp, vp, vp, vp]),
     "pcd_normalize_to_cube": (i32, [vp, i32, i32, vp, vp]),

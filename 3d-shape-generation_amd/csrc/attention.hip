@@ -308,6 +308,287 @@ __global__ __launch_bounds__(256) void set_attention_kernel(const half_t* __rest
 }
 
 
+
+// ------------------------------------------------------------ software-pipelined kernel (d = 64, n % 256 == 0)
+// The kernel above keeps one 32-query block per wave and leaves the MFMA / softmax overlap to whichever waves share
+// a SIMD; measured, the two add up (583 cycles per 32 x 32 score tile for 256 cycles of MFMA, 66 VALU instructions per
+// tile).  Here a wave owns TWO 32-query blocks A and B and interleaves them by hand, half a step apart:
+//
+//   phase 1 of key sub-tile i:   MFMA  O_B += V(i-1)^T P_B(i-1),  S_A(i+1) = K(i+1) Q_A^T   |  VALU  P_A(i) = 2^S_A(i)
+//   phase 2 of key sub-tile i:   MFMA  S_B(i+1) = K(i+1) Q_B^T,   O_A += V(i)^T P_A(i)      |  VALU  P_B(i) = 2^S_B(i)
+//
+// so every basic block holds 8 independent MFMAs beside the 16 v_exp_f32 + packing of the other block, written out
+// gap by gap.  The per-score VALU work is exp2, fp16 pack and HALF a packed-fp16 add: the running max is not tracked
+// per tile.  m is set exactly by the first 32 keys (every row then has a P = 1 term, l >= 1); afterwards a tile is
+// exponentiated against the old m optimistically, its lane-partial row sum is formed from the fp16 P (the numbers the
+// PV MFMA really multiplies) by a packed-fp16 tree, and only if some lane's sum reaches 2^13 (a score ~9 or more above
+// the running max; an fp16 overflow shows up as +inf in the sum) the wave takes the rare path: exact row maxima,
+// rescale O / l / the pending S(i+1), redo the tile.  Softmax is invariant to m, so the result is the same function
+// as the reference's; P < 2^13 keeps every product inside fp16 / fp32 range.
+// Registers: single K and V fragment sets (the four MFMAs that read the operand about to be reloaded come first in
+// their phase, the LDS reads that overwrite it are issued behind them) keep the kernel at 256 registers = two waves
+// per SIMD, which hide each other's LDS / branch / dependency stalls.  K/V tiles (64 keys) arrive by LDS-DMA into a
+// 4-slot ring, two tiles ahead; the tile loop is unrolled by the ring so every LDS address is a lane-constant base
+// plus an immediate: no address arithmetic in the loop.
+#define SP_SB() __builtin_amdgcn_sched_barrier(0)
+#define SP_MF(a, b, cacc) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, cacc, 0, 0, 0)
+constexpr unsigned SP_BIG_BITS = 0x70007000u;          // both halves hold the same fp16 sum T: T > 8192 (0x7000), inf, NaN
+
+__device__ __forceinline__ half2_ sp_pk(float a, float b) { half2_ r; r.x = (half_t)a; r.y = (half_t)b; return r; }
+
+__device__ __forceinline__ float sp_rowmax(const f32x16& s) {
+    float mx = max3(s[0], s[1], s[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) mx = max3(mx, s[r], s[r + 1]);
+    return xhalf_max(fmaxf(mx, s[15]));
+}
+
+// lane-partial row sum of the fp16 P of one tile, both halves of the result hold the total
+__device__ __forceinline__ half2_ sp_tile_sum(const half8& p0, const half8& p1) {
+    const half8 a = p0 + p1;
+    const half4 b4 = a.lo + a.hi;
+    const half2_ c2 = b4.lo + b4.hi;
+    return c2 + c2.yx;
+}
+
+// rare path: raise the running max of the rows that need it, rescale everything that was formed against the old one
+// (O, l, the -m accumulator seed, the pending next score tile) and redo this tile's exponentials
+__device__ __forceinline__ half2_ sp_fix(f32x16& s_cur, f32x16& s_nxt, f32x16& negm, f32x16 (&o)[2], float& l,
+                                         half8& p0, half8& p1) {
+    const float delta = fmaxf(sp_rowmax(s_cur), 0.f);
+    const float alpha = __builtin_amdgcn_exp2f(-delta);
+    l *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        negm[r] -= delta; s_cur[r] -= delta; s_nxt[r] -= delta;
+        o[0][r] *= alpha; o[1][r] *= alpha;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        p0[j] = (half_t)__builtin_amdgcn_exp2f(s_cur[j]);
+        p1[j] = (half_t)__builtin_amdgcn_exp2f(s_cur[8 + j]);
+    }
+    return sp_tile_sum(p0, p1);
+}
+
+// One phase, gap by gap (sched_barrier(0) between gaps pins the order): MFMA k of the 8, then the two v_exp_f32 of the
+// pair the sum tree needs next, then the pack / tree adds whose inputs are a gap old.  Per gap: 8 (MFMA issue) + 16
+// (2 exp) + 4..8 (1-2 VALU) cycles against the MFMA's 32.
+//   PV_FIRST: O += V^T P_other (gaps 0-3), mid() reloads V, then sn = K Q^T + negm (gaps 4-7)
+//   else    : sn = K Q^T + negm (gaps 0-3), mid() reloads K, then O += V^T P_other (gaps 4-7)
+// Returns the tile's lane-partial row sum (fp16, in both halves).
+template <bool PV_FIRST, typename Mid>
+__device__ __forceinline__ half2_ sp_phase(const f32x16& s, half8& p0, half8& p1, const half8 (&kf)[4],
+                                           const half8 (&qf)[4], const f32x16& negm, f32x16& sn, f32x16 (&o)[2],
+                                           const half8 (&vf)[2][2], const half8& y0, const half8& y1, Mid&& mid) {
+#define SP_M(k)                                                                                    \
+    do {                                                                                           \
+        constexpr int j = (k) & 3;                                                                 \
+        if (((k) < 4) == PV_FIRST) o[j & 1] = SP_MF(vf[j >> 1][j & 1], (j >> 1) ? y1 : y0, o[j & 1]); \
+        else sn = SP_MF(kf[j], qf[j], j == 0 ? negm : sn);                                         \
+    } while (0)
+    SP_SB();
+    SP_M(0);
+    const float e0 = __builtin_amdgcn_exp2f(s[0]), e1 = __builtin_amdgcn_exp2f(s[1]);
+    SP_SB();
+    SP_M(1);
+    const float e8 = __builtin_amdgcn_exp2f(s[8]), e9 = __builtin_amdgcn_exp2f(s[9]);
+    const half2_ c0 = sp_pk(e0, e1);
+    SP_SB();
+    SP_M(2);
+    const float e2 = __builtin_amdgcn_exp2f(s[2]), e3 = __builtin_amdgcn_exp2f(s[3]);
+    const half2_ c4 = sp_pk(e8, e9);
+    SP_SB();
+    SP_M(3);
+    const float e10 = __builtin_amdgcn_exp2f(s[10]), e11 = __builtin_amdgcn_exp2f(s[11]);
+    const half2_ c1 = sp_pk(e2, e3);
+    const half2_ a0 = c0 + c4;
+    SP_SB();
+    mid();
+    SP_SB();
+    SP_M(4);
+    const float e4 = __builtin_amdgcn_exp2f(s[4]), e5 = __builtin_amdgcn_exp2f(s[5]);
+    const half2_ c5 = sp_pk(e10, e11);
+    SP_SB();
+    SP_M(5);
+    const float e12 = __builtin_amdgcn_exp2f(s[12]), e13 = __builtin_amdgcn_exp2f(s[13]);
+    const half2_ c2 = sp_pk(e4, e5);
+    const half2_ a1 = c1 + c5;
+    SP_SB();
+    SP_M(6);
+    const float e6 = __builtin_amdgcn_exp2f(s[6]), e7 = __builtin_amdgcn_exp2f(s[7]);
+    const half2_ c6 = sp_pk(e12, e13);
+    const half2_ b0 = a0 + a1;
+    SP_SB();
+    SP_M(7);
+    const float e14 = __builtin_amdgcn_exp2f(s[14]), e15 = __builtin_amdgcn_exp2f(s[15]);
+    const half2_ c3 = sp_pk(e6, e7);
+    const half2_ a2 = c2 + c6;
+    const half2_ b1 = b0 + a2;
+    SP_SB();
+#undef SP_M
+    const half2_ c7 = sp_pk(e14, e15);
+    const half2_ t = b1 + (c3 + c7);
+    p0 = __builtin_shufflevector(__builtin_shufflevector(c0, c1, 0, 1, 2, 3), __builtin_shufflevector(c2, c3, 0, 1, 2, 3),
+                                 0, 1, 2, 3, 4, 5, 6, 7);
+    p1 = __builtin_shufflevector(__builtin_shufflevector(c4, c5, 0, 1, 2, 3), __builtin_shufflevector(c6, c7, 0, 1, 2, 3),
+                                 0, 1, 2, 3, 4, 5, 6, 7);
+    return t + t.yx;
+}
+
+__global__ __launch_bounds__(256, 2) void set_attention_sp_kernel(const half_t* __restrict__ qkv, int n, int c, int heads,
+                                                                   float scale_log2e, half_t* __restrict__ out) {
+    constexpr int D = 64, KSTEPS = 4, KRB = 128, NSLOT = 4;
+    constexpr int KBYTES = KT * KRB, STAGE = 2 * KBYTES;
+    constexpr int AHEAD = NSLOT - 2;                          // tiles in flight beyond the one being consumed
+    __shared__ __attribute__((aligned(16))) char smem[NSLOT * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qr = lane & 31, hh = lane >> 5;
+    const int bh = blockIdx.y, b = bh / heads, head = bh - b * heads;
+    const int q0 = blockIdx.x * 256 + wave * 64;
+    const int64_t row_base = (int64_t)b * n;
+    const int ld = 3 * c;
+
+    const half_t* kbase = qkv + row_base * ld + c + head * D;
+    const half_t* vbase = qkv + row_base * ld + 2 * c + head * D;
+    const int ntiles = n / KT;                                // a multiple of NSLOT (n % 256 == 0)
+    auto stage = [&](int kt, int slot) {
+        char* base = smem + slot * STAGE;
+        stage_tile<KT, KRB, false, 4, true>(kbase, ld, kt * KT, n, base, wave, lane);
+        stage_tile<KT, KRB, true, 4, true>(vbase, ld, kt * KT, n, base + KBYTES, wave, lane);
+    };
+    // K/V tiles 0 .. AHEAD go out first (4 LDS-DMA instructions per wave and tile), the Q rows behind them
+#pragma unroll
+    for (int t = 0; t <= AHEAD; ++t) stage(t, t);
+
+    half8 qA[KSTEPS], qB[KSTEPS];
+    {
+        const half_t* qpA = qkv + (row_base + q0 + qr) * ld + head * D;
+        const half_t* qpB = qpA + (int64_t)32 * ld;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            // pre-scaled by log2(e)/sqrt(d) (one fp16 rounding) so the MFMA output is already in the exp2 domain
+            const half8 ra = *(const half8*)(qpA + 16 * s + 8 * hh), rb = *(const half8*)(qpB + 16 * s + 8 * hh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                qA[s][e] = (half_t)((float)ra[e] * scale_log2e);
+                qB[s][e] = (half_t)((float)rb[e] * scale_log2e);
+            }
+        }
+    }
+
+    // lane-constant LDS addresses (slot 0, key sub-tile 0); every read adds a compile-time offset.
+    //   K fragment s: row qr (+32 per sub-tile), 16-byte chunk (2s + hh) ^ swizzle(row): the swizzle only depends
+    //   on qr (row bits 1..3), so sub-tile and slot are pure offsets.
+    //   V^T fragments (ds_read_b64_tr_b16, see the generic kernel): key 4*(tg>>1) + tq (+8, +16 per MFMA k-step,
+    //   +32 per sub-tile), chunk (dd0>>3) + (tp>>1) ^ swizzle(key & 2): one base per 32-row O^T tile.
+    const int tq = (lane >> 2) & 3, tp = lane & 3, tg = lane >> 4;
+    const char* kaddr[KSTEPS];
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) kaddr[s] = smem + qr * KRB + (k_swz<KRB>(qr, 2 * s + hh) << 4);
+    const char* vaddr[2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const int key = 4 * (tg >> 1) + tq;
+        const int ch = ((o * 32 + 16 * (tg & 1)) >> 3) + (tp >> 1);
+        vaddr[o] = smem + KBYTES + key * KRB + (v_swz<KRB>(key, ch) << 4) + (tp & 1) * 8;
+    }
+    auto load_k = [&](int off, half8 (&kf)[KSTEPS]) {         // off = slot * STAGE + sub * 32 * KRB
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) kf[s] = *(const half8*)(kaddr[s] + off);
+    };
+    auto load_v = [&](int off, half8 (&vf)[2][2]) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                const char* a0 = vaddr[o] + off + 16 * s2 * KRB;
+                const fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)a0);
+                const fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(a0 + 8 * KRB));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { vf[s2][o][e] = (half_t)lo[e]; vf[s2][o][4 + e] = (half_t)hi[e]; }
+            }
+    };
+
+    f32x16 oA[2], oB[2], negmA, negmB, sA, sB, sAn, sBn;
+    float lA = 0.f, lB = 0.f;
+    half8 pA0, pA1, pB0, pB1, kf[KSTEPS], vf[2][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oA[0][r] = oA[1][r] = oB[0][r] = oB[1][r] = 0.f; negmA[r] = negmB[r] = 0.f; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {                              // the first phase's O_B += V(-1)^T P_B(-1) adds zero
+        pB0[e] = pB1[e] = (half_t)0.f;
+        vf[0][0][e] = vf[0][1][e] = vf[1][0][e] = vf[1][1][e] = (half_t)0.f;
+    }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // the first 32 keys fix the running max exactly: S(0) - rowmax, seed accumulators = -rowmax
+    load_k(0, kf);
+    sA = SP_MF(kf[0], qA[0], negmA);
+    sB = SP_MF(kf[0], qB[0], negmB);
+#pragma unroll
+    for (int s = 1; s < KSTEPS; ++s) { sA = SP_MF(kf[s], qA[s], sA); sB = SP_MF(kf[s], qB[s], sB); }
+    {
+        const float ma = sp_rowmax(sA), mb = sp_rowmax(sB);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { negmA[r] = -ma; sA[r] -= ma; negmB[r] = -mb; sB[r] -= mb; }
+    }
+    load_k(32 * KRB, kf);                                     // K(1) for the first sub-tile's S(i+1) products
+
+    // one key sub-tile i (32 keys): kf holds K(i+1) and vf V(i-1) on entry; V(i) at voff, K(i+2) at koff
+    auto sub_iter = [&](int voff, int koff) {
+        half2_ t = sp_phase<true>(sA, pA0, pA1, kf, qA, negmA, sAn, oB, vf, pB0, pB1, [&]() { load_v(voff, vf); });
+        if (__builtin_expect(__any(__builtin_bit_cast(unsigned, t) > SP_BIG_BITS), 0)) t = sp_fix(sA, sAn, negmA, oA, lA, pA0, pA1);
+        lA = __builtin_fmaf((float)t.x, 1.f, lA);
+        t = sp_phase<false>(sB, pB0, pB1, kf, qB, negmB, sBn, oA, vf, pA0, pA1, [&]() { load_k(koff, kf); });
+        if (__builtin_expect(__any(__builtin_bit_cast(unsigned, t) > SP_BIG_BITS), 0)) t = sp_fix(sB, sBn, negmB, oB, lB, pB0, pB1);
+        lB = __builtin_fmaf((float)t.x, 1.f, lB);
+        sA = sAn; sB = sBn;
+    };
+
+    for (int t0 = 0; t0 < ntiles; t0 += NSLOT) {
+#pragma unroll
+        for (int u = 0; u < NSLOT; ++u) {                     // tile t0 + u lives in ring slot u
+            const int t = t0 + u;
+            // tile t+1 has landed (all but the youngest stage's 4 LDS-DMA) and every wave is done with tile t-1
+            if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t + AHEAD + 1 < ntiles) stage(t + AHEAD + 1, (u + AHEAD + 1) % NSLOT);    // == slot of tile t-1
+            constexpr int dummy = 0; (void)dummy;
+            const int cur = u * STAGE, nxt = ((u + 1) % NSLOT) * STAGE;   // last tile: nxt holds stale bytes, S(i+1) unused
+            sub_iter(cur, nxt);                               // sub-tile 2t:   V(2t),   K(2t+2) = tile t+1 rows 0..31
+            sub_iter(cur + 32 * KRB, nxt + 32 * KRB);         // sub-tile 2t+1: V(2t+1), K(2t+3) = tile t+1 rows 32..63
+        }
+    }
+#pragma unroll
+    for (int oo = 0; oo < 2; ++oo) {                          // O_B += V(last)^T P_B(last)
+        oB[oo] = SP_MF(vf[0][oo], pB0, oB[oo]);
+        oB[oo] = SP_MF(vf[1][oo], pB1, oB[oo]);
+    }
+
+    // epilogue: lane (query qr, half hh) holds O^T rows dd = oo*32 + (r&3) + 8*(r>>2) + 4*hh
+    auto store = [&](const f32x16 (&o)[2], float l, int qi) {
+        const float l_tot = l + __shfl_xor(l, 32);
+        const float inv = 1.f / l_tot;
+        half_t* orow = out + (row_base + qi) * c + head * D;
+#pragma unroll
+        for (int oo = 0; oo < 2; ++oo)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                half4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = to_half_sat(o[oo][4 * g + e] * inv);
+                *(half4*)(orow + oo * 32 + 8 * g + 4 * hh) = ov;
+            }
+    };
+    store(oA, lA, q0 + qr);
+    store(oB, lB, q0 + 32 + qr);
+}
+
 }  // namespace pcd
 
 using namespace pcd;
@@ -326,6 +607,13 @@ extern "C" size_t pcd_set_attention_workspace_bytes(int batch, int n_points, int
     return 0;   // V is transposed on the fly by ds_read_b64_tr_b16: no workspace needed any more
 }
 
+static int g_attn_force_generic = 0;   // tuning/testing hook: 1 = always the generic kernel
+
+extern "C" int pcd_set_attention_config(int force_generic) {
+    g_attn_force_generic = force_generic;
+    return PCD_OK;
+}
+
 extern "C" int pcd_set_attention_f16(const void* qkv, int batch, int n_points, int c, int heads, void* out,
                                      void* workspace, size_t workspace_bytes, void* stream) {
     (void)workspace; (void)workspace_bytes;
@@ -338,6 +626,13 @@ extern "C" int pcd_set_attention_f16(const void* qkv, int batch, int n_points, i
     // 32*QT queries per wave.  QT = 1 measured fastest (836 vs 764 TFLOP/s at d = 64): at QT = 2 the kernel
     // sits at 256 VGPRs (2 waves/SIMD) and the shared K/V fragments do not pay for the lost occupancy.
     constexpr int QT = 1;
+    if (d == 64 && n_points % 256 == 0 && !g_attn_force_generic) {   // software-pipelined kernel: 64 queries per wave, 256 per workgroup
+        dim3 sgrid((unsigned)(n_points / 256), (unsigned)(batch * heads));
+        hipLaunchKernelGGL(set_attention_sp_kernel, sgrid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads,
+                           scale_log2e, (half_t*)out);
+        PCD_CHECK_LAUNCH();
+        return PCD_OK;
+    }
     dim3 grid((unsigned)ceil_div(n_points, 128 * QT), (unsigned)(batch * heads));
     if (d == 16)
         hipLaunchKernelGGL((set_attention_kernel<16, QT>), grid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads,

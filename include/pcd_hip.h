@@ -291,6 +291,9 @@ int pcd_layernorm_f16(const void* x, int64_t rows, int c, const float* gamma, co
 size_t pcd_set_attention_workspace_bytes(int batch, int n_points, int c);
 int pcd_set_attention_f16(const void* qkv, int batch, int n_points, int c, int heads,
                           void* out, void* workspace, size_t workspace_bytes, void* stream);
+/* testing / tuning hook: force_generic = 1 routes every call through the generic kernel (any N, d = 16/32/64)
+ * instead of the software-pipelined d = 64 kernel that N % 256 == 0 selects; 0 restores the default. */
+int pcd_set_attention_config(int force_generic);
 
 /* x[m][c] + e[m / rows_per_shape][c] -> out (fp16 in/out, e fp32): the additive per-level time
  * embeddings of UNetAttentionPointExperimental (networks.py:669-698). */

@@ -52,6 +52,48 @@ def test_attention_kernel_softmax_rescale_path():
     assert rel_l2(got, want) < 2e-3
 
 
+def _attention_fp64(qkv16, B, N, C, H):
+    q, k, v = qkv16.float().split(C, dim=1)
+    d = C // H
+    qh, kh, vh = (z.reshape(B, N, H, d).permute(0, 2, 1, 3).double() for z in (q, k, v))
+    w = torch.softmax(qh @ kh.transpose(2, 3) / d ** 0.5, dim=-1)
+    return (w @ vh).permute(0, 2, 1, 3).reshape(B * N, C)
+
+
+@pytest.mark.parametrize("pattern", ["plain", "late_spike", "rising", "falling", "huge_first"])
+def test_attention_pipelined_kernel_d64(pattern):
+    """The software-pipelined d = 64 kernel (N % 256 == 0) runs its softmax without tracking the row max per tile:
+    force its rare path (a tile whose scores overflow the optimistic bound) in every position, rows that never
+    take it, score ranges that move up or down along the keys, and compare with fp64 and with the generic kernel."""
+    from shapegen_amd import _lib, ops
+    B, N, C, H = 2, 512, 256, 4
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(B * N, 3 * C, generator=g)
+    k = qkv[:, C:2 * C]
+    if pattern == "late_spike":
+        k[N + 400] *= 14.0                       # shape 1, key 400: far above the running max, in tile 6
+        k[37] *= 9.0                             # shape 0, key 37: second sub-tile
+    elif pattern == "rising":                    # key norms grow along the sequence: the max moves at many tiles
+        k *= torch.linspace(0.2, 6.0, N).repeat(B)[:, None]
+    elif pattern == "falling":                   # the first tile holds the max: later P underflow towards 0
+        k *= torch.linspace(8.0, 0.1, N).repeat(B)[:, None]
+    elif pattern == "huge_first":
+        k[:32] *= 20.0
+    qkv16 = qkv.half()
+    want = _attention_fp64(qkv16, B, N, C, H)
+    got = ops.set_attention_f16(qkv16.cuda(), B, N, C, H).float().cpu()
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, want) < 2e-3, pattern
+    lib = _lib.load()
+    _lib.check(lib.pcd_set_attention_config(1))                  # the generic kernel on the same input
+    try:
+        gen = ops.set_attention_f16(qkv16.cuda(), B, N, C, H).float().cpu()
+    finally:
+        _lib.check(lib.pcd_set_attention_config(0))
+    assert rel_l2(gen, want) < 2e-3
+    assert rel_l2(got, gen) < 2e-3
+
+
 def test_unet_attention_golden(golden):
     from shapegen_amd.networks import UNetAttentionPointExperimental
     g = golden("attention.npz")

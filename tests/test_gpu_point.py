@@ -180,8 +180,19 @@ def test_linear_schedule_samplers(linear_model, golden):
     tab = m.ddim_table(8, 4)
     assert tab.width == 4 and tab.stride == 1
     assert np.array_equal(torch.stack([tab.n, tab.s, tab.a, tab.b], dim=1).cpu().numpy(), g["sample_rates"])
+    # sample2's table has a sqrt and a division: bit-identical to the oracle's reference-order torch ops on THIS host,
+    # and within 1 ulp of the table captured on the build container (same convention as test_step_tables_bit_exact)
+    from oracle import torch_oracle as O
     tab = m.ddpm_table(8, 4)
-    assert np.array_equal(torch.stack([tab.n, tab.s, tab.a, tab.b], dim=1).cpu().numpy(), g["sample2_rates"])
+    got = torch.stack([tab.n, tab.s, tab.a, tab.b], dim=1).cpu().numpy()
+    np.testing.assert_allclose(got, g["sample2_rates"], rtol=2.5e-7, atol=1e-9)
+    for k, i in enumerate(reversed(range(8))):
+        n, s = O.linear_schedule(torch.ones(4) * i / 8)
+        want = [n, s, torch.zeros(4), torch.zeros(4)]
+        if i > 0:
+            npv, sp = O.linear_schedule(torch.ones(4) * (i - 1) / 8)
+            want = [n, s, torch.sqrt(npv / n), sp]
+        assert np.array_equal(got[k], torch.stack(want).numpy()), k
     out = m.sample(4, 128, num_steps=8, x_T=torch.from_numpy(g["sample_xT"]).cuda())
     assert rel_l2(out.cpu(), g["sample_out"]) < 5e-3
     out = m.sample2(4, 128, num_steps=8, x_T=torch.from_numpy(g["s2_xT"]).cuda(), noises=torch.from_numpy(g["s2_z"]).cuda())
