@@ -380,7 +380,8 @@ __device__ __forceinline__ half2_ sp_fix(f32x16& s_cur, f32x16& s_nxt, f32x16& n
 template <bool PV_FIRST, typename Mid>
 __device__ __forceinline__ half2_ sp_phase(const f32x16& s, half8& p0, half8& p1, const half8 (&kf)[4],
                                            const half8 (&qf)[4], const f32x16& negm, f32x16& sn, f32x16 (&o)[2],
-                                           const half8 (&vf)[2][2], const half8& y0, const half8& y1, Mid&& mid) {
+                                           const half8 (&vf)[2][2], const half8& y0, const half8& y1, half2_ t_other,
+                                           float& l_other, Mid&& mid) {
 #define SP_M(k)                                                                                    \
     do {                                                                                           \
         constexpr int j = (k) & 3;                                                                 \
@@ -427,8 +428,13 @@ __device__ __forceinline__ half2_ sp_phase(const f32x16& s, half8& p0, half8& p1
     const half2_ b1 = b0 + a2;
     SP_SB();
 #undef SP_M
+    // tail: the dependent packed adds need a wait state each; the OTHER block's pending row sum (its tile was
+    // checked a phase ago) is folded into its fp32 l in those slots
     const half2_ c7 = sp_pk(e14, e15);
-    const half2_ t = b1 + (c3 + c7);
+    const half2_ a3 = c3 + c7;
+    const float lo = (float)t_other.x;
+    const half2_ t = b1 + a3;
+    l_other += lo;
     p0 = __builtin_shufflevector(__builtin_shufflevector(c0, c1, 0, 1, 2, 3), __builtin_shufflevector(c2, c3, 0, 1, 2, 3),
                                  0, 1, 2, 3, 4, 5, 6, 7);
     p1 = __builtin_shufflevector(__builtin_shufflevector(c4, c5, 0, 1, 2, 3), __builtin_shufflevector(c6, c7, 0, 1, 2, 3),
@@ -446,22 +452,55 @@ __global__ __launch_bounds__(256, 2) void set_attention_sp_kernel(const half_t* 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qr = lane & 31, hh = lane >> 5;
-    const int bh = blockIdx.y, b = bh / heads, head = bh - b * heads;
-    const int q0 = blockIdx.x * 256 + wave * 64;
+    // XCD-aware block -> (shape, head, query block) map.  Workgroups are dealt round-robin over the 8 XCDs
+    // (block L runs on XCD L % 8, speed only, never correctness), and the n/256 query blocks of one (shape, head)
+    // all stream the same K/V: give them to ONE XCD, next to each other in time, so its L2 fetches that K/V once
+    // instead of 8 L2s fetching it once each.
+    const int nqb = n >> 8;                                   // query blocks per (shape, head)
+    int bh, qb;
+    {
+        const int L = blockIdx.x, total_bh = gridDim.x / nqb;
+        const int xcd = L & 7, i = L >> 3;                    // i-th block of this XCD
+        const int j = i / nqb;
+        bh = xcd + 8 * j;
+        qb = i - j * nqb;
+        if (bh >= total_bh || (total_bh & 7)) { bh = L / nqb; qb = L - bh * nqb; }   // batch*heads not a multiple of 8: plain order
+    }
+    const int b = bh / heads, head = bh - b * heads;
+    const int q0 = qb * 256 + wave * 64;
     const int64_t row_base = (int64_t)b * n;
     const int ld = 3 * c;
 
     const half_t* kbase = qkv + row_base * ld + c + head * D;
     const half_t* vbase = qkv + row_base * ld + 2 * c + head * D;
     const int ntiles = n / KT;                                // a multiple of NSLOT (n % 256 == 0)
-    auto stage = [&](int kt, int slot) {
-        char* base = smem + slot * STAGE;
-        stage_tile<KT, KRB, false, 4, true>(kbase, ld, kt * KT, n, base, wave, lane);
-        stage_tile<KT, KRB, true, 4, true>(vbase, ld, kt * KT, n, base + KBYTES, wave, lane);
+    // LDS-DMA staging (global_load_lds_dwordx4, 1 KiB per wave-instruction = 8 rows of a [64 keys][64] tile): a tile is
+    // 8 K pieces + 8 V pieces, wave w moves K pieces w, w+4 and V pieces w, w+4.  Source = wave-uniform SGPR base
+    // (tile, piece rows, K or V) + a lane-constant 32-bit offset that carries the XOR swizzles of the generic kernel
+    // (they only depend on the row inside the piece and on w & 1): no vector arithmetic per piece, so the four pieces
+    // of a tile are issued one per phase, in an MFMA gap each.
+    const unsigned lrow = lane >> 3, lch = lane & 7;
+    const unsigned koff32 = lrow * (unsigned)ld * 2u + ((lch ^ ((4u * (wave & 1) + (lane >> 4)) & 7u)) << 4);
+    const unsigned voff32 = lrow * (unsigned)ld * 2u + ((lch ^ ((lrow & 2u) << 1)) << 4);
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const size_t tile_bytes = (size_t)KT * ld * 2, half_bytes = (size_t)32 * ld * 2;
+    const char* kwave = (const char*)kbase + (size_t)(8 * wave) * ld * 2;     // this wave's first piece of tile 0
+    const char* vwave = (const char*)vbase + (size_t)(8 * wave) * ld * 2;
+    auto dma = [&](const char* sbase, unsigned voff, unsigned lds_addr) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr)
+                     : "memory", "m0");
+    };
+    // piece j (0..3) of tile kt into ring slot `slot`: K rows 8w.., K rows 8w+32.., V rows 8w.., V rows 8w+32..
+    auto stage_piece = [&](int kt, int slot, int j) __attribute__((always_inline)) {
+        const char* src = ((j & 2) ? vwave : kwave) + (size_t)kt * tile_bytes + ((j & 1) ? half_bytes : 0);
+        const unsigned dst = lds0 + slot * STAGE + ((j & 2) ? KBYTES : 0) + (wave + 4 * (j & 1)) * 1024;
+        dma(src, (j & 2) ? voff32 : koff32, dst);
     };
     // K/V tiles 0 .. AHEAD go out first (4 LDS-DMA instructions per wave and tile), the Q rows behind them
 #pragma unroll
-    for (int t = 0; t <= AHEAD; ++t) stage(t, t);
+    for (int t = 0; t <= AHEAD; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) stage_piece(t, t, j);
 
     half8 qA[KSTEPS], qB[KSTEPS];
     {
@@ -495,11 +534,11 @@ __global__ __launch_bounds__(256, 2) void set_attention_sp_kernel(const half_t* 
         const int ch = ((o * 32 + 16 * (tg & 1)) >> 3) + (tp >> 1);
         vaddr[o] = smem + KBYTES + key * KRB + (v_swz<KRB>(key, ch) << 4) + (tp & 1) * 8;
     }
-    auto load_k = [&](int off, half8 (&kf)[KSTEPS]) {         // off = slot * STAGE + sub * 32 * KRB
+    auto load_k = [&](int off, half8 (&kf)[KSTEPS]) __attribute__((always_inline)) {         // off = slot * STAGE + sub * 32 * KRB
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) kf[s] = *(const half8*)(kaddr[s] + off);
     };
-    auto load_v = [&](int off, half8 (&vf)[2][2]) {
+    auto load_v = [&](int off, half8 (&vf)[2][2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -538,32 +577,41 @@ __global__ __launch_bounds__(256, 2) void set_attention_sp_kernel(const half_t* 
     }
     load_k(32 * KRB, kf);                                     // K(1) for the first sub-tile's S(i+1) products
 
-    // one key sub-tile i (32 keys): kf holds K(i+1) and vf V(i-1) on entry; V(i) at voff, K(i+2) at koff
-    auto sub_iter = [&](int voff, int koff) {
-        half2_ t = sp_phase<true>(sA, pA0, pA1, kf, qA, negmA, sAn, oB, vf, pB0, pB1, [&]() { load_v(voff, vf); });
-        if (__builtin_expect(__any(__builtin_bit_cast(unsigned, t) > SP_BIG_BITS), 0)) t = sp_fix(sA, sAn, negmA, oA, lA, pA0, pA1);
-        lA = __builtin_fmaf((float)t.x, 1.f, lA);
-        t = sp_phase<false>(sB, pB0, pB1, kf, qB, negmB, sBn, oA, vf, pA0, pA1, [&]() { load_k(koff, kf); });
-        if (__builtin_expect(__any(__builtin_bit_cast(unsigned, t) > SP_BIG_BITS), 0)) t = sp_fix(sB, sBn, negmB, oB, lB, pB0, pB1);
-        lB = __builtin_fmaf((float)t.x, 1.f, lB);
+    // one key sub-tile i (32 keys): kf holds K(i+1) and vf V(i-1) on entry; V(i) at voff, K(i+2) at koff; pieces j0 and
+    // j0 + 1 of tile st (if any) leave for ring slot sslot, one in front of each phase
+    half2_ tA, tB;                                              // row sums of the last tile of A / B, not yet in lA / lB
+    tA.x = tA.y = tB.x = tB.y = (half_t)0.f;
+    // one key sub-tile i (32 keys): kf holds K(i+1) and vf V(i-1) on entry; V(i) at voff, K(i+2) at koff; when STAGE_ON,
+    // pieces j0 and j0 + 1 of tile st leave for ring slot sslot, one in front of each phase
+    auto sub_iter = [&](int voff, int koff, bool stage_on, int st, int sslot, int j0) __attribute__((always_inline)) {
+        if (stage_on) stage_piece(st, sslot, j0);
+        tA = sp_phase<true>(sA, pA0, pA1, kf, qA, negmA, sAn, oB, vf, pB0, pB1, tB, lB, [&]() { load_v(voff, vf); });
+        if (__builtin_expect(__any(__builtin_bit_cast(unsigned, tA) > SP_BIG_BITS), 0)) tA = sp_fix(sA, sAn, negmA, oA, lA, pA0, pA1);
+        if (stage_on) stage_piece(st, sslot, j0 + 1);
+        tB = sp_phase<false>(sB, pB0, pB1, kf, qB, negmB, sBn, oA, vf, pA0, pA1, tA, lA, [&]() { load_k(koff, kf); });
+        if (__builtin_expect(__any(__builtin_bit_cast(unsigned, tB) > SP_BIG_BITS), 0)) tB = sp_fix(sB, sBn, negmB, oB, lB, pB0, pB1);
         sA = sAn; sB = sBn;
     };
-
-    for (int t0 = 0; t0 < ntiles; t0 += NSLOT) {
+    // NSLOT tiles, tile t0 + u in ring slot u.  LAST = the final group: only its first tile still has a tile to stage
+    // (t0 + 3 = ntiles - 1), and the waits drain instead of leaving the youngest stage in flight.
+    auto tile_group = [&](int t0, auto last_tag) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_tag)::value;
 #pragma unroll
-        for (int u = 0; u < NSLOT; ++u) {                     // tile t0 + u lives in ring slot u
-            const int t = t0 + u;
+        for (int u = 0; u < NSLOT; ++u) {
             // tile t+1 has landed (all but the youngest stage's 4 LDS-DMA) and every wave is done with tile t-1
-            if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (!LAST || u < 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (t + AHEAD + 1 < ntiles) stage(t + AHEAD + 1, (u + AHEAD + 1) % NSLOT);    // == slot of tile t-1
-            constexpr int dummy = 0; (void)dummy;
             const int cur = u * STAGE, nxt = ((u + 1) % NSLOT) * STAGE;   // last tile: nxt holds stale bytes, S(i+1) unused
-            sub_iter(cur, nxt);                               // sub-tile 2t:   V(2t),   K(2t+2) = tile t+1 rows 0..31
-            sub_iter(cur + 32 * KRB, nxt + 32 * KRB);         // sub-tile 2t+1: V(2t+1), K(2t+3) = tile t+1 rows 32..63
+            const int st = t0 + u + AHEAD + 1, sslot = (u + AHEAD + 1) % NSLOT;   // tile to stage; its slot == slot of tile t-1
+            const bool on = !LAST || u == 0;
+            sub_iter(cur, nxt, on, st, sslot, 0);                       // sub-tile 2t:   V(2t),   K(2t+2) = tile t+1 rows 0..31
+            sub_iter(cur + 32 * KRB, nxt + 32 * KRB, on, st, sslot, 2); // sub-tile 2t+1: V(2t+1), K(2t+3) = tile t+1 rows 32..63
         }
-    }
+    };
+    int t0 = 0;
+    for (; t0 + NSLOT < ntiles; t0 += NSLOT) tile_group(t0, std::false_type{});
+    tile_group(t0, std::true_type{});
 #pragma unroll
     for (int oo = 0; oo < 2; ++oo) {                          // O_B += V(last)^T P_B(last)
         oB[oo] = SP_MF(vf[0][oo], pB0, oB[oo]);
@@ -586,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void set_attention_sp_kernel(const half_t* 
             }
     };
     store(oA, lA, q0 + qr);
-    store(oB, lB, q0 + 32 + qr);
+    store(oB, lB + (float)tB.x, q0 + 32 + qr);                 // B's last tile sum is still pending (A's went in with B's last phase)
 }
 
 }  // namespace pcd
@@ -610,7 +658,7 @@ extern "C" size_t pcd_set_attention_workspace_bytes(int batch, int n_points, int
 static int g_attn_force_generic = 0;   // tuning/testing hook: 1 = always the generic kernel
 
 extern "C" int pcd_set_attention_config(int force_generic) {
-    g_attn_force_generic = force_generic;
+    g_attn_force_generic = force_generic ? 1 : 0;
     return PCD_OK;
 }
 
@@ -627,7 +675,7 @@ extern "C" int pcd_set_attention_f16(const void* qkv, int batch, int n_points, i
     // sits at 256 VGPRs (2 waves/SIMD) and the shared K/V fragments do not pay for the lost occupancy.
     constexpr int QT = 1;
     if (d == 64 && n_points % 256 == 0 && !g_attn_force_generic) {   // software-pipelined kernel: 64 queries per wave, 256 per workgroup
-        dim3 sgrid((unsigned)(n_points / 256), (unsigned)(batch * heads));
+        dim3 sgrid((unsigned)((n_points / 256) * batch * heads));
         hipLaunchKernelGGL(set_attention_sp_kernel, sgrid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads,
                            scale_log2e, (half_t*)out);
         PCD_CHECK_LAUNCH();

@@ -208,21 +208,29 @@ def attention_roofline(device, launches=20):
     """HIP events (torch's current stream is the stream the kernel is launched on) around
     pcd_set_attention_f16 at B=64, N=2048, C=256, 4 heads."""
     import torch
-    from shapegen_amd import ops
+    from shapegen_amd import _lib
+    lib = _lib.load()
     g = torch.Generator(device="cpu").manual_seed(7)
-    qkv = (torch.randn(B_PER_GPU * N_POINTS, 3 * ATT_C, generator=g) * 1.0).to(device, torch.float16)
-    for _ in range(3):
-        ops.set_attention_f16(qkv, B_PER_GPU, N_POINTS, ATT_C, ATT_HEADS)
+    qkv = torch.randn(B_PER_GPU * N_POINTS, 3 * ATT_C, generator=g).to(device, torch.float16)     # unit-variance q, k, v
+    out = torch.empty(B_PER_GPU * N_POINTS, ATT_C, dtype=torch.float16, device=device)
+
+    def launch():
+        _lib.check(lib.pcd_set_attention_f16(qkv.data_ptr(), B_PER_GPU, N_POINTS, ATT_C, ATT_HEADS, out.data_ptr(), 0, 0,
+                                             _lib.stream_ptr()), "set_attention")
+    for _ in range(10):
+        launch()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(launches + 1)]
     torch.cuda.synchronize()
     ev[0].record()
     for i in range(launches):
-        ops.set_attention_f16(qkv, B_PER_GPU, N_POINTS, ATT_C, ATT_HEADS)
+        launch()
         ev[i + 1].record()
     torch.cuda.synchronize()
+    if not torch.isfinite(out.float()).all():
+        raise SystemExit("set attention produced non-finite values")
     ms = sum(ev[i].elapsed_time(ev[i + 1]) for i in range(launches)) / launches
     achieved = ATT_FLOP_PER_LAUNCH / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "set_attention_kernel<64> (QK^T, online softmax, PV; d_head 64)",
+    return {"bound": "mfma", "kernel": "set_attention_sp_kernel (QK^T, softmax, PV; d_head 64; software-pipelined, 2 query blocks per wave)",
             "achieved": achieved, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": None,
             "avg_launch_ms": ms, "launches_timed": launches, "flop_per_launch": ATT_FLOP_PER_LAUNCH,
