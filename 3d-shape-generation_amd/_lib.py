@@ -50,6 +50,24 @@ class LatentDesc(C.Structure):
                 ("gn_gamma", vp * PCD_LATENT_NLIN), ("gn_beta", vp * PCD_LATENT_NLIN)]
 
 
+class SabDesc(C.Structure):
+    _fields_ = [("dim", i32), ("w_in", vp), ("b_in", vp), ("w_out", vp), ("b_out", vp),
+                ("ln1_g", vp), ("ln1_b", vp), ("ln2_g", vp), ("ln2_b", vp),
+                ("w_ff1", vp), ("b_ff1", vp), ("w_ff2", vp), ("b_ff2", vp)]
+
+
+PCD_ATTN_UNET_NLIN, PCD_ATTN_UNET_NSAB, PCD_ATTN_UNET_NEMB, PCD_ATTN_UNET_TB = 14, 7, 6, 704
+
+
+class AttnUnetDesc(C.Structure):
+    _fields_ = [("dim", i32), ("time_dim", i32), ("heads", i32), ("freqs", vp),
+                ("tw0", vp), ("tb0", vp), ("tw2", vp), ("tb2", vp),
+                ("emb_w", vp * PCD_ATTN_UNET_NEMB), ("emb_b", vp * PCD_ATTN_UNET_NEMB),
+                ("e1w", vp), ("e1b", vp),
+                ("lin", LinearDesc * PCD_ATTN_UNET_NLIN), ("sab", SabDesc * PCD_ATTN_UNET_NSAB),
+                ("t_w1", vp), ("t_b1", vp), ("t_w234", vp), ("t_b234", vp)]
+
+
 class Conv3dDesc(C.Structure):
     _fields_ = [("inp", vp), ("batch", i32), ("in_d", i32), ("in_h", i32), ("in_w", i32), ("cin", i32),
                 ("rows_d", i32), ("rows_h", i32), ("rows_w", i32), ("stride", i32),
@@ -59,6 +77,27 @@ class Conv3dDesc(C.Structure):
                 ("out_d", i32), ("out_h", i32), ("out_w", i32), ("out_scale", i32),
                 ("out_off_z", i32), ("out_off_y", i32), ("out_off_x", i32),
                 ("zero_page", vp)]
+
+
+class VaeConv(C.Structure):
+    _fields_ = [("w", vp), ("b", vp), ("kpad", i32), ("cin", i32), ("cout", i32), ("k", i32)]
+
+
+class VaeRes(C.Structure):
+    _fields_ = [("c1", VaeConv), ("c2", VaeConv), ("ds", VaeConv), ("has_ds", i32)]
+
+
+class VaeConvT(C.Structure):
+    _fields_ = [("w", vp * 8), ("taps", vp * 8), ("b", vp), ("cin", i32), ("cout", i32)]
+
+
+class VaeDesc(C.Structure):
+    _fields_ = [("latent_dim", i32), ("enc0_w", vp), ("enc0_b", vp),
+                ("enc_res", VaeRes * 4), ("enc_down", VaeConv * 3), ("enc_last", VaeConv),
+                ("fc_w", vp), ("fc_b", vp), ("din_w", vp), ("din_b", vp),
+                ("dec_up", VaeConvT * 3), ("dec_res", VaeRes * 4), ("dec_conv9", VaeConv),
+                ("last_w", vp), ("last_b", f32),
+                ("taps3", vp), ("taps4s2", vp), ("taps4p0", vp), ("taps1", vp), ("zero_page", vp)]
 
 
 # name -> (restype, argtypes).  Kept in the order of include/pcd_hip.h.
@@ -114,12 +153,25 @@ _SIGS = {
     "pcd_convt3d_last_sigmoid": (i32, [vp, i32, i32, i32, i32, i32, vp, f32, vp, vp]),
     "pcd_conv3d_last_sigmoid": (i32, [vp, i32, i32, i32, i32, i32, vp, f32, vp, vp]),
     "pcd_reparameterize": (i32, [vp, vp, vp, vp, i64, vp]),
+    "pcd_vae_create": (i32, [C.POINTER(VaeDesc), C.POINTER(vp)]),
+    "pcd_vae_destroy": (None, [vp]),
+    "pcd_vae_workspace_bytes": (sz, [i32]),
+    "pcd_vae_encode": (i32, [vp, vp, i32, vp, vp, sz, vp]),
+    "pcd_vae_decode": (i32, [vp, vp, i32, vp, vp, sz, vp]),
     "pcd_layernorm_f16": (i32, [vp, i64, i32, vp, vp, vp, vp]),
     "pcd_set_attention_workspace_bytes": (sz, [i32, i32, i32]),
     "pcd_set_attention_f16": (i32, [vp, i32, i32, i32, i32, vp, vp, sz, vp]),
     "pcd_set_attention_config": (i32, [i32]),
     "pcd_add_shape_bias_f16": (i32, [vp, i64, i32, i32, vp, vp, vp]),
+    "pcd_add_shape_bias_strided_f16": (i32, [vp, i64, i32, i32, vp, i64, vp, vp]),
     "pcd_tail3": (i32, [vp, i32, vp, i32, i64, vp, vp, vp, vp, vp, vp]),
+    "pcd_sab_workspace_bytes": (sz, [i64, i32]),
+    "pcd_sab_forward": (i32, [C.POINTER(SabDesc), vp, i32, i32, i32, vp, vp, sz, vp]),
+    "pcd_attn_unet_create": (i32, [C.POINTER(AttnUnetDesc), C.POINTER(vp)]),
+    "pcd_attn_unet_destroy": (None, [vp]),
+    "pcd_attn_unet_workspace_bytes": (sz, [i32, i32]),
+    "pcd_attn_unet_time_bias": (i32, [vp, vp, i32, vp, vp, vp]),
+    "pcd_attn_unet_forward": (i32, [vp, vp, i32, i32, vp, i32, vp, vp, sz, vp]),
     "pcd_normalize_to_cube": (i32, [vp, i32, i32, vp, vp]),
     "pcd_chamfer_sums": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "pcd_voxelize": (i32, [vp, i32, i32, i32, vp, vp]),

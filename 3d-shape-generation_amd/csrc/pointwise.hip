@@ -238,13 +238,13 @@ __global__ __launch_bounds__(256) void f16_to_f32_kernel(const half_t* __restric
 // x[m][c] += e[m / rows_per_shape][c]   (additive per-level time embeddings, networks.py:669-698)
 __global__ __launch_bounds__(256) void add_shape_bias_kernel(const half_t* __restrict__ x, int64_t m, int c,
                                                               int rows_per_shape, const float* __restrict__ e,
-                                                              half_t* __restrict__ out) {
+                                                              int64_t e_stride, half_t* __restrict__ out) {
     const int chunks = c / 8;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= m * chunks) return;
     const int64_t row = idx / chunks;
     const int ch = (int)(idx - row * chunks);
-    const float* er = e + (row / rows_per_shape) * c + ch * 8;
+    const float* er = e + (row / rows_per_shape) * e_stride + ch * 8;
     half8 v = *(const half8*)(x + row * c + ch * 8);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = to_half_sat((float)v[i] + er[i]);
@@ -394,7 +394,7 @@ extern "C" int pcd_enc1_xyz(const float* x, int64_t m, int rows_per_shape, const
                             const float* tbias, int tbias_shape_stride, void* out, void* stream) {
     PCD_CHECK_ARG(x && w_xyz && tbias && out);
     PCD_CHECK_ARG(m > 0 && rows_per_shape > 0 && c1 > 0 && c1 % 8 == 0);
-    PCD_CHECK_ARG(tbias_shape_stride == 0 || tbias_shape_stride == 1);
+    PCD_CHECK_ARG(tbias_shape_stride >= 0);
     hipLaunchKernelGGL(enc1_xyz_kernel, dim3(nblk(m * (c1 / 8))), dim3(256), 0, (hipStream_t)stream,
                        x, m, rows_per_shape, w_xyz, c1, tbias, tbias_shape_stride, (half_t*)out);
     PCD_CHECK_LAUNCH();
@@ -481,13 +481,18 @@ extern "C" int pcd_f16_to_f32(const void* src, float* dst, int64_t n, void* stre
     return PCD_OK;
 }
 
-extern "C" int pcd_add_shape_bias_f16(const void* x, int64_t m, int c, int rows_per_shape, const float* e, void* out,
-                                      void* stream) {
-    PCD_CHECK_ARG(x && e && out && m > 0 && c > 0 && c % 8 == 0 && rows_per_shape > 0);
+extern "C" int pcd_add_shape_bias_strided_f16(const void* x, int64_t m, int c, int rows_per_shape, const float* e,
+                                              int64_t e_stride, void* out, void* stream) {
+    PCD_CHECK_ARG(x && e && out && m > 0 && c > 0 && c % 8 == 0 && rows_per_shape > 0 && e_stride >= 0);
     hipLaunchKernelGGL(add_shape_bias_kernel, dim3(nblk(m * (c / 8))), dim3(256), 0, (hipStream_t)stream,
-                       (const half_t*)x, m, c, rows_per_shape, e, (half_t*)out);
+                       (const half_t*)x, m, c, rows_per_shape, e, e_stride, (half_t*)out);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
+}
+
+extern "C" int pcd_add_shape_bias_f16(const void* x, int64_t m, int c, int rows_per_shape, const float* e, void* out,
+                                      void* stream) {
+    return pcd_add_shape_bias_strided_f16(x, m, c, rows_per_shape, e, c, out, stream);
 }
 
 extern "C" int pcd_tail3(const void* a, int ka, const void* b, int kb, int64_t m, const float* w1, const float* b1,

@@ -1,0 +1,191 @@
+// a12: VAE3DLarge.encode / decode (reference networks.py:2299-2310, 2327-2339; nets :2225-2264, ResidualBlock3D
+// :471-504) as single enqueues behind a handle.
+//
+// Host-side sequencing only: every launch goes through the layer-level entry points of this library (direct first /
+// last layers, LDS-halo k3 convolution, implicit-GEMM convolution with the ConvTranspose3d parity classes in one
+// launch and split-K for the small-grid layers, fp16 GEMMs for the Linear layers).  Activations NDHWC fp16, eval-mode
+// BatchNorm3d folded into the weights by the host packer.
+#include <new>
+#include "common.h"
+
+struct pcd_vae {
+    pcd_vae_desc_t d;
+};
+
+namespace pcd {
+
+static inline size_t vae_align(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// three rotating activation buffers (the largest activation is 32^3 x 64 channels), the split-K scratch of the
+// convolution launches, and the small GEMM operands
+struct VaeWs { size_t a, b, c, scratch, scratch_bytes, small, total; };
+static constexpr size_t kConvScratchPerSample = (size_t)8 << 20;     // >= the split-K slabs of any layer (checked per launch)
+static VaeWs vae_carve(int batch) {
+    VaeWs w{};
+    const size_t act = vae_align((size_t)batch * 32768 * 64 * 2);
+    size_t o = 0;
+    w.a = o; o += act;
+    w.b = o; o += act;
+    w.c = o; o += act;
+    w.scratch = o;
+    w.scratch_bytes = vae_align(kConvScratchPerSample * (size_t)(batch < 4 ? 4 : batch));
+    o += w.scratch_bytes;
+    w.small = o; o += vae_align((size_t)batch * 1024 * 4);
+    w.total = o;
+    return w;
+}
+
+struct Runner {
+    const pcd_vae_desc_t& d;
+    int batch;
+    char* scratch;
+    size_t scratch_bytes;
+    hipStream_t s;
+
+    void fill(pcd_conv3d_desc_t& c, const pcd_vae_conv_t& L, const void* in, int din, int stride, const int* taps, int ntaps,
+              int dout, int relu, const void* resid, void* out) const {
+        c = pcd_conv3d_desc_t{};
+        c.in = in; c.batch = batch; c.in_d = c.in_h = c.in_w = din; c.cin = L.cin;
+        c.rows_d = c.rows_h = c.rows_w = dout; c.stride = stride;
+        c.taps = taps; c.ntaps = ntaps; c.kpad = L.kpad;
+        c.w = L.w; c.bias = L.b; c.resid = resid; c.relu = relu;
+        c.out = out; c.cout = L.cout;
+        c.out_d = c.out_h = c.out_w = dout; c.out_scale = 1;
+        c.zero_page = d.zero_page;
+    }
+    int launch(const pcd_conv3d_desc_t* descs, int n) const {
+        size_t need = pcd_conv3d_workspace_bytes(descs, n);
+        if (need > scratch_bytes) need = 0;                           // too small: the launch simply runs unsplit
+        return pcd_conv3d_f16_multi(descs, n, need ? scratch : nullptr, need, s);
+    }
+    // Conv3d(k, stride, pad) [+ residual] [+ ReLU]
+    int conv(const pcd_vae_conv_t& L, const void* in, int din, int stride, const int* taps, int dout, int relu,
+             const void* resid, void* out) const {
+        pcd_conv3d_desc_t c;
+        fill(c, L, in, din, stride, taps, L.k * L.k * L.k, dout, relu, resid, out);
+        if (L.k == 3 && stride == 1 && pcd_conv3d_k3s1_supported(&c)) return pcd_conv3d_k3s1_f16(&c, s);   // LDS-resident halo
+        return launch(&c, 1);
+    }
+    // ResidualBlock3D: relu(bn2(conv2(relu(bn1(conv1 x)))) + (downsample(x) | x))
+    int res(const pcd_vae_res_t& R, const void* x, int dim, void* h, void* r, void* out) const {
+        int rc = conv(R.c1, x, dim, 1, d.taps3, dim, 1, nullptr, h);
+        if (rc) return rc;
+        const void* resid = x;
+        if (R.has_ds) {
+            rc = conv(R.ds, x, dim, 1, d.taps1, dim, 0, nullptr, r);
+            if (rc) return rc;
+            resid = r;
+        }
+        return conv(R.c2, h, dim, 1, d.taps3, dim, 1, resid, out);
+    }
+    // ConvTranspose3d(k4, s2, p1) + ReLU: the 8 output-parity classes (2x2x2 taps each) in one launch
+    int convT(const pcd_vae_convT_t& T, const void* in, int din, void* out) const {
+        pcd_conv3d_desc_t c[8];
+        for (int k = 0; k < 8; ++k) {
+            c[k] = pcd_conv3d_desc_t{};
+            c[k].in = in; c[k].batch = batch; c[k].in_d = c[k].in_h = c[k].in_w = din; c[k].cin = T.cin;
+            c[k].rows_d = c[k].rows_h = c[k].rows_w = din; c[k].stride = 1;
+            c[k].taps = T.taps[k]; c[k].ntaps = 8; c[k].kpad = 8 * T.cin;
+            c[k].w = T.w[k]; c[k].bias = T.b; c[k].resid = nullptr; c[k].relu = 1;
+            c[k].out = out; c[k].cout = T.cout;
+            c[k].out_d = c[k].out_h = c[k].out_w = 2 * din; c[k].out_scale = 2;
+            c[k].out_off_z = (k >> 2) & 1; c[k].out_off_y = (k >> 1) & 1; c[k].out_off_x = k & 1;
+            c[k].zero_page = d.zero_page;
+        }
+        return launch(c, 8);
+    }
+};
+
+static bool conv_ok(const pcd_vae_conv_t& L) { return L.w && L.b && L.cin > 0 && L.cout > 0 && L.kpad > 0 && L.k > 0; }
+static bool res_ok(const pcd_vae_res_t& R) { return conv_ok(R.c1) && conv_ok(R.c2) && (!R.has_ds || conv_ok(R.ds)); }
+
+}  // namespace pcd
+
+using namespace pcd;
+
+extern "C" int pcd_vae_create(const pcd_vae_desc_t* desc, pcd_vae_t** out) {
+    PCD_CHECK_ARG(desc != nullptr && out != nullptr);
+    PCD_CHECK_ARG(desc->latent_dim > 0 && desc->latent_dim % 64 == 0);
+    PCD_CHECK_ARG(desc->enc0_w && desc->enc0_b && desc->fc_w && desc->fc_b && desc->din_w && desc->din_b && desc->last_w);
+    PCD_CHECK_ARG(desc->taps3 && desc->taps4s2 && desc->taps4p0 && desc->taps1 && desc->zero_page);
+    for (int i = 0; i < 4; ++i) PCD_CHECK_ARG(res_ok(desc->enc_res[i]) && res_ok(desc->dec_res[i]));
+    for (int i = 0; i < 3; ++i) {
+        PCD_CHECK_ARG(conv_ok(desc->enc_down[i]) && desc->dec_up[i].b && desc->dec_up[i].cin > 0 && desc->dec_up[i].cout > 0);
+        for (int k = 0; k < 8; ++k) PCD_CHECK_ARG(desc->dec_up[i].w[k] && desc->dec_up[i].taps[k]);
+    }
+    PCD_CHECK_ARG(conv_ok(desc->enc_last) && conv_ok(desc->dec_conv9));
+    // the channel plan of networks.py:2225-2264
+    PCD_CHECK_ARG(desc->enc_res[0].c1.cin == 32 && desc->enc_res[3].c2.cout == 512 && desc->enc_last.cout == 512);
+    PCD_CHECK_ARG(desc->dec_up[0].cin == 512 && desc->dec_conv9.cin == 64 && desc->dec_conv9.cout == 32);
+    pcd_vae* h = new (std::nothrow) pcd_vae;
+    PCD_CHECK_ARG(h != nullptr);
+    h->d = *desc;
+    *out = h;
+    return PCD_OK;
+}
+
+extern "C" void pcd_vae_destroy(pcd_vae_t* h) { delete h; }
+
+extern "C" size_t pcd_vae_workspace_bytes(int batch) {
+    if (batch <= 0) return 0;
+    return vae_carve(batch).total;
+}
+
+#define VAE_PROLOGUE()                                                                        \
+    const VaeWs w = vae_carve(batch);                                                         \
+    if (workspace_bytes < w.total) {                                                          \
+        set_error("%s: workspace %zu < required %zu", __func__, workspace_bytes, w.total);    \
+        return PCD_ERR_WORKSPACE;                                                             \
+    }                                                                                         \
+    char* ws = (char*)workspace;                                                              \
+    void *A = ws + w.a, *B = ws + w.b, *Cc = ws + w.c;                                        \
+    const pcd_vae_desc_t& d = h->d;                                                           \
+    hipStream_t s = (hipStream_t)stream;                                                      \
+    const Runner R{d, batch, ws + w.scratch, w.scratch_bytes, s};                             \
+    int rc
+#define RUN(expr) do { rc = (expr); if (rc) return rc; } while (0)
+
+extern "C" int pcd_vae_encode(pcd_vae_t* h, const float* vox, int batch, float* mu_logvar, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    PCD_CHECK_ARG(h && vox && mu_logvar && workspace && batch > 0);
+    VAE_PROLOGUE();
+    // encoder.0/1: Conv3d(1, 32, k3, p1) + ReLU straight from the fp32 occupancy grid
+    RUN(pcd_conv3d_first(vox, batch, 32, 32, 32, 1, d.enc0_w, d.enc0_b, 32, A, s));
+    RUN(R.res(d.enc_res[0], A, 32, B, Cc, A));                                   // encoder.2   32 -> 64 @ 32^3   (A <- out)
+    RUN(R.conv(d.enc_down[0], A, 32, 2, d.taps4s2, 16, 1, nullptr, B));          // encoder.3/4 k4 s2 -> 16^3
+    RUN(R.res(d.enc_res[1], B, 16, A, Cc, B));                                   // encoder.5   64 -> 128
+    RUN(R.conv(d.enc_down[1], B, 16, 2, d.taps4s2, 8, 1, nullptr, A));           // encoder.6/7 -> 8^3
+    RUN(R.res(d.enc_res[2], A, 8, B, Cc, A));                                    // encoder.8   128 -> 256
+    RUN(R.conv(d.enc_down[2], A, 8, 2, d.taps4s2, 4, 1, nullptr, B));            // encoder.9/10 -> 4^3
+    RUN(R.res(d.enc_res[3], B, 4, A, Cc, B));                                    // encoder.11  256 -> 512
+    RUN(R.conv(d.enc_last, B, 4, 1, d.taps4p0, 1, 1, nullptr, A));               // encoder.12/13 k4 p0 -> (B, 512)
+    pcd_gemm_desc_t g{};                                                         // [fc_mu ; fc_logvar]: 512 -> 2 * latent
+    g.a1 = A; g.k1 = 512; g.lda1 = 512; g.w = d.fc_w; g.ldw = 512; g.bias = d.fc_b; g.relu = 0; g.m = batch;
+    g.c = 2 * d.latent_dim;
+    RUN(pcd_gemm_f16_out32(&g, mu_logvar, 2 * d.latent_dim, s));
+    return PCD_OK;
+}
+
+extern "C" int pcd_vae_decode(pcd_vae_t* h, const float* z, int batch, float* out, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+    PCD_CHECK_ARG(h && z && out && workspace && batch > 0);
+    VAE_PROLOGUE();
+    void* z16 = ws + w.small;
+    RUN(pcd_f32_to_f16(z, z16, (int64_t)batch * d.latent_dim, s));
+    pcd_gemm_desc_t g{};                                                         // decoder_input, columns already in NDHWC order
+    g.a1 = z16; g.k1 = d.latent_dim; g.lda1 = d.latent_dim; g.w = d.din_w; g.ldw = d.latent_dim; g.bias = d.din_b;
+    g.relu = 0; g.m = batch; g.c = 512 * 64;
+    RUN(pcd_gemm_f16(&g, A, 512 * 64, s));                                       // (B, 4,4,4, 512)
+    RUN(R.convT(d.dec_up[0], A, 4, B));                                          // decoder.0/1  512 -> 256 @ 8^3
+    RUN(R.res(d.dec_res[0], B, 8, A, Cc, B));                                    // decoder.2
+    RUN(R.convT(d.dec_up[1], B, 8, A));                                          // decoder.3/4  256 -> 128 @ 16^3
+    RUN(R.res(d.dec_res[1], A, 16, B, Cc, A));                                   // decoder.5
+    RUN(R.convT(d.dec_up[2], A, 16, B));                                         // decoder.6/7  128 -> 64 @ 32^3
+    RUN(R.res(d.dec_res[2], B, 32, A, Cc, B));                                   // decoder.8
+    RUN(R.conv(d.dec_conv9, B, 32, 1, d.taps3, 32, 1, nullptr, A));              // decoder.9/10  64 -> 32
+    RUN(R.res(d.dec_res[3], A, 32, B, Cc, A));                                   // decoder.11
+    RUN(pcd_conv3d_last_sigmoid(A, batch, 32, 32, 32, 32, d.last_w, d.last_b, out, s));   // decoder.12/13
+    return PCD_OK;
+}
+#undef RUN
+#undef VAE_PROLOGUE

@@ -339,11 +339,23 @@ class PointCloudDiffusion(_DiffusionBase):
     """Drop-in for reference diffusion.py:14-358 (sampling surface)."""
     _sample_dims = 2   # one sample is (N, 3)
 
-    def __init__(self, num_points, dim=256, time_dim=256, lr=1e-4, noise_schedule="cosine"):
+    def __init__(self, num_points, dim=256, time_dim=256, lr=1e-4, noise_schedule="cosine", backbone="pointnet"):
+        """`backbone` is this build's one addition to the reference signature: "pointnet" =
+        UNetPointNetLarge, the denoiser diffusion.py:28 wires in; "attention" = UNetAttentionPointExperimental
+        (networks.py:597-722), which the reference only reaches by editing the import at diffusion.py:11.  The
+        state_dict keys are `model.*` of the chosen class either way."""
         super().__init__()
         self.hparams = _HParams(num_points=num_points, dim=dim, time_dim=time_dim, lr=lr,
                                 noise_schedule=noise_schedule)
-        self.model = UNetPointNetLarge(dim, time_dim)
+        if backbone == "pointnet":
+            self.model = UNetPointNetLarge(dim, time_dim)
+        elif backbone == "attention":
+            from .networks import UNetAttentionPointExperimental
+            self.model = UNetAttentionPointExperimental(num_points, dim=dim, time_dim=time_dim)
+            self.hparams["backbone"] = backbone
+        else:
+            raise ValueError(f"backbone must be 'pointnet' or 'attention', got {backbone!r}")
+        self.backbone = backbone
         self.num_points = num_points
         self.lr = lr
         self._init_schedule(noise_schedule)
@@ -354,7 +366,7 @@ class PointCloudDiffusion(_DiffusionBase):
         from .checkpoint import load_lightning_checkpoint
         hp, sd = load_lightning_checkpoint(path, map_location)
         hp.update(kwargs)
-        obj = cls(**{k: hp[k] for k in ("num_points", "dim", "time_dim", "lr", "noise_schedule") if k in hp})
+        obj = cls(**{k: hp[k] for k in ("num_points", "dim", "time_dim", "lr", "noise_schedule", "backbone") if k in hp})
         obj.load_state_dict(sd, strict=True)
         return obj
 
@@ -366,6 +378,8 @@ class PointCloudDiffusion(_DiffusionBase):
         """AdamW(lr, weight_decay=1e-5) + ReduceLROnPlateau(min, factor 0.5, patience 5) on `val_loss`
         (diffusion.py:60-68); the optimizer object is the HIP trainer, which also owns forward/backward."""
         from .training import PointTrainer, ReduceLROnPlateau
+        if self.backbone != "pointnet":
+            raise RuntimeError("training is implemented for the reference's wired denoiser (backbone='pointnet') only")
         if getattr(self, "_trainer", None) is None:
             self._trainer = PointTrainer(self.model, lr=self.lr, weight_decay=1e-5)
         return {"optimizer": self._trainer,

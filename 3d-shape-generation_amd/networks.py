@@ -223,7 +223,7 @@ class UNetPointNetLarge(_HipModule):
 
 # ------------------------------------------------------------------ set attention
 class _PackedSAB:
-    """Device weights of one SetAttentionBlock (reference networks.py:51-68)."""
+    """Device weights of one SetAttentionBlock (reference networks.py:51-68) and their C descriptor."""
 
     def __init__(self, sd, prefix: str, dim: int, dev):
         g = lambda k: sd[prefix + k].detach().to("cpu", torch.float64).numpy()
@@ -235,20 +235,15 @@ class _PackedSAB:
         self.w_ff1, self.b_ff1 = _dev16(g("ff.0.weight"), dev), _dev32(g("ff.0.bias"), dev)
         self.w_ff2, self.b_ff2 = _dev16(g("ff.2.weight"), dev), _dev32(g("ff.2.bias"), dev)
 
-    def run(self, x16: torch.Tensor, batch: int, n: int, heads: int) -> torch.Tensor:
-        """x16 fp16 [B*N][C] -> fp16 [B*N][C]  (networks.py:80-83, without the two transposes)."""
-        from . import ops
-        h = ops.layernorm_f16(x16, self.ln1_g, self.ln1_b)                       # LN1 (q = k = v source)
-        qkv = ops.gemm_f16(h, self.w_in, self.b_in)                              # in_proj C -> 3C
-        att = ops.set_attention_f16(qkv, batch, n, self.dim, heads)              # softmax(QK^T/sqrt d) V
-        x16 = ops.gemm_f16_residual(att, self.w_out, self.b_out, x16)            # x + out_proj(.)
-        h = ops.layernorm_f16(x16, self.ln2_g, self.ln2_b)
-        h = ops.gemm_f16(h, self.w_ff1, self.b_ff1, relu=True)                   # Linear(C,4C)+ReLU
-        return ops.gemm_f16_residual(h, self.w_ff2, self.b_ff2, x16)             # x + Linear(4C,C)
+    def fill(self, d: "_lib.SabDesc") -> "_lib.SabDesc":
+        d.dim = self.dim
+        for k in ("w_in", "b_in", "w_out", "b_out", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "w_ff1", "b_ff1", "w_ff2", "b_ff2"):
+            setattr(d, k, getattr(self, k).data_ptr())
+        return d
 
 
 class SetAttentionBlock(_HipModule):
-    """Drop-in for reference networks.py:51-83: (B, N, C) -> (B, N, C), pre-LN MHA + FFN."""
+    """Drop-in for reference networks.py:51-83: (B, N, C) -> (B, N, C), pre-LN MHA + FFN, one pcd_sab_forward call."""
 
     def __init__(self, dim: int, num_heads: int):
         super().__init__()
@@ -259,7 +254,8 @@ class SetAttentionBlock(_HipModule):
         if self._packed is None:
             dev = self._need_cuda()
             _lib.require_gpu()
-            self._packed = _PackedSAB(self.state_dict(), "", self.dim, dev)
+            pk = _PackedSAB(self.state_dict(), "", self.dim, dev)
+            self._packed = (pk, pk.fill(_lib.SabDesc()))
         return self._packed
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -267,29 +263,39 @@ class SetAttentionBlock(_HipModule):
         b, n, c = x.shape
         if c != self.dim:
             raise ValueError(f"expected {self.dim} channels, got {c}")
-        pk = self._ensure_packed()
+        _, desc = self._ensure_packed()
+        lib = _lib.load()
         x16 = x.to(torch.float16).contiguous().reshape(b * n, c)
-        return pk.run(x16, b, n, self.num_heads).reshape(b, n, c).to(x.dtype)
-
-
-class _PackedPNL:
-    """PointNetLayer (networks.py:16-49) with BN folded: three (W fp16, b fp32) stages."""
-
-    def __init__(self, sd, prefix: str, dev):
-        self.stages = []
-        for i in (1, 2, 3):
-            w, b = packing.fold_conv_bn(sd, f"{prefix}.conv{i}", f"{prefix}.bn{i}")
-            self.stages.append((w, b))
-        self.dev = [( _dev16(w, dev), _dev32(b, dev)) for w, b in self.stages]
+        y16 = torch.empty_like(x16)
+        ws = self._workspace((b, n), lib.pcd_sab_workspace_bytes(b * n, c))
+        _lib.check(lib.pcd_sab_forward(C.byref(desc), x16.data_ptr(), b, n, self.num_heads, y16.data_ptr(), ws.data_ptr(),
+                                       ws.numel(), _lib.stream_ptr()), "sab_forward")
+        return y16.reshape(b, n, c).to(x.dtype)
 
 
 class UNetAttentionPointExperimental(_HipModule):
-    """Drop-in for reference networks.py:597-722 (the carrier of the set-attention blocks)."""
+    """Drop-in for reference networks.py:597-722 (the carrier of the set-attention blocks): eps = model(x (B,N,3), t (B,)).
+    One pcd_attn_unet_forward call per forward; `time_bias` / `forward_with_bias` give the samplers the same two-stage
+    surface as UNetPointNetLarge (the whole time path once per sampler call, one 704-float row per timestep)."""
+
+    TB = _lib.PCD_ATTN_UNET_TB
 
     def __init__(self, num_points, dim=256, num_heads=4, num_blocks=3, time_dim=256):
         super().__init__()
         self.num_points, self.dim, self.num_heads, self.time_dim = num_points, dim, num_heads, time_dim
         self._build_from_spec(specs.unet_attention_spec(dim, time_dim))
+        self._handle = None
+
+    def _release(self):
+        if getattr(self, "_handle", None):
+            _lib.load().pcd_attn_unet_destroy(self._handle)
+        self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
 
     def _ensure_packed(self):
         if self._packed is not None:
@@ -301,80 +307,77 @@ class UNetAttentionPointExperimental(_HipModule):
         _lib.require_gpu()
         sd = self.state_dict()
         g = lambda k: sd[k].detach().to("cpu", torch.float64).numpy()
-        pk = {"freqs": packing.timestep_freqs(self.time_dim).to(dev)}
-        for k in ("time_mlp.0", "time_mlp.2") + tuple(n for n, _ in specs.ATTN_UNET_EMB):
-            pk[k + ".w"], pk[k + ".b"] = _dev32(g(k + ".weight"), dev), _dev32(g(k + ".bias"), dev)
+        keep = {"freqs": packing.timestep_freqs(self.time_dim).to(dev)}
+        desc = _lib.AttnUnetDesc()
+        desc.dim, desc.time_dim, desc.heads = self.dim, self.time_dim, self.num_heads
+        desc.freqs = keep["freqs"].data_ptr()
+        for name, field in (("time_mlp.0", "t*0"), ("time_mlp.2", "t*2")):
+            keep[name + ".w"], keep[name + ".b"] = _dev32(g(name + ".weight"), dev), _dev32(g(name + ".bias"), dev)
+            setattr(desc, field.replace("*", "w"), keep[name + ".w"].data_ptr())
+            setattr(desc, field.replace("*", "b"), keep[name + ".b"].data_ptr())
+        for i, (name, _) in enumerate(specs.ATTN_UNET_EMB):
+            keep[name + ".w"], keep[name + ".b"] = _dev32(g(name + ".weight"), dev), _dev32(g(name + ".bias"), dev)
+            desc.emb_w[i], desc.emb_b[i] = keep[name + ".w"].data_ptr(), keep[name + ".b"].data_ptr()
         # enc1 = PointNetLayer(3, 64): the K=3 first conv runs in the xyz kernel
         w, b = packing.fold_conv_bn(sd, "enc1.conv1", "enc1.bn1")
-        pk["e1w"], pk["e1b"] = _dev32(w, dev), _dev32(b, dev)
-        pk["enc1"] = [(_dev16(w, dev), _dev32(b, dev)) for w, b in
-                      (packing.fold_conv_bn(sd, f"enc1.conv{i}", f"enc1.bn{i}") for i in (2, 3))]
-        for name in ("enc2", "enc3", "dec3", "dec2"):
-            pk[name] = _PackedPNL(sd, name, dev).dev
-        for name, c in (("att1", 64), ("att2", 128), ("att3", 256), ("bottleneck", 256), ("att_dec3", 256),
-                        ("att_dec2", 128), ("att_dec1", 64)):
-            pk[name] = _PackedSAB(sd, name + ".", c, dev)
+        keep["e1w"], keep["e1b"] = _dev32(w, dev), _dev32(b, dev)
+        desc.e1w, desc.e1b = keep["e1w"].data_ptr(), keep["e1b"].data_ptr()
+        stages = [("enc1", 2), ("enc1", 3)] + [(n, i) for n in ("enc2", "enc3", "dec3", "dec2") for i in (1, 2, 3)]
+        for j, (name, i) in enumerate(stages):
+            w, b = packing.fold_conv_bn(sd, f"{name}.conv{i}", f"{name}.bn{i}")
+            keep[f"w{j}"], keep[f"b{j}"] = _dev16(w, dev), _dev32(b, dev)
+            desc.lin[j].w, desc.lin[j].b = keep[f"w{j}"].data_ptr(), keep[f"b{j}"].data_ptr()
+            desc.lin[j].c, desc.lin[j].k = w.shape
+        for j, (name, c) in enumerate((("att1", 64), ("att2", 128), ("att3", 256), ("bottleneck", 256), ("att_dec3", 256),
+                                       ("att_dec2", 128), ("att_dec1", 64))):
+            keep[name] = _PackedSAB(sd, name + ".", c, dev)
+            keep[name].fill(desc.sab[j])
         # tail: dec1 = PointNetLayer(128, 3, 3) + output Conv1d(3,3)
         w1, b1 = packing.fold_conv_bn(sd, "dec1.conv1", "dec1.bn1")
         w2, b2 = packing.fold_conv_bn(sd, "dec1.conv2", "dec1.bn2")
         w3, b3 = packing.fold_conv_bn(sd, "dec1.conv3", "dec1.bn3")
         w4, b4 = packing.fold_conv_bn(sd, "output", None)
-        pk["t_w1"], pk["t_b1"] = _dev32(w1, dev), _dev32(b1, dev)
-        pk["t_w234"] = _dev32(np.stack([w2, w3, w4]), dev)
-        pk["t_b234"] = _dev32(np.stack([b2, b3, b4]), dev)
-        self._packed = pk
-        return pk
+        keep["t_w1"], keep["t_b1"] = _dev32(w1, dev), _dev32(b1, dev)
+        keep["t_w234"] = _dev32(np.stack([w2, w3, w4]), dev)
+        keep["t_b234"] = _dev32(np.stack([b2, b3, b4]), dev)
+        for k in ("t_w1", "t_b1", "t_w234", "t_b234"):
+            setattr(desc, k, keep[k].data_ptr())
+        handle = C.c_void_p()
+        _lib.check(_lib.load().pcd_attn_unet_create(C.byref(desc), C.byref(handle)), "attn_unet_create")
+        self._handle, self._packed = handle, keep
+        return keep
+
+    def time_bias(self, t: torch.Tensor) -> torch.Tensor:
+        """Every time-dependent vector of the network for each value of t: (len(t), 704) fp32 rows
+        [enc1 bias | emb2 | emb3 | emb_dec3 | emb_dec2 | emb_dec1] (networks.py:664-698)."""
+        self._ensure_packed()
+        t = t.to(self.device, torch.float32).contiguous()
+        out = torch.empty(t.numel(), self.TB, dtype=torch.float32, device=self.device)
+        scratch = torch.empty(t.numel(), self.dim, dtype=torch.float32, device=self.device)
+        _lib.check(_lib.load().pcd_attn_unet_time_bias(self._handle, t.data_ptr(), t.numel(), scratch.data_ptr(),
+                                                       out.data_ptr(), _lib.stream_ptr()), "attn_unet_time_bias")
+        return out
+
+    def forward_with_bias(self, x: torch.Tensor, tbias: torch.Tensor, shape_stride: int,
+                          out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self._ensure_packed()
+        b, n, _ = x.shape
+        lib = _lib.load()
+        ws = self._workspace((b, n), lib.pcd_attn_unet_workspace_bytes(b, n))
+        if out is None:
+            out = torch.empty_like(x)
+        _lib.check(lib.pcd_attn_unet_forward(self._handle, x.data_ptr(), b, n, tbias.data_ptr(), shape_stride,
+                                             out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "attn_unet_forward")
+        return out
 
     def forward(self, x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
-        from . import ops
         self._need_cuda(x, t)
-        pk = self._ensure_packed()
-        lib = _lib.load()
-        b, n, _ = x.shape
-        m = b * n
-        dev = self.device
+        if x.dim() != 3 or x.shape[2] != 3:
+            raise ValueError(f"x must be (B, N, 3), got {tuple(x.shape)}")
+        if t.dim() != 1 or t.shape[0] != x.shape[0]:
+            raise ValueError(f"t must be (B,), got {tuple(t.shape)} for batch {x.shape[0]}")
         x = x.to(torch.float32).contiguous()
-        t = t.to(torch.float32).contiguous()
-        st = _lib.stream_ptr()
-        # time path (fp32): t_embed = time_mlp(sinusoidal(t)); per-level embeddings emb*(t_embed)
-        temb = torch.empty(b, self.dim, dtype=torch.float32, device=dev)
-        _lib.check(lib.pcd_time_embed(t.data_ptr(), b, pk["freqs"].data_ptr(), self.time_dim, self.dim,
-                                      pk["time_mlp.0.w"].data_ptr(), pk["time_mlp.0.b"].data_ptr(),
-                                      pk["time_mlp.2.w"].data_ptr(), pk["time_mlp.2.b"].data_ptr(),
-                                      temb.data_ptr(), 0, 0, 0, 0, st), "time_embed")
-        emb = {name: ops.linear_f32(temb, pk[name + ".w"], pk[name + ".b"]) for name, _ in specs.ATTN_UNET_EMB}
-
-        def add(h, e, c):
-            out = torch.empty_like(h)
-            _lib.check(lib.pcd_add_shape_bias_f16(h.data_ptr(), m, c, n, e.data_ptr(), out.data_ptr(), st), "add_bias")
-            return out
-
-        def pnl(stages, a1, a2=None):
-            h = ops.gemm_f16(a1, stages[0][0], stages[0][1], a2=a2, relu=True)
-            for w, bb in stages[1:]:
-                h = ops.gemm_f16(h, w, bb, relu=True)
-            return h
-
-        # enc1.conv1(x + e1) = W x + (W e1 + b): per-shape bias of the K=3 kernel
-        tb1 = ops.linear_f32(emb["emb1"], pk["e1w"], pk["e1b"])
-        h = torch.empty(m, 64, dtype=torch.float16, device=dev)
-        _lib.check(lib.pcd_enc1_xyz(x.data_ptr(), m, n, pk["e1w"].data_ptr(), 64, tb1.data_ptr(), 1, h.data_ptr(), st), "enc1")
-        x1 = pnl(pk["enc1"], h)
-        x1 = pk["att1"].run(x1, b, n, self.num_heads)
-        x1 = add(x1, emb["emb2"], 64)
-        x2 = pk["att2"].run(pnl(pk["enc2"], x1), b, n, self.num_heads)
-        x2 = add(x2, emb["emb3"], 128)
-        x3 = pk["att3"].run(pnl(pk["enc3"], x2), b, n, self.num_heads)
-        xb = pk["bottleneck"].run(x3, b, n, self.num_heads)
-        xb = pk["att_dec3"].run(add(xb, emb["emb_dec3"], 256), b, n, self.num_heads)
-        h = pnl(pk["dec3"], xb, x3)
-        h = pk["att_dec2"].run(add(h, emb["emb_dec2"], 128), b, n, self.num_heads)
-        h = pnl(pk["dec2"], h, x2)
-        h = pk["att_dec1"].run(add(h, emb["emb_dec1"], 64), b, n, self.num_heads)
-        out = torch.empty(b, n, 3, dtype=torch.float32, device=dev)
-        _lib.check(lib.pcd_tail3(h.data_ptr(), 64, x1.data_ptr(), 64, m, pk["t_w1"].data_ptr(), pk["t_b1"].data_ptr(),
-                                 pk["t_w234"].data_ptr(), pk["t_b234"].data_ptr(), out.data_ptr(), st), "tail3")
-        return out
+        return self.forward_with_bias(x, self.time_bias(t), 1)
 
 
 # ------------------------------------------------------------------ latent denoiser

@@ -7,6 +7,7 @@ The training surface (`calculate_loss`, `training_step`, `configure_optimizers`)
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Dict, List, Tuple
 
 import numpy as np
@@ -85,6 +86,7 @@ class VAE3DLarge(_HipModule):
             raise ValueError("VAE3DLarge's encoder reduces 32^3 to 1^3; other input shapes fail in the reference too")
         self.latent_dim = latent_dim
         self._build_from_spec(specs.vae3d_large_spec(latent_dim))
+        self._handle = None
         # reference init_weights (networks.py:2281-2283): xavier-normal(gain 0.01) for the latent heads
         with torch.no_grad():
             for name in ("fc_mu", "fc_logvar"):
@@ -209,80 +211,70 @@ class VAE3DLarge(_HipModule):
         wl_, bl_ = g("decoder.12.weight"), g("decoder.12.bias")
         pk["last_w"] = _dev32(np.transpose(wl_[0], (1, 2, 3, 0)).reshape(27, -1), dev)
         pk["last_b"] = float(bl_[0])
+        # the C descriptor of pcd_vae_create: the encode / decode programs run behind one handle
+        def cdesc(dst, L):
+            dst.w, dst.b, dst.kpad, dst.cin, dst.cout, dst.k = L["w"].data_ptr(), L["b"].data_ptr(), L["kpad"], L["cin"], L["cout"], L["k"]
+
+        def rdesc(dst, R):
+            cdesc(dst.c1, R["c1"]); cdesc(dst.c2, R["c2"])
+            dst.has_ds = 1 if "ds" in R else 0
+            if "ds" in R:
+                cdesc(dst.ds, R["ds"])
+
+        def tdesc(dst, T):
+            for cls in T["classes"]:
+                pz, py, px = cls["p"]
+                k = 4 * pz + 2 * py + px
+                dst.w[k], dst.taps[k] = cls["w"].data_ptr(), cls["taps"].data_ptr()
+            dst.b, dst.cin, dst.cout = T["b"].data_ptr(), T["cin"], T["cout"]
+
+        d = _lib.VaeDesc()
+        d.latent_dim = self.latent_dim
+        d.enc0_w, d.enc0_b = pk["enc0_w"].data_ptr(), pk["enc0_b"].data_ptr()
+        for i, idx in enumerate((2, 5, 8, 11)):
+            rdesc(d.enc_res[i], pk[f"enc{idx}"])
+            rdesc(d.dec_res[i], pk[f"dec{idx}"])
+        for i, idx in enumerate((3, 6, 9)):
+            cdesc(d.enc_down[i], pk[f"enc{idx}"])
+        for i, idx in enumerate((0, 3, 6)):
+            tdesc(d.dec_up[i], pk[f"dec{idx}"])
+        cdesc(d.enc_last, pk["enc12"])
+        cdesc(d.dec_conv9, pk["dec9"])
+        d.fc_w, d.fc_b, d.din_w, d.din_b = (pk[k].data_ptr() for k in ("fc_w", "fc_b", "din_w", "din_b"))
+        d.last_w, d.last_b = pk["last_w"].data_ptr(), pk["last_b"]
+        d.taps3, d.taps4s2, d.taps4p0, d.taps1 = (pk[k].data_ptr() for k in ("taps3", "taps4s2", "taps4p0", "taps1"))
+        d.zero_page = pk["zero"].data_ptr()
+        handle = C.c_void_p()
+        _lib.check(_lib.load().pcd_vae_create(C.byref(d), C.byref(handle)), "vae_create")
+        self._handle = handle
         self._packed = pk
         return pk
 
-    # ---------------------------------------------------------------- launches
-    def _conv(self, L, x, b, din, stride, taps, relu, resid=None, dout=None):
-        lib = _lib.load()
-        pk = self._packed
-        k = L["k"]
-        if dout is None:
-            dout = din if (k == 3 or k == 1) else (din // 2 if stride == 2 else 1)
-        out = torch.empty(b * dout ** 3, L["cout"], dtype=torch.float16, device=x.device)
-        d = _lib.Conv3dDesc()
-        d.inp, d.batch, d.in_d, d.in_h, d.in_w, d.cin = x.data_ptr(), b, din, din, din, L["cin"]
-        d.rows_d = d.rows_h = d.rows_w = dout
-        d.stride = stride
-        d.taps, d.ntaps, d.kpad = taps.data_ptr(), taps.numel(), L["kpad"]
-        d.w, d.bias, d.resid, d.relu = L["w"].data_ptr(), L["b"].data_ptr(), _lib.ptr(resid), 1 if relu else 0
-        d.out, d.cout = out.data_ptr(), L["cout"]
-        d.out_d = d.out_h = d.out_w = dout
-        d.out_scale, d.out_off_z, d.out_off_y, d.out_off_x = 1, 0, 0, 0
-        d.zero_page = pk["zero"].data_ptr()
-        if k == 3 and stride == 1 and lib.pcd_conv3d_k3s1_supported(d):
-            _lib.check(lib.pcd_conv3d_k3s1_f16(d, _lib.stream_ptr()), "conv3d_k3s1")   # LDS-resident halo
-        else:
-            _launch_convs([d], x.device, "conv3d")
-        return out
+    def _release(self):
+        if getattr(self, "_handle", None):
+            _lib.load().pcd_vae_destroy(self._handle)
+        self._handle = None
 
-    def _convT(self, L, x, b, din):
-        dout = 2 * din
-        out = torch.empty(b * dout ** 3, L["cout"], dtype=torch.float16, device=x.device)
-        descs = []
-        for cls in L["classes"]:
-            d = _lib.Conv3dDesc()
-            d.inp, d.batch, d.in_d, d.in_h, d.in_w, d.cin = x.data_ptr(), b, din, din, din, L["cin"]
-            d.rows_d = d.rows_h = d.rows_w = din
-            d.stride = 1
-            d.taps, d.ntaps, d.kpad = cls["taps"].data_ptr(), 8, 8 * L["cin"]
-            d.w, d.bias, d.resid, d.relu = cls["w"].data_ptr(), L["b"].data_ptr(), 0, 1
-            d.out, d.cout = out.data_ptr(), L["cout"]
-            d.out_d = d.out_h = d.out_w = dout
-            d.out_scale = 2
-            d.out_off_z, d.out_off_y, d.out_off_x = cls["p"]
-            d.zero_page = self._packed["zero"].data_ptr()
-            descs.append(d)
-        _launch_convs(descs, x.device, "conv3d(T)")                 # the 8 parity classes in one launch
-        return out
-
-    def _res(self, R, x, b, dim):
-        pk = self._packed
-        h = self._conv(R["c1"], x, b, dim, 1, pk["taps3"], relu=True)
-        resid = self._conv(R["ds"], x, b, dim, 1, pk["taps1"], relu=False) if "ds" in R else x
-        return self._conv(R["c2"], h, b, dim, 1, pk["taps3"], relu=True, resid=resid)   # relu(bn2(conv2) + residual)
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
 
     # ---------------------------------------------------------------- reference API
     def encode(self, x: torch.Tensor):
-        """networks.py:2299-2310: (B,1,32,32,32) -> (mu, logvar), each (B, latent_dim)."""
-        from . import ops
+        """networks.py:2299-2310: (B,1,32,32,32) -> (mu, logvar), each (B, latent_dim).  One pcd_vae_encode call."""
         self._need_cuda(x)
-        pk = self._ensure_packed()
+        self._ensure_packed()
         lib = _lib.load()
         b = x.shape[0]
+        if tuple(x.shape[1:]) != (1, 32, 32, 32):
+            raise ValueError(f"x must be (B, 1, 32, 32, 32), got {tuple(x.shape)}")
         x = x.to(torch.float32).contiguous()
-        h = torch.empty(b * 32768, 32, dtype=torch.float16, device=x.device)
-        _lib.check(lib.pcd_conv3d_first(x.data_ptr(), b, 32, 32, 32, 1, pk["enc0_w"].data_ptr(), pk["enc0_b"].data_ptr(),
-                                        32, h.data_ptr(), _lib.stream_ptr()), "conv3d_first")
-        h = self._res(pk["enc2"], h, b, 32)
-        h = self._conv(pk["enc3"], h, b, 32, 2, pk["taps4s2"], relu=True)
-        h = self._res(pk["enc5"], h, b, 16)
-        h = self._conv(pk["enc6"], h, b, 16, 2, pk["taps4s2"], relu=True)
-        h = self._res(pk["enc8"], h, b, 8)
-        h = self._conv(pk["enc9"], h, b, 8, 2, pk["taps4s2"], relu=True)
-        h = self._res(pk["enc11"], h, b, 4)
-        h = self._conv(pk["enc12"], h, b, 4, 1, pk["taps4p0"], relu=True, dout=1)      # (B, 512)
-        out = ops.gemm_f16_out32(h, pk["fc_w"], pk["fc_b"])
+        out = torch.empty(b, 2 * self.latent_dim, dtype=torch.float32, device=x.device)
+        ws = self._workspace((b,), lib.pcd_vae_workspace_bytes(b))
+        _lib.check(lib.pcd_vae_encode(self._handle, x.data_ptr(), b, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                      _lib.stream_ptr()), "vae_encode")
         return out[:, :self.latent_dim].contiguous(), out[:, self.latent_dim:].contiguous()
 
     def reparameterize(self, mu, logvar, eps=None):
@@ -304,25 +296,16 @@ class VAE3DLarge(_HipModule):
         return z
 
     def decode(self, z: torch.Tensor) -> torch.Tensor:
-        """networks.py:2327-2339: (B, latent_dim) -> occupancy probabilities (B,1,32,32,32) fp32."""
-        from . import ops
+        """networks.py:2327-2339: (B, latent_dim) -> occupancy probabilities (B,1,32,32,32) fp32.  One pcd_vae_decode call."""
         self._need_cuda(z)
-        pk = self._ensure_packed()
+        self._ensure_packed()
         lib = _lib.load()
         b = z.shape[0]
-        z16 = z.to(torch.float16).contiguous()
-        h = ops.gemm_f16(z16, pk["din_w"], pk["din_b"]).reshape(b * 64, 512)           # NDHWC (B,4,4,4,512)
-        h = self._convT(pk["dec0"], h, b, 4)
-        h = self._res(pk["dec2"], h, b, 8)
-        h = self._convT(pk["dec3"], h, b, 8)
-        h = self._res(pk["dec5"], h, b, 16)
-        h = self._convT(pk["dec6"], h, b, 16)
-        h = self._res(pk["dec8"], h, b, 32)
-        h = self._conv(pk["dec9"], h, b, 32, 1, pk["taps3"], relu=True)
-        h = self._res(pk["dec11"], h, b, 32)
+        z = z.to(torch.float32).contiguous()
         out = torch.empty(b, 1, 32, 32, 32, dtype=torch.float32, device=z.device)
-        _lib.check(lib.pcd_conv3d_last_sigmoid(h.data_ptr(), b, 32, 32, 32, 32, pk["last_w"].data_ptr(), pk["last_b"],
-                                               out.data_ptr(), _lib.stream_ptr()), "conv3d_last")
+        ws = self._workspace((b,), lib.pcd_vae_workspace_bytes(b))
+        _lib.check(lib.pcd_vae_decode(self._handle, z.data_ptr(), b, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                      _lib.stream_ptr()), "vae_decode")
         return out
 
     def forward(self, x, eps=None):

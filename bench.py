@@ -204,7 +204,7 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
-def attention_roofline(device, launches=20):
+def attention_roofline(device, launches=100):
     """HIP events (torch's current stream is the stream the kernel is launched on) around
     pcd_set_attention_f16 at B=64, N=2048, C=256, 4 heads."""
     import torch
@@ -219,16 +219,18 @@ def attention_roofline(device, launches=20):
                                              _lib.stream_ptr()), "set_attention")
     for _ in range(10):
         launch()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(launches + 1)]
+    # one event pair around the whole train of launches (an event record between kernels costs tens of microseconds of
+    # its own, comparable to the kernel)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
-    ev[0].record()
-    for i in range(launches):
+    e0.record()
+    for _ in range(launches):
         launch()
-        ev[i + 1].record()
+    e1.record()
     torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / launches
     if not torch.isfinite(out.float()).all():
         raise SystemExit("set attention produced non-finite values")
-    ms = sum(ev[i].elapsed_time(ev[i + 1]) for i in range(launches)) / launches
     achieved = ATT_FLOP_PER_LAUNCH / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": "set_attention_sp_kernel (QK^T, softmax, PV; d_head 64; software-pipelined, 2 query blocks per wave)",
             "achieved": achieved, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -103,7 +103,8 @@ int pcd_linear_f32(const float* x, int rows, int k, const float* w, const float*
 
 /* enc1.conv1 xyz half (K=3) + per-shape time bias + ReLU -> fp16 [M][c1]
  * x fp32 [M][3]; w_xyz fp32 [c1][3]; tbias fp32 [n_t][c1] with row index
- * (m / rows_per_shape) * tbias_shape_stride (stride 0 = same t for all shapes). */
+ * (m / rows_per_shape) * tbias_shape_stride (stride 0 = same t for all shapes; rows are c1 floats, so a
+ * stride > 1 walks a wider table whose rows are a multiple of c1 apart). */
 int pcd_enc1_xyz(const float* x, int64_t m, int rows_per_shape, const float* w_xyz, int c1,
                  const float* tbias, int tbias_shape_stride, void* out, void* stream);
 
@@ -278,6 +279,39 @@ int pcd_convt3d_last_sigmoid(const void* in, int batch, int d, int h, int w, int
 /* z = mu + eps * exp(0.5 * logvar)  (networks.py:2323-2325), fp32 */
 int pcd_reparameterize(const float* mu, const float* logvar, const float* eps, float* z, int64_t n, void* stream);
 
+/* ---- whole VAE3DLarge.encode / decode (networks.py:2299-2310, 2327-2339) behind a handle ----
+ * The host packer folds eval-mode BatchNorm3d into the conv weights and lays them out as the layer-level entry
+ * points above expect: Conv3d [cout][k^3 * cin] tap-major zero-padded to kpad; each ConvTranspose3d(k4,s2,p1) as 8
+ * output-parity classes [cout][8 * cin] with their 2x2x2 tap tables (class index = 4 pz + 2 py + px). */
+typedef struct { const void* w; const float* b; int kpad, cin, cout, k; } pcd_vae_conv_t;
+typedef struct { pcd_vae_conv_t c1, c2, ds; int has_ds; } pcd_vae_res_t;              /* ResidualBlock3D */
+typedef struct { const void* w[8]; const int* taps[8]; const float* b; int cin, cout; } pcd_vae_convT_t;
+typedef struct {
+    int latent_dim;
+    const float* enc0_w; const float* enc0_b;          /* encoder.0 fp32 [32][27], [32] */
+    pcd_vae_res_t enc_res[4];                          /* encoder.2, 5, 8, 11 */
+    pcd_vae_conv_t enc_down[3];                        /* encoder.3, 6, 9   (k4, s2, p1) */
+    pcd_vae_conv_t enc_last;                           /* encoder.12        (k4, p0) */
+    const void* fc_w; const float* fc_b;               /* [fc_mu ; fc_logvar] fp16 [2*latent][512], fp32 [2*latent] */
+    const void* din_w; const float* din_b;             /* decoder_input fp16 [512*64][latent], rows permuted to (z,y,x,c) */
+    pcd_vae_convT_t dec_up[3];                         /* decoder.0, 3, 6 */
+    pcd_vae_res_t dec_res[4];                          /* decoder.2, 5, 8, 11 */
+    pcd_vae_conv_t dec_conv9;                          /* decoder.9 */
+    const float* last_w; float last_b;                 /* decoder.12 fp32 [27][32] tap-major, bias */
+    const int* taps3; const int* taps4s2; const int* taps4p0; const int* taps1;   /* regular tap tables (k3 p1, k4 p1, k4 p0, k1) */
+    const void* zero_page;                             /* >= 128 bytes of zeros */
+} pcd_vae_desc_t;
+typedef struct pcd_vae pcd_vae_t;
+int pcd_vae_create(const pcd_vae_desc_t* desc, pcd_vae_t** out);
+void pcd_vae_destroy(pcd_vae_t* h);
+size_t pcd_vae_workspace_bytes(int batch);
+/* vox fp32 [B][1][32][32][32] in [0,1] -> mu_logvar fp32 [B][2*latent] = [mu | logvar] */
+int pcd_vae_encode(pcd_vae_t* h, const float* vox, int batch, float* mu_logvar, void* workspace, size_t workspace_bytes,
+                   void* stream);
+/* z fp32 [B][latent] -> occupancy probabilities fp32 [B][1][32][32][32] */
+int pcd_vae_decode(pcd_vae_t* h, const float* z, int batch, float* out, void* workspace, size_t workspace_bytes,
+                   void* stream);
+
 /* -------------------------------------------------------- set attention (K6/K7)
  * LayerNorm over C (eps 1e-5, biased var; networks.py:62,68) fp16 in -> fp16 out. */
 int pcd_layernorm_f16(const void* x, int64_t rows, int c, const float* gamma, const float* beta,
@@ -299,11 +333,55 @@ int pcd_set_attention_config(int force_generic);
  * embeddings of UNetAttentionPointExperimental (networks.py:669-698). */
 int pcd_add_shape_bias_f16(const void* x, int64_t m, int c, int rows_per_shape, const float* e,
                            void* out, void* stream);
+/* the same with the per-shape rows of e `e_stride` floats apart (0: one row shared by every shape) */
+int pcd_add_shape_bias_strided_f16(const void* x, int64_t m, int c, int rows_per_shape, const float* e,
+                                   int64_t e_stride, void* out, void* stream);
 /* tail of UNetAttentionPointExperimental (networks.py:647-650,700-702): dec1 = PointNetLayer(128,3,3)
  * on cat[a | b] then Conv1d(3,3); BN folded.  w1 fp32 [3][ka+kb], w234 fp32 [3][3][3], b234 [3][3];
  * out fp32 [M][3]. */
 int pcd_tail3(const void* a, int ka, const void* b, int kb, int64_t m, const float* w1, const float* b1,
               const float* w234, const float* b234, float* out, void* stream);
+
+/* ---- whole SetAttentionBlock (networks.py:51-83) and UNetAttentionPointExperimental (networks.py:597-722) ----
+ * Weights fp16 [C_out][C_in] (nn.Linear / in_proj layout), biases and LayerNorm affine fp32. */
+typedef struct {
+    int dim;                                         /* C: 64, 128 or 256 */
+    const void* w_in;  const float* b_in;            /* attention.in_proj  [3C][C] */
+    const void* w_out; const float* b_out;           /* attention.out_proj [C][C] */
+    const float* ln1_g; const float* ln1_b; const float* ln2_g; const float* ln2_b;
+    const void* w_ff1; const float* b_ff1;           /* ff.0 [4C][C] */
+    const void* w_ff2; const float* b_ff2;           /* ff.2 [C][4C] */
+} pcd_sab_desc_t;
+/* bytes of scratch one block needs for `rows` = B*N points */
+size_t pcd_sab_workspace_bytes(int64_t rows, int dim);
+/* y = x + MHA(LN1 x); y = y + W2 relu(W1 LN2 y)   x, y fp16 [B*N][C], y must not alias x */
+int pcd_sab_forward(const pcd_sab_desc_t* d, const void* x, int batch, int n_points, int heads, void* y,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+#define PCD_ATTN_UNET_NLIN 14       /* enc1.conv2,3  enc2.conv1-3  enc3.conv1-3  dec3.conv1-3  dec2.conv1-3 (BN folded) */
+#define PCD_ATTN_UNET_NSAB 7        /* att1 att2 att3 bottleneck att_dec3 att_dec2 att_dec1 */
+#define PCD_ATTN_UNET_NEMB 6        /* emb1 emb2 emb3 emb_dec3 emb_dec2 emb_dec1 */
+#define PCD_ATTN_UNET_TB 704        /* floats of one time-bias row: [enc1 bias 64 | emb2 64 | emb3 128 | emb_dec3 256 | emb_dec2 128 | emb_dec1 64] */
+typedef struct {
+    int dim, time_dim, heads;
+    const float* freqs;                              /* sinusoidal frequencies [time_dim/2] */
+    const float* tw0; const float* tb0; const float* tw2; const float* tb2;    /* time_mlp */
+    const float* emb_w[PCD_ATTN_UNET_NEMB]; const float* emb_b[PCD_ATTN_UNET_NEMB];   /* [c][dim], c = 3,64,128,256,128,64 */
+    const float* e1w; const float* e1b;              /* enc1.conv1 + bn1 folded, fp32 [64][3], [64] */
+    pcd_linear_desc_t lin[PCD_ATTN_UNET_NLIN];
+    pcd_sab_desc_t sab[PCD_ATTN_UNET_NSAB];
+    const float* t_w1; const float* t_b1; const float* t_w234; const float* t_b234;   /* dec1 + output, see pcd_tail3 */
+} pcd_attn_unet_desc_t;
+typedef struct pcd_attn_unet pcd_attn_unet_t;
+int pcd_attn_unet_create(const pcd_attn_unet_desc_t* desc, pcd_attn_unet_t** out);
+void pcd_attn_unet_destroy(pcd_attn_unet_t* h);
+size_t pcd_attn_unet_workspace_bytes(int batch, int n_points);
+/* time path for n_t values of t: tbias fp32 [n_t][PCD_ATTN_UNET_TB] (time_mlp, the six emb* layers, and emb1 pushed
+ * through enc1.conv1: conv(x + e) = W x + (W e + b), networks.py:664-672); scratch fp32 [n_t][dim] */
+int pcd_attn_unet_time_bias(pcd_attn_unet_t* h, const float* t, int n_t, float* scratch, float* tbias, void* stream);
+/* eps = model(x, t) given the time-bias rows: tbias row (b * tbias_shape_stride), stride 0 = one t for every shape */
+int pcd_attn_unet_forward(pcd_attn_unet_t* h, const float* x, int batch, int n_points, const float* tbias,
+                          int tbias_shape_stride, float* eps, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------- metrics (K10-K12)
  * normalize_to_cube (metrics.py:7-21) for B clouds of N points, fp32 in/out. */

@@ -102,3 +102,40 @@ def test_unet_attention_golden(golden):
     net = net.to("cuda").eval()
     eps = net(torch.from_numpy(g["una_x"]).cuda(), torch.from_numpy(g["una_t"]).cuda()).cpu()
     assert rel_l2(eps, g["una_eps"]) < 1e-2   # 7 attention blocks + 15 GEMMs deep in fp16
+
+
+def test_attention_backbone_under_the_samplers():
+    """the attention U-Net as an alternative backbone selectable at construction, driven by the same
+    sampler loops (device-side step select of its 704-float time-bias rows, HIP-graph replay).  DDIM `sample` (T = 12,
+    graph path) and DDPM `sample2` (injected noise) against the oracle; state_dict keys = `model.*` of the class."""
+    from oracle import torch_oracle as O
+    from shapegen_amd import specs
+    from shapegen_amd.diffusion import PointCloudDiffusion
+    sd = {"model." + k: v for k, v in una_sd().items()}
+    m = PointCloudDiffusion(num_points=128, backbone="attention")
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == [(k, s) for k, s, _ in specs.unet_attention_spec(prefix="model.")]
+    m.load_state_dict(sd, strict=True)
+    m = m.to("cuda").eval()
+    model = lambda x, t: O.unet_attention(sd, "model.", x, t)
+    g = torch.Generator().manual_seed(4)
+    xT = torch.randn(2, 128, 3, generator=g)
+    want = O.ddim_sample(model, xT, 12)
+    got = m.sample(2, 128, num_steps=12, x_T=xT.cuda())
+    assert rel_l2(got.cpu(), want) < 2e-2
+    zs = torch.randn(5, 2, 128, 3, generator=g)
+    want = O.ddpm_sample(model, xT, 6, list(zs))
+    got = m.sample2(2, 128, num_steps=6, x_T=xT.cuda(), noises=zs.cuda())
+    assert rel_l2(got.cpu(), want) < 2e-2
+    with pytest.raises(ValueError):
+        PointCloudDiffusion(num_points=128, backbone="transformer")
+
+
+def test_sab_c_entry_rejects_bad_arguments():
+    from shapegen_amd import _lib
+    import ctypes as C
+    lib = _lib.load()
+    d = _lib.SabDesc()
+    d.dim = 96
+    x = torch.zeros(256, 96, dtype=torch.float16, device="cuda")
+    assert lib.pcd_sab_forward(C.byref(d), x.data_ptr(), 1, 256, 4, x.data_ptr(), x.data_ptr(), 1 << 20, 0) != 0
+    assert b"bad argument" in lib.pcd_last_error()
