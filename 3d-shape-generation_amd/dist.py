@@ -124,13 +124,10 @@ def evaluate_sharded(original, reconstructed, use_approximate_gpu_emd: bool = Fa
     all-gathered; returns (rows (B_global, 3), their nan-mean).  `original` / `reconstructed` are (B, N, 3)
     tensors or python lists of ragged (n_i, 3) clouds (the latent samplers' output); a pair with an empty
     cloud has no metrics (the reference would raise) and gets a NaN row."""
-    from .metrics import compute_metrics
-    dev = reconstructed[0].device if len(reconstructed) else torch.device("cpu")
-    rows = torch.full((len(reconstructed), 3), float("nan"), dtype=torch.float32, device=dev)
-    for i, (o, r) in enumerate(zip(original, reconstructed)):
-        if o.shape[0] == 0 or r.shape[0] == 0:
-            continue
-        cd, emd, rec = compute_metrics(o, r, use_approximate_gpu_emd)
-        rows[i] = torch.stack([torch.as_tensor(v, dtype=torch.float32, device=dev).reshape(()) for v in (cd, emd, rec)])
+    from . import metrics
+    if len(reconstructed) == 0:
+        rows = torch.zeros(0, 3, dtype=torch.float32)
+    else:
+        rows = metrics.pair_metrics(original, reconstructed, use_approximate_gpu_emd)   # one batched enqueue, no host sync per pair
     allrows = all_gather_rows(rows)
     return allrows, torch.nanmean(allrows, dim=0)

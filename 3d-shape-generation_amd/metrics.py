@@ -31,26 +31,36 @@ def normalize_to_cube(points: torch.Tensor) -> torch.Tensor:
 def chamfer_distance(x, y, scaling_factor=1e+3):
     """metrics.py:23-47: mean_i min_j |x_i-y_j| + mean_j min_i |x_i-y_j| (unsquared L2), one scalar
     for the whole batch, times `scaling_factor`.  Distances are direct differences in fp32, which is
-    closer to the exact value than the reference's matmul-form `torch.cdist`."""
-    xn, yn = normalize_to_cube(x), normalize_to_cube(y)
-    if xn.shape[0] != yn.shape[0]:
-        raise ValueError("batch sizes must match")
-    b, n1, n2 = xn.shape[0], xn.shape[1], yn.shape[1]
-    sums = torch.empty(b, 2, dtype=torch.float32, device=xn.device)
-    _lib.check(_lib.load().pcd_chamfer_sums(xn.data_ptr(), yn.data_ptr(), b, n1, n2, sums.data_ptr(),
-                                            _lib.stream_ptr()), "chamfer_sums")
-    tot = sums.sum(dim=0)
-    return (tot[0] / (b * n1) + tot[1] / (b * n2)) * scaling_factor
+    closer to the exact value than the reference's matmul-form `torch.cdist`.
+    Runs through the batched pair kernels (`pcd_pair_metrics`: queries x target splits x pairs blocks, so a single
+    cloud pair still spreads over the chip); with equal sizes the batch-joint mean is the mean of the per-pair values."""
+    return chamfer_per_sample(x, y, scaling_factor).mean()
 
 
 def chamfer_per_sample(x, y, scaling_factor=1e+3) -> torch.Tensor:
     """Chamfer distance of each (x_b, y_b) pair, (B,) -- what test_point_ddpm.py:85-86 loops over."""
-    xn, yn = normalize_to_cube(x), normalize_to_cube(y)
-    b, n1, n2 = xn.shape[0], xn.shape[1], yn.shape[1]
-    sums = torch.empty(b, 2, dtype=torch.float32, device=xn.device)
-    _lib.check(_lib.load().pcd_chamfer_sums(xn.data_ptr(), yn.data_ptr(), b, n1, n2, sums.data_ptr(),
-                                            _lib.stream_ptr()), "chamfer_sums")
-    return (sums[:, 0] / n1 + sums[:, 1] / n2) * scaling_factor
+    x, y = _prep(x), _prep(y)
+    if x.shape[0] != y.shape[0]:
+        raise ValueError("batch sizes must match")
+    return _pair_rows(x, y, False)[:, 0] * scaling_factor
+
+
+def _pair_rows(a: torch.Tensor, b: torch.Tensor, sinkhorn: bool, epsilon=1e-2, thresh=1e-5, max_iter=100) -> torch.Tensor:
+    """pcd_pair_metrics on dense (P, N, 3) / (P, M, 3) clouds: rows (P, 3) = (Chamfer x1, Sinkhorn EMD | 0, voxel BCE)."""
+    P, n, m = a.shape[0], a.shape[1], b.shape[1]
+    dev = a.device
+    na = torch.full((P,), n, dtype=torch.int32, device=dev)
+    nb = torch.full((P,), m, dtype=torch.int32, device=dev)
+    log_mu = torch.log(torch.ones(P) / n + 1e-10).to(dev)
+    log_nu = torch.log(torch.ones(P) / m + 1e-10).to(dev)
+    lib = _lib.load()
+    out = torch.empty(P, 3, dtype=torch.float32, device=dev)
+    need = int(lib.pcd_pair_metrics_workspace_bytes(P, n, m))
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    _lib.check(lib.pcd_pair_metrics(a.data_ptr(), na.data_ptr(), n, b.data_ptr(), nb.data_ptr(), m, P, 1 if sinkhorn else 0,
+                                    float(epsilon), float(thresh), int(max_iter), log_mu.data_ptr(), log_nu.data_ptr(),
+                                    out.data_ptr(), ws.data_ptr(), need, _lib.stream_ptr()), "pair_metrics")
+    return out
 
 
 def earth_mover_distance_cpu(x, y, scaling_factor=1):
@@ -70,7 +80,11 @@ def earth_mover_distance_cpu(x, y, scaling_factor=1):
 
 def earth_mover_distance_gpu(x, y, epsilon=1e-2, thresh=1e-5, max_iter=100, scaling_factor=1):
     """metrics.py:94-158: log-domain Sinkhorn on the device."""
-    from .sinkhorn import sinkhorn_emd
+    x, y = _prep(x), _prep(y)
+    if x.shape[0] == 1 and y.shape[0] == 1:
+        # one pair: batch-global C.max() and convergence test ARE per pair, so the device-resident loop applies
+        return _pair_rows(x, y, True, epsilon, thresh, max_iter)[0, 1] * scaling_factor
+    from .sinkhorn import sinkhorn_emd           # batch-joint cost normalisation and convergence test, as the reference
     return sinkhorn_emd(normalize_to_cube(x), normalize_to_cube(y), epsilon, thresh, max_iter) * scaling_factor
 
 
@@ -83,6 +97,55 @@ def voxel_bce(gen: torch.Tensor, ref: torch.Tensor) -> torch.Tensor:
     _lib.check(_lib.load().pcd_binary_bce_mean(gen.data_ptr(), ref.data_ptr(), gen.numel(), out.data_ptr(),
                                                _lib.stream_ptr()), "binary_bce_mean")
     return out[0]
+
+
+def pair_metrics(a_clouds, b_clouds, use_approximate_gpu_emd=False, epsilon=1e-2, thresh=1e-5, max_iter=100) -> torch.Tensor:
+    """(P, 3) rows [Chamfer x1e3, EMD, voxel BCE] of the independent pairs (a_p, b_p): row p is what
+    `compute_metrics(a_p, b_p, use_approximate_gpu_emd)` returns for that pair alone (the per-sample loop of
+    test_point_ddpm.py:85-92), but all pairs run in ONE enqueue of batched kernels (`pcd_pair_metrics`) with no host
+    synchronisation.  `a_clouds` / `b_clouds`: (P, N, 3) tensors or python lists of ragged (n_i, 3) clouds; a pair with
+    an empty cloud has no metrics (the reference would raise) and gets a NaN row.  The exact Hungarian EMD
+    (use_approximate_gpu_emd=False) stays a host-side scipy solve per pair, exactly as in the reference."""
+    P = len(a_clouds)
+    dev = a_clouds[0].device if P else torch.device("cuda")
+    rows = torch.full((P, 3), float("nan"), dtype=torch.float32, device=dev)
+    keep = [i for i in range(P) if a_clouds[i].shape[0] > 0 and b_clouds[i].shape[0] > 0]
+    if not keep:
+        return rows
+    if dev.type != "cuda":
+        raise RuntimeError("metrics run only on an MI355X device: move the clouds to 'cuda' (no CPU path)")
+
+    def pack(clouds):
+        counts = [int(clouds[i].shape[0]) for i in keep]
+        nmax = max(counts)
+        if isinstance(clouds, torch.Tensor) and len(keep) == P:
+            return clouds.to(torch.float32).contiguous(), counts, nmax
+        buf = torch.zeros(len(keep), nmax, 3, dtype=torch.float32, device=dev)
+        for j, i in enumerate(keep):
+            buf[j, :counts[j]] = clouds[i]
+        return buf, counts, nmax
+
+    a, ca, na_max = pack(a_clouds)
+    b, cb, nb_max = pack(b_clouds)
+    na = torch.tensor(ca, dtype=torch.int32, device=dev)
+    nb = torch.tensor(cb, dtype=torch.int32, device=dev)
+    # log(mu + 1e-10) with the reference's fp32 torch ops (metrics.py:133-134,141), one value per pair
+    log_mu = torch.log(torch.ones(len(keep)) / torch.tensor(ca, dtype=torch.float32) + 1e-10).to(dev)
+    log_nu = torch.log(torch.ones(len(keep)) / torch.tensor(cb, dtype=torch.float32) + 1e-10).to(dev)
+    lib = _lib.load()
+    out = torch.empty(len(keep), 3, dtype=torch.float32, device=dev)
+    need = int(lib.pcd_pair_metrics_workspace_bytes(len(keep), na_max, nb_max))
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    _lib.check(lib.pcd_pair_metrics(a.data_ptr(), na.data_ptr(), na_max, b.data_ptr(), nb.data_ptr(), nb_max, len(keep),
+                                    1 if use_approximate_gpu_emd else 0, float(epsilon), float(thresh), int(max_iter),
+                                    log_mu.data_ptr(), log_nu.data_ptr(), out.data_ptr(), ws.data_ptr(), need,
+                                    _lib.stream_ptr()), "pair_metrics")
+    out[:, 0] *= 1e3                                         # chamfer_distance's default scaling_factor
+    if not use_approximate_gpu_emd:
+        for j, i in enumerate(keep):
+            out[j, 1] = earth_mover_distance_cpu(a_clouds[i], b_clouds[i]).to(torch.float32)
+    rows[torch.tensor(keep, device=dev)] = out
+    return rows
 
 
 def compute_metrics(generated_samples, reference_samples, use_approximate_gpu_emd=False):

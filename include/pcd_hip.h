@@ -414,6 +414,18 @@ int pcd_sinkhorn_cost(const float* x, const float* y, int batch, int n, int m, c
                       float epsilon, const float* alpha, const float* beta, float* row_scratch,
                       float* cost, void* stream);
 
+/* ---- a batch of independent cloud pairs in one enqueue (the evaluation loop of test_point_ddpm.py:85-92) ----
+ * Pair p = a[p][0..na[p]) vs b[p][0..nb[p]) inside padded fp32 arrays [P][na_max][3] / [P][nb_max][3]; na, nb device
+ * int32 [P], every count >= 1.  rows fp32 [P][3] = (Chamfer with scaling 1 (metrics.py:23-47), Sinkhorn EMD
+ * (metrics.py:94-158, only when with_sinkhorn, else 0), voxel BCE (metrics.py:177-181)), each computed exactly as
+ * compute_metrics(a_p, b_p) would for that pair alone: per-pair normalize_to_cube, per-pair cost normalisation, per-pair
+ * convergence test (kept on the device: all max_iter iterations are enqueued, converged pairs skip theirs; no host
+ * synchronisation).  log_mu[p] = log(1/na[p] + 1e-10), log_nu likewise, fp32 device arrays from the host's torch ops. */
+size_t pcd_pair_metrics_workspace_bytes(int pairs, int na_max, int nb_max);
+int pcd_pair_metrics(const float* a, const int* na, int na_max, const float* b, const int* nb, int nb_max, int pairs,
+                     int with_sinkhorn, float epsilon, float thresh, int max_iter, const float* log_mu,
+                     const float* log_nu, float* rows, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------ training step of the point denoiser
  * diffusion.py:70-86,170-186 (add_noise -> model in train() mode -> F.l1_loss -> AdamW, diffusion.py:60).
  * The dense products (forward, backward-data, backward-weight) are pcd_gemm_f16* calls; these entry points
