@@ -327,6 +327,30 @@ def test_skinny_fused_layer(k1, k2, c, mode, m):
     assert lib.pcd_skinny_fused_supported(2048, 4096, 0, 8) == 0 and lib.pcd_skinny_fused_supported(96, 128, 0, 8) == 0
 
 
+def test_latent_forward_chained_equals_one_launch_per_layer(ldm, golden):
+    """enc1 -> enc2 -> enc3 and dec1 -> output.0 -> output.2 as ONE launch each (intermediates in LDS, the first two layers
+    recomputed in every workgroup): the results of the one-launch-per-layer form up to the order in which the GroupNorm
+    statistics are summed (fp16 outputs may differ by one rounding), at a full tile, a ragged row
+    count and several row tiles, with a shared time-bias row and with one row per sample."""
+    from shapegen_amd import _lib
+    lib = _lib.load()
+    g = golden("latent.npz")
+    z, t = torch.from_numpy(g["lat_z"]).cuda(), torch.from_numpy(g["lat_t"]).cuda()
+    for rows in (32, 5, 70):
+        zz = z.repeat(3, 1)[:rows].contiguous() * torch.linspace(0.5, 1.5, rows, device="cuda")[:, None]
+        tt = t.repeat(3)[:rows].contiguous()
+        for per_sample in (True, False):
+            tb = ldm.model.time_bias(tt if per_sample else tt[:1])
+            a = ldm.model.forward_with_bias(zz, tb, 1 if per_sample else 0)
+            _lib.check(lib.pcd_latent_config(0))
+            try:
+                b = ldm.model.forward_with_bias(zz, tb, 1 if per_sample else 0)
+            finally:
+                _lib.check(lib.pcd_latent_config(1))
+            assert float((a - b).abs().max()) <= 2e-3 and rel_l2(a.cpu(), b.cpu()) < 2e-4, (rows, per_sample)
+    assert rel_l2(ldm.model(z, t).cpu(), g["lat_eps"]) < 3e-3
+
+
 def test_skinny_fused_fp32_input_equals_converted_input():
     """enc1 of the latent denoiser reads the fp32 state directly: same bits as converting to fp16 first."""
     from shapegen_amd import _lib
