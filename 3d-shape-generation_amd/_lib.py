@@ -68,10 +68,6 @@ class AttnUnetDesc(C.Structure):
                 ("t_w1", vp), ("t_b1", vp), ("t_w234", vp), ("t_b234", vp)]
 
 
-class ChainLayer(C.Structure):
-    _fields_ = [("w", vp), ("bias", vp), ("gamma", vp), ("beta", vp)]
-
-
 class Conv3dDesc(C.Structure):
     _fields_ = [("inp", vp), ("batch", i32), ("in_d", i32), ("in_h", i32), ("in_w", i32), ("cin", i32),
                 ("rows_d", i32), ("rows_h", i32), ("rows_w", i32), ("stride", i32),
@@ -141,16 +137,14 @@ _SIGS = {
     "pcd_skinny_slabs": (i32, [i32, i32]),
     "pcd_skinny_gemm_f16": (i32, [vp, i32, vp, i32, vp, i64, i32, i32, vp, vp]),
     "pcd_skinny_finish": (i32, [vp, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
+    "pcd_skinny_config": (i32, [i32]),
     "pcd_skinny_fused_supported": (i32, [i32, i32, i32, i32]),
     "pcd_skinny_fused": (i32, [vp, i32, vp, i32, vp, i64, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
     "pcd_skinny_fused_f32in": (i32, [vp, i32, vp, i64, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
-    "pcd_latent_chain_enc": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp]),
-    "pcd_latent_chain_out": (i32, [vp, vp, i32, vp, vp, vp]),
     "pcd_latent_create": (i32, [C.POINTER(LatentDesc), C.POINTER(vp)]),
     "pcd_latent_destroy": (None, [vp]),
     "pcd_latent_workspace_bytes": (sz, [i32]),
     "pcd_latent_forward": (i32, [vp, vp, i32, vp, i32, vp, vp, sz, vp]),
-    "pcd_latent_config": (i32, [i32]),
     "pcd_conv3d_f16": (i32, [C.POINTER(Conv3dDesc), vp]),
     "pcd_conv3d_k3s1_supported": (i32, [C.POINTER(Conv3dDesc)]),
     "pcd_conv3d_k3s1_f16": (i32, [C.POINTER(Conv3dDesc), vp]),

@@ -44,4 +44,12 @@ __device__ __forceinline__ half_t to_half_sat(float v) {
     return (half_t)v;
 }
 
+// LDS-DMA of 16 bytes per lane (1 KiB per wave-instruction): global `g` (per-lane address) -> LDS at the wave-uniform
+// address `lds_wave_base` + lane * 16.  Issued from inline asm so the compiler does not serialise later LDS reads behind
+// it; the caller owns the `s_waitcnt vmcnt` and the barrier that make the bytes visible.
+__device__ __forceinline__ void lds_dma16(const void* g, const void* lds_wave_base) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m0v) : "memory", "m0");
+}
+
 }  // namespace pcd

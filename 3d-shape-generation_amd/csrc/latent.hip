@@ -4,9 +4,8 @@
 // step, B <= 256 rows).  Algebra applied by the host packer: refine_k folded into the skip half
 // of dec_k (linear into linear); the time half of enc1 hoisted into a per-t bias (pcd_time_embed).
 //
-// The step is bound by dependent-launch latency (~4 us per launch), so launches are merged where a workgroup can hold
-// the work: enc1 -> enc2 -> enc3 and dec1 -> output.0 -> output.2 are ONE launch each (pcd_latent_chain_enc/out), dec2 one
-// fused launch; layers 3-7 (>= 1 MB of weights) run as a weight-streaming split-K GEMM + finishing kernel (csrc/skinny.hip).
+// Layers 3-7 (>= 1 MB of weights) run as a weight-streaming split-K GEMM + finishing kernel; the other seven as one
+// fused launch each (csrc/skinny.hip).
 //
 // lin[] execution order (K -> C):  0 enc1 256->128 (+tbias)   1 enc2 128->256   2 enc3 256->512
 //   3 enc4 512->1024   4 global_feat.0 1024->2048   5 global_feat.3 2048->4096
@@ -85,13 +84,6 @@ extern "C" int pcd_groupnorm_relu_f16(const float* x, int rows, int c, int group
     return PCD_OK;
 }
 
-static int g_latent_chains = 1;     // tuning / testing hook: 0 = one launch per layer
-
-extern "C" int pcd_latent_config(int use_chains) {
-    g_latent_chains = use_chains ? 1 : 0;
-    return PCD_OK;
-}
-
 extern "C" int pcd_latent_create(const pcd_latent_desc_t* desc, pcd_latent_t** out) {
     PCD_CHECK_ARG(desc != nullptr && out != nullptr);
     for (int i = 0; i < PCD_LATENT_NLIN; ++i) {
@@ -150,38 +142,23 @@ extern "C" int pcd_latent_forward(pcd_latent_t* h, const float* z, int batch, co
     };
     auto lin_gn = [&](int idx, const void* a1, const void* a2, int k2, const float* bias, const float* sbias,
                       void* out) -> int { return lin(idx, a1, a2, k2, bias, sbias, 0, out, nullptr); };
-    // enc1 -> enc2 -> enc3 in ONE launch (enc1 reads the fp32 state directly, rounded to fp16 on load; its time half is
-    // hoisted into tbias: one shared row, or one row per sample)
+    // enc1: reads the fp32 state directly (rounded to fp16 on load); time half hoisted into tbias (one row, or one
+    // row per sample)
     (void)z16;
-    auto chain_layer = [&](int idx) {
-        return pcd_chain_layer_t{d.lin[idx].w, d.lin[idx].b, idx < 10 ? d.gn_gamma[idx] : nullptr, idx < 10 ? d.gn_beta[idx] : nullptr};
-    };
-    if (g_latent_chains) {
-        pcd_chain_layer_t enc[3] = {chain_layer(0), chain_layer(1), chain_layer(2)};
-        enc[0].bias = nullptr;                   // enc1's bias is part of tbias (pcd_time_embed adds it to the hoisted time half)
-        RUN(pcd_latent_chain_enc(z, batch, tbias_shape_stride ? tbias : nullptr, tbias_shape_stride ? nullptr : tbias, enc, z1, z2,
-                                 z3, s));
-    } else {
-        RUN(pcd_skinny_fused_f32in(z, d.lin[0].k, d.lin[0].w, d.lin[0].k, batch, d.lin[0].c,
-                                   tbias_shape_stride ? nullptr : tbias, tbias_shape_stride ? tbias : nullptr, 0, 8,
-                                   d.gn_gamma[0], d.gn_beta[0], z1, nullptr, s));
-        RUN(lin_gn(1, z1, nullptr, 0, d.lin[1].b, nullptr, z2));
-        RUN(lin_gn(2, z2, nullptr, 0, d.lin[2].b, nullptr, z3));
-    }
+    RUN(pcd_skinny_fused_f32in(z, d.lin[0].k, d.lin[0].w, d.lin[0].k, batch, d.lin[0].c,
+                               tbias_shape_stride ? nullptr : tbias, tbias_shape_stride ? tbias : nullptr, 0, 8,
+                               d.gn_gamma[0], d.gn_beta[0], z1, nullptr, s));
+    RUN(lin_gn(1, z1, nullptr, 0, d.lin[1].b, nullptr, z2));
+    RUN(lin_gn(2, z2, nullptr, 0, d.lin[2].b, nullptr, z3));
     RUN(lin_gn(3, z3, nullptr, 0, d.lin[3].b, nullptr, z4));
     RUN(lin_gn(4, z4, nullptr, 0, d.lin[4].b, nullptr, g0));
     RUN(lin_gn(5, g0, nullptr, 0, d.lin[5].b, nullptr, g1));
     RUN(lin_gn(6, g1, z4, 1024, d.lin[6].b, nullptr, da));
     RUN(lin_gn(7, da, z3, 512, d.lin[7].b, nullptr, db));
     RUN(lin_gn(8, db, z2, 256, d.lin[8].b, nullptr, da));
-    if (g_latent_chains) {                                                  // dec1 -> output.0 -> output.2 in ONE launch
-        const pcd_chain_layer_t tail[3] = {chain_layer(9), chain_layer(10), chain_layer(11)};
-        RUN(pcd_latent_chain_out(da, z1, batch, tail, eps, s));
-    } else {
-        RUN(lin_gn(9, da, z1, 128, d.lin[9].b, nullptr, db));
-        RUN(lin(10, db, nullptr, 0, d.lin[10].b, nullptr, 1, da, nullptr));     // output.0 + ReLU
-        RUN(lin(11, da, nullptr, 0, d.lin[11].b, nullptr, 2, nullptr, eps));    // output.2 -> eps fp32
-    }
+    RUN(lin_gn(9, da, z1, 128, d.lin[9].b, nullptr, db));
+    RUN(lin(10, db, nullptr, 0, d.lin[10].b, nullptr, 1, da, nullptr));     // output.0 + ReLU
+    RUN(lin(11, da, nullptr, 0, d.lin[11].b, nullptr, 2, nullptr, eps));    // output.2 -> eps fp32
 #undef RUN
     return PCD_OK;
 }

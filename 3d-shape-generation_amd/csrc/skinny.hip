@@ -78,6 +78,76 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyParams p) {
     }
 }
 
+// M <= 32 form with the operands staged through LDS by LDS-DMA.  The register-fragment loads of the kernel above are
+// "fragment shaped" (each load instruction touches 32 rows x 2 pieces of 16 bytes): a workgroup then streams its weights
+// at only ~10-13 GB/s (measured: 32 KB per workgroup in ~5 us, the same rate in every skinny kernel).  Here every
+// 64-deep chunk of the weight slice and of the activation slice is one [32 rows][128 B] image filled by four 1-KiB
+// LDS-DMA instructions in full 128-byte lines (8 rows each), ALL chunks of the slice requested at kernel entry, with the
+// XOR swizzle of the attention K tile on the source address so that the ds_read_b128 fragment reads are conflict free.
+// Same products, same summation order as skinny_gemm_kernel<1>: bitwise identical slabs.
+__device__ __forceinline__ int sk_swz(int row, int ch) { return ch ^ ((row >> 1) & 7); }
+
+// stage rows [0, 32) x 128 bytes at byte column `kbyte` of a row-major fp16 matrix (row stride `ld` halfs, rows clamped
+// to `row_limit - 1`) into the 4-KiB image at `img`: instruction i of 4 covers rows 8 i .. 8 i + 7
+__device__ __forceinline__ void sk_stage_chunk(const half_t* base, int64_t ld, int row0, int row_limit, int k0, char* img,
+                                               int i, int lane) {
+    const int row = 8 * i + (lane >> 3), ch = lane & 7;
+    int gr = row0 + row;
+    gr = gr < row_limit ? gr : row_limit - 1;
+    lds_dma16(base + (int64_t)gr * ld + k0 + sk_swz(row, ch) * 8, img + i * 1024);
+}
+
+__device__ __forceinline__ half8 sk_frag(const char* img, int row, int hh, int j) {
+    return *(const half8*)(img + row * 128 + (sk_swz(row, 4 * hh + j) << 4));
+}
+
+__global__ __launch_bounds__(256) void skinny_gemm_dma_kernel(SkinnyParams p) {
+    extern __shared__ __attribute__((aligned(16))) char sk_smem[];     // [chunks][W image 4 KiB | A image 4 KiB]; reused for the reduction
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int n0 = blockIdx.x * 32;
+    const int slice = blockIdx.y;
+    const int kbeg = slice * p.ks;
+    const int chunks = p.ks / 64;
+    // every chunk of the slice goes out now: 8 LDS-DMA instructions per chunk, dealt round-robin to the four waves
+    for (int t = wave; t < chunks * 8; t += 4) {
+        const int ch = t >> 3, i = t & 7;
+        const int k = kbeg + ch * 64;
+        char* img = sk_smem + ch * 8192;
+        if (i < 4) {
+            sk_stage_chunk(p.w, p.ldw, n0, p.c, k, img, i, lane);
+        } else {
+            const half_t* src = k < p.k1 ? p.a1 : p.a2;
+            const int lda = k < p.k1 ? p.k1 : p.k2;
+            sk_stage_chunk(src, lda, 0, p.m, k < p.k1 ? k : k - p.k1, img + 4096, i - 4, lane);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int ch = wave; ch < chunks; ch += 4) {
+        const char* img = sk_smem + ch * 8192;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(sk_frag(img + 4096, r, hh, j), sk_frag(img, r, hh, j), acc, 0, 0, 0);
+    }
+    __syncthreads();                                    // the images are dead: the reduction reuses their space
+    float (*red)[32][33] = (float (*)[32][33])sk_smem;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[wave][(e & 3) + 8 * (e >> 2) + 4 * hh][r] = acc[e];
+    __syncthreads();
+    float* out = p.slabs + (int64_t)slice * p.m * p.c;
+    for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+        const int row = i >> 5, col = i & 31;
+        const float v = (red[0][row][col] + red[1][row][col]) + (red[2][row][col] + red[3][row][col]);
+        const int gc = n0 + col;
+        if (row < p.m && gc < p.c) out[(int64_t)row * p.c + gc] = v;
+    }
+}
+
 // out = act( sum_s slabs[s] + bias [+ per-row bias] ), act: 0 = GroupNorm(groups)+affine+ReLU -> fp16,
 // 1 = ReLU -> fp16, 2 = identity -> fp32.  One block per (row, channel group): GroupNorm statistics
 // are per (row, group), so the groups of a row are independent (modes 1/2 just use the same split).
@@ -277,223 +347,16 @@ __global__ __launch_bounds__(1024) void skinny_fused_kernel(SkinnyFusedParams p)
     }
 }
 
-
-// ---- Chains of small layers in ONE launch.  The latent denoiser step is bound by dependent-launch latency (~4 us per
-// launch, 19 launches), not by bytes: enc1 -> enc2 -> enc3 and dec1 -> output.0 -> output.2 each stream <= 160 KB of
-// weights per workgroup, so a workgroup computes the first two layers of its chain completely (redundantly in every
-// workgroup: their weights are a few tens of KB) and its own column slice of the third, with the intermediate
-// activations held in LDS.  All three layers' weight fragments are requested at kernel entry -- they do not depend on
-// the activations -- so the chain costs about one memory latency plus three short LDS-resident products.
-// A layer inside the chain is the product of skinny_fused_kernel: 16 waves = CT column tiles x (16 / CT) K splits, MFMA
-// 32x32x16 with the A operand (32 rows) read from an LDS image [32][K + 8] (the 16-byte pad keeps ds_read_b128 conflict
-// free), K splits summed through LDS slabs in split order, then bias (+ per-row bias) + GroupNorm(gsz) + ReLU by 32
-// threads per row.  Same products and K-split order as the one-launch-per-layer form; the GroupNorm statistics are
-// summed in a different (still fixed) order, so fp16 outputs can differ from that form by one rounding.
-struct ChainLayer {
-    const half_t* w; int ldw;            // [C][ldw] fp16
-    const float* bias; const float* gamma; const float* beta;
-};
-struct SkinnyChainParams {
-    int m;
-    // chain A input: latent state fp32 [m][256] + per-row or shared time bias; chain B input: fp16 [m][256] | skip [m][128]
-    const float* x32; const half_t* x16; const half_t* skip16;
-    const float* row_bias; const float* shared_bias;        // enc1's hoisted time half: one of the two
-    ChainLayer l0, l1, l2;
-    half_t* out0; half_t* out1; half_t* out2_16; float* out2_32;      // layer outputs that later layers read (or eps)
-};
-
-constexpr int CH_ZT_FLOATS = 4 * 32 * 129;       // largest K-split slab set: 4 splits x 32 rows x (128 + 1) == 2 x 32 x 257 rounded
-template <int K> struct ActImg { static constexpr int STRIDE = K + 8; };   // halfs per LDS activation row
-
-// one wave's share of a layer: column tile ct, K split ksi of KSPL; A from the LDS image, W fragments preloaded
-template <int K, int KSPL, int MAXCH>
-__device__ __forceinline__ f32x16 chain_product(const half_t* act, const half8 (&wf)[MAXCH][4], int ksi, int r, int hh) {
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXCH; ++i) {
-        const int ch = ksi + i * KSPL;
-        if (ch < K / 64) {
-            const half_t* arow = act + r * ActImg<K>::STRIDE + ch * 64 + 32 * hh;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8*)(arow + 8 * j), wf[i][j], acc, 0, 0, 0);
-        }
-    }
-    return acc;
-}
-
-template <int K, int KSPL, int MAXCH>
-__device__ __forceinline__ void chain_load_w(half8 (&wf)[MAXCH][4], const ChainLayer& L, int col, int ksi, int hh) {
-#pragma unroll
-    for (int i = 0; i < MAXCH; ++i) {
-        const int ch = ksi + i * KSPL;
-        if (ch < K / 64) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) wf[i][j] = *(const half8*)(L.w + (int64_t)col * L.ldw + ch * 64 + 32 * hh + 8 * j);
-        }
-    }
-}
-
-// finish of a layer whose BC = 32 * CT columns (starting at global column c_base) sit in zt[KSPL][32][BC + 1]:
-// thread (frow, part) owns CT consecutive columns of row frow.  MODE 0: GroupNorm(gsz) + ReLU, 1: ReLU, 2: identity.
-template <int CT, int KSPL, int MODE>
-__device__ __forceinline__ void chain_finish(const float* zt, int c_base, int gsz, const ChainLayer& L, const float* extra_bias,
-                                             float (&v)[CT]) {
-    constexpr int BC = 32 * CT;
-    const int frow = threadIdx.x >> 5, part = threadIdx.x & 31;
-    float s1 = 0.f;
-#pragma unroll
-    for (int i = 0; i < CT; ++i) {
-        float x = 0.f;
-#pragma unroll
-        for (int sidx = 0; sidx < KSPL; ++sidx) x += zt[(sidx * 32 + frow) * (BC + 1) + part * CT + i];
-        const int ch = c_base + part * CT + i;
-        if (L.bias != nullptr) x += L.bias[ch];
-        if (extra_bias != nullptr) x += extra_bias[ch];
-        v[i] = x;
-        s1 += x;
-    }
-    if (MODE == 0) {
-        const int tpg = gsz / CT;
-        for (int o = 1; o < tpg; o <<= 1) s1 += __shfl_xor(s1, o);
-        const float mean = s1 / (float)gsz;
-        float s2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < CT; ++i) { const float dlt = v[i] - mean; s2 += dlt * dlt; }
-        for (int o = 1; o < tpg; o <<= 1) s2 += __shfl_xor(s2, o);
-        const float rstd = rsqrtf(s2 / (float)gsz + 1e-5f);
-#pragma unroll
-        for (int i = 0; i < CT; ++i) {
-            const int ch = c_base + part * CT + i;
-            v[i] = fmaxf((v[i] - mean) * rstd * L.gamma[ch] + L.beta[ch], 0.f);
-        }
-    } else if (MODE == 1) {
-#pragma unroll
-        for (int i = 0; i < CT; ++i) v[i] = fmaxf(v[i], 0.f);
-    }
-}
-
-template <int CT, int KSPL>
-__device__ __forceinline__ void chain_store_tile(float* zt, const f32x16& acc, int ksi, int ct, int r, int hh) {
-    constexpr int BC = 32 * CT;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) zt[(ksi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh) * (BC + 1) + ct * 32 + r] = acc[e];
-}
-
-// CHAIN 0: enc1 (256 -> 128, + time bias) -> enc2 (128 -> 256) -> enc3 (256 -> 512); grid (8, row tiles): workgroup b owns
-//          GroupNorm group b (64 columns) of enc3; workgroup 0 also writes z1 and z2.
-// CHAIN 1: dec1 ([256 | z1 128] -> 128) -> output.0 (128 -> 128, ReLU) -> output.2 (128 -> 256, fp32); grid (8, row tiles):
-//          workgroup b owns columns 32 b .. of output.2.
-template <int CHAIN>
-__global__ __launch_bounds__(1024) void skinny_chain_kernel(SkinnyChainParams p) {
-    constexpr int K0 = CHAIN == 0 ? 256 : 384, C0 = 128;
-    constexpr int K1 = 128, C1 = CHAIN == 0 ? 256 : 128;
-    constexpr int K2 = CHAIN == 0 ? 256 : 128, BC2 = CHAIN == 0 ? 64 : 32;
-    constexpr int CT0 = C0 / 32, KS0 = 16 / CT0, MC0 = (K0 / 64 + KS0 - 1) / KS0;
-    constexpr int CT1 = C1 / 32, KS1 = 16 / CT1, MC1 = (K1 / 64 + KS1 - 1) / KS1;
-    constexpr int CT2 = BC2 / 32, KS2 = 16 / CT2, MC2 = 1;                      // K2 / 64 <= 4 chunks <= KS2 splits
-    __shared__ __attribute__((aligned(16))) float zt[CH_ZT_FLOATS];
-    __shared__ __attribute__((aligned(16))) half_t actA[32 * ActImg<384>::STRIDE];
-    __shared__ __attribute__((aligned(16))) half_t actB[32 * ActImg<256>::STRIDE];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    const int row0 = blockIdx.y * 32;
-    const int frow = threadIdx.x >> 5, part = threadIdx.x & 31;
-    const int grow = row0 + frow;
-    const bool row_ok = grow < p.m;
-    const bool writer = blockIdx.x == 0;
-
-    // every layer's weight fragments are requested now: they do not depend on the activations
-    half8 w0[MC0][4], w1[MC1][4], w2[MC2][4];
-    const int ct0 = wave % CT0, ks0 = wave / CT0, ct1 = wave % CT1, ks1 = wave / CT1, ct2 = wave % CT2, ks2 = wave / CT2;
-    chain_load_w<K0, KS0, MC0>(w0, p.l0, ct0 * 32 + r, ks0, hh);
-    chain_load_w<K1, KS1, MC1>(w1, p.l1, ct1 * 32 + r, ks1, hh);
-    chain_load_w<K2, KS2, MC2>(w2, p.l2, blockIdx.x * BC2 + ct2 * 32 + r, ks2, hh);
-
-    // input activations -> LDS image actA [32][K0 + 8] (rows beyond m repeat the last row: their results are not stored)
-    for (int i = threadIdx.x; i < 32 * (K0 / 8); i += 1024) {
-        const int rr = i / (K0 / 8), c8 = i - rr * (K0 / 8);
-        int gr = row0 + rr;
-        gr = gr < p.m ? gr : p.m - 1;
-        half8 hv;
-        if (CHAIN == 0) {
-            const float* src = p.x32 + (int64_t)gr * K0 + c8 * 8;
-            const float4 lo = *(const float4*)src, hi = *(const float4*)(src + 4);
-            hv = (half8){to_half_sat(lo.x), to_half_sat(lo.y), to_half_sat(lo.z), to_half_sat(lo.w),
-                         to_half_sat(hi.x), to_half_sat(hi.y), to_half_sat(hi.z), to_half_sat(hi.w)};
-        } else {
-            hv = c8 < 32 ? *(const half8*)(p.x16 + (int64_t)gr * 256 + c8 * 8) : *(const half8*)(p.skip16 + (int64_t)gr * 128 + (c8 - 32) * 8);
-        }
-        *(half8*)(actA + rr * ActImg<K0>::STRIDE + c8 * 8) = hv;
-    }
-    __syncthreads();
-
-    // ---- layer 0
-    {
-        const f32x16 acc = chain_product<K0, KS0, MC0>(actA, w0, ks0, r, hh);
-        chain_store_tile<CT0, KS0>(zt, acc, ks0, ct0, r, hh);
-    }
-    __syncthreads();
-    {
-        float v[CT0];
-        const float* eb = nullptr;
-        if (CHAIN == 0) eb = p.row_bias != nullptr ? p.row_bias + (int64_t)(row_ok ? grow : p.m - 1) * C0 : p.shared_bias;
-        chain_finish<CT0, KS0, 0>(zt, 0, C0 / 8, p.l0, eb, v);
-        half_t* dst = actB + frow * ActImg<K1>::STRIDE + part * CT0;
-#pragma unroll
-        for (int i = 0; i < CT0; ++i) {
-            const half_t hvv = to_half_sat(v[i]);
-            dst[i] = hvv;
-            if (writer && row_ok && p.out0 != nullptr) p.out0[(int64_t)grow * C0 + part * CT0 + i] = hvv;
-        }
-    }
-    __syncthreads();
-
-    // ---- layer 1 (A = actB [32][128 + 8])
-    {
-        const f32x16 acc = chain_product<K1, KS1, MC1>(actB, w1, ks1, r, hh);
-        chain_store_tile<CT1, KS1>(zt, acc, ks1, ct1, r, hh);
-    }
-    __syncthreads();
-    {
-        float v[CT1];
-        chain_finish<CT1, KS1, CHAIN == 0 ? 0 : 1>(zt, 0, C1 / 8, p.l1, nullptr, v);
-        half_t* dst = actA + frow * ActImg<K2>::STRIDE + part * CT1;
-#pragma unroll
-        for (int i = 0; i < CT1; ++i) {
-            const half_t hvv = to_half_sat(v[i]);
-            dst[i] = hvv;
-            if (writer && row_ok && p.out1 != nullptr) p.out1[(int64_t)grow * C1 + part * CT1 + i] = hvv;
-        }
-    }
-    __syncthreads();
-
-    // ---- layer 2: this workgroup's BC2 columns (A = actA [32][K2 + 8])
-    {
-        const f32x16 acc = chain_product<K2, KS2, MC2>(actA, w2, ks2, r, hh);
-        chain_store_tile<CT2, KS2>(zt, acc, ks2, ct2, r, hh);
-    }
-    __syncthreads();
-    {
-        float v[CT2];
-        const int cb = blockIdx.x * BC2;
-        chain_finish<CT2, KS2, CHAIN == 0 ? 0 : 2>(zt, cb, 64, p.l2, nullptr, v);
-        if (row_ok) {
-#pragma unroll
-            for (int i = 0; i < CT2; ++i) {
-                const int ch = cb + part * CT2 + i;
-                if (CHAIN == 0) p.out2_16[(int64_t)grow * 512 + ch] = to_half_sat(v[i]);
-                else p.out2_32[(int64_t)grow * 256 + ch] = v[i];
-            }
-        }
-    }
-}
-
 }  // namespace pcd
 
 using namespace pcd;
+
+static int g_skinny_dma = 1;          // tuning / testing hook (pcd_skinny_config): 0 = register-fragment loads everywhere
+
+extern "C" int pcd_skinny_config(int use_lds_dma) {
+    g_skinny_dma = use_lds_dma ? 1 : 0;
+    return PCD_OK;
+}
 
 // K slice per block: aim for >= ~256 blocks per layer, slices of at least 256 (4 waves x one 64-chunk)
 static int pick_ks(int k, int c) {
@@ -522,7 +385,10 @@ extern "C" int pcd_skinny_gemm_f16(const void* a1, int k1, const void* a2, int k
     dim3 grid((unsigned)ceil_div(c, 32), (unsigned)((k1 + k2) / p.ks));
     hipStream_t s = (hipStream_t)stream;
     const int mt = (int)ceil_div(m, 32);
-    if (mt <= 1) hipLaunchKernelGGL((skinny_gemm_kernel<1>), grid, dim3(256), 0, s, p);
+    const size_t dma_lds = (size_t)(p.ks / 64) * 8192;                 // >= the 4 x 32 x 33 floats of the reduction
+    if (mt <= 1 && g_skinny_dma && dma_lds >= sizeof(float) * 4 * 32 * 33 && dma_lds <= 65536)
+        hipLaunchKernelGGL(skinny_gemm_dma_kernel, grid, dim3(256), dma_lds, s, p);
+    else if (mt <= 1) hipLaunchKernelGGL((skinny_gemm_kernel<1>), grid, dim3(256), 0, s, p);
     else if (mt <= 2) hipLaunchKernelGGL((skinny_gemm_kernel<2>), grid, dim3(256), 0, s, p);
     else if (mt <= 4) hipLaunchKernelGGL((skinny_gemm_kernel<4>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((skinny_gemm_kernel<8>), grid, dim3(256), 0, s, p);
@@ -598,38 +464,4 @@ extern "C" int pcd_skinny_fused_f32in(const float* a, int k, const void* w, int6
     PCD_CHECK_ARG(a != nullptr);
     return skinny_fused_launch(nullptr, a, k, nullptr, 0, w, ldw, m, c, bias, row_bias, mode, groups, gamma, beta, out16,
                                out32, stream);
-}
-
-// enc1 -> enc2 -> enc3 of SimpleLatentUNetPointNet in one launch (see skinny_chain_kernel).  z fp32 [m][256];
-// exactly one of row_bias [m][128] / shared_bias [128] (enc1's hoisted time half); l[3] = {W fp16, ldw = K, bias, gamma,
-// beta} of the three layers; outputs z1 [m][128], z2 [m][256], z3 [m][512] fp16.
-extern "C" int pcd_latent_chain_enc(const float* z, int m, const float* row_bias, const float* shared_bias,
-                                    const pcd_chain_layer_t* l, void* z1, void* z2, void* z3, void* stream) {
-    PCD_CHECK_ARG(z && l && z1 && z2 && z3 && m > 0 && m <= 256 && ((row_bias != nullptr) != (shared_bias != nullptr)));
-    for (int i = 0; i < 3; ++i) PCD_CHECK_ARG(l[i].w && (i == 0 || l[i].bias) && l[i].gamma && l[i].beta);   // l[0].bias may be NULL: the time bias carries it
-    SkinnyChainParams p{};
-    p.m = m; p.x32 = z; p.row_bias = row_bias; p.shared_bias = shared_bias;
-    p.l0 = ChainLayer{(const half_t*)l[0].w, 256, l[0].bias, l[0].gamma, l[0].beta};
-    p.l1 = ChainLayer{(const half_t*)l[1].w, 128, l[1].bias, l[1].gamma, l[1].beta};
-    p.l2 = ChainLayer{(const half_t*)l[2].w, 256, l[2].bias, l[2].gamma, l[2].beta};
-    p.out0 = (half_t*)z1; p.out1 = (half_t*)z2; p.out2_16 = (half_t*)z3;
-    hipLaunchKernelGGL((skinny_chain_kernel<0>), dim3(8, (unsigned)ceil_div(m, 32)), dim3(1024), 0, (hipStream_t)stream, p);
-    PCD_CHECK_LAUNCH();
-    return PCD_OK;
-}
-
-// dec1 -> output.0 -> output.2 in one launch: x fp16 [m][256] (dec2's output) | skip fp16 [m][128] (z1) -> eps fp32 [m][256]
-extern "C" int pcd_latent_chain_out(const void* x, const void* skip, int m, const pcd_chain_layer_t* l, float* eps,
-                                    void* stream) {
-    PCD_CHECK_ARG(x && skip && l && eps && m > 0 && m <= 256);
-    PCD_CHECK_ARG(l[0].w && l[0].bias && l[0].gamma && l[0].beta && l[1].w && l[1].bias && l[2].w && l[2].bias);
-    SkinnyChainParams p{};
-    p.m = m; p.x16 = (const half_t*)x; p.skip16 = (const half_t*)skip;
-    p.l0 = ChainLayer{(const half_t*)l[0].w, 384, l[0].bias, l[0].gamma, l[0].beta};
-    p.l1 = ChainLayer{(const half_t*)l[1].w, 128, l[1].bias, nullptr, nullptr};
-    p.l2 = ChainLayer{(const half_t*)l[2].w, 128, l[2].bias, nullptr, nullptr};
-    p.out2_32 = eps;
-    hipLaunchKernelGGL((skinny_chain_kernel<1>), dim3(8, (unsigned)ceil_div(m, 32)), dim3(1024), 0, (hipStream_t)stream, p);
-    PCD_CHECK_LAUNCH();
-    return PCD_OK;
 }

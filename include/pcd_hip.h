@@ -197,6 +197,9 @@ int pcd_skinny_gemm_f16(const void* a1, int k1, const void* a2, int k2, const vo
 int pcd_skinny_finish(const float* slabs, int nslabs, int m, int c, const float* bias, const float* row_bias,
                       int mode, int groups, const float* gamma, const float* beta,
                       void* out16, float* out32, void* stream);
+/* testing / tuning hook: use_lds_dma = 0 makes the skinny kernels load their MFMA fragments straight from global memory
+ * (the first form) instead of staging full 128-byte lines through LDS by LDS-DMA; 1 restores the default.  Same bits. */
+int pcd_skinny_config(int use_lds_dma);
 /* The same layer in ONE launch for small weights (k * c <= 768 * 256): a workgroup owns whole GroupNorm groups
  * over the full K, so Linear + bias + GroupNorm + ReLU need no second kernel (enc1-3, dec1-2 and the output head of
  * SimpleLatentUNetPointNet, networks.py:984-1049).  pcd_skinny_fused_supported() tells (1/0) whether a shape
@@ -210,20 +213,6 @@ int pcd_skinny_fused(const void* a1, int k1, const void* a2, int k2, const void*
 int pcd_skinny_fused_f32in(const float* a, int k, const void* w, int64_t ldw, int m, int c, const float* bias,
                            const float* row_bias, int mode, int groups, const float* gamma, const float* beta,
                            void* out16, float* out32, void* stream);
-/* Chains of small latent layers in ONE launch each (the step is bound by dependent-launch latency, not bytes): every
- * workgroup computes the first two layers of the chain in full, its own column slice of the third, intermediates in
- * LDS, all weights requested at kernel entry.  Deterministic; equal to the one-launch-per-layer calls up to the (fixed)
- * order in which the GroupNorm statistics are summed.
- *   enc:  z fp32 [m][256] (+ enc1's hoisted time bias: row_bias [m][128] XOR shared_bias [128])
- *         -> enc1 -> z1 [m][128] -> enc2 -> z2 [m][256] -> enc3 -> z3 [m][512]   (Linear + GroupNorm(8) + ReLU each)
- *   out:  [x fp16 [m][256] | skip z1 [m][128]] -> dec1 (Linear + GroupNorm(8) + ReLU) -> output.0 (+ ReLU) -> output.2
- *         -> eps fp32 [m][256]
- * l[3]: the chain's layers in order; w fp16 [C][K] with row stride K (256, 128, 256 / 384, 128, 128); enc's l[0].bias may
- * be NULL (the time bias already contains enc1's bias). */
-typedef struct { const void* w; const float* bias; const float* gamma; const float* beta; } pcd_chain_layer_t;
-int pcd_latent_chain_enc(const float* z, int m, const float* row_bias, const float* shared_bias,
-                         const pcd_chain_layer_t* l, void* z1, void* z2, void* z3, void* stream);
-int pcd_latent_chain_out(const void* x, const void* skip, int m, const pcd_chain_layer_t* l, float* eps, void* stream);
 /* SimpleLatentUNetPointNet.forward (networks.py:1051-1086), latent_dim=256, dim=512, time_dim=256.
  * lin[] order documented in csrc/latent.hip; refine_k folded into dec_k, enc1's time half hoisted
  * into tbias [n_t][128] (pcd_time_embed with c1=128). */
@@ -241,9 +230,6 @@ size_t pcd_latent_workspace_bytes(int batch);
 int pcd_latent_forward(pcd_latent_t* h, const float* z, int batch, const float* tbias,
                        int tbias_shape_stride, float* eps, void* workspace, size_t workspace_bytes,
                        void* stream);
-/* testing / tuning hook: use_chains = 0 runs every small layer as its own launch (pcd_skinny_fused) instead of the
- * chained kernels; 1 restores the default. */
-int pcd_latent_config(int use_chains);
 
 /* ------------------------------------------------------ 3-D convolution (a12, K9)
  * Implicit-GEMM Conv3d on NDHWC fp16 activations (replaces nn.Conv3d / nn.ConvTranspose3d +

@@ -327,28 +327,32 @@ def test_skinny_fused_layer(k1, k2, c, mode, m):
     assert lib.pcd_skinny_fused_supported(2048, 4096, 0, 8) == 0 and lib.pcd_skinny_fused_supported(96, 128, 0, 8) == 0
 
 
-def test_latent_forward_chained_equals_one_launch_per_layer(ldm, golden):
-    """enc1 -> enc2 -> enc3 and dec1 -> output.0 -> output.2 as ONE launch each (intermediates in LDS, the first two layers
-    recomputed in every workgroup): the results of the one-launch-per-layer form up to the order in which the GroupNorm
-    statistics are summed (fp16 outputs may differ by one rounding), at a full tile, a ragged row
-    count and several row tiles, with a shared time-bias row and with one row per sample."""
+@pytest.mark.parametrize("k1,k2,c,m", [(512, 0, 1024, 32), (2048, 0, 4096, 32), (4096, 1024, 1024, 32), (1024, 512, 512, 7),
+                                        (1024, 0, 2048, 1)])
+def test_skinny_gemm_lds_dma_is_bitwise_the_register_form(k1, k2, c, m):
+    """The split-K weight-streaming GEMM with both operands staged through LDS by LDS-DMA (full 128-byte lines, swizzled
+    images) against the register-fragment form it replaces: identical products and summation order, so identical bits."""
     from shapegen_amd import _lib
     lib = _lib.load()
-    g = golden("latent.npz")
-    z, t = torch.from_numpy(g["lat_z"]).cuda(), torch.from_numpy(g["lat_t"]).cuda()
-    for rows in (32, 5, 70):
-        zz = z.repeat(3, 1)[:rows].contiguous() * torch.linspace(0.5, 1.5, rows, device="cuda")[:, None]
-        tt = t.repeat(3)[:rows].contiguous()
-        for per_sample in (True, False):
-            tb = ldm.model.time_bias(tt if per_sample else tt[:1])
-            a = ldm.model.forward_with_bias(zz, tb, 1 if per_sample else 0)
-            _lib.check(lib.pcd_latent_config(0))
-            try:
-                b = ldm.model.forward_with_bias(zz, tb, 1 if per_sample else 0)
-            finally:
-                _lib.check(lib.pcd_latent_config(1))
-            assert float((a - b).abs().max()) <= 2e-3 and rel_l2(a.cpu(), b.cpu()) < 2e-4, (rows, per_sample)
-    assert rel_l2(ldm.model(z, t).cpu(), g["lat_eps"]) < 3e-3
+    g = torch.Generator().manual_seed(k1 + c + m)
+    a1 = torch.randn(m, k1, generator=g).half().cuda()
+    a2 = torch.randn(m, k2, generator=g).half().cuda() if k2 else None
+    w = (torch.randn(c, k1 + k2, generator=g) / (k1 + k2) ** 0.5).half().cuda()
+    ns = lib.pcd_skinny_slabs(k1 + k2, c)
+    outs = []
+    for dma in (1, 0):
+        _lib.check(lib.pcd_skinny_config(dma))
+        slabs = torch.full((ns, m, c), float("nan"), dtype=torch.float32, device="cuda")
+        try:
+            _lib.check(lib.pcd_skinny_gemm_f16(a1.data_ptr(), k1, _lib.ptr(a2), k2, w.data_ptr(), k1 + k2, m, c, slabs.data_ptr(),
+                                               _lib.stream_ptr()))
+        finally:
+            _lib.check(lib.pcd_skinny_config(1))
+        outs.append(slabs.cpu())
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+    a = torch.cat([a1, a2], 1) if k2 else a1
+    want = a.float().cpu() @ w.float().cpu().T
+    assert (outs[0].sum(0) - want).abs().max() <= 2e-3 * max(1.0, float(want.abs().max()))
 
 
 def test_skinny_fused_fp32_input_equals_converted_input():
