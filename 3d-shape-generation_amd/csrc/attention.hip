@@ -428,18 +428,26 @@ __device__ __forceinline__ half2_ sp_phase(const f32x16& s, half8& p0, half8& p1
     const half2_ b1 = b0 + a2;
     SP_SB();
 #undef SP_M
-    // tail: the dependent packed adds need a wait state each; the OTHER block's pending row sum (its tile was
-    // checked a phase ago) is folded into its fp32 l in those slots
+    // tail: on gfx950 a packed (VOP3P) result needs one wait state before any VALU reads it, so the compiler puts an
+    // s_nop behind each of the three dependent v_pk_add_f16 of this tail.  Written out by hand, the OTHER block's pending
+    // row sum (its tile was checked a phase ago) is folded into its fp32 l in those slots instead:
+    //   a3 = c3 + c7 | lo = f32(t_other) | t = b1 + a3 | l_other += lo | tt = t + swap(t)   (the compiler adds the one
+    //   wait state between the asm block and its own compare of tt)
     const half2_ c7 = sp_pk(e14, e15);
-    const half2_ a3 = c3 + c7;
-    const float lo = (float)t_other.x;
-    const half2_ t = b1 + a3;
-    l_other += lo;
+    half2_ a3, t, tt;
+    float lo;
+    asm volatile("v_pk_add_f16 %0, %5, %6\n\t"
+                 "v_cvt_f32_f16_e32 %3, %8\n\t"
+                 "v_pk_add_f16 %1, %7, %0\n\t"
+                 "v_add_f32_e32 %4, %4, %3\n\t"
+                 "v_pk_add_f16 %2, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]"
+                 : "=&v"(a3), "=&v"(t), "=&v"(tt), "=&v"(lo), "+v"(l_other)
+                 : "v"(c3), "v"(c7), "v"(b1), "v"(t_other));
     p0 = __builtin_shufflevector(__builtin_shufflevector(c0, c1, 0, 1, 2, 3), __builtin_shufflevector(c2, c3, 0, 1, 2, 3),
                                  0, 1, 2, 3, 4, 5, 6, 7);
     p1 = __builtin_shufflevector(__builtin_shufflevector(c4, c5, 0, 1, 2, 3), __builtin_shufflevector(c6, c7, 0, 1, 2, 3),
                                  0, 1, 2, 3, 4, 5, 6, 7);
-    return t + t.yx;
+    return tt;
 }
 
 __global__ __launch_bounds__(256, 2) void set_attention_sp_kernel(const half_t* __restrict__ qkv, int n, int c, int heads,
