@@ -259,3 +259,21 @@ def test_philox_stream_positions_across_graph_replays(model):
     model._philox_offset = 1000
     whole = model._randn_like(torch.empty(B, N, 3, device="cuda"))
     assert torch.equal(part[0], whole[1])
+
+
+def test_full_size_ddpm_on_device_noise_is_shard_invariant(model):
+    """BASELINE config 2 size (B=64, N=2048) through `sample2` WITH the on-device Philox noise (graph replay): the
+    noise of sample i is addressed by its global index (dist.shard_context), so running samples [40, 44) alone, as a
+    rank of a sharded job would, reproduces rows 40..43 of the full-batch run -- a size-independent check of the
+    whole loop (step select, forward, Philox draw, fused update) at the size bench.py times."""
+    from shapegen_amd import dist as D
+    torch.manual_seed(2024)
+    model._philox_offset = 0
+    full = model.sample2(64, 2048, num_steps=12)
+    assert torch.isfinite(full).all() and float(full.abs().max()) < 1e3
+    torch.manual_seed(2024)
+    model._philox_offset = 0
+    with D.shard_context(model, 40, 64):
+        part = model.sample2(4, 2048, num_steps=12)
+    assert rel_l2(part.cpu(), full[40:44].cpu()) < 1e-5
+    assert not torch.equal(full[0], full[1])                       # samples really draw different noise
