@@ -67,39 +67,55 @@ __global__ __launch_bounds__(256) void pair_normalize_kernel(const float* __rest
 }
 
 constexpr int PT = 512;     // targets per LDS tile
+constexpr int CQ = 4;       // queries per thread in the Chamfer kernel: one LDS read of a target serves CQ distances
 
-// grid (query blocks, target splits, 2 * P); mins[(2p + dir)][q] = min_j |q - t_j|^2 as float bits (init +inf)
+// grid (query blocks of 256 * CQ, target splits, 2 * P); mins[(2p + dir)][q] = min_j |q - t_j|^2 as float bits (init
+// +inf).  Targets sit in LDS as float4 (one ds_read_b128, broadcast to the wave); every thread keeps CQ queries in
+// registers, so the kernel issues 1 LDS read + 7 CQ VALU operations per CQ distances instead of 3 + 7 per distance.
 __global__ __launch_bounds__(256) void pair_chamfer_min_kernel(const float* __restrict__ an, const int* __restrict__ na, int NA,
                                                                 const float* __restrict__ bn, const int* __restrict__ nb, int NB,
                                                                 int NQ, unsigned* __restrict__ mins) {
-    __shared__ float tile[PT * 3];
+    __shared__ float4 tile[PT];
     const int p = blockIdx.z >> 1, dir = blockIdx.z & 1;
     const float* q = dir == 0 ? an + (int64_t)p * NA * 3 : bn + (int64_t)p * NB * 3;
     const float* r = dir == 0 ? bn + (int64_t)p * NB * 3 : an + (int64_t)p * NA * 3;
     const int nq = dir == 0 ? na[p] : nb[p], nr = dir == 0 ? nb[p] : na[p];
-    if ((int)(blockIdx.x * blockDim.x) >= nq) return;
+    const int q0 = blockIdx.x * (256 * CQ);
+    if (q0 >= nq) return;
     const int per = (nr + gridDim.y - 1) / gridDim.y;
     const int r_lo = blockIdx.y * per, r_hi = min(nr, r_lo + per);
     if (r_lo >= r_hi) return;
-    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = qi < nq;
-    float qx = 0.f, qy = 0.f, qz = 0.f;
-    if (live) { qx = q[qi * 3]; qy = q[qi * 3 + 1]; qz = q[qi * 3 + 2]; }
-    float best = INFINITY;
+    float qx[CQ], qy[CQ], qz[CQ], best[CQ];
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) {
+        int qi = q0 + c * 256 + threadIdx.x;
+        qi = qi < nq ? qi : nq - 1;                          // clamped duplicates are not stored
+        qx[c] = q[qi * 3]; qy[c] = q[qi * 3 + 1]; qz[c] = q[qi * 3 + 2];
+        best[c] = INFINITY;
+    }
     for (int r0 = r_lo; r0 < r_hi; r0 += PT) {
         const int cnt = min(PT, r_hi - r0);
         __syncthreads();
-        for (int i = threadIdx.x; i < cnt * 3; i += blockDim.x) tile[i] = r[(int64_t)r0 * 3 + i];
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const float* t = r + (int64_t)(r0 + i) * 3;
+            tile[i] = make_float4(t[0], t[1], t[2], 0.f);
+        }
         __syncthreads();
-        if (live) {
 #pragma unroll 4
-            for (int j = 0; j < cnt; ++j) {
-                const float dx = qx - tile[j * 3], dy = qy - tile[j * 3 + 1], dz = qz - tile[j * 3 + 2];
-                best = fminf(best, dx * dx + dy * dy + dz * dz);
+        for (int j = 0; j < cnt; ++j) {
+            const float4 t = tile[j];
+#pragma unroll
+            for (int c = 0; c < CQ; ++c) {
+                const float dx = qx[c] - t.x, dy = qy[c] - t.y, dz = qz[c] - t.z;
+                best[c] = fminf(best[c], dx * dx + dy * dy + dz * dz);
             }
         }
     }
-    if (live) atomicMin(mins + (int64_t)blockIdx.z * NQ + qi, __float_as_uint(best));
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) {
+        const int qi = q0 + c * 256 + threadIdx.x;
+        if (qi < nq) atomicMin(mins + (int64_t)blockIdx.z * NQ + qi, __float_as_uint(best[c]));
+    }
 }
 
 // grid (P): cd[p] = sum_i sqrt(min_a[i]) / na + sum_j sqrt(min_b[j]) / nb, fixed summation order (metrics.py:41-46)
@@ -350,10 +366,11 @@ extern "C" int pcd_pair_metrics(const float* a, const int* na, int na_max, const
     hipLaunchKernelGGL(pair_normalize_kernel, dim3(P, 2), dim3(256), 0, s, a, na, NA, b, nb, NB, an, bn);
     // Chamfer: split the targets so that ~1024 blocks exist even for one pair
     const int qblocks = (int)ceil_div(NQ, 256);
-    int tsplit = (int)ceil_div(1024, (int64_t)qblocks * 2 * P);
+    const int cqblocks = (int)ceil_div(NQ, 256 * CQ);
+    int tsplit = (int)ceil_div(1024, (int64_t)cqblocks * 2 * P);
     const int max_split = (int)ceil_div(NQ, 128);
     tsplit = tsplit < 1 ? 1 : (tsplit > max_split ? max_split : tsplit);
-    hipLaunchKernelGGL(pair_chamfer_min_kernel, dim3(qblocks, tsplit, 2 * P), dim3(256), 0, s, an, na, NA, bn, nb, NB, NQ, mins);
+    hipLaunchKernelGGL(pair_chamfer_min_kernel, dim3(cqblocks, tsplit, 2 * P), dim3(256), 0, s, an, na, NA, bn, nb, NB, NQ, mins);
     hipLaunchKernelGGL(pair_chamfer_sum_kernel, dim3(P), dim3(256), 0, s, mins, na, nb, NQ, rows);
     hipLaunchKernelGGL(pair_voxelize_bits_kernel, dim3(qblocks, P, 2), dim3(256), 0, s, a, na, NA, b, nb, NB, bits);   // the RAW clouds (metrics.py:181)
     hipLaunchKernelGGL(pair_bce_kernel, dim3(P), dim3(256), 0, s, bits, rows);
