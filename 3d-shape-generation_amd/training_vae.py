@@ -386,8 +386,10 @@ class VAETrainer:
                  self.logvar.data_ptr(), 256)
         if eps is None:
             eps = torch.empty(b, 256, device=self.dev)
-            self._chk(lib.pcd_randn(eps.data_ptr(), eps.numel(), int(torch.initial_seed()) & (2 ** 64 - 1), (1 << 42) + self.step_count * 4096, st),
+            self._eps_offset = getattr(self, "_eps_offset", 0)       # running Philox position: every draw (training or validation) is fresh
+            self._chk(lib.pcd_randn(eps.data_ptr(), eps.numel(), int(torch.initial_seed()) & (2 ** 64 - 1), (1 << 42) + self._eps_offset, st),
                       "randn")
+            self._eps_offset += (eps.numel() + 3) // 4
         self.eps_draw = eps.to(self.dev, torch.float32).contiguous()
         self.zlat = self._buf("z", (b, 256), torch.float32)
         self._chk(lib.pcd_reparameterize(self.mu.data_ptr(), self.logvar.data_ptr(), self.eps_draw.data_ptr(), self.zlat.data_ptr(), b * 256, st),

@@ -132,3 +132,84 @@ def test_bench_parent_stays_gpu_free_and_reports_failed_ranks():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode != 0 and "ranks failed" in p.stderr
+
+
+class _ToyModel(torch.nn.Module):
+    """Stands in for a HIP-trained module in `training.fit`: the control flow under test (how batches are dealt to ranks,
+    which collectives pair up, what is broadcast) does not depend on the kernels."""
+
+    def __init__(self, rank):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.full((3,), float(rank + 1)))     # ranks start DIFFERENT: fit must broadcast rank 0
+        self.register_buffer("stat", torch.full((2,), float(10 * (rank + 1))))
+        self.hparams = {}
+        self.steps, self.seen = 0, []
+        outer = self
+
+        class _Opt:
+            lr = 1e-3
+
+            def step(self_inner):
+                g = outer.w.detach().clone()
+                dist.all_reduce(g)                                           # one collective per optimizer step, like the trainers
+                outer.steps += 1
+
+        class _Sched:
+            def step(self_inner, metric):
+                outer.sched_metric = metric
+
+        self._opt, self._sched = _Opt(), _Sched()
+
+    @property
+    def device(self):
+        return torch.device("cpu")
+
+    def configure_optimizers(self):
+        return {"optimizer": self._opt, "lr_scheduler": {"scheduler": self._sched, "monitor": "val_loss"}}
+
+    def training_step(self, batch, i):
+        self.seen.append(i)
+        return batch.mean()
+
+    def validation_step(self, batch, i):
+        return batch.mean() + dist.get_rank()                              # ranks disagree: fit must average
+
+
+class _ToyData:
+    def __init__(self, n):
+        self.n = n
+
+    def setup(self):
+        pass
+
+    def train_dataloader(self):
+        return [torch.full((2, 2), float(i)) for i in range(self.n)]
+
+    def val_dataloader(self):
+        return [torch.zeros(2, 2)]
+
+
+def _fit_worker(rank, world, port, tmp):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import shapegen_amd  # noqa: F401
+    from shapegen_amd import dist as D
+    from shapegen_amd.training import fit
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    D.init_from_env("gloo")
+    model = _ToyModel(rank)
+    hist = fit(model, _ToyData(5), max_epochs=2, log=lambda *_: None)       # 5 batches, 2 ranks: the odd one is dropped
+    assert torch.equal(model.w.detach(), torch.ones(3)) and torch.equal(model.stat, torch.full((2,), 10.0))   # rank 0's values
+    assert model.steps == 4 and model.seen == ([0, 2, 0, 2] if rank == 0 else [1, 3, 1, 3])
+    assert abs(hist[-1][2] - 0.5) < 1e-12 and abs(model.sched_metric - 0.5) < 1e-12      # val_loss = mean over ranks of (0, 1)
+    dist.barrier()                                                          # no unmatched collective is left behind
+    dist.destroy_process_group()
+    open(os.path.join(tmp, f"fit_ok{rank}"), "w").write("ok")
+
+
+def test_two_rank_fit_with_odd_batch_count(tmp_path):
+    """ranks must take the same number of optimizer steps (each step is an all-reduce), start from rank 0's
+    parameters / buffers, and feed ONE averaged val_loss to the scheduler."""
+    port = _free_port()
+    mp.spawn(_fit_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "fit_ok0").exists() and (tmp_path / "fit_ok1").exists()
