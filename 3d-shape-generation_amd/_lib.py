@@ -126,6 +126,10 @@ _SIGS = {
     "pcd_step_select": (i32, [vp, i32, vp, i32, vp, vp, i32, vp, vp]),
     "pcd_randn_step": (i32, [vp, i64, u64, u64, u64, vp, vp]),
     "pcd_head3": (i32, [vp, i64, i32, vp, vp, vp, vp]),
+    "pcd_pw_chain_enc1": (i32, [vp, i64, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
+    "pcd_pw_chain_128": (i32, [vp, i64, vp, vp, vp, vp, vp, vp]),
+    "pcd_pw_chain_tail": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "pcd_unet_config": (i32, [i32]),
     "pcd_unet_create": (i32, [C.POINTER(UnetDesc), C.POINTER(vp)]),
     "pcd_unet_destroy": (None, [vp]),
     "pcd_unet_workspace_bytes": (sz, [i32, i32]),

@@ -1,0 +1,237 @@
+// Chains of narrow pointwise layers of UNetPointNetLarge (reference networks.py:16-49, 779-818) in one launch each.
+//
+// The 64..128-channel layers at the two ends of the U-net are HBM / launch bound as separate GEMMs: each reads and writes
+// a [B*N][64..128] fp16 tensor (17-33 MB) for 2-4 GFLOP of work and costs 12-20 us.  Here a wave owns 32 points and
+// carries them through the whole chain with the intermediate activations in its own LDS buffers; the chain's weights
+// (24-64 KB, BatchNorm folded) sit in LDS for the lifetime of the persistent workgroup:
+//   E1: xyz (fp32) -> enc1.conv1 (K = 3, per-shape time bias, VALU) -> enc1.conv2 64->64 -> enc1.conv3 64->128 -> x1
+//   E2: x1 -> enc2.conv1 128->128 -> enc2.conv2 128->128 -> (enc2.conv3 128->256 stays a GEMM: its 67 MB output bounds it)
+//   D1: dec1.conv1's output -> dec1.conv2 128->128 -> dec1.conv3 128->64 -> output.0 64->64 -> output.3 64->3 (fp32 eps)
+// Every layer is the transposed product D[channel][point] = W[channel][k] . act[point][k] on v_mfma_f32_32x32x16_f16
+// (weights as the A operand): a lane then holds 4 consecutive channels of one point per accumulator group, which is an
+// 8-byte piece of the next layer's [point][channel] LDS image (or of the output row).  Waves never synchronise after the
+// weights are in place.  fp32 accumulation, bias + ReLU + fp16 rounding per layer exactly as the GEMM epilogue does.
+#include "common.h"
+
+namespace pcd {
+
+constexpr int PW_MAXL = 3;
+constexpr int PW_WAVES = 8, PW_THREADS = 64 * PW_WAVES, PW_TILE = 32 * PW_WAVES;      // 2 waves per SIMD, 256 points per workgroup tile
+struct PwChainParams {
+    int64_t m;                       // points (B * N)
+    int rows_per_shape;
+    // E1 input
+    const float* xyz; const float* w_xyz; const float* tbias; int tb_stride;      // [m][3], [64][3], [n_t][64], row stride
+    // E2 / D1 input
+    const half_t* in16;              // [m][128]
+    const half_t* w[PW_MAXL]; const float* b[PW_MAXL];                             // fp16 [C][K], fp32 [C]
+    const float* head_w; const float* head_b;                                      // D1: fp32 [3][64], [3]
+    half_t* out16; float* out32;
+};
+
+template <int K> struct PwImg { static constexpr int STR = K + 8; };              // halfs per LDS row (16-byte pad)
+
+// one layer for this wave's 32 points: act_in [32][K + 8] (LDS) x W image [C][K + 8] (LDS) -> act_out [32][C + 8] (LDS) or
+// global rows [pt0 + point][C]
+template <int K, int C, bool TO_GLOBAL>
+__device__ __forceinline__ void pw_layer(const half_t* act_in, const half_t* wimg, const float* __restrict__ bias,
+                                         half_t* act_out, half_t* __restrict__ gout, int64_t pt0, int64_t m, int lane) {
+    constexpr int NT = C / 32;
+    const int pnt = lane & 31, hh = lane >> 5;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+#pragma unroll 2
+    for (int s = 0; s < K / 16; ++s) {
+        const half8 bfrag = *(const half8*)(act_in + pnt * PwImg<K>::STR + 16 * s + 8 * hh);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const half8 afrag = *(const half8*)(wimg + (32 * t + pnt) * PwImg<K>::STR + 16 * s + 8 * hh);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag, bfrag, acc[t], 0, 0, 0);
+        }
+    }
+    // accumulator register 4 g + e of tile t: channel 32 t + 8 g + 4 hh + e of point pnt
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c0 = 32 * t + 8 * g + 4 * hh;
+            const f32x4 bv = *(const f32x4*)(bias + c0);
+            half4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (half_t)__builtin_amdgcn_fmed3f(acc[t][4 * g + e] + bv[e], 0.f, 65504.f);   // ReLU + fp16 saturation
+            *(half4*)(act_out + pnt * PwImg<C>::STR + c0) = o;
+        }
+    if (TO_GLOBAL) {
+        // rows leave through the wave's LDS image as whole 16-byte chunks: 2 C / 16 lanes cover one point's row, so a
+        // store instruction writes complete cache lines (the accumulator layout itself would write 16 B of 32 different rows)
+        constexpr int CPR = C / 8;                    // chunks per row
+#pragma unroll
+        for (int i = 0; i < 32 * CPR / 64; ++i) {
+            const int c = i * 64 + lane, row = c / CPR, ch = c - row * CPR;
+            const half8 v = *(const half8*)(act_out + row * PwImg<C>::STR + ch * 8);
+            if (pt0 + row < m) *(half8*)(gout + (pt0 + row) * C + ch * 8) = v;
+        }
+    }
+}
+
+// weights [C][K] fp16 (global, row stride K) -> LDS image [C][K + 8], all PW_THREADS threads; every load of the layer is
+// in flight before the first LDS store
+template <int K, int C>
+__device__ __forceinline__ void pw_load_w(const half_t* __restrict__ w, half_t* img) {
+    constexpr int CH = C * (K / 8), IT = CH / PW_THREADS;
+    static_assert(CH % PW_THREADS == 0, "weight image must split evenly");
+    half8 r[IT];
+#pragma unroll
+    for (int j = 0; j < IT; ++j) r[j] = *(const half8*)(w + (int64_t)(j * PW_THREADS + threadIdx.x) * 8);
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+        const int i = j * PW_THREADS + threadIdx.x, row = i / (K / 8), ch = i - row * (K / 8);
+        *(half8*)(img + row * PwImg<K>::STR + ch * 8) = r[j];
+    }
+}
+
+template <int CHAIN>
+__global__ __launch_bounds__(PW_THREADS) void pw_chain_kernel(PwChainParams p) {
+    // layer shapes of the chain
+    constexpr int K0 = CHAIN == 0 ? 64 : 128, C0 = CHAIN == 0 ? 64 : 128;
+    constexpr int K1 = C0, C1 = CHAIN == 0 ? 128 : (CHAIN == 1 ? 128 : 64);
+    constexpr int K2 = 64, C2 = 64;                                              // D1 only: output.0
+    constexpr int W0 = C0 * PwImg<K0>::STR, W1 = C1 * PwImg<K1>::STR, W2 = CHAIN == 2 ? C2 * PwImg<K2>::STR : 0;
+    constexpr int ACT = 32 * PwImg<128>::STR;
+    __shared__ __attribute__((aligned(16))) half_t wimg[W0 + W1 + W2];
+    __shared__ __attribute__((aligned(16))) half_t act[PW_WAVES][ACT];      // one buffer per wave, rewritten in place layer by layer
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pnt = lane & 31, hh = lane >> 5;
+    pw_load_w<K0, C0>(p.w[0], wimg);
+    pw_load_w<K1, C1>(p.w[1], wimg + W0);
+    if (CHAIN == 2) pw_load_w<K2, C2>(p.w[2], wimg + W0 + W1);
+    __syncthreads();
+    half_t* buf = act[wave];
+    const int64_t ntiles = (p.m + PW_TILE - 1) / PW_TILE;
+    // E2 / D1: the next tile's [32 points][128] fp16 rows travel in registers while this tile computes (one wave per
+    // SIMD: nothing else hides the load latency).  16 chunks of 16 B per point, 8 per lane.
+    half8 pre[8];
+    auto fetch = [&](int64_t tile) __attribute__((always_inline)) {
+        const int64_t pt0 = tile * PW_TILE + wave * 32;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = i * 64 + lane;
+            int64_t pt = pt0 + (c >> 4);
+            pt = pt < p.m ? pt : p.m - 1;
+            pre[i] = *(const half8*)(p.in16 + pt * 128 + (c & 15) * 8);
+        }
+    };
+    if (CHAIN != 0 && (int64_t)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t pt0 = tile * PW_TILE + wave * 32;
+        // ---- input -> buf
+        if (CHAIN == 0) {
+            // enc1.conv1: K = 3 half + per-shape time bias + ReLU (the arithmetic of enc1_xyz_kernel); lane = (point, 32 channels)
+            int64_t pt = pt0 + pnt;
+            pt = pt < p.m ? pt : p.m - 1;
+            const float px = p.xyz[pt * 3 + 0], py = p.xyz[pt * 3 + 1], pz = p.xyz[pt * 3 + 2];
+            const float* tb = p.tbias + (int64_t)(pt / p.rows_per_shape) * p.tb_stride * 64 + 32 * hh;
+            const float* wr = p.w_xyz + (int64_t)(32 * hh) * 3;
+#pragma unroll
+            for (int c8 = 0; c8 < 4; ++c8) {
+                half8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = c8 * 8 + e;
+                    float v = tb[c];
+                    v = fmaf(wr[c * 3 + 0], px, v);
+                    v = fmaf(wr[c * 3 + 1], py, v);
+                    v = fmaf(wr[c * 3 + 2], pz, v);
+                    o[e] = to_half_sat(fmaxf(v, 0.f));
+                }
+                *(half8*)(buf + pnt * PwImg<64>::STR + 32 * hh + c8 * 8) = o;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = i * 64 + lane;
+                *(half8*)(buf + (c >> 4) * PwImg<128>::STR + (c & 15) * 8) = pre[i];
+            }
+            if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
+        }
+        // ---- layers
+        pw_layer<K0, C0, false>(buf, wimg, p.b[0], buf, nullptr, pt0, p.m, lane);
+        if (CHAIN != 2) {
+            pw_layer<K1, C1, true>(buf, wimg + W0, p.b[1], buf, p.out16, pt0, p.m, lane);
+        } else {
+            pw_layer<K1, C1, false>(buf, wimg + W0, p.b[1], buf, nullptr, pt0, p.m, lane);
+            pw_layer<K2, C2, false>(buf, wimg + W0 + W1, p.b[2], buf, nullptr, pt0, p.m, lane);
+            // output.3: 64 -> 3, fp32 (the arithmetic of head3_kernel): lanes 0..31, one point each
+            if (hh == 0 && pt0 + pnt < p.m) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int c8 = 0; c8 < 8; ++c8) {
+                    const half8 v = *(const half8*)(buf + pnt * PwImg<64>::STR + c8 * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float f = (float)v[e];
+                        a0 = fmaf(p.head_w[c8 * 8 + e], f, a0);
+                        a1 = fmaf(p.head_w[64 + c8 * 8 + e], f, a1);
+                        a2 = fmaf(p.head_w[128 + c8 * 8 + e], f, a2);
+                    }
+                }
+                float* o = p.out32 + (pt0 + pnt) * 3;
+                o[0] = a0 + p.head_b[0];
+                o[1] = a1 + p.head_b[1];
+                o[2] = a2 + p.head_b[2];
+            }
+        }
+    }
+}
+
+}  // namespace pcd
+
+using namespace pcd;
+
+static inline unsigned pw_grid(int64_t m) {
+    const int64_t tiles = (m + PW_TILE - 1) / PW_TILE;
+    return (unsigned)(tiles < 256 ? tiles : 256);        // persistent: the weight image is loaded once per workgroup
+}
+
+extern "C" int pcd_pw_chain_enc1(const float* x, int64_t m, int rows_per_shape, const float* w_xyz, const float* tbias,
+                                 int tbias_shape_stride, const void* w_conv2, const float* b_conv2, const void* w_conv3,
+                                 const float* b_conv3, void* x1, void* stream) {
+    PCD_CHECK_ARG(x && w_xyz && tbias && w_conv2 && b_conv2 && w_conv3 && b_conv3 && x1);
+    PCD_CHECK_ARG(m > 0 && rows_per_shape > 0 && tbias_shape_stride >= 0);
+    PwChainParams p{};
+    p.m = m; p.rows_per_shape = rows_per_shape; p.xyz = x; p.w_xyz = w_xyz; p.tbias = tbias; p.tb_stride = tbias_shape_stride;
+    p.w[0] = (const half_t*)w_conv2; p.b[0] = b_conv2; p.w[1] = (const half_t*)w_conv3; p.b[1] = b_conv3;
+    p.out16 = (half_t*)x1;
+    hipLaunchKernelGGL((pw_chain_kernel<0>), dim3(pw_grid(m)), dim3(PW_THREADS), 0, (hipStream_t)stream, p);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_pw_chain_128(const void* in, int64_t m, const void* w_a, const float* b_a, const void* w_b,
+                                const float* b_b, void* out, void* stream) {
+    PCD_CHECK_ARG(in && w_a && b_a && w_b && b_b && out && m > 0);
+    PwChainParams p{};
+    p.m = m; p.rows_per_shape = 1; p.in16 = (const half_t*)in;
+    p.w[0] = (const half_t*)w_a; p.b[0] = b_a; p.w[1] = (const half_t*)w_b; p.b[1] = b_b;
+    p.out16 = (half_t*)out;
+    hipLaunchKernelGGL((pw_chain_kernel<1>), dim3(pw_grid(m)), dim3(PW_THREADS), 0, (hipStream_t)stream, p);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_pw_chain_tail(const void* in, int64_t m, const void* w_a, const float* b_a, const void* w_b,
+                                 const float* b_b, const void* w_c, const float* b_c, const float* head_w,
+                                 const float* head_b, float* eps, void* stream) {
+    PCD_CHECK_ARG(in && w_a && b_a && w_b && b_b && w_c && b_c && head_w && head_b && eps && m > 0);
+    PwChainParams p{};
+    p.m = m; p.rows_per_shape = 1; p.in16 = (const half_t*)in;
+    p.w[0] = (const half_t*)w_a; p.b[0] = b_a; p.w[1] = (const half_t*)w_b; p.b[1] = b_b; p.w[2] = (const half_t*)w_c; p.b[2] = b_c;
+    p.head_w = head_w; p.head_b = head_b; p.out32 = eps;
+    hipLaunchKernelGGL((pw_chain_kernel<2>), dim3(pw_grid(m)), dim3(PW_THREADS), 0, (hipStream_t)stream, p);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}

@@ -72,6 +72,13 @@ static const int kLinK[PCD_UNET_NLIN] = {64, 64, 128, 128, 128, 256, 256, 256, 5
 static const int kLinC[PCD_UNET_NLIN] = {64, 128, 128, 128, 256, 256, 256, 512, 512, 512, 1024, 2048, 4096,
                                          1024, 1024, 512, 512, 512, 256, 256, 256, 128, 128, 128, 64, 64};
 
+static int g_unet_chains = 1;        // tuning / testing hook (pcd_unet_config): 0 = one GEMM launch per layer
+
+extern "C" int pcd_unet_config(int use_chains) {
+    g_unet_chains = use_chains ? 1 : 0;
+    return PCD_OK;
+}
+
 extern "C" int pcd_unet_create(const pcd_unet_desc_t* desc, pcd_unet_t** out) {
     PCD_CHECK_ARG(desc != nullptr && out != nullptr);
     PCD_CHECK_ARG(desc->freqs && desc->tw0 && desc->tb0 && desc->tw2 && desc->tb2);
@@ -158,11 +165,19 @@ extern "C" int pcd_unet_forward(pcd_unet_t* h, const float* x, int batch, int n_
     const pcd_unet_desc_t& d = h->d;
     int rc;
 #define RUN(expr) do { rc = (expr); if (rc) return rc; } while (0)
-    RUN(pcd_enc1_xyz(x, m, n_points, d.e1w_xyz, 64, tbias, tbias_shape_stride, s0, s));
-    RUN(run_lin(d, 0, m, s0, nullptr, 0, nullptr, 0, s1, s));
-    RUN(run_lin(d, 1, m, s1, nullptr, 0, nullptr, 0, x1, s));
-    RUN(run_lin(d, 2, m, x1, nullptr, 0, nullptr, 0, s0, s));
-    RUN(run_lin(d, 3, m, s0, nullptr, 0, nullptr, 0, s1, s));
+    const bool chains = g_unet_chains != 0;
+    if (chains) {
+        // enc1 (xyz -> 64 -> 64 -> 128) and enc2.conv1-2 (128 -> 128 -> 128): one launch each, intermediates in LDS
+        RUN(pcd_pw_chain_enc1(x, m, n_points, d.e1w_xyz, tbias, tbias_shape_stride, d.lin[0].w, d.lin[0].b, d.lin[1].w,
+                              d.lin[1].b, x1, s));
+        RUN(pcd_pw_chain_128(x1, m, d.lin[2].w, d.lin[2].b, d.lin[3].w, d.lin[3].b, s1, s));
+    } else {
+        RUN(pcd_enc1_xyz(x, m, n_points, d.e1w_xyz, 64, tbias, tbias_shape_stride, s0, s));
+        RUN(run_lin(d, 0, m, s0, nullptr, 0, nullptr, 0, s1, s));
+        RUN(run_lin(d, 1, m, s1, nullptr, 0, nullptr, 0, x1, s));
+        RUN(run_lin(d, 2, m, x1, nullptr, 0, nullptr, 0, s0, s));
+        RUN(run_lin(d, 3, m, s0, nullptr, 0, nullptr, 0, s1, s));
+    }
     RUN(run_lin(d, 4, m, s1, nullptr, 0, nullptr, 0, x2, s));
     RUN(run_lin(d, 5, m, x2, nullptr, 0, nullptr, 0, s0, s));
     RUN(run_lin(d, 6, m, s0, nullptr, 0, nullptr, 0, s1, s));
@@ -212,10 +227,16 @@ extern "C" int pcd_unet_forward(pcd_unet_t* h, const float* x, int batch, int n_
     RUN(run_lin(d, 20, m, s1, nullptr, 0, nullptr, 0, s0, s));
     RUN(run_lin(d, 21, m, s0, nullptr, 0, nullptr, 0, s1, s));
     RUN(run_lin(d, 22, m, s1, x1, 128, nullptr, 0, s0, s));
-    RUN(run_lin(d, 23, m, s0, nullptr, 0, nullptr, 0, s1, s));
-    RUN(run_lin(d, 24, m, s1, nullptr, 0, nullptr, 0, s0, s));
-    RUN(run_lin(d, 25, m, s0, nullptr, 0, nullptr, 0, s1, s));
-    RUN(pcd_head3(s1, m, 64, d.head_w, d.head_b, eps, s));
+    if (chains) {
+        // dec1.conv2 -> conv3 -> output.0 -> output.3 (128 -> 128 -> 64 -> 64 -> 3): one launch
+        RUN(pcd_pw_chain_tail(s0, m, d.lin[23].w, d.lin[23].b, d.lin[24].w, d.lin[24].b, d.lin[25].w, d.lin[25].b, d.head_w,
+                              d.head_b, eps, s));
+    } else {
+        RUN(run_lin(d, 23, m, s0, nullptr, 0, nullptr, 0, s1, s));
+        RUN(run_lin(d, 24, m, s1, nullptr, 0, nullptr, 0, s0, s));
+        RUN(run_lin(d, 25, m, s0, nullptr, 0, nullptr, 0, s1, s));
+        RUN(pcd_head3(s1, m, 64, d.head_w, d.head_b, eps, s));
+    }
 #undef RUN
     return PCD_OK;
 }

@@ -165,6 +165,22 @@ typedef struct {
     const float* head_w; const float* head_b; /* output.3 fp32 [3][64], [3] */
 } pcd_unet_desc_t;
 
+/* Chains of the narrow pointwise layers of UNetPointNetLarge in one launch each (csrc/chain.hip): a wave carries 32
+ * points through the chain with the intermediates in LDS, the chain's weights (fp16 [C][K], BatchNorm folded) resident
+ * in LDS.  Every layer = Conv1d(k=1) + BN + ReLU with fp32 accumulation and one fp16 rounding, like pcd_gemm_f16.
+ *   enc1:  x fp32 [m][3] -> conv1 (K = 3, + per-shape time bias, as pcd_enc1_xyz) -> conv2 64->64 -> conv3 64->128 -> x1
+ *   128:   in fp16 [m][128] -> 128->128 -> 128->128 -> out fp16 [m][128]                 (enc2.conv1, enc2.conv2)
+ *   tail:  in fp16 [m][128] -> 128->128 -> 128->64 -> 64->64 -> 64->3 fp32 (no ReLU)     (dec1.conv2, conv3, output.0, output.3) */
+int pcd_pw_chain_enc1(const float* x, int64_t m, int rows_per_shape, const float* w_xyz, const float* tbias,
+                      int tbias_shape_stride, const void* w_conv2, const float* b_conv2, const void* w_conv3,
+                      const float* b_conv3, void* x1, void* stream);
+int pcd_pw_chain_128(const void* in, int64_t m, const void* w_a, const float* b_a, const void* w_b, const float* b_b,
+                     void* out, void* stream);
+int pcd_pw_chain_tail(const void* in, int64_t m, const void* w_a, const float* b_a, const void* w_b, const float* b_b,
+                      const void* w_c, const float* b_c, const float* head_w, const float* head_b, float* eps, void* stream);
+/* testing / tuning hook for pcd_unet_forward: 0 = one GEMM launch per layer, 1 (default) = the chained kernels above */
+int pcd_unet_config(int use_chains);
+
 typedef struct pcd_unet pcd_unet_t;
 int pcd_unet_create(const pcd_unet_desc_t* desc, pcd_unet_t** out);
 void pcd_unet_destroy(pcd_unet_t* h);

@@ -55,6 +55,29 @@ def test_forward_mid_per_shape_time(model, golden):
     assert float((eps - torch.from_numpy(g["fw_mid_eps"])).abs().max()) < 5e-3
 
 
+@pytest.mark.parametrize("B,N", [(2, 64), (3, 100), (1, 257), (5, 512)])
+def test_chained_narrow_layers_match_per_layer_launches(model, B, N):
+    """pcd_unet_forward runs enc1, enc2.conv1-2 and dec1.conv2..output.3 as LDS-resident chains (csrc/chain.hip);
+    pcd_unet_config(0) selects one GEMM launch per layer.  Both sum the same fp16 products in fp32 in the same k order
+    and round once per layer, so eps and the x1 tap agree bit for bit - on whole and on ragged 256-point tiles."""
+    from shapegen_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    x = torch.randn(B, N, 3, generator=g).cuda()
+    t = torch.randint(0, 1000, (B,), generator=g).cuda()
+    eps_chain = model.model(x, t).clone()
+    x1_chain = model.model.tap("x1", B, N).clone()
+    _lib.check(lib.pcd_unet_config(0))
+    try:
+        eps_layers = model.model(x, t).clone()
+        x1_layers = model.model.tap("x1", B, N).clone()
+    finally:
+        _lib.check(lib.pcd_unet_config(1))
+    assert torch.isfinite(eps_chain).all()
+    assert torch.equal(x1_chain, x1_layers)
+    assert torch.equal(eps_chain, eps_layers)
+
+
 def test_forward_ragged_sizes(model):
     """N not a multiple of any tile (exercises row masking and the slow column-max path)."""
     from oracle import torch_oracle as O
