@@ -18,6 +18,7 @@ constexpr int CROWB = CBK * 2;
 
 constexpr int MAX_VARIANTS = 8;      // the 2x2x2 output-parity classes of a stride-2 ConvTranspose3d
 constexpr int MAX_TAPS = 64;
+constexpr int TAP_SLOTS = 128;     // LDS tap table of the implicit GEMM: ntaps real entries + the K padding's (kpad / Cin <= 128)
 
 // what differs between the problems of one launch (blockIdx.y): tap table, weights, output parity
 struct ConvVariant {
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
     constexpr int LDS_BYTES = (2 * STAGE_BYTES > BM * OUT_LD) ? 2 * STAGE_BYTES : BM * OUT_LD;
     constexpr int AR = BM / 32, BR = BN / 32;
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
-    __shared__ int taps_s[MAX_TAPS];
+    __shared__ int4 taps_s[TAP_SLOTS];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -69,15 +70,30 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
     const int kt0 = (int)((int64_t)sp * nk_all / p.splits), kt1 = (int)((int64_t)(sp + 1) * nk_all / p.splits);
     const ConvVariant& cv = p.var[cls];
     const half_t* __restrict__ wgt = cv.w;
-    // tap table -> LDS once: a global lookup inside stage() would put two dependent memory latencies
-    // on every K tile, which is what bounds the small-grid layers
-    if (tid < MAX_TAPS) taps_s[tid] = tid < p.ntaps ? cv.taps[tid] : 0;
+    // Tap table -> LDS once, in the form the gather wants (the address arithmetic of a K tile is what bounds this
+    // kernel's issue slots, not the MFMAs): x, y = the tap's (dz, dy, dx) as three biased byte fields, +64 + d and
+    // 64 - d; z = its offset in elements of the NDHWC input.  A row keeps (z, y, x) + 64 and (D-1-z, H-1-y, W-1-x) + 64
+    // in the same byte fields, so "input voxel inside the grid" is: bit 7 of every field of both sums set -- two
+    // adds, two ands and one compare for all six bounds (dims <= 64, |d| < 64: no carry between fields).  Slots past
+    // ntaps (K padding) hold 0 and fail that test.
+    if (tid < TAP_SLOTS) {
+        int4 e = {0, 0, 0, 0};
+        if (tid < p.ntaps) {
+            const int pk = cv.taps[tid];
+            const int dz = (int)(signed char)(pk & 0xff), dy = (int)(signed char)((pk >> 8) & 0xff),
+                      dx = (int)(signed char)((pk >> 16) & 0xff);
+            e.x = (dz + 64) | (dy + 64) << 8 | (dx + 64) << 16;
+            e.y = (64 - dz) | (64 - dy) << 8 | (64 - dx) << 16;
+            e.z = ((dz * p.H + dy) * p.W + dx) * p.Cin;
+        }
+        taps_s[tid] = e;
+    }
     __syncthreads();
 
     // the rows this thread stages (fixed for the whole K loop): decode the output voxel once
     const int srow = wave * 8 + (lane >> 3);                 // + r*32
     const int lchunk = (lane & 7) ^ ((srow >> 1) & 7);       // logical 16-B chunk (same for every r)
-    int rb[AR], rz[AR], ry[AR], rx[AR];
+    int rp1[AR], rp2[AR], rbase[AR];
 #pragma unroll
     for (int r = 0; r < AR; ++r) {
         int m = m0 + r * 32 + srow;
@@ -85,36 +101,35 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
         const int ox = m % p.Wo; int t = m / p.Wo;
         const int oy = t % p.Ho; t /= p.Ho;
         const int oz = t % p.Do;
-        rb[r] = t / p.Do;
-        rz[r] = oz * p.stride; ry[r] = oy * p.stride; rx[r] = ox * p.stride;
+        const int b = t / p.Do;
+        const int rz = oz * p.stride, ry = oy * p.stride, rx = ox * p.stride;
+        rp1[r] = (rz + 64) | (ry + 64) << 8 | (rx + 64) << 16;
+        rp2[r] = (p.D - 1 - rz + 64) | (p.H - 1 - ry + 64) << 8 | (p.W - 1 - rx + 64) << 16;
+        rbase[r] = (((b * p.D + rz) * p.H + ry) * p.W + rx) * p.Cin;
     }
+    const half_t* wrow[BR];
+#pragma unroll
+    for (int r = 0; r < BR; ++r) {
+        int n = n0 + r * 32 + srow;
+        n = n < p.Cout ? n : p.Cout - 1;
+        wrow[r] = wgt + (int64_t)n * p.kpad;
+    }
+    const half_t* zlane = p.zero + (lane & 7) * 8;
 
     auto stage = [&](int kt, int buf) {
         char* base = smem + buf * STAGE_BYTES;
         const int kidx = kt * CBK + lchunk * 8;
-        const int tap = kidx >> p.cin_shift, c = kidx & (p.Cin - 1);
-        const bool tap_ok = tap < p.ntaps;
-        int dz = 0, dy = 0, dx = 0;
-        if (tap_ok) {
-            const int pk = taps_s[tap];
-            dz = (int)(signed char)(pk & 0xff); dy = (int)(signed char)((pk >> 8) & 0xff);
-            dx = (int)(signed char)((pk >> 16) & 0xff);
-        }
+        const int4 te = taps_s[kidx >> p.cin_shift];
+        const int dc = te.z + (kidx & (p.Cin - 1));
 #pragma unroll
         for (int r = 0; r < AR; ++r) {
-            const int iz = rz[r] + dz, iy = ry[r] + dy, ix = rx[r] + dx;
-            const bool ok = tap_ok && (unsigned)iz < (unsigned)p.D && (unsigned)iy < (unsigned)p.H &&
-                            (unsigned)ix < (unsigned)p.W;
-            const half_t* g = ok ? p.in + ((((int64_t)rb[r] * p.D + iz) * p.H + iy) * p.W + ix) * p.Cin + c
-                                 : p.zero + (lane & 7) * 8;
+            const bool ok = (((rp1[r] + te.x) & (rp2[r] + te.y)) & 0x808080) == 0x808080;
+            const half_t* g = p.in + (rbase[r] + dc);
+            g = ok ? g : zlane;
             cglds16(g, base + (r * 32 + wave * 8) * CROWB);
         }
 #pragma unroll
-        for (int r = 0; r < BR; ++r) {
-            int n = n0 + r * 32 + srow;
-            n = n < p.Cout ? n : p.Cout - 1;
-            cglds16(wgt + (int64_t)n * p.kpad + kidx, base + BM * CROWB + (r * 32 + wave * 8) * CROWB);
-        }
+        for (int r = 0; r < BR; ++r) cglds16(wrow[r] + kidx, base + BM * CROWB + (r * 32 + wave * 8) * CROWB);
     };
 
     f32x4 acc[MI][NI];
@@ -738,6 +753,11 @@ static int conv_check(const pcd_conv3d_desc_t* d) {
     PCD_CHECK_ARG(d->cin >= 8 && (d->cin & (d->cin - 1)) == 0);
     PCD_CHECK_ARG(d->cout > 0 && d->cout % 8 == 0);
     PCD_CHECK_ARG(d->ntaps > 0 && d->ntaps <= MAX_TAPS && d->kpad % CBK == 0 && d->kpad >= d->ntaps * d->cin);
+    PCD_CHECK_ARG(d->kpad / d->cin <= TAP_SLOTS);
+    // the gather tests all six grid bounds in packed byte fields (conv3d_igemm_kernel): coordinates below 64
+    PCD_CHECK_ARG(d->in_d <= 64 && d->in_h <= 64 && d->in_w <= 64);
+    PCD_CHECK_ARG((d->rows_d - 1) * d->stride < 64 && (d->rows_h - 1) * d->stride < 64 && (d->rows_w - 1) * d->stride < 64);
+    PCD_CHECK_ARG((int64_t)d->batch * d->in_d * d->in_h * d->in_w * d->cin <= 0x7fffffff);
     PCD_CHECK_ARG(d->rows_d > 0 && d->rows_h > 0 && d->rows_w > 0 && d->stride > 0);
     PCD_CHECK_ARG(d->out_scale > 0 && d->out_d > 0 && d->out_h > 0 && d->out_w > 0);
     PCD_CHECK_ARG((int64_t)d->batch * d->rows_d * d->rows_h * d->rows_w <= 0x7fffffff);

@@ -11,6 +11,7 @@
 //
 // Tile: BM x BN x 64, 256 threads = 4 waves as 2(M) x 2(N).
 #include "common.h"
+#include <type_traits>
 
 namespace pcd {
 
@@ -254,46 +255,53 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
         // tail of a tile is issue-bound, not bandwidth-bound (cdna guide T21).
         const int qq = lane >> 4;
         static_assert(NI % 2 == 0, "store epilogue pairs column tiles");
+        // two instances: whole tiles without per-row shape bias run straight-line code (no per-lane predicates, no
+        // exec-masked branches around the stores); edge tiles and per-row biases take the predicated form
+        auto store_rows = [&](auto full_c) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int row = m0 + wm * WM + i * 16 + pr;
-            const bool row_ok = full || row < p.m;
-            half_t* orow = p.out16 + (int64_t)(row_ok ? row : 0) * p.ldo;
-            const float* sbrow = (sb_rows != nullptr && row_ok) ? sb_rows + (int64_t)(row / p.rows_per_shape) * p.c : nullptr;
+            for (int i = 0; i < MI; ++i) {
+                const int row = m0 + wm * WM + i * 16 + pr;
+                const bool row_ok = FULL || row < p.m;
+                half_t* orow = p.out16 + (int64_t)(row_ok ? row : 0) * p.ldo;
+                const float* sbrow = (!FULL && sb_rows != nullptr && row_ok) ? sb_rows + (int64_t)(row / p.rows_per_shape) * p.c : nullptr;
 #pragma unroll
-            for (int j = 0; j < NI; j += 2) {
-                unsigned pk[2][2];
+                for (int j = 0; j < NI; j += 2) {
+                    unsigned pk[2][2];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int col = n0 + wn * WN + (j + t) * 16 + q4;
-                    f32x4 v = acc[i][j + t] + bv[j + t];
-                    if (sbrow != nullptr && col < p.c) v += *(const f32x4*)(sbrow + col);
-                    half2_ lo2, hi2;
-                    lo2[0] = (half_t)__builtin_amdgcn_fmed3f(v[0], lo, 65504.f);
-                    lo2[1] = (half_t)__builtin_amdgcn_fmed3f(v[1], lo, 65504.f);
-                    hi2[0] = (half_t)__builtin_amdgcn_fmed3f(v[2], lo, 65504.f);
-                    hi2[1] = (half_t)__builtin_amdgcn_fmed3f(v[3], lo, 65504.f);
-                    pk[t][0] = __builtin_bit_cast(unsigned, lo2);
-                    pk[t][1] = __builtin_bit_cast(unsigned, hi2);
-                }
-                const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
-                const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
-                // lane group qq now holds: s0[0], s1[0] = channels +0..3 ; s0[1], s1[1] = channels +4..7
-                const int col = n0 + wn * WN + (j + (qq & 1)) * 16 + (qq >> 1) * 8;
-                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
-                if (row_ok && (full || col < p.c)) {
-                    if constexpr (EPI == EPI_RESID) {
-                        half8 ov = __builtin_bit_cast(half8, o);
-                        const half8 rs = *(const half8*)(p.resid + (int64_t)row * p.ldr + col);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) ov[e] = to_half_sat((float)ov[e] + (float)rs[e]);
-                        o = __builtin_bit_cast(u32x4, ov);
+                    for (int t = 0; t < 2; ++t) {
+                        const int col = n0 + wn * WN + (j + t) * 16 + q4;
+                        f32x4 v = acc[i][j + t] + bv[j + t];
+                        if (!FULL && sbrow != nullptr && col < p.c) v += *(const f32x4*)(sbrow + col);
+                        half2_ lo2, hi2;
+                        lo2[0] = (half_t)__builtin_amdgcn_fmed3f(v[0], lo, 65504.f);
+                        lo2[1] = (half_t)__builtin_amdgcn_fmed3f(v[1], lo, 65504.f);
+                        hi2[0] = (half_t)__builtin_amdgcn_fmed3f(v[2], lo, 65504.f);
+                        hi2[1] = (half_t)__builtin_amdgcn_fmed3f(v[3], lo, 65504.f);
+                        pk[t][0] = __builtin_bit_cast(unsigned, lo2);
+                        pk[t][1] = __builtin_bit_cast(unsigned, hi2);
                     }
-                    *(u32x4*)(orow + col) = o;
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                    // lane group qq now holds: s0[0], s1[0] = channels +0..3 ; s0[1], s1[1] = channels +4..7
+                    const int col = n0 + wn * WN + (j + (qq & 1)) * 16 + (qq >> 1) * 8;
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                    if (FULL || (row_ok && col < p.c)) {
+                        if constexpr (EPI == EPI_RESID) {
+                            half8 ov = __builtin_bit_cast(half8, o);
+                            const half8 rs = *(const half8*)(p.resid + (int64_t)row * p.ldr + col);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) ov[e] = to_half_sat((float)ov[e] + (float)rs[e]);
+                            o = __builtin_bit_cast(u32x4, ov);
+                        }
+                        *(u32x4*)(orow + col) = o;
+                    }
                 }
             }
-        }
+        };
+        if (full) store_rows(std::true_type{});
+        else store_rows(std::false_type{});
         counted_wait = XPREF && (EPI == EPI_F16) && full;
         continue;
     }
