@@ -33,7 +33,7 @@ template <int K> struct PwImg { static constexpr int STR = K + 8; };            
 
 // one layer for this wave's 32 points: act_in [32][K + 8] (LDS) x W image [C][K + 8] (LDS) -> act_out [32][C + 8] (LDS) or
 // global rows [pt0 + point][C]
-template <int K, int C, bool TO_GLOBAL>
+template <int K, int C, bool TO_GLOBAL, bool RELU = true>
 __device__ __forceinline__ void pw_layer(const half_t* act_in, const half_t* wimg, const float* __restrict__ bias,
                                          half_t* act_out, half_t* __restrict__ gout, int64_t pt0, int64_t m, int lane) {
     constexpr int NT = C / 32;
@@ -61,7 +61,7 @@ __device__ __forceinline__ void pw_layer(const half_t* act_in, const half_t* wim
             const f32x4 bv = *(const f32x4*)(bias + c0);
             half4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (half_t)__builtin_amdgcn_fmed3f(acc[t][4 * g + e] + bv[e], 0.f, 65504.f);   // ReLU + fp16 saturation
+            for (int e = 0; e < 4; ++e) o[e] = (half_t)__builtin_amdgcn_fmed3f(acc[t][4 * g + e] + bv[e], RELU ? 0.f : -65504.f, 65504.f);   // (ReLU +) fp16 saturation
             *(half4*)(act_out + pnt * PwImg<C>::STR + c0) = o;
         }
     if (TO_GLOBAL) {
@@ -77,19 +77,21 @@ __device__ __forceinline__ void pw_layer(const half_t* act_in, const half_t* wim
     }
 }
 
-// weights [C][K] fp16 (global, row stride K) -> LDS image [C][K + 8], all PW_THREADS threads; every load of the layer is
-// in flight before the first LDS store
-template <int K, int C>
-__device__ __forceinline__ void pw_load_w(const half_t* __restrict__ w, half_t* img) {
-    constexpr int CH = C * (K / 8), IT = CH / PW_THREADS;
-    static_assert(CH % PW_THREADS == 0, "weight image must split evenly");
+// weights [C][K] fp16 (global, row stride ldw) -> LDS image [C][K + 8], all NTHR threads; every load of the layer is in
+// flight before the first LDS store
+template <int K, int C, int NTHR = PW_THREADS>
+__device__ __forceinline__ void pw_load_w(const half_t* __restrict__ w, int64_t ldw, half_t* img) {
+    constexpr int CH = C * (K / 8), IT = (CH + NTHR - 1) / NTHR;
     half8 r[IT];
 #pragma unroll
-    for (int j = 0; j < IT; ++j) r[j] = *(const half8*)(w + (int64_t)(j * PW_THREADS + threadIdx.x) * 8);
+    for (int j = 0; j < IT; ++j) {
+        const int i = j * NTHR + threadIdx.x, row = i / (K / 8), ch = i - row * (K / 8);
+        if (CH % NTHR == 0 || i < CH) r[j] = *(const half8*)(w + row * ldw + ch * 8);
+    }
 #pragma unroll
     for (int j = 0; j < IT; ++j) {
-        const int i = j * PW_THREADS + threadIdx.x, row = i / (K / 8), ch = i - row * (K / 8);
-        *(half8*)(img + row * PwImg<K>::STR + ch * 8) = r[j];
+        const int i = j * NTHR + threadIdx.x, row = i / (K / 8), ch = i - row * (K / 8);
+        if (CH % NTHR == 0 || i < CH) *(half8*)(img + row * PwImg<K>::STR + ch * 8) = r[j];
     }
 }
 
@@ -106,9 +108,9 @@ __global__ __launch_bounds__(PW_THREADS) void pw_chain_kernel(PwChainParams p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pnt = lane & 31, hh = lane >> 5;
-    pw_load_w<K0, C0>(p.w[0], wimg);
-    pw_load_w<K1, C1>(p.w[1], wimg + W0);
-    if (CHAIN == 2) pw_load_w<K2, C2>(p.w[2], wimg + W0 + W1);
+    pw_load_w<K0, C0>(p.w[0], K0, wimg);
+    pw_load_w<K1, C1>(p.w[1], K1, wimg + W0);
+    if (CHAIN == 2) pw_load_w<K2, C2>(p.w[2], K2, wimg + W0 + W1);
     __syncthreads();
     half_t* buf = act[wave];
     const int64_t ntiles = (p.m + PW_TILE - 1) / PW_TILE;
@@ -188,6 +190,49 @@ __global__ __launch_bounds__(PW_THREADS) void pw_chain_kernel(PwChainParams p) {
     }
 }
 
+// One pointwise layer out[m][C] = act(in[m][K] . W^T + bias): the 1x1x1 shortcut convolutions of ResidualBlock3D
+// (reference networks.py:485-490; NDHWC rows) on the same scheme.  The implicit-GEMM convolution kernel spends a
+// prologue of index arithmetic and an LDS epilogue per 128-row workgroup on what is one K tile of work.
+template <int K, int C, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void pw_1x1_kernel(const half_t* __restrict__ in, int64_t m,
+                                                          const half_t* __restrict__ w, int64_t ldw,
+                                                          const float* __restrict__ bias, int relu,
+                                                          half_t* __restrict__ out) {
+    constexpr int KC = K > C ? K : C, ACT = 32 * (KC + 8), NCH = K / 16;      // NCH: 16-byte input chunks per lane and tile
+    __shared__ __attribute__((aligned(16))) half_t wimg[C * PwImg<K>::STR];
+    __shared__ __attribute__((aligned(16))) half_t act[WAVES][ACT];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    pw_load_w<K, C, 64 * WAVES>(w, ldw, wimg);
+    __syncthreads();
+    half_t* buf = act[wave];
+    constexpr int TILE = 32 * WAVES, CPR = K / 8;
+    const int64_t ntiles = (m + TILE - 1) / TILE;
+    half8 pre[NCH];
+    auto fetch = [&](int64_t tile) __attribute__((always_inline)) {
+        const int64_t pt0 = tile * TILE + wave * 32;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = i * 64 + lane;
+            int64_t pt = pt0 + c / CPR;
+            pt = pt < m ? pt : m - 1;
+            pre[i] = *(const half8*)(in + pt * K + (c % CPR) * 8);
+        }
+    };
+    if ((int64_t)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t pt0 = tile * TILE + wave * 32;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = i * 64 + lane;
+            *(half8*)(buf + (c / CPR) * PwImg<K>::STR + (c % CPR) * 8) = pre[i];
+        }
+        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
+        if (relu) pw_layer<K, C, true, true>(buf, wimg, bias, buf, out, pt0, m, lane);
+        else pw_layer<K, C, true, false>(buf, wimg, bias, buf, out, pt0, m, lane);
+    }
+}
+
 }  // namespace pcd
 
 using namespace pcd;
@@ -232,6 +277,24 @@ extern "C" int pcd_pw_chain_tail(const void* in, int64_t m, const void* w_a, con
     p.w[0] = (const half_t*)w_a; p.b[0] = b_a; p.w[1] = (const half_t*)w_b; p.b[1] = b_b; p.w[2] = (const half_t*)w_c; p.b[2] = b_c;
     p.head_w = head_w; p.head_b = head_b; p.out32 = eps;
     hipLaunchKernelGGL((pw_chain_kernel<2>), dim3(pw_grid(m)), dim3(PW_THREADS), 0, (hipStream_t)stream, p);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_conv1x1_supported(int k, int c) {
+    return (k == 32 && c == 64) || (k == 64 && c == 128) || (k == 128 && c == 256);
+}
+
+extern "C" int pcd_conv1x1_f16(const void* in, int64_t m, int k, const void* w, int64_t ldw, const float* bias, int relu,
+                               int c, void* out, void* stream) {
+    PCD_CHECK_ARG(in && w && bias && out && m > 0 && ldw >= k && ldw % 8 == 0);
+    PCD_CHECK_ARG(pcd_conv1x1_supported(k, c));
+    hipStream_t s = (hipStream_t)stream;
+    const half_t* in16 = (const half_t*)in; const half_t* w16 = (const half_t*)w; half_t* o16 = (half_t*)out;
+    auto grid = [&](int tile) { const int64_t t = (m + tile - 1) / tile; return dim3((unsigned)(t < 512 ? t : 512)); };
+    if (k == 32) hipLaunchKernelGGL((pw_1x1_kernel<32, 64, 8>), grid(256), dim3(512), 0, s, in16, m, w16, ldw, bias, relu, o16);
+    else if (k == 64) hipLaunchKernelGGL((pw_1x1_kernel<64, 128, 8>), grid(256), dim3(512), 0, s, in16, m, w16, ldw, bias, relu, o16);
+    else hipLaunchKernelGGL((pw_1x1_kernel<128, 256, 4>), grid(128), dim3(256), 0, s, in16, m, w16, ldw, bias, relu, o16);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

@@ -63,7 +63,11 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x - tm * p.tiles_n;
+    // consecutive workgroups go round-robin over the 8 XCDs: give each XCD a contiguous run of row tiles, so that the
+    // tiles that gather the same input voxels (neighbouring output rows, all 27 taps) meet in one L2
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int nk_all = p.kpad / CBK;
     const int cls = blockIdx.y, sp = blockIdx.z;

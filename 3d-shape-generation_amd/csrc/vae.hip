@@ -72,7 +72,11 @@ struct Runner {
         if (rc) return rc;
         const void* resid = x;
         if (R.has_ds) {
-            rc = conv(R.ds, x, dim, 1, d.taps1, dim, 0, nullptr, r);
+            // 1x1x1 shortcut + BN: a pointwise layer over the NDHWC rows (weights in LDS) where the shape has one
+            if (pcd_conv1x1_supported(R.ds.cin, R.ds.cout))
+                rc = pcd_conv1x1_f16(x, (int64_t)batch * dim * dim * dim, R.ds.cin, R.ds.w, R.ds.kpad, R.ds.b, 0, R.ds.cout, r, s);
+            else
+                rc = conv(R.ds, x, dim, 1, d.taps1, dim, 0, nullptr, r);
             if (rc) return rc;
             resid = r;
         }

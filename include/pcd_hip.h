@@ -178,6 +178,12 @@ int pcd_pw_chain_128(const void* in, int64_t m, const void* w_a, const float* b_
                      void* out, void* stream);
 int pcd_pw_chain_tail(const void* in, int64_t m, const void* w_a, const float* b_a, const void* w_b, const float* b_b,
                       const void* w_c, const float* b_c, const float* head_w, const float* head_b, float* eps, void* stream);
+/* One pointwise layer out[m][c] = act(in[m][k] . W^T + bias) with the weights resident in LDS: the 1x1x1 shortcut
+ * convolutions of ResidualBlock3D (reference networks.py:485-490) on NDHWC rows.  in fp16 [m][k]; w fp16 [c][ldw] (k used);
+ * bias fp32 [c]; relu 0/1; out fp16 [m][c].  Shapes: (k, c) = (32, 64), (64, 128), (128, 256) -- pcd_conv1x1_supported(). */
+int pcd_conv1x1_supported(int k, int c);
+int pcd_conv1x1_f16(const void* in, int64_t m, int k, const void* w, int64_t ldw, const float* bias, int relu, int c,
+                    void* out, void* stream);
 /* testing / tuning hook for pcd_unet_forward: 0 = one GEMM launch per layer, 1 (default) = the chained kernels above */
 int pcd_unet_config(int use_chains);
 

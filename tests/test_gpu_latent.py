@@ -120,6 +120,29 @@ def test_conv3d_k3s1_halo_exact(cin, cout, dims, b):
     assert lib.pcd_conv3d_k3s1_supported(d) == 0 and lib.pcd_conv3d_k3s1_f16(d, _lib.stream_ptr()) != 0
 
 
+@pytest.mark.parametrize("k,c,ldw,m,relu", [(32, 64, 64, 1000, 0), (32, 64, 32, 77, 1), (64, 128, 64, 4096 + 31, 0),
+                                            (128, 256, 128, 515, 0), (128, 256, 192, 128, 1)])
+def test_conv1x1_pointwise_exact_integers(k, c, ldw, m, relu):
+    """ResidualBlock3D's 1x1x1 shortcut (reference networks.py:485-490) as a pointwise layer with LDS-resident weights:
+    small integers make every fp32 partial sum exact, so the result equals the integer product bit for bit; ragged m,
+    padded weight rows (ldw > k), with and without ReLU."""
+    from shapegen_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(k + m)
+    x = torch.randint(-3, 4, (m, k), generator=g).half().cuda()
+    w = torch.randint(-3, 4, (c, ldw), generator=g).half().cuda()
+    b = torch.randint(-8, 9, (c,), generator=g).float().cuda()
+    out = torch.full((m, c), 7.0, dtype=torch.float16, device="cuda")
+    assert lib.pcd_conv1x1_supported(k, c) == 1 and lib.pcd_conv1x1_supported(k, c + 64) == 0
+    _lib.check(lib.pcd_conv1x1_f16(x.data_ptr(), m, k, w.data_ptr(), ldw, b.data_ptr(), relu, c, out.data_ptr(),
+                                   _lib.stream_ptr()))
+    want = x.float() @ w[:, :k].float().t() + b
+    if relu:
+        want = want.clamp_min(0)
+    assert torch.equal(out.float(), want)
+    assert lib.pcd_conv1x1_f16(x.data_ptr(), m, 48, w.data_ptr(), ldw, b.data_ptr(), relu, c, out.data_ptr(), 0) != 0
+
+
 @pytest.mark.parametrize("dims,stride", [((8, 8, 8), 1), ((4, 8, 16), 1), ((6, 5, 7), 1), ((8, 8, 8), 2)])
 def test_conv3d_first_and_last_layers(dims, stride):
     """encoder.0 (Cin = 1, ReLU, fp16 NDHWC out) and decoder.12/13 (Cout = 1, sigmoid) against F.conv3d in fp64:
