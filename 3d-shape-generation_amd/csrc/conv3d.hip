@@ -486,20 +486,25 @@ __global__ __launch_bounds__(256) void conv3d_finish_kernel(ConvParams p) {
     float a[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) a[e] = 0.f;
-    // slabs added in split order, two splits' loads in flight together
+    // slabs added in split order (deterministic), eight splits' loads in flight together: the small-grid layers that
+    // split K deepest (up to 64 ways) have the fewest threads here, so this loop is pure load latency
     const int64_t sstride = (int64_t)p.nvar * p.M * p.Cout;
     const float* sp = p.slabs + ((int64_t)cls * p.M + m) * p.Cout + col;
-    for (int s = 0; s < p.splits; s += 2) {
-        const float4* s0 = (const float4*)(sp + (int64_t)s * sstride);
-        const bool two = s + 1 < p.splits;
-        const float4* s1 = (const float4*)(sp + (int64_t)(two ? s + 1 : s) * sstride);
-        const float4 u0 = s0[0], v0 = s0[1], u1 = s1[0], v1 = s1[1];
-        a[0] += u0.x; a[1] += u0.y; a[2] += u0.z; a[3] += u0.w;
-        a[4] += v0.x; a[5] += v0.y; a[6] += v0.z; a[7] += v0.w;
-        if (two) {
-            a[0] += u1.x; a[1] += u1.y; a[2] += u1.z; a[3] += u1.w;
-            a[4] += v1.x; a[5] += v1.y; a[6] += v1.z; a[7] += v1.w;
+    constexpr int FL = 8;
+    for (int s = 0; s < p.splits; s += FL) {
+        float4 u[FL], v[FL];
+#pragma unroll
+        for (int j = 0; j < FL; ++j) {
+            const int sj = s + j < p.splits ? s + j : s;
+            const float4* q = (const float4*)(sp + (int64_t)sj * sstride);
+            u[j] = q[0]; v[j] = q[1];
         }
+#pragma unroll
+        for (int j = 0; j < FL; ++j)
+            if (s + j < p.splits) {
+                a[0] += u[j].x; a[1] += u[j].y; a[2] += u[j].z; a[3] += u[j].w;
+                a[4] += v[j].x; a[5] += v[j].y; a[6] += v[j].z; a[7] += v[j].w;
+            }
     }
     const int ox = m % p.Wo; int t = m / p.Wo;
     const int oy = t % p.Ho; t /= p.Ho;
