@@ -50,13 +50,35 @@ __device__ __forceinline__ void cglds16(const half_t* g, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN>
+// The same LDS-DMA from inline asm.  The compiler models the builtin as a FLAT access that may touch both
+// memory and LDS, and while one is pending it turns every later s_waitcnt into vmcnt(0) / lgkmcnt(0) -- which
+// drains the fragment prefetch of the halo kernel below.  Issued from asm, the DMA is invisible to that
+// bookkeeping; the caller owns the vmcnt wait and the barrier.
+__device__ __forceinline__ void cglds16_asm(const half_t* g, char* lds_wave_base) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m0v) : "memory", "m0");
+}
+
+template <int N>
+__device__ __forceinline__ void conv_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// K tile BKT (64 or 32 halfs: 128- or 64-byte LDS rows) in a ring of NST stages.  A stage is requested NST - 1 K tiles before
+// the barrier that publishes it and NST - 2 younger stages stay in flight behind that barrier's counted vmcnt: with two
+// stages the gather of K tile kt+1 has one K tile of MFMAs (~500 cycles per wave) to come back from L2, and the waves
+// spend more than half their time at the wait (SQ_WAIT_ANY 56 % of SQ_WAVE_CYCLES on the 128 -> 128 layers).
+template <int BM, int BN, int BKT, int NST>
 __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
+    constexpr int CBK = BKT, CROWB = BKT * 2;                 // shadow the file-level K tile
+    constexpr int LPR = BKT / 8, RPW = 64 / LPR, RPI = 4 * RPW;   // lanes per staged row, rows per wave instruction / per round
+    constexpr int KS = BKT / 32;
     constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
     constexpr int STAGE_BYTES = (BM + BN) * CROWB;
     constexpr int OUT_LD = BN * 2 + 16;
-    constexpr int LDS_BYTES = (2 * STAGE_BYTES > BM * OUT_LD) ? 2 * STAGE_BYTES : BM * OUT_LD;
-    constexpr int AR = BM / 32, BR = BN / 32;
+    constexpr int LDS_BYTES = (NST * STAGE_BYTES > BM * OUT_LD) ? NST * STAGE_BYTES : BM * OUT_LD;
+    constexpr int AR = BM / RPI, BR = BN / RPI, LPT = AR + BR;  // LPT: LDS-DMA instructions per thread and stage
+    static_assert(BM % RPI == 0 && BN % RPI == 0 && NST >= 2 && NST <= 4, "stage layout");
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
     __shared__ int4 taps_s[TAP_SLOTS];
 
@@ -69,7 +91,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
     if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
     const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int nk_all = p.kpad / CBK;
+    const int nk_all = p.kpad / BKT;
     const int cls = blockIdx.y, sp = blockIdx.z;
     const int kt0 = (int)((int64_t)sp * nk_all / p.splits), kt1 = (int)((int64_t)(sp + 1) * nk_all / p.splits);
     const ConvVariant& cv = p.var[cls];
@@ -95,12 +117,13 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
     __syncthreads();
 
     // the rows this thread stages (fixed for the whole K loop): decode the output voxel once
-    const int srow = wave * 8 + (lane >> 3);                 // + r*32
-    const int lchunk = (lane & 7) ^ ((srow >> 1) & 7);       // logical 16-B chunk (same for every r)
+    const int srow = wave * RPW + lane / LPR;                // + r*RPI
+    // logical 16-B chunk (same for every r): the XOR swizzles of gemm_f16.hip for 128- and 64-byte rows
+    const int lchunk = (lane % LPR) ^ (BKT == 64 ? (srow >> 1) & 7 : (-(srow >> 2)) & 3);
     int rp1[AR], rp2[AR], rbase[AR];
 #pragma unroll
     for (int r = 0; r < AR; ++r) {
-        int m = m0 + r * 32 + srow;
+        int m = m0 + r * RPI + srow;
         m = m < p.M ? m : p.M - 1;
         const int ox = m % p.Wo; int t = m / p.Wo;
         const int oy = t % p.Ho; t /= p.Ho;
@@ -114,12 +137,13 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
     const half_t* wrow[BR];
 #pragma unroll
     for (int r = 0; r < BR; ++r) {
-        int n = n0 + r * 32 + srow;
+        int n = n0 + r * RPI + srow;
         n = n < p.Cout ? n : p.Cout - 1;
         wrow[r] = wgt + (int64_t)n * p.kpad;
     }
-    const half_t* zlane = p.zero + (lane & 7) * 8;
+    const half_t* zlane = p.zero + (lane % LPR) * 8;
 
+    // LDS-DMA from asm (the compiler would serialise every later wait behind the builtin form); the K loop owns vmcnt
     auto stage = [&](int kt, int buf) {
         char* base = smem + buf * STAGE_BYTES;
         const int kidx = kt * CBK + lchunk * 8;
@@ -130,10 +154,10 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
             const bool ok = (((rp1[r] + te.x) & (rp2[r] + te.y)) & 0x808080) == 0x808080;
             const half_t* g = p.in + (rbase[r] + dc);
             g = ok ? g : zlane;
-            cglds16(g, base + (r * 32 + wave * 8) * CROWB);
+            cglds16_asm(g, base + (r * RPI + wave * RPW) * CROWB);
         }
 #pragma unroll
-        for (int r = 0; r < BR; ++r) cglds16(wrow[r] + kidx, base + BM * CROWB + (r * 32 + wave * 8) * CROWB);
+        for (int r = 0; r < BR; ++r) cglds16_asm(wrow[r] + kidx, base + BM * CROWB + (r * RPI + wave * RPW) * CROWB);
     };
 
     f32x4 acc[MI][NI];
@@ -143,22 +167,35 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
         for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int ra = wm * WM + (lane & 15), rbw = wn * WN + (lane & 15);
-    const int swa = (ra >> 1) & 7, swb = (rbw >> 1) & 7, q = lane >> 4;
-    int offa[2], offb[2];
+    const int swa = BKT == 64 ? (ra >> 1) & 7 : (-(ra >> 2)) & 3, swb = BKT == 64 ? (rbw >> 1) & 7 : (-(rbw >> 2)) & 3;
+    const int q = lane >> 4;
+    int offa[KS], offb[KS];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
         offa[ks] = ra * CROWB + (((ks * 4 + q) ^ swa) << 4);
         offb[ks] = BM * CROWB + rbw * CROWB + (((ks * 4 + q) ^ swb) << 4);
     }
 
-    stage(kt0, 0);
-    for (int kt = kt0; kt < kt1; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < kt1) stage(kt + 1, (kt + 1 - kt0) & 1);
-        const char* base = smem + ((kt - kt0) & 1) * STAGE_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+    for (int t = 0; t < NST - 1; ++t)
+        if (kt0 + t < kt1) stage(kt0 + t, t);
+    int buf = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        // stage kt must have landed; up to NST - 2 younger stages stay in flight
+        const int younger = min(NST - 2, kt1 - 1 - kt);
+        if (NST >= 4 && younger == 2) conv_wait_vmcnt<2 * LPT>();
+        else if (NST >= 3 && younger == 1) conv_wait_vmcnt<LPT>();
+        else conv_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();      // every wave's share of K tile kt is in LDS; the buffer of K tile kt-1 is free
+        if (kt + NST - 1 < kt1) {
+            int nb = buf + NST - 1;
+            nb = nb >= NST ? nb - NST : nb;
+            stage(kt + NST - 1, nb);
+        }
+        const char* base = smem + buf * STAGE_BYTES;
+        buf = buf + 1 == NST ? 0 : buf + 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
             half8 af[MI], bf[NI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) af[i] = *(const half8*)(base + offa[ks] + i * 16 * CROWB);
@@ -259,20 +296,6 @@ struct HaloParams {
 };
 
 constexpr int HTZ = 4, HTY = 4, HTX = 8, HHY = HTY + 2, HHX = HTX + 2, HROWS = (HTZ + 2) * HHY * HHX;
-
-// The same LDS-DMA from inline asm.  The compiler models the builtin as a FLAT access that may touch both
-// memory and LDS, and while one is pending it turns every later s_waitcnt into vmcnt(0) / lgkmcnt(0) -- which
-// drains the fragment prefetch of the halo kernel below.  Issued from asm, the DMA is invisible to that
-// bookkeeping; the caller owns the vmcnt wait and the barrier.
-__device__ __forceinline__ void cglds16_asm(const half_t* g, char* lds_wave_base) {
-    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m0v) : "memory", "m0");
-}
-
-template <int N>
-__device__ __forceinline__ void conv_wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 // NW waves per workgroup: 4 (2 x 2 or 4 x 1 wave grid, 64 x 32 / 32 x 32 wave tiles; what the launcher uses) or, for
 // C_out = 64, 2 waves of 64 x 64 (8 fragment reads per 16 MFMAs instead of 6 per 8, but one wave per SIMD: measured
@@ -849,8 +872,14 @@ extern "C" int pcd_conv3d_f16_multi(const pcd_conv3d_desc_t* descs, int n, void*
     p.slabs = splits > 1 ? (float*)workspace : nullptr;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(ceil_div(m, 128) * p.tiles_n), (unsigned)n, (unsigned)splits);
-    if (d->cout <= 64) hipLaunchKernelGGL((conv3d_igemm_kernel<128, 64>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((conv3d_igemm_kernel<128, 128>), grid, dim3(256), 0, s, p);
+    // C_out <= 64, long K (the k4 s2 down-convolutions): three stages, the gather of K tile kt+2 in flight behind the
+    // barrier of kt (enc.3 141 -> 112 us); short K and the 128-wide tile measured equal or slower with deeper rings
+    if (d->cout <= 64) {
+        if (d->kpad / CBK >= 32) hipLaunchKernelGGL((conv3d_igemm_kernel<128, 64, 64, 3>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv3d_igemm_kernel<128, 64, 64, 2>), grid, dim3(256), 0, s, p);
+    } else {
+        hipLaunchKernelGGL((conv3d_igemm_kernel<128, 128, 64, 2>), grid, dim3(256), 0, s, p);
+    }
     PCD_CHECK_LAUNCH();
     if (splits > 1) {
         const int64_t total = (int64_t)n * m * (d->cout / 8);
