@@ -162,11 +162,30 @@ extern "C" int pcd_vae_encode(pcd_vae_t* h, const float* vox, int batch, float* 
     RUN(R.res(d.enc_res[2], A, 8, B, Cc, A));                                    // encoder.8   128 -> 256
     RUN(R.conv(d.enc_down[2], A, 8, 2, d.taps4s2, 4, 1, nullptr, B));            // encoder.9/10 -> 4^3
     RUN(R.res(d.enc_res[3], B, 4, A, Cc, B));                                    // encoder.11  256 -> 512
-    RUN(R.conv(d.enc_last, B, 4, 1, d.taps4p0, 1, 1, nullptr, A));               // encoder.12/13 k4 p0 -> (B, 512)
-    pcd_gemm_desc_t g{};                                                         // [fc_mu ; fc_logvar]: 512 -> 2 * latent
-    g.a1 = A; g.k1 = 512; g.lda1 = 512; g.w = d.fc_w; g.ldw = 512; g.bias = d.fc_b; g.relu = 0; g.m = batch;
-    g.c = 2 * d.latent_dim;
-    RUN(pcd_gemm_f16_out32(&g, mu_logvar, 2 * d.latent_dim, s));
+    // encoder.12/13: k4 p0 on a 4^3 grid = one row of 32768 inputs per sample -> (B, 512).  With <= 256 samples that is the
+    // weight-streaming GEMM of the latent denoiser (33.5 MB of weights against B rows), not a 128-row convolution tile
+    const int k_last = d.enc_last.cin * 64;
+    const size_t slab_bytes = (size_t)pcd_skinny_slabs(k_last, d.enc_last.cout) * batch * d.enc_last.cout * sizeof(float);
+    if (batch <= 256 && d.enc_last.kpad == k_last && slab_bytes <= w.scratch_bytes) {
+        float* slabs = (float*)(ws + w.scratch);
+        RUN(pcd_skinny_gemm_f16(B, k_last, nullptr, 0, d.enc_last.w, d.enc_last.kpad, batch, d.enc_last.cout, slabs, s));
+        RUN(pcd_skinny_finish(slabs, pcd_skinny_slabs(k_last, d.enc_last.cout), batch, d.enc_last.cout, d.enc_last.b, nullptr,
+                              1, 0, nullptr, nullptr, A, nullptr, s));
+    } else {
+        RUN(R.conv(d.enc_last, B, 4, 1, d.taps4p0, 1, 1, nullptr, A));
+    }
+    // [fc_mu ; fc_logvar]: 512 -> 2 * latent, fp32 out
+    const int c_fc = 2 * d.latent_dim, s_fc = pcd_skinny_slabs(512, c_fc);
+    if (batch <= 256 && (size_t)s_fc * batch * c_fc * sizeof(float) <= w.scratch_bytes) {
+        float* slabs = (float*)(ws + w.scratch);
+        RUN(pcd_skinny_gemm_f16(A, 512, nullptr, 0, d.fc_w, 512, batch, c_fc, slabs, s));
+        RUN(pcd_skinny_finish(slabs, s_fc, batch, c_fc, d.fc_b, nullptr, 2, 0, nullptr, nullptr, nullptr, mu_logvar, s));
+    } else {
+        pcd_gemm_desc_t g{};
+        g.a1 = A; g.k1 = 512; g.lda1 = 512; g.w = d.fc_w; g.ldw = 512; g.bias = d.fc_b; g.relu = 0; g.m = batch;
+        g.c = c_fc;
+        RUN(pcd_gemm_f16_out32(&g, mu_logvar, c_fc, s));
+    }
     return PCD_OK;
 }
 
