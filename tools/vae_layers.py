@@ -28,7 +28,7 @@ ENC = [("enc.0 conv 1>32", conv(32768, 32, 1, 27), None), ("enc.2 res conv1 32>6
 def passes(rows):
     groups = []
     for n, s, e, *_ in rows:
-        if "conv3d_finish" in n and groups: groups[-1][1] += (e - s) / 1000; groups[-1][2] += 1
+        if ("conv3d_finish" in n or "skinny_finish" in n) and groups: groups[-1][1] += (e - s) / 1000; groups[-1][2] += 1
         elif "elementwise" in n or "f32_to_f16" in n: continue
         else: groups.append([n, (e - s) / 1000, 1])
     return groups
