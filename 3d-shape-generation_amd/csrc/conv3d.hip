@@ -300,14 +300,19 @@ constexpr int HTZ = 4, HTY = 4, HTX = 8, HHY = HTY + 2, HHX = HTX + 2, HROWS = (
 // NW waves per workgroup: 4 (2 x 2 or 4 x 1 wave grid, 64 x 32 / 32 x 32 wave tiles; what the launcher uses) or, for
 // C_out = 64, 2 waves of 64 x 64 (8 fragment reads per 16 MFMAs instead of 6 per 8, but one wave per SIMD: measured
 // slower, kept as a template parameter only).
-template <int CIN, int BN, int G, int NSTAGE, int NW>
+// TY = 4: 4 x 4 x 8 output voxels (128 rows) per workgroup of four waves.  TY = 8: 4 x 8 x 8 voxels (256 rows) per workgroup of
+// eight waves with the same wave tiles: the weights of a tap (and a smaller share of halo) are filled once per 256 rows.
+// Used for 32 -> 32, where two such workgroups still fit a CU (64 KB of LDS each): 77 -> 69 us.  At C_in = 64 (94-110 KB,
+// one workgroup per CU) it measured equal or slower, also as a persistent kernel that prefetches its next halo.
+template <int CIN, int BN, int G, int NSTAGE, int NW, int TY = 4>
 __global__ __launch_bounds__(64 * NW) void conv3d_halo_kernel(HaloParams p) {
     constexpr int NT = 64 * NW;
+    constexpr int HHY = TY + 2, HROWS = (HTZ + 2) * HHY * HHX, ROWS = HTZ * TY * HTX, YSH = TY == 8 ? 3 : 2;   // shadow the 128-row geometry
     constexpr int RB = CIN * 2, P = RB, CPR = RB / 16, KS = CIN / 32;
     constexpr int NXV = CIN == 64 ? 3 : 1;                      // address variants per k_x (the swizzle of C_in = 64 depends on hx)
     constexpr int HALO_BYTES = HROWS * P;
     constexpr int BST = G * BN * RB;                          // bytes per weight stage
-    constexpr int WAVES_N = (NW == 4) ? BN / 32 : 1, WAVES_M = NW / WAVES_N, WMR = 128 / WAVES_M, MI = WMR / 16;
+    constexpr int WAVES_N = (NW >= 4) ? BN / 32 : 1, WAVES_M = NW / WAVES_N, WMR = ROWS / WAVES_M, MI = WMR / 16;
     constexpr int WNC = BN / WAVES_N, NI = WNC / 16;
     constexpr int OUT_LD = BN * 2 + 16;
     constexpr int NS = 27 / G;
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_halo_kernel(HaloParams p) {
     constexpr int NINSTR = G * BN / RPI;
     constexpr int U = (NINSTR + NW - 1) / NW;                       // DMA instructions per wave and stage (uniform, so
     constexpr int DUMP = (NINSTR % NW) ? 1024 : 0;             // the vmcnt arithmetic is: spare ones hit a dump KB)
-    static_assert(27 % G == 0 && 128 * OUT_LD <= HALO_BYTES && HALO_BYTES % 16 == 0 && NS >= NSTAGE, "layout");
+    static_assert(27 % G == 0 && ROWS * OUT_LD <= HALO_BYTES && HALO_BYTES % 16 == 0 && NS >= NSTAGE, "layout");
     __shared__ __attribute__((aligned(16))) char smem[HALO_BYTES + NSTAGE * BST + DUMP];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_halo_kernel(HaloParams p) {
     const int tx = t % p.tx; t /= p.tx;
     const int ty = t % p.ty; t /= p.ty;
     const int tz = t % p.tz; const int b = t / p.tz;
-    const int z0 = tz * HTZ, y0 = ty * HTY, x0 = tx * HTX, n0 = tn * BN;
+    const int z0 = tz * HTZ, y0 = ty * TY, x0 = tx * HTX, n0 = tn * BN;
 
     // ---- halo: global -> registers -> LDS (once)
     // (loads are unconditional from a clamped address and zeroed afterwards: no divergent branches,
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_halo_kernel(HaloParams p) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = wm * WMR + i * 16 + (lane & 15);
-        const int x = m & 7, y = (m >> 3) & 3, z = m >> 5;
+        const int x = m & 7, y = (m >> 3) & (TY - 1), z = m >> (3 + YSH);
         const int vrow = ((z * HHY + y) * HHX + x) * P;
 #pragma unroll
         for (int kx = 0; kx < NXV; ++kx)
@@ -494,14 +499,14 @@ __global__ __launch_bounds__(64 * NW) void conv3d_halo_kernel(HaloParams p) {
             }
     }
     __syncthreads();
-    constexpr int OCPR = BN / 8, TOTAL = 128 * OCPR;
+    constexpr int OCPR = BN / 8, TOTAL = ROWS * OCPR;
 #pragma unroll
     for (int it = 0; it < TOTAL / NT; ++it) {
         const int idx = it * NT + tid;
         const int lrow = idx / OCPR, ch = idx - lrow * OCPR;
         const int col = n0 + ch * 8;
         if (col < p.Cout) {
-            const int x = lrow & 7, y = (lrow >> 3) & 3, z = lrow >> 5;
+            const int x = lrow & 7, y = (lrow >> 3) & (TY - 1), z = lrow >> (3 + YSH);
             const int64_t orow = (((int64_t)b * p.D + z0 + z) * p.H + y0 + y) * p.W + x0 + x;
             half8 v = *(const half8*)(smem + lrow * OUT_LD + ch * 16);
             if (p.resid != nullptr) {
@@ -894,6 +899,13 @@ extern "C" int pcd_conv3d_f16(const pcd_conv3d_desc_t* d, void* stream) {
     return pcd_conv3d_f16_multi(d, 1, nullptr, 0, stream);
 }
 
+static int g_halo_tall = 1;          // tuning / testing hook (pcd_conv3d_config)
+extern "C" int pcd_conv3d_config(int tall_halo_tiles) {
+    PCD_CHECK_ARG(tall_halo_tiles >= 0 && tall_halo_tiles <= 2);
+    g_halo_tall = tall_halo_tiles;
+    return PCD_OK;
+}
+
 static bool halo_supported(const pcd_conv3d_desc_t* d) {
     return d->ntaps == 27 && d->stride == 1 && d->out_scale == 1 && (d->cin == 32 || d->cin == 64) &&
            d->cout % 8 == 0 && d->kpad >= 27 * d->cin &&
@@ -917,15 +929,21 @@ extern "C" int pcd_conv3d_k3s1_f16(const pcd_conv3d_desc_t* d, void* stream) {
     p.out = (half_t*)d->out; p.Cout = d->cout; p.relu = d->relu;
     const int bn = d->cout <= 32 ? 32 : 64;
     p.tiles_n = (int)ceil_div(d->cout, bn);
-    p.tz = d->in_d / HTZ; p.ty = d->in_h / HTY; p.tx = d->in_w / HTX;
+    // 32 -> 32: 256-row workgroups (4 x 8 x 8 voxels, eight waves) where they still give every CU two rounds of work
+    const int64_t blocks256 = (int64_t)d->batch * (d->in_d / HTZ) * (d->in_h / 8) * (d->in_w / HTX) * p.tiles_n;
+    const bool tall = d->cin == 32 && bn == 32 && d->in_h % 8 == 0 &&
+                      (g_halo_tall == 2 || (g_halo_tall == 1 && blocks256 >= 512));
+    const int ty_rows = tall ? 8 : HTY;
+    p.tz = d->in_d / HTZ; p.ty = d->in_h / ty_rows; p.tx = d->in_w / HTX;
     const int64_t blocks = (int64_t)d->batch * p.tz * p.ty * p.tx * p.tiles_n;
     PCD_CHECK_ARG(blocks <= 0x7fffffff);
     p.nblocks = (int)blocks;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((unsigned)blocks), blk(256);
+    const dim3 grid((unsigned)blocks), blk(tall ? 512 : 256);
     // weight stage = one tap (three taps for 32 -> 32, where a tap is only 4 MFMAs per wave); 4 waves: the
     // 2-wave / 64 x 64 wave-tile form (fewer LDS reads per MFMA, but one wave per SIMD) measured 345 vs 304 us
-    if (d->cin == 64 && bn == 64) hipLaunchKernelGGL((conv3d_halo_kernel<64, 64, 1, 4, 4>), grid, blk, 0, s, p);
+    if (tall) hipLaunchKernelGGL((conv3d_halo_kernel<32, 32, 3, 4, 8, 8>), grid, blk, 0, s, p);
+    else if (d->cin == 64 && bn == 64) hipLaunchKernelGGL((conv3d_halo_kernel<64, 64, 1, 4, 4>), grid, blk, 0, s, p);
     else if (d->cin == 64) hipLaunchKernelGGL((conv3d_halo_kernel<64, 32, 1, 4, 4>), grid, blk, 0, s, p);
     else if (bn == 64) hipLaunchKernelGGL((conv3d_halo_kernel<32, 64, 1, 4, 4>), grid, blk, 0, s, p);
     else hipLaunchKernelGGL((conv3d_halo_kernel<32, 32, 3, 4, 4>), grid, blk, 0, s, p);

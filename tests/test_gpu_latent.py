@@ -78,7 +78,8 @@ def test_conv3d_exact_integers(cin, cout, k, stride, pad, din):
 
 
 @pytest.mark.parametrize("cin,cout,dims,b", [(64, 64, (8, 8, 8), 4), (64, 32, (4, 8, 16), 3), (32, 64, (8, 4, 8), 3),
-                                             (32, 32, (4, 4, 8), 8), (64, 24, (4, 4, 8), 3), (32, 72, (4, 8, 8), 3)])
+                                             (32, 32, (4, 4, 8), 8), (64, 24, (4, 4, 8), 3), (32, 72, (4, 8, 8), 3),
+                                             (32, 32, (8, 16, 8), 2), (64, 40, (4, 8, 16), 5)])
 def test_conv3d_k3s1_halo_exact(cin, cout, dims, b):
     """The LDS-halo kernel (32^3 layers of VAE3DLarge) against F.conv3d on exactly representable integers:
     every border, partial / multiple C_out tiles, non-cubic volumes, residual + ReLU epilogue; block counts that
@@ -111,6 +112,17 @@ def test_conv3d_k3s1_halo_exact(cin, cout, dims, b):
         ref = want.half().double()
         ref = (ref + resid.double()).clamp_min(0).half().double() if use_resid else ref.clamp_min(0)
         assert torch.equal(got, ref)
+        if dims[1] % 8 == 0:
+            # the 256-row workgroups (4 x 8 x 8 voxels, eight waves; what large grids run) on the same descriptor
+            out3 = torch.full_like(out, 3.0)
+            d.out = out3.data_ptr()
+            _lib.check(lib.pcd_conv3d_config(2))
+            try:
+                _lib.check(lib.pcd_conv3d_k3s1_f16(d, _lib.stream_ptr()))
+            finally:
+                _lib.check(lib.pcd_conv3d_config(1))
+            assert torch.equal(out, out3)
+            d.out = out.data_ptr()
         # and the generic implicit-GEMM kernel gives the same bits on the same descriptor
         out2 = torch.empty_like(out)
         d.out = out2.data_ptr()
