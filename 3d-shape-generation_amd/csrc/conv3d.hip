@@ -668,6 +668,84 @@ __global__ __launch_bounds__(256) void conv3d_first32_kernel(const float* __rest
     }
 }
 
+// encoder.0 on the matrix cores (stride 1, cout = 32, D % 4 == H % 4 == W % 8 == 0).  The VALU form above spends 864 fp32 FMAs
+// per voxel (27 taps x 32 channels): 57 us at B = 32, five times what writing the 67 MB of output takes.  Here the layer is
+// the product D[channel][voxel] = W[channel][tap] . im2col[tap][voxel] with K = 27 taps padded to one 32-deep MFMA step:
+// weights (rounded to fp16 like every other layer's) are the A operand, held in registers; a workgroup keeps the fp16 image of
+// its 6 x 6 x 10 input halo in LDS (720 B) and a lane gathers the eight taps of its k chunk for its voxel from it; the
+// accumulator of a lane is 4 consecutive channels of one voxel = an 8-byte piece of the NDHWC output row.
+__global__ __launch_bounds__(256) void conv3d_first32_mfma_kernel(const float* __restrict__ x, int B, int D, int H, int W,
+                                                                   const float* __restrict__ w,
+                                                                   const float* __restrict__ bias, half_t* __restrict__ out,
+                                                                   int ntz, int nty, int ntx, int ntiles) {
+    __shared__ half_t halo[2][HROWS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    // weights and tap offsets once per workgroup (it walks several tiles)
+    half8 wa[2];
+    int off[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int tap = 8 * q + j;                         // taps 27..31 are K padding: zero weights, any finite input
+        const bool real = tap < 27;
+        const int tc = real ? tap : 0;
+        wa[0][j] = real ? (half_t)w[r * 27 + tc] : (half_t)0.f;
+        wa[1][j] = real ? (half_t)w[(16 + r) * 27 + tc] : (half_t)0.f;
+        off[j] = ((tc / 9) * HHY + (tc / 3) % 3) * HHX + tc % 3;
+    }
+    const f32x4 b0 = *(const f32x4*)(bias + 4 * q), b1 = *(const f32x4*)(bias + 16 + 4 * q);
+    int buf = 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        int t = tile;
+        const int tx = t % ntx; t /= ntx;
+        const int ty = t % nty; t /= nty;
+        const int tz = t % ntz; const int b = t / ntz;
+        const int z0 = tz * HTZ, y0 = ty * HTY, x0 = tx * HTX;
+        for (int i = tid; i < HROWS; i += 256) {
+            const int hx = i % HHX; const int r2 = i / HHX;
+            const int hy = r2 % HHY, hz = r2 / HHY;
+            const int iz = z0 - 1 + hz, iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+            const bool ok = (unsigned)iz < (unsigned)D && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const int cz = min(max(iz, 0), D - 1), cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+            const float v = x[(((int64_t)b * D + cz) * H + cy) * W + cx];
+            halo[buf][i] = (half_t)(ok ? v : 0.f);
+        }
+        __syncthreads();                                   // two halo buffers: one barrier per tile is enough
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = (wave * 2 + i) * 16 + r;         // this lane's voxel: the MFMA column
+            const int vx = m & 7, vy = (m >> 3) & 3, vz = m >> 5;
+            const int base = (vz * HHY + vy) * HHX + vx;
+            half8 col;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) col[j] = halo[buf][base + off[j]];
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[0], col, zero, 0, 0, 0);
+            const f32x4 a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[1], col, zero, 0, 0, 0);
+            // lane (voxel, q) holds channels 4q..4q+3 of each 16-channel block; the two blocks exchange halves between the
+            // 16-lane groups (v_permlane16_swap, as in the GEMM epilogue): group q then owns 8 consecutive channels
+            unsigned pk[2][2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                half2_ h0, h1;
+                h0[0] = (half_t)__builtin_amdgcn_fmed3f(a0[2 * e] + b0[2 * e], 0.f, 65504.f);
+                h0[1] = (half_t)__builtin_amdgcn_fmed3f(a0[2 * e + 1] + b0[2 * e + 1], 0.f, 65504.f);
+                h1[0] = (half_t)__builtin_amdgcn_fmed3f(a1[2 * e] + b1[2 * e], 0.f, 65504.f);
+                h1[1] = (half_t)__builtin_amdgcn_fmed3f(a1[2 * e + 1] + b1[2 * e + 1], 0.f, 65504.f);
+                pk[0][e] = __builtin_bit_cast(unsigned, h0);
+                pk[1][e] = __builtin_bit_cast(unsigned, h1);
+            }
+            const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+            half_t* orow = out + ((((int64_t)b * D + z0 + vz) * H + y0 + vy) * W + x0 + vx) * 32;
+            *(u32x4*)(orow + (q & 1) * 16 + (q >> 1) * 8) = o;
+        }
+    }
+}
+
 // last layer: fp16 NDHWC [..][CIN] -> fp32 [B][D][H][W], k3 s1 p1, Cout = 1, sigmoid.
 // w fp32 [27][CIN], one thread per output voxel.
 template <int CIN>
@@ -956,6 +1034,14 @@ extern "C" int pcd_conv3d_first(const float* x, int batch, int d, int h, int w, 
     PCD_CHECK_ARG(x && wgt && bias && out && batch > 0 && d > 0 && h > 0 && w > 0 && cout > 0 && cout % 8 == 0);
     PCD_CHECK_ARG(stride == 1 || stride == 2);
     const int64_t ovox = (int64_t)((d - 1) / stride + 1) * ((h - 1) / stride + 1) * ((w - 1) / stride + 1);
+    if (cout == 32 && stride == 1 && d % HTZ == 0 && h % HTY == 0 && w % HTX == 0 && (int64_t)batch * ovox / 128 <= 0x7fffffff) {
+        const int64_t tiles = (int64_t)batch * ovox / 128;
+        hipLaunchKernelGGL(conv3d_first32_mfma_kernel, dim3((unsigned)(tiles < 2048 ? tiles : 2048)), dim3(256), 0,
+                           (hipStream_t)stream, x, batch, d, h, w, wgt, bias, (half_t*)out, d / HTZ, h / HTY, w / HTX,
+                           (int)tiles);
+        PCD_CHECK_LAUNCH();
+        return PCD_OK;
+    }
     if (cout == 32) {
         hipLaunchKernelGGL(conv3d_first32_kernel, dim3((unsigned)ceil_div((int64_t)batch * ovox, 256)), dim3(256), 0,
                            (hipStream_t)stream, x, batch, d, h, w, stride, wgt, bias, (half_t*)out);
