@@ -38,6 +38,42 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
     for (int i = lane; i < c; i += 64) orow[i] = to_half_sat(((float)xr[i] - mean) * rstd * gamma[i] + beta[i]);
 }
 
+// C = 8 * LPR (64 / 128 / 256, the widths of the attention U-Net): a row is LPR lanes x 16 bytes, read once and kept in
+// registers through both statistics passes and the output (the kernel above reads every element three times, two bytes
+// per lane and access: 3x off the HBM time of this purely bandwidth-bound step); 64 / LPR rows per wave.
+template <int LPR>
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(const half_t* __restrict__ x, int64_t rows,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             half_t* __restrict__ out) {
+    constexpr int C = LPR * 8, RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, l = lane % LPR;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const int64_t rr = row < rows ? row : rows - 1;                    // whole groups stay active for the shuffles
+    const half8 v = *(const half8*)(x + rr * C + l * 8);
+    float f[8];
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { f[e] = (float)v[e]; s += f[e]; }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { f[e] -= mean; q += f[e] * f[e]; }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / (float)C + 1e-5f);
+    const f32x4 g0 = *(const f32x4*)(gamma + l * 8), g1 = *(const f32x4*)(gamma + l * 8 + 4);
+    const f32x4 b0 = *(const f32x4*)(beta + l * 8), b1 = *(const f32x4*)(beta + l * 8 + 4);
+    half8 o8;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        o8[e] = to_half_sat(f[e] * rstd * g0[e] + b0[e]);
+        o8[4 + e] = to_half_sat(f[4 + e] * rstd * g1[e] + b1[e]);
+    }
+    if (row < rows) *(half8*)(out + row * C + l * 8) = o8;
+}
+
 // ------------------------------------------------------------ flash attention
 // block = 4 waves, each wave owns QT x 32 queries of one (shape, head); K [64][D] and Vt [D][64]
 // tiles arrive by LDS-DMA (global_load_lds 16 B/lane) into a 2-deep ring, XOR-swizzled through the
@@ -652,8 +688,12 @@ using namespace pcd;
 extern "C" int pcd_layernorm_f16(const void* x, int64_t rows, int c, const float* gamma, const float* beta,
                                  void* out, void* stream) {
     PCD_CHECK_ARG(x && gamma && beta && out && rows > 0 && c > 0);
-    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const half_t*)x, rows, c, gamma, beta, (half_t*)out);
+    hipStream_t s = (hipStream_t)stream;
+    const half_t* x16 = (const half_t*)x; half_t* o16 = (half_t*)out;
+    if (c == 64) hipLaunchKernelGGL((layernorm_vec_kernel<8>), dim3((unsigned)ceil_div(rows, 32)), dim3(256), 0, s, x16, rows, gamma, beta, o16);
+    else if (c == 128) hipLaunchKernelGGL((layernorm_vec_kernel<16>), dim3((unsigned)ceil_div(rows, 16)), dim3(256), 0, s, x16, rows, gamma, beta, o16);
+    else if (c == 256) hipLaunchKernelGGL((layernorm_vec_kernel<32>), dim3((unsigned)ceil_div(rows, 8)), dim3(256), 0, s, x16, rows, gamma, beta, o16);
+    else hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, s, x16, rows, c, gamma, beta, o16);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

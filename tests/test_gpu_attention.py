@@ -94,6 +94,20 @@ def test_attention_pipelined_kernel_d64(pattern):
     assert rel_l2(got, gen) < 2e-3
 
 
+@pytest.mark.parametrize("rows,c", [(4096 + 5, 64), (1000, 128), (777, 256), (64, 96), (3, 256)])
+def test_layernorm_rows(rows, c):
+    """nn.LayerNorm over the channel axis (reference networks.py:66-67, eps 1e-5, biased variance) on fp16 rows: the vectorised
+    kernel for C = 64 / 128 / 256 (several rows per wave, ragged row counts) and the generic one (C = 96) against fp64."""
+    from shapegen_amd import ops
+    g = torch.Generator().manual_seed(rows + c)
+    x = (torch.randn(rows, c, generator=g) * 2 + 0.5).half()
+    gamma, beta = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    want = torch.nn.functional.layer_norm(x.double(), (c,), gamma.double(), beta.double(), 1e-5)
+    got = ops.layernorm_f16(x.cuda(), gamma.cuda(), beta.cuda()).cpu()
+    assert got.shape == x.shape and got.dtype == torch.float16
+    assert float((got.double() - want).abs().max()) <= 2e-3 * max(1.0, float(want.abs().max()))      # one fp16 rounding
+
+
 def test_unet_attention_golden(golden):
     from shapegen_amd.networks import UNetAttentionPointExperimental
     g = golden("attention.npz")
