@@ -210,8 +210,9 @@ __global__ __launch_bounds__(256) void set_attention_kernel(const half_t* __rest
 
     auto stage = [&](int kt, int buf) {
         char* base = smem + buf * STAGE;
-        stage_tile<KT, KRB, false>(kbase, ld, kt * KT, n, base, wave, lane);
-        stage_tile<KT, KRB, true>(vbase, ld, kt * KT, n, base + KBYTES, wave, lane);
+        // LDS-DMA from asm: with the builtin pending the compiler drains vmcnt and lgkmcnt in front of every fragment read
+        stage_tile<KT, KRB, false, 4, true>(kbase, ld, kt * KT, n, base, wave, lane);
+        stage_tile<KT, KRB, true, 4, true>(vbase, ld, kt * KT, n, base + KBYTES, wave, lane);
     };
 
     // one KV tile; MASK only for the last, partial tile (keys >= n get -inf) so full tiles carry no
