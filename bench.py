@@ -217,7 +217,9 @@ def attention_roofline(device, launches=100):
     def launch():
         _lib.check(lib.pcd_set_attention_f16(qkv.data_ptr(), B_PER_GPU, N_POINTS, ATT_C, ATT_HEADS, out.data_ptr(), 0, 0,
                                              _lib.stream_ptr()), "set_attention")
-    for _ in range(10):
+    # warm-up: the chip takes ~100 launches (27 ms) from idle to its running clocks (tools/bench_attn_sustained.py: the first
+    # 100-launch chunk measures 10 % below the following nine); the timed train starts after that ramp
+    for _ in range(200):
         launch()
     # one event pair around the whole train of launches (an event record between kernels costs tens of microseconds of
     # its own, comparable to the kernel)
@@ -342,7 +344,7 @@ def run_cfg2(args, R: Ranks):
                            "avg_launch_ms": gf3_ms, "launches_timed": launches,
                            "flop_per_launch": GF3_FLOP_PER_LAUNCH}
     if att is not None:
-        att["measured"] = "before the timed region"
+        att["measured"] = "before the timed region, after 200 warm-up launches"
         out["roofline_attention"] = att
         if not pointnet:
             out["roofline"] = att
