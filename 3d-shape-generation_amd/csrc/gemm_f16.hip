@@ -35,10 +35,10 @@ struct GemmParams {
 
 constexpr int BK = 64;          // K granularity required by the API (k1, k2 multiples of 64)
 
-__device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
+// LDS-DMA from inline asm (common.h): with the builtin form pending, the compiler treats it as a FLAT access and drains vmcnt and
+// lgkmcnt in front of the fragment reads that follow; the kernel owns its vmcnt waits and barriers anyway (+0.7-1 % on the step,
+// A/B on one box; +25 % on the implicit-GEMM convolution, where it was found)
+__device__ __forceinline__ void glds16(const half_t* g, char* lds_wave_base) { lds_dma16(g, lds_wave_base); }
 
 // XOR swizzle of the 16-B chunk index inside a staged row (applied to the LDS-DMA source address and
 // again on the fragment reads): makes the four 16-lane groups of a ds_read_b128 hit 16 distinct
