@@ -526,13 +526,12 @@ __global__ __launch_bounds__(64 * NW) void conv3d_halo_kernel(HaloParams p) {
 // split-K finish: sum the slabs in split order (deterministic), then the same epilogue as above.
 // thread = (variant, row, 8-column chunk)
 __global__ __launch_bounds__(256) void conv3d_finish_kernel(ConvParams p) {
-    const int cpr = p.Cout / 8;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t per = (int64_t)p.M * cpr;
-    if (idx >= per * p.nvar) return;
-    const int cls = (int)(idx / per);
-    const int64_t rem = idx - cls * per;
-    const int m = (int)(rem / cpr), col = (int)(rem - (int64_t)m * cpr) * 8;
+    // grid = (chunks of a variant, variant): 32-bit index arithmetic (64-bit divisions by run-time values were most of this kernel)
+    const unsigned cpr = (unsigned)p.Cout / 8;
+    const unsigned rem = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rem >= (unsigned)p.M * cpr) return;
+    const int cls = blockIdx.y;
+    const int m = (int)(rem / cpr), col = (int)(rem - (unsigned)m * cpr) * 8;
     const ConvVariant& cv = p.var[cls];
     float a[8];
 #pragma unroll
@@ -562,19 +561,27 @@ __global__ __launch_bounds__(256) void conv3d_finish_kernel(ConvParams p) {
     const int oz = t % p.Do; const int b = t / p.Do;
     const int64_t orow = (((int64_t)b * p.OD + oz * p.os + cv.pz) * p.OH + oy * p.os + cv.py) * p.OW + ox * p.os + cv.px;
     half8 o;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+    if (p.bias != nullptr) {
+        const f32x4 b0 = *(const f32x4*)(p.bias + col), b1 = *(const f32x4*)(p.bias + col + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+    }
     if (p.resid != nullptr) {
         const half8 rs = *(const half8*)(p.resid + orow * p.Cout + col);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             // same rounding points as the unsplit epilogue: fp16(acc + bias), then + residual in fp32
-            float f = (float)to_half_sat(a[e] + (p.bias ? p.bias[col + e] : 0.f)) + (float)rs[e];
+            float f = (float)to_half_sat(a[e] + bv[e]) + (float)rs[e];
             if (p.relu) f = fmaxf(f, 0.f);
             o[e] = to_half_sat(f);
         }
     } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float f = a[e] + (p.bias ? p.bias[col + e] : 0.f);
+            float f = a[e] + bv[e];
             if (p.relu) f = fmaxf(f, 0.f);
             o[e] = to_half_sat(f);
         }
@@ -965,8 +972,9 @@ extern "C" int pcd_conv3d_f16_multi(const pcd_conv3d_desc_t* descs, int n, void*
     }
     PCD_CHECK_LAUNCH();
     if (splits > 1) {
-        const int64_t total = (int64_t)n * m * (d->cout / 8);
-        hipLaunchKernelGGL(conv3d_finish_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, p);
+        const int64_t per = m * (d->cout / 8);                       // < 2^31: conv_check bounds the rows, cout / 8 <= 2^12 here
+        PCD_CHECK_ARG(per <= 0x7fffffff);
+        hipLaunchKernelGGL(conv3d_finish_kernel, dim3((unsigned)ceil_div(per, 256), (unsigned)n), dim3(256), 0, s, p);
         PCD_CHECK_LAUNCH();
     }
     return PCD_OK;
