@@ -126,7 +126,11 @@ def evaluate_sharded(original, reconstructed, use_approximate_gpu_emd: bool = Fa
     cloud has no metrics (the reference would raise) and gets a NaN row."""
     from . import metrics
     if len(reconstructed) == 0:
-        rows = torch.zeros(0, 3, dtype=torch.float32)
+        # an empty local shard (global batch < world size) still takes part in the collective: under nccl its (0, 3)
+        # block must live on this rank's device like everybody else's rows, or the all-gather raises / hangs the peers
+        on_gpu = dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
+        dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+        rows = torch.zeros(0, 3, dtype=torch.float32, device=dev)
     else:
         rows = metrics.pair_metrics(original, reconstructed, use_approximate_gpu_emd)   # one batched enqueue, no host sync per pair
     allrows = all_gather_rows(rows)

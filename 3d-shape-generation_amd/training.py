@@ -738,6 +738,14 @@ def fit(model, data_module, max_epochs: int = 500, ckpt_dir: Optional[str] = Non
             _collective_inplace(dist.broadcast, t.data, 0)
         if hasattr(opt, "refresh_weights"):
             opt.refresh_weights()
+        for sub in model.modules():            # packed fp16 weight images (incl. a frozen VAE's handle) were built from the
+            inv = getattr(sub, "invalidate", None)      # pre-broadcast values on ranks > 0: rebuild them on next use
+            if callable(inv):
+                inv()
+        # ranks hold different data batches and must not draw the same (t, noise, dropout) for them: every torch draw and the
+        # on-device Philox stream (seeded by torch.initial_seed()) are moved to a per-rank seed; val_loss is all-reduced
+        # below, so the scheduler and the top-k logic still see one number on every rank
+        torch.manual_seed((torch.initial_seed() + 0x9E3779B1 * rank) & 0x7FFFFFFFFFFFFFFF)
     kept: List[Tuple[float, str]] = []
     steps = 0
     history = []

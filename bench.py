@@ -1,6 +1,6 @@
 """Headline benchmark: denoising-steps/sec of the point-cloud diffusion sampler hot path.
 
-    python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg3|cfg5] [--backbone pointnet|attention]
+    python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg3|cfg4|cfg5] [--backbone pointnet|attention]
 
 Default (`--config cfg2`, BASELINE.json configs[1]): one "step" = one ancestral denoising step (`sample2`
 loop body, reference diffusion.py:241-257) of a whole batch: denoiser forward (HIP kernels) + on-device Philox
@@ -10,12 +10,15 @@ region.  With N > 1 every rank runs the same per-GPU batch (weak scaling, no dat
 independent).
 
 Launching: with N > 1 and no WORLD_SIZE in the environment this process never touches the GPU: it starts N
-child processes (one rank per GPU, RCCL rendezvous on 127.0.0.1), relays rank 0's JSON line and exits non-zero if
-any rank failed.  Under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks are
+child processes (one rank per GPU, RCCL rendezvous on 127.0.0.1; `shapegen_amd/launcher.py`), polls all of them,
+terminates the siblings of the first rank that fails, enforces `--timeout`, keeps per-rank logs, relays rank 0's JSON
+line and exits non-zero (with the ranks' stderr tails) if any rank failed.  Under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks are
 already there and each process is one rank.
 
 Other workloads (parity-test configurations of BASELINE.json, reported with the same JSON contract):
   --config cfg3   DDIM `sample`, 50 steps, 64 shapes per GPU through `dist.sample_sharded` (clouds all-gathered)
+  --config cfg4   latent diffusion on one GPU: VAE3DLarge encode of 32 grids, 1000-step latent DDIM, decode,
+                  voxel->points; `roofline` = the latent step against HBM, `roofline_vae_decode` against MFMA
   --config cfg5   latent diffusion: 1000-step latent DDIM, 32 latents per GPU, VAE decode, voxel->points,
                   RCCL all-gather of the ragged clouds, per-sample Chamfer / Sinkhorn-EMD / voxel-BCE rows
 
@@ -25,7 +28,10 @@ Prints ONE JSON line (rank 0) with the driver's contract plus
   "roofline_attention":  the set-attention kernel (QK^T / softmax / PV, reference networks.py:61,80-81) at
                          batch 64 x 2048 points, C = 256, 4 heads, timed the same way (N = 1 only);
   "cpu_baseline":        the CPU oracle (PyTorch-CPU fp32 restatement) timed on the host cores on a bounded
-                         sample of the same workload (rank 0, N = 1 only).
+                         sample of the same workload at its real shape (rank 0, N = 1 only);
+  "cpu_baseline_cfg1":   BASELINE configs[0] (DDIM, B = 4, N = 512, 100 steps) run in full on the oracle;
+  "config.other_configs": the other single-GPU workloads measured after the headline region (cfg3 DDIM-50 steps/s,
+                         cfg4 end to end, latent step, VAE encode / decode), so the driver's record carries them.
 """
 from __future__ import annotations
 
@@ -33,7 +39,6 @@ import argparse
 import ctypes as C
 import json
 import os
-import subprocess
 import sys
 import time
 
@@ -55,7 +60,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)     # 100 x ~4 ms; the GPU reaches steady clocks after ~10 steps
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", choices=("cfg2", "cfg3", "cfg5"), default="cfg2")
+    ap.add_argument("--config", choices=("cfg2", "cfg3", "cfg4", "cfg5"), default="cfg2")
+    ap.add_argument("--timeout", type=float, default=600.0, help="overall limit of an N > 1 run, seconds")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the config.other_configs legs of the default line")
     ap.add_argument("--backbone", choices=("pointnet", "attention"), default="pointnet",
                     help="denoiser behind the cfg2 sampler: UNetPointNetLarge (the reference's wiring) or "
                          "UNetAttentionPointExperimental (the set-attention carrier)")
@@ -70,27 +77,10 @@ def parse_args():
 
 # ------------------------------------------------------------------------------------------ launcher (GPU-free)
 def launch_children(args) -> int:
-    """Parent of an N-rank run.  Runs BEFORE anything imports torch.cuda: starts one child per GPU, waits,
-    relays rank 0's stdout, returns non-zero if any rank failed."""
-    import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for rank in range(args.gpus):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, stderr=None, text=True))
-    out0 = procs[0].communicate()[0]
-    codes = [p.wait() for p in procs]
-    sys.stdout.write(out0)
-    sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
-        return 1
-    return 0
+    """Parent of an N-rank run.  Runs BEFORE anything imports torch.cuda (`shapegen_amd.launcher` is standard library
+    only): one child per GPU, all polled, siblings of a failed rank terminated, overall --timeout, per-rank logs."""
+    from shapegen_amd import launcher
+    return launcher.main_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus, args.timeout)
 
 
 # ------------------------------------------------------------------------------------------ helpers
@@ -116,24 +106,59 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(sd, sample_batch=2, reps=4):
-    """Oracle (port of the reference's PyTorch-CPU path) on a bounded sample: `reps` DDPM steps at
-    B=sample_batch, N=2048 after one warm-up step, scaled to the B=64 step by the batch ratio."""
+def host_memory_gb() -> float:
+    """Memory this process may still take: MemAvailable capped by the cgroup limit (v2 or v1) where one is set."""
+    avail = 0.0
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) / 1e6
+    except Exception:
+        pass
+    for lim, cur in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                     ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            v = open(lim).read().strip()
+            if v != "max" and int(v) < (1 << 60):
+                avail = min(avail, (int(v) - int(open(cur).read())) / 1e9) if avail else (int(v) - int(open(cur).read())) / 1e9
+        except Exception:
+            pass
+    return avail
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sd, reps=3):
+    """Oracle (port of the reference's PyTorch-CPU path, diffusion.py:241-257 over networks.py:779-818) MEASURED at the
+    configuration's real shape: `reps` DDPM steps at B = 64, N = 2048 after one warm-up step (a step keeps ~8 GB of fp32
+    activations alive: the (64, 4096, 2048) global feature and the (64, 5120, 2048) concat the reference materialises).
+    Only if the host cannot hold that is the batch halved until it fits, and `sample` says so."""
     import torch
     from oracle import torch_oracle as O   # checker/baseline only
     cores = usable_cores()
     torch.set_num_threads(cores)
+    batch, mem = B_PER_GPU, host_memory_gb()
+    while batch > 1 and mem and batch * 0.25 > mem:          # 0.125 GB per shape measured, x2 margin
+        batch //= 2
     g = torch.Generator().manual_seed(24)
-    x = torch.randn(sample_batch, N_POINTS, 3, generator=g)
+    x = torch.randn(batch, N_POINTS, 3, generator=g)
     model = lambda xx, tt: O.unet_pointnet_large(sd, "model.", xx, tt)
-    z = [torch.randn(sample_batch, N_POINTS, 3, generator=g) for _ in range(reps + 1)]
+    z = [torch.randn(batch, N_POINTS, 3, generator=g) for _ in range(reps + 1)]
 
     def one(i, xx):
-        t = torch.ones(sample_batch) * (SCHEDULE_STEPS - 1 - i) / SCHEDULE_STEPS
+        t = torch.ones(batch) * (SCHEDULE_STEPS - 1 - i) / SCHEDULE_STEPS
         n, s = O.offset_cosine_schedule(t)
         eps = model(xx, t)
         x0 = O.remove_noise(xx, eps, n, s)
-        tp = torch.ones(sample_batch) * (SCHEDULE_STEPS - 2 - i) / SCHEDULE_STEPS
+        tp = torch.ones(batch) * (SCHEDULE_STEPS - 2 - i) / SCHEDULE_STEPS
         npv, sp = O.offset_cosine_schedule(tp)
         return sp.view(-1, 1, 1) * x0 + (torch.sqrt(npv / n) * n).view(-1, 1, 1) * z[i]
 
@@ -143,10 +168,62 @@ def cpu_baseline(sd, sample_batch=2, reps=4):
         for i in range(1, reps + 1):
             x = one(i, x)
         dt = (time.perf_counter() - t0) / reps
-    per_full_step = dt * (B_PER_GPU / sample_batch)
-    return {"value": 1.0 / per_full_step, "unit": "denoising-steps/sec", "cores": cores, "kind": "port",
-            "sample": f"{reps} DDPM steps at B={sample_batch}, N={N_POINTS} (1/{B_PER_GPU // sample_batch} of the "
-                      f"batch) after one warm-up step, scaled x{B_PER_GPU // sample_batch}; torch CPU fp32, {cores} threads"}
+    scale = B_PER_GPU / batch
+    what = (f"{reps} DDPM steps measured at the real shape B={batch}, N={N_POINTS} after one warm-up step" if batch == B_PER_GPU else
+            f"{reps} DDPM steps at B={batch}, N={N_POINTS} (host memory {mem:.0f} GB does not hold B={B_PER_GPU}), scaled x{scale:.0f}")
+    return {"value": 1.0 / (dt * scale), "unit": "denoising-steps/sec", "cores": cores, "kind": "port",
+            "sample": f"{what}; torch CPU fp32, {cores} threads, {cpu_model()}", "seconds_per_step": dt * scale}
+
+
+def cpu_baseline_cfg1(sd):
+    """BASELINE configs[0] in full on the oracle: DDIM `sample` (what test_point_ddpm.py:36 calls), B = 4, N = 512,
+    100 steps, after two warm-up forwards (SURVEY section 6 anchor: the reference itself ran 5.41 steps/s on 8 cores)."""
+    import torch
+    from oracle import torch_oracle as O   # checker/baseline only
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(24)
+    x = torch.randn(4, 512, 3, generator=g)
+    model = lambda xx, tt: O.unet_pointnet_large(sd, "model.", xx, tt)
+    with torch.no_grad():
+        for _ in range(2):
+            model(x, torch.ones(4))
+        t0 = time.perf_counter()
+        O.ddim_sample(model, x, 100)
+        dt = time.perf_counter() - t0
+    return {"value": 100 / dt, "unit": "denoising-steps/sec", "cores": cores, "kind": "port",
+            "sample": f"BASELINE configs[0] in full: 100 DDIM steps, B=4, N=512 ({dt:.1f} s); torch CPU fp32, {cores} threads, {cpu_model()}"}
+
+
+def cpu_baseline_latent(sd, steps=200):
+    """Oracle for BASELINE configs[3]: `steps` latent DDIM steps at B = 32 (diffusion.py:637-645 over networks.py:1051-1086)
+    and VAE3DLarge encode / decode of 32 grids (networks.py:2299-2339), each after one warm-up call."""
+    import torch
+    from oracle import torch_oracle as O   # checker/baseline only
+    from shapegen_amd import specs
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(24)
+    z = torch.randn(32, 256, generator=g)
+    model = lambda zz, tt: O.latent_unet(sd, "model.", zz, tt)
+    with torch.no_grad():
+        O.ddim_sample(model, z, 3)
+        t0 = time.perf_counter()
+        O.ddim_sample(model, z, steps)
+        per_step = (time.perf_counter() - t0) / steps
+        vox = (torch.rand(32, 1, 32, 32, 32, generator=g) > 0.9).float()
+        O.vae_decode(sd, "vae.", z[:2], specs.VAE_DEC)
+        t0 = time.perf_counter()
+        O.vae_decode(sd, "vae.", z, specs.VAE_DEC)
+        dec = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O.vae_encode(sd, "vae.", vox, specs.VAE_ENC)
+        enc = time.perf_counter() - t0
+    return {"value": 1.0 / per_step, "unit": "denoising-steps/sec", "cores": cores, "kind": "port",
+            "sample": f"{steps} latent DDIM steps at B=32 after a 3-step warm-up; VAE3DLarge decode / encode of 32 grids once each; "
+                      f"torch CPU fp32, {cores} threads, {cpu_model()}",
+            "latent_us_per_step": per_step * 1e6, "vae_decode_ms": dec * 1e3, "vae_encode_ms": enc * 1e3,
+            "cfg4_ms_extrapolated": (enc + dec + 1000 * per_step) * 1e3}
 
 
 class Ranks:
@@ -170,6 +247,10 @@ class Ranks:
             import torch.distributed as dist
             self.backend = "gloo" if self.shared else "nccl"
             kw = {} if self.shared else {"device_id": self.device}
+            import datetime
+            # explicit rendezvous / collective timeout (the launcher sets it to half its own --timeout): a rank whose
+            # peer died raises here instead of waiting for the 10-minute default
+            kw["timeout"] = datetime.timedelta(seconds=int(os.environ.get("PCD_COLLECTIVE_TIMEOUT_S", "300")))
             dist.init_process_group(self.backend, **kw)
             self.dist = dist
 
@@ -241,15 +322,141 @@ def attention_roofline(device, launches=100):
             "shape": {"batch": B_PER_GPU, "points": N_POINTS, "channels": ATT_C, "heads": ATT_HEADS}}
 
 
+def _sha16(path):
+    import hashlib
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def measured_traffic():
     """HBM/fabric bytes per launch of the dominant kernel from the committed PMC recipe (tools/pmc_gf3.sh writes
-    profiles/gf3_pmc_latest.json with the git hash it was taken at); None when absent."""
+    profiles/gf3_pmc_latest.json with the git hash AND the sha256 of csrc/gemm_f16.hip it was taken at).  Returns
+    (bytes, git_head, stale): stale = the kernel source is no longer the one that was measured (the GPU box has no
+    .git, so the source hash is what can be compared at run time)."""
     pmc = os.path.join(ROOT, "profiles", "gf3_pmc_latest.json")
     try:
         rec = json.load(open(pmc))
-        return rec.get("hbm_bytes_per_launch"), rec.get("git_head")
     except Exception:
-        return None, None
+        return None, None, None
+    now = _sha16(os.path.join(ROOT, "3d-shape-generation_amd", "csrc", "gemm_f16.hip"))
+    stale = rec.get("kernel_source_sha16") is None or rec.get("kernel_source_sha16") != now
+    return rec.get("hbm_bytes_per_launch"), rec.get("git_head"), stale
+
+
+LATENT_WEIGHT_BYTES = 38174720.0              # SURVEY 8(d): 19 087 360 fp16 weights streamed per latent step
+VAE_DECODE_FLOP_PER_SAMPLE = 40.20e9          # SURVEY 8(d)
+VAE_ENCODE_FLOP_PER_SAMPLE = 24.48e9
+HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8 TB/s HBM3E
+
+
+def build_latent_model(device):
+    import numpy as np
+    import torch
+    from shapegen_amd import specs
+    from shapegen_amd.diffusion import LatentDiffusion
+    from shapegen_amd.vae import VAE3DLarge
+    sd = specs.synth_state_dict(specs.latent_unet_spec(prefix="model."), seed=0, gain=1.3)
+    sd.update(specs.synth_state_dict(specs.vae3d_large_spec(prefix="vae."), seed=0, gain=1.3))
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    m = LatentDiffusion(VAE3DLarge())
+    m.load_state_dict(sd, strict=True)
+    return m.to(device).eval(), sd
+
+
+def latent_legs(m, device, B=32, T=SCHEDULE_STEPS):
+    """BASELINE configs[3] on one GPU, piece by piece, inputs resident in HBM: VAE3DLarge.encode of B grids, the T-step
+    latent DDIM loop (LatentDiffusion.sample's loop: diffusion.py:637-645), decode + voxel->points; every piece is run
+    once untimed first.  HIP events on torch's current stream, which is the stream every kernel of the path is launched on."""
+    import torch
+    g = torch.Generator().manual_seed(24)
+    vox = (torch.rand(B, 1, 32, 32, 32, generator=g) > 0.9).float().to(device)
+
+    def timed(fn, reps):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(reps):
+            out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps, (time.perf_counter() - t0) / reps * 1e3, out
+
+    enc_ms, _, (mu, logvar) = timed(lambda: m.vae.encode(vox), 10)
+    zT = m.vae.reparameterize(mu, logvar)
+
+    def loop():
+        z = m._start(B, zT)
+        tab = m.ddim_table(T, B)
+        return m._run(z, tab, m.model.time_bias(tab.t), m._forward_fn(), "ddim")
+
+    _, loop_wall_ms, z0 = timed(loop, 2)
+    dec_ms, _, dec = timed(lambda: m.vae.decode(z0), 10)
+    _, fin_wall_ms, clouds = timed(lambda: m._finish(z0, 0.4), 3)
+
+    def whole():
+        mu_, lv_ = m.vae.encode(vox)
+        return m.sample(num_samples=B, num_steps=T, z_T=m.vae.reparameterize(mu_, lv_))
+
+    _, whole_wall_ms, _ = timed(whole, 2)
+    if not torch.isfinite(z0).all():
+        raise SystemExit("non-finite latents after the latent loop")
+    return {"batch": B, "steps": T, "encode_ms": enc_ms, "loop_ms": loop_wall_ms, "latent_us_per_step": loop_wall_ms * 1e3 / T,
+            "decode_ms": dec_ms, "decode_and_voxel_to_points_ms": fin_wall_ms, "cfg4_ms": whole_wall_ms,
+            "clouds": [int(c.shape[0]) for c in clouds[:4]]}
+
+
+def latent_rooflines(legs):
+    B = legs["batch"]
+    step_s = legs["latent_us_per_step"] * 1e-6
+    lat = LATENT_WEIGHT_BYTES / step_s / 1e9
+    dec = VAE_DECODE_FLOP_PER_SAMPLE * B / (legs["decode_ms"] * 1e-3) / 1e12
+    enc = VAE_ENCODE_FLOP_PER_SAMPLE * B / (legs["encode_ms"] * 1e-3) / 1e12
+    return ({"bound": "hbm", "kernel": "latent denoiser step (SimpleLatentUNetPointNet forward + DDIM update; all launches of one step)",
+             "achieved": lat, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lat / HBM_PEAK_GBS, "traffic": None,
+             "avg_launch_ms": step_s * 1e3, "launches_timed": legs["steps"], "bytes_per_launch": LATENT_WEIGHT_BYTES,
+             "note": "algorithmic bytes = the fp16 weights of the 12 Linear layers, streamed once per step (they fit the 256 MB "
+                     "Infinity Cache, so the bytes come from on-die cache, not HBM); wall clock of the whole loop / steps"},
+            {"bound": "mfma", "kernel": "VAE3DLarge.decode, batch 32 (all launches of one decode)", "achieved": dec,
+             "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dec / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": None,
+             "avg_launch_ms": legs["decode_ms"], "launches_timed": 10, "flop_per_launch": VAE_DECODE_FLOP_PER_SAMPLE * B},
+            {"bound": "mfma", "kernel": "VAE3DLarge.encode, batch 32 (all launches of one encode)", "achieved": enc,
+             "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": enc / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": None,
+             "avg_launch_ms": legs["encode_ms"], "launches_timed": 10, "flop_per_launch": VAE_ENCODE_FLOP_PER_SAMPLE * B})
+
+
+def gf3_roofline(gf3_ms, launches, how=None):
+    achieved = GF3_FLOP_PER_LAUNCH / (gf3_ms * 1e-3) / 1e12
+    traffic, traffic_head, stale = measured_traffic()
+    r = {"bound": "mfma", "kernel": "gemm_f16_kernel<256,256,2,4,2,COLMAX> persistent (global_feat.3 2048->4096 + max over N)",
+         "achieved": achieved, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+         "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": traffic, "traffic_measured_at": traffic_head,
+         "traffic_stale": stale, "avg_launch_ms": gf3_ms, "launches_timed": launches, "flop_per_launch": GF3_FLOP_PER_LAUNCH}
+    if how:
+        r["measured"] = how
+    return r
+
+
+def eager_gf3_profile(model, fn):
+    """Average duration of the dominant GEMM over the launches `fn` makes, by HIP events on the launch stream inside
+    pcd_unet_forward; events cannot be recorded in a captured graph, so `fn` runs with graph replay off."""
+    from shapegen_amd import _lib
+    lib = _lib.load()
+    handle = model.model._handle
+    keep = model.use_graphs
+    model.use_graphs = False
+    try:
+        _lib.check(lib.pcd_unet_profile(handle, 1))
+        fn()
+        tot_ms, launches = C.c_double(0), C.c_int(0)
+        _lib.check(lib.pcd_unet_profile_read(handle, C.byref(tot_ms), C.byref(launches)))
+        _lib.check(lib.pcd_unet_profile(handle, 0))
+    finally:
+        model.use_graphs = keep
+    return tot_ms.value / max(launches.value, 1), launches.value
 
 
 # ------------------------------------------------------------------------------------------ cfg2 (headline)
@@ -335,22 +542,42 @@ def run_cfg2(args, R: Ranks):
                    "rccl_ranks": rccl_ranks, "collective_backend": R.backend},
     }
     if pointnet:
-        gf3_ms = tot_ms / max(launches, 1)
-        achieved = GF3_FLOP_PER_LAUNCH / (gf3_ms * 1e-3) / 1e12
-        traffic, traffic_head = measured_traffic()
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_f16_kernel<256,256,2,4,2,COLMAX> persistent (global_feat.3 2048->4096 + max over N)",
-                           "achieved": achieved, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": traffic, "traffic_measured_at": traffic_head,
-                           "avg_launch_ms": gf3_ms, "launches_timed": launches,
-                           "flop_per_launch": GF3_FLOP_PER_LAUNCH}
+        out["roofline"] = gf3_roofline(tot_ms / max(launches, 1), launches)
     if att is not None:
         att["measured"] = "before the timed region, after 200 warm-up launches"
         out["roofline_attention"] = att
         if not pointnet:
             out["roofline"] = att
+    if world == 1 and pointnet and not args.no_other_configs:
+        out["config"]["other_configs"] = other_configs(model, R.device)
     if world == 1 and not args.no_cpu_baseline and pointnet:
         out["cpu_baseline"] = cpu_baseline(sd)
+        out["cpu_baseline_cfg1"] = cpu_baseline_cfg1(sd)
     return out
+
+
+def other_configs(model, device):
+    """The other single-GPU workloads of BASELINE.json, measured AFTER the headline region so that the driver's default
+    line carries them (each is also a `--config` of its own with its own roofline block): configs[2]'s per-GPU workload
+    (DDIM `sample`, 50 steps, 64 shapes: whole sampler calls) and configs[3] (latent path at B = 32)."""
+    import torch
+    T = 50
+    model.sample(B_PER_GPU, N_POINTS, num_steps=T)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        model.sample(B_PER_GPU, N_POINTS, num_steps=T)
+    torch.cuda.synchronize()
+    cfg3 = 2 * T / (time.perf_counter() - t0)
+    m, _ = build_latent_model(device)
+    legs = latent_legs(m, device)
+    lat, dec, enc = latent_rooflines(legs)
+    return {"cfg3_ddim50_steps_per_sec": cfg3, "cfg4_ms": legs["cfg4_ms"], "cfg4_steps_per_sec": legs["steps"] / (legs["loop_ms"] * 1e-3),
+            "latent_us_per_step": legs["latent_us_per_step"], "latent_step_frac_of_hbm_roofline": lat["frac"],
+            "vae_decode_ms": legs["decode_ms"], "vae_decode_frac_of_mfma_peak": dec["frac"],
+            "vae_encode_ms": legs["encode_ms"], "vae_encode_frac_of_mfma_peak": enc["frac"],
+            "note": "cfg3: two whole DDIM-50 sampler calls at B=64, N=2048 (tables, graph capture included); cfg4: encode 32 grids + "
+                    "1000 latent DDIM steps + decode + voxel->points, wall clock; VAE legs by HIP events over 10 calls"}
 
 
 # ------------------------------------------------------------------------------------------ cfg3
@@ -377,10 +604,14 @@ def run_cfg3(args, R: Ranks):
     elapsed = R.max_over_ranks(time.perf_counter() - t0)
     ranks = R.collective_ranks()
     assert tuple(clouds.shape) == (gb, N_POINTS, 3) and torch.isfinite(clouds).all()
+    # dominant kernel, timed live after the timed region: one more sampler call with graph replay off (HIP events
+    # cannot be recorded inside a captured step), same 50 steps, same shapes
+    gf3_ms, gf3_launches = eager_gf3_profile(model, lambda: D.sample_sharded(model, gb, N_POINTS, T, gather=False))
     if R.rank != 0:
         return None
     steps = runs * T
     return {"metric": "denoising-steps/sec (whole node), 2048-pt DDIM 50 steps, batch 64 per GPU", "value": R.world * steps / elapsed,
+            "roofline": gf3_roofline(gf3_ms, gf3_launches, "eager run of the same 50 steps after the timed region (rank 0)"),
             "unit": "denoising-steps/sec", "n_gpus": R.world, "steps": steps, "warmup": max(1, args.warmup // T) * T,
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
@@ -393,19 +624,11 @@ def run_cfg3(args, R: Ranks):
 def run_cfg5(args, R: Ranks):
     """BASELINE configs[4]: latent diffusion, 1000 latent DDIM steps on 32 latents per GPU, VAE decode, voxel->points,
     all-gather of the ragged clouds, per-sample Chamfer / Sinkhorn EMD / voxel BCE rows against the input grids' clouds."""
-    import numpy as np
     import torch
     from shapegen_amd import dist as D
-    from shapegen_amd import specs
-    from shapegen_amd.diffusion import LatentDiffusion
     from shapegen_amd.utils import voxel_tensor_to_point_clouds
-    from shapegen_amd.vae import VAE3DLarge
     B, T = 32, SCHEDULE_STEPS
-    sd = specs.synth_state_dict(specs.latent_unet_spec(prefix="model."), seed=0, gain=1.3)
-    sd.update(specs.synth_state_dict(specs.vae3d_large_spec(prefix="vae."), seed=0, gain=1.3))
-    m = LatentDiffusion(VAE3DLarge())
-    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
-    m = m.to(R.device).eval()
+    m, _ = build_latent_model(R.device)
     torch.manual_seed(24)
     gb = B * R.world
     lo, hi = D.shard_range(gb, R.rank, R.world)
@@ -431,15 +654,47 @@ def run_cfg5(args, R: Ranks):
     loop_s, eval_s = R.max_over_ranks(loop_s), R.max_over_ranks(eval_s)
     ranks = R.collective_ranks()
     assert len(allc) == gb and rows.shape == (gb, 3)
+    legs = latent_legs(m, R.device) if R.rank == 0 else None       # after the timed region: the latent step / decode on their own
     if R.rank != 0:
         return None
+    lat, dec, _ = latent_rooflines(legs)
     return {"metric": "denoising-steps/sec (whole node), latent diffusion 1000 steps, batch 32 per GPU", "value": R.world * T / loop_s,
+            "roofline": lat, "roofline_vae_decode": dec,
             "unit": "denoising-steps/sec", "n_gpus": R.world, "steps": T, "warmup": T, "ms_per_step": loop_s / T * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[4]: latent diffusion, 1000 DDIM steps over (32, 256) latents per GPU + VAE3DLarge decode "
                                    "+ voxel->points (timed as the loop), then all-gather of ragged clouds + per-sample Chamfer/Sinkhorn-EMD/voxel-BCE",
                        "global_batch": gb, "eval_seconds": eval_s, "mean_metrics": [float(v) for v in rows.nanmean(dim=0)],
                        "rccl_ranks": ranks, "collective_backend": R.backend}}
+
+
+# ------------------------------------------------------------------------------------------ cfg4
+def run_cfg4(args, R: Ranks):
+    """BASELINE configs[3]: VAE3DLarge.encode of 32 grids -> 1000 latent DDIM steps (`LatentDiffusion.sample`,
+    diffusion.py:619-653) -> decode -> voxel->points, one GPU per rank (replicas when N > 1: no collective on this path)."""
+    m, sd = build_latent_model(R.device)
+    R.sync_all()
+    legs = latent_legs(m, R.device)
+    R.sync_all()
+    loop_s = R.max_over_ranks(legs["loop_ms"] * 1e-3)
+    ranks = R.collective_ranks()
+    if R.rank != 0:
+        return None
+    lat, dec, enc = latent_rooflines(legs)
+    T = legs["steps"]
+    out = {"metric": "denoising-steps/sec (whole node), latent diffusion 1000 steps, batch 32 per GPU", "value": R.world * T / loop_s,
+           "unit": "denoising-steps/sec", "n_gpus": R.world, "steps": T, "warmup": T, "ms_per_step": loop_s / T * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[3]: latent diffusion on one GPU per rank: VAE3DLarge encode of 32 voxel grids, 1000 DDIM steps over "
+                                  "(32, 256) latents (timed as the loop: value), VAE3DLarge decode, voxel->points; synthetic weights",
+                      "batch_per_gpu": legs["batch"], "encode_ms": legs["encode_ms"], "decode_ms": legs["decode_ms"],
+                      "decode_and_voxel_to_points_ms": legs["decode_and_voxel_to_points_ms"], "cfg4_ms_end_to_end": legs["cfg4_ms"],
+                      "latent_us_per_step": legs["latent_us_per_step"], "clouds_first4": legs["clouds"],
+                      "rccl_ranks": ranks, "collective_backend": R.backend},
+           "roofline": lat, "roofline_vae_decode": dec, "roofline_vae_encode": enc}
+    if R.world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_latent(sd)
+    return out
 
 
 def main():
@@ -451,7 +706,7 @@ def main():
     import shapegen_amd  # noqa: F401
     torch.set_grad_enabled(False)
     R = Ranks(args)
-    out = {"cfg2": run_cfg2, "cfg3": run_cfg3, "cfg5": run_cfg5}[args.config](args, R)
+    out = {"cfg2": run_cfg2, "cfg3": run_cfg3, "cfg4": run_cfg4, "cfg5": run_cfg5}[args.config](args, R)
     if R.rank == 0:
         print(json.dumps(out), flush=True)
     R.finish()

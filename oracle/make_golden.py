@@ -13,7 +13,9 @@ Fixture map: G1 schedule.npz, G2-G4 point_unet.npz,
 G5-G7 point_samplers.npz, G8 latent.npz, G9 metrics.npz, G10 attention.npz; beyond the survey's list:
 G11 vae3d_small.npz (`make_golden.py vae3d`), G12 data.npz (`make_golden.py data`), G13 train.npz
 (`make_golden.py train`), G14 train_latent.npz (`make_golden.py train_latent`), G15 train_vae.npz (`make_golden.py train_vae`),
-G16 linear.npz (`make_golden.py linear`: the linear schedule's per-shape rate tables and sampler outputs).
+G16 linear.npz (`make_golden.py linear`: the linear schedule's per-shape rate tables and sampler outputs),
+G17 cfg4.npz (`make_golden.py cfg4`: BASELINE configs[3] at its real launch shape -- 32 grids through `VAE3DLarge.encode`,
+`LatentDiffusion.sample(32, num_steps=1000)` with the start noise recorded, the decoded grids of four rows).
 """
 from __future__ import annotations
 
@@ -119,6 +121,49 @@ def capture_linear_schedule(rd):
     g["s3_out"] = pcd.sample3(B, N, x=noisy, start_t=tt, num_steps=Tn).numpy()
     np.savez_compressed(os.path.join(OUT, "linear.npz"), **g)
     print("linear done: |sample| max", float(out.abs().max()), "|sample2| max", float(out2.abs().max()))
+
+
+def capture_cfg4(rd, rn, ru):
+    """G17: the reference at BASELINE configs[3]'s launch shape (diffusion.py:619-653, networks.py:2299-2339): B = 32,
+    T = 1000.  The 32 input grids are `synth_voxels(32, 4)` (the test rebuilds them from the same integer hash; the
+    occupancy counts are stored as a check), z_T is the first `torch.randn` after `manual_seed(24)`."""
+    vae = rn.VAE3DLarge().eval()
+    ldm = rd.LatentDiffusion(vae).eval()
+    sd_l = specs.synth_state_dict(specs.latent_unet_spec(prefix="model."), seed=0, gain=LATENT_GAIN)
+    sd_v = specs.synth_state_dict(specs.vae3d_large_spec(prefix="vae."), seed=0, gain=VAE_GAIN)
+    ldm.load_state_dict(T({**sd_l, **sd_v}), strict=True)
+    g = {}
+    t0 = time.time()
+    vox = torch.from_numpy(synth_voxels(32, 4))
+    g["vox_counts"] = vox.reshape(32, -1).sum(1).numpy().astype(np.int64)
+    mu, logvar = vae.encode(vox)
+    g["enc_mu"], g["enc_logvar"] = mu.numpy(), logvar.numpy()
+    print("cfg4 encode", time.time() - t0)
+    captured = {}
+    orig_decode = vae.decode
+
+    def spy(zz):
+        captured["z0"] = zz.detach().clone()
+        captured["dec"] = orig_decode(zz)
+        return captured["dec"]
+
+    vae.decode = spy
+    torch.manual_seed(24)
+    pcs = ldm.sample(32, num_steps=1000)
+    vae.decode = orig_decode
+    torch.manual_seed(24)
+    g["zT"] = torch.randn(32, 256).numpy()
+    g["z0"] = captured["z0"].numpy()
+    g["counts"] = np.array([len(p) for p in pcs], np.int64)
+    rows = np.array([0, 9, 18, 31])
+    g["dec_rows"] = rows
+    g["dec"] = captured["dec"].numpy()[rows].astype(np.float16)          # probabilities in [0, 1]: fp16 is 5e-4 absolute
+    g["dec_occ_frac"] = (captured["dec"] > 0.4).float().reshape(32, -1).mean(1).numpy()
+    # decode of the encoder means of four rows (the encode -> decode bracket of configs[3])
+    g["dec_of_mu"] = orig_decode(mu[rows]).numpy().astype(np.float16)
+    print("cfg4 sample", time.time() - t0, "|z0| max", float(captured["z0"].abs().max()), "counts", g["counts"][:6])
+    np.savez_compressed(os.path.join(OUT, "cfg4.npz"), **g)
+    print("cfg4.npz", os.path.getsize(os.path.join(OUT, "cfg4.npz")))
 
 
 def capture_vae3d_small(rn):
@@ -349,6 +394,9 @@ def main():
     t_start = time.time()
     if "vae3d" in sys.argv[1:]:
         capture_vae3d_small(rn)
+        return
+    if "cfg4" in sys.argv[1:]:
+        capture_cfg4(rd, rn, ru)
         return
     if "linear" in sys.argv[1:]:
         capture_linear_schedule(rd)

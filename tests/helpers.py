@@ -48,3 +48,18 @@ def voxels_from_idx(idx_list):
 
 def vae3d_small_sd():
     return as_torch(specs.synth_state_dict(specs.vae3d_small_spec(), seed=3, gain=VAE_GAIN))
+
+
+def synth_voxels(b, seed):
+    """(B,1,32,32,32) occupancy in {0,1}: three axis-aligned ellipsoids per grid from the integer hash of `specs`
+    (the inputs `oracle/make_golden.py cfg4` fed the reference; `cfg4.npz` stores the occupancy counts as a check)."""
+    v = np.zeros((b, 1, 32, 32, 32), np.float32)
+    zz, yy, xx = np.meshgrid(np.arange(32), np.arange(32), np.arange(32), indexing="ij")
+    for i in range(b):
+        u = specs.hash_uniform(f"vox{i}", 3 * 6, seed).reshape(3, 6) * 0.5 + 0.5
+        for j in range(3):
+            c = 6 + u[j, :3] * 20
+            r = 3 + u[j, 3:] * 6
+            m = ((zz - c[0]) / r[0]) ** 2 + ((yy - c[1]) / r[1]) ** 2 + ((xx - c[2]) / r[2]) ** 2 <= 1
+            v[i, 0][m] = 1
+    return torch.from_numpy(v)

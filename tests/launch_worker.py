@@ -1,0 +1,24 @@
+"""Rank of a launcher rehearsal (tests/test_dist_gloo.py): gloo rendezvous, one barrier, then rank FAULT_RANK dies
+(FAULT_MODE=exit), hangs (FAULT_MODE=hang) or nobody does; the others wait in a second barrier like ranks whose peer
+died at RCCL init would."""
+import datetime
+import os
+import sys
+import time
+
+import torch.distributed as dist
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world,
+                        timeout=datetime.timedelta(seconds=int(os.environ.get("PCD_COLLECTIVE_TIMEOUT_S", "300"))))
+dist.barrier()
+mode, bad = os.environ.get("FAULT_MODE", "none"), int(os.environ.get("FAULT_RANK", "-1"))
+if rank == bad and mode == "exit":
+    print(f"rank {rank}: simulated failure", file=sys.stderr, flush=True)
+    os._exit(3)
+if rank == bad and mode == "hang":
+    time.sleep(3600)
+dist.barrier()
+if rank == 0:
+    print('{"ok": true}', flush=True)
+dist.destroy_process_group()

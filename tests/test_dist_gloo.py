@@ -134,6 +134,31 @@ def test_bench_parent_stays_gpu_free_and_reports_failed_ranks():
     assert p.returncode != 0 and "ranks failed" in p.stderr
 
 
+@pytest.mark.parametrize("mode,want", [("none", 0), ("exit", 1), ("hang", 124)])
+def test_launcher_kills_siblings_of_a_dead_rank_and_enforces_the_timeout(tmp_path, mode, want):
+    """`shapegen_amd.launcher.launch_ranks` (bench.py's N > 1 parent): a rank that dies after the rendezvous leaves its peer
+    in a barrier; the parent must notice the exit code, terminate the peer, return non-zero well inside the timeout and
+    quote the dead rank's stderr.  A rank that hangs is cut by the overall timeout (exit 124)."""
+    import sys
+    import time
+    from shapegen_amd import launcher
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(FAULT_MODE=mode, FAULT_RANK="1", PYTHONPATH=root)
+    t0 = time.monotonic()
+    code, out0, report = launcher.launch_ranks([sys.executable, os.path.join(root, "tests", "launch_worker.py")], 2,
+                                               timeout_s=120.0 if mode != "hang" else 25.0, log_dir=str(tmp_path), env=env)
+    took = time.monotonic() - t0
+    assert code == want, report
+    if mode == "none":
+        assert '{"ok": true}' in out0 and report == ""
+    elif mode == "exit":
+        assert took < 60 and "(1, 3)" in report and "simulated failure" in report and "siblings terminated" in report
+    else:
+        assert 25 <= took < 60 and "timeout" in report
+    assert (tmp_path / "rank1.err").exists()              # per-rank logs, not DEVNULL
+
+
 class _ToyModel(torch.nn.Module):
     """Stands in for a HIP-trained module in `training.fit`: the control flow under test (how batches are dealt to ranks,
     which collectives pair up, what is broadcast) does not depend on the kernels."""

@@ -41,13 +41,13 @@ def test_two_rank_sampling_and_evaluation_match_one_process(tmp_path):
     np.testing.assert_allclose(r["mean"], r["want_rows"].mean(0), rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("config", ["cfg2", "cfg3"])
+@pytest.mark.parametrize("config", ["cfg2", "cfg3", "cfg5"])
 def test_bench_launches_its_own_ranks(config):
     """`python bench.py --gpus 2` with no WORLD_SIZE: the parent starts the ranks (PCD_BENCH_SHARE_GPU=1: both on
     this box's one GPU, collectives over gloo) and relays rank 0's JSON line."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env.update(PCD_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    steps = ["--steps", "6", "--warmup", "2"] if config == "cfg2" else ["--steps", "50", "--warmup", "50"]
+    steps = ["--steps", "6", "--warmup", "2"] if config == "cfg2" else ["--steps", "50", "--warmup", "50"]   # cfg5 ignores both (T = 1000)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", config,
                         "--no-cpu-baseline", "--no-attention"] + steps, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -55,3 +55,23 @@ def test_bench_launches_its_own_ranks(config):
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
     assert rec["config"]["rccl_ranks"] == 2 and rec["config"]["collective_backend"] == "gloo"
+    roof = rec["roofline"]                                  # every config's line carries a live-timed dominant kernel
+    assert roof["achieved"] > 0 and 0 < roof["frac"] < 1.5 and roof["avg_launch_ms"] > 0 and roof["bound"] in ("mfma", "hbm")
+    if config == "cfg5":
+        assert rec["steps"] == 1000 and rec["config"]["global_batch"] == 64 and len(rec["config"]["mean_metrics"]) == 3
+        assert rec["roofline_vae_decode"]["bound"] == "mfma"
+
+
+def test_bench_cfg4_line():
+    """`python bench.py --config cfg4` (BASELINE configs[3] on one GPU): encode 32 grids, 1000 latent steps, decode,
+    voxel -> points; the line carries the latent step against the HBM roofline and the VAE legs against the MFMA peak."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "cfg4", "--no-cpu-baseline"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["steps"] == 1000 and rec["value"] > 1000
+    assert rec["roofline"]["bound"] == "hbm" and rec["roofline"]["bytes_per_launch"] == 38174720.0
+    assert abs(rec["roofline"]["achieved"] - 38174720.0 / (rec["config"]["latent_us_per_step"] * 1e-6) / 1e9) < 1e-6 * rec["roofline"]["achieved"]
+    assert rec["roofline_vae_decode"]["frac"] > 0.05 and rec["roofline_vae_encode"]["frac"] > 0.05
+    assert rec["config"]["cfg4_ms_end_to_end"] > rec["config"]["encode_ms"] + rec["config"]["decode_ms"]

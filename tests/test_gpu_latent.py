@@ -7,7 +7,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import latent_sd, rel_l2, voxels_from_idx
+from helpers import latent_sd, rel_l2, voxels_from_idx, synth_voxels
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
@@ -296,6 +296,40 @@ def test_latent_ddim(ldm, golden, T):
     counts = np.array([len(p) for p in pcs])
     assert np.all(np.abs(counts - g[f"ldm_T{T}_counts"]) <= 0.02 * g[f"ldm_T{T}_counts"] + 8)
     assert all(p.shape[1] == 3 and float(p.abs().max()) <= 1.0 for p in pcs if len(p))
+
+
+def test_cfg4_launch_shapes_vs_reference(ldm, golden):
+    """BASELINE configs[3] at the launch shapes the bench line quotes (B = 32): encode 32 grids, 1000 latent DDIM steps from
+    the recorded z_T, decode, voxel -> points -- against G17, captured from the reference at B = 32, T = 1000
+    (diffusion.py:619-653, networks.py:2299-2339)."""
+    from shapegen_amd.utils import voxel_tensor_to_point_clouds
+    g = golden("cfg4.npz")
+    rows = g["dec_rows"]
+    vox = synth_voxels(32, 4).cuda()
+    mu, logvar = ldm.vae.encode(vox)
+    assert mu.shape == (32, 256)
+    assert rel_l2(mu.cpu(), g["enc_mu"]) < 1e-2 and rel_l2(logvar.cpu(), g["enc_logvar"]) < 1e-2
+    for i in rows:                                                   # per row too: no sample hides behind the batch norm
+        assert rel_l2(mu[i].cpu(), g["enc_mu"][i]) < 1.5e-2, i
+    pcs, z0 = ldm.sample(32, num_steps=1000, z_T=torch.from_numpy(g["zT"]).cuda(), return_latent=True)
+    err = rel_l2(z0.cpu(), g["z0"])
+    assert err < 5e-3, err
+    assert max(rel_l2(z0[i].cpu(), g["z0"][i]) for i in range(32)) < 1e-2
+    counts = np.array([len(p) for p in pcs])
+    assert np.all(np.abs(counts - g["counts"]) <= 0.02 * g["counts"] + 8)
+    # decode at B = 32 of the REFERENCE's latents (so the comparison is of the decoder alone), four rows kept in the fixture
+    dec = ldm.vae.decode(torch.from_numpy(g["z0"]).cuda())
+    assert dec.shape == (32, 1, 32, 32, 32)
+    derr = (dec[torch.from_numpy(rows).cuda()].cpu() - torch.from_numpy(g["dec"]).float()).abs()
+    assert float(derr.max()) < 2e-2 and float(derr.mean()) < 2e-3
+    occ = (dec > 0.4).float().reshape(32, -1).mean(1).cpu().numpy()
+    assert np.abs(occ - g["dec_occ_frac"]).max() < 5e-3
+    # the encode -> decode bracket: decode of the batch of 32 encoder means
+    dm = ldm.vae.decode(mu)
+    merr = (dm[torch.from_numpy(rows).cuda()].cpu() - torch.from_numpy(g["dec_of_mu"]).float()).abs()
+    assert float(merr.max()) < 3e-2 and float(merr.mean()) < 3e-3
+    got = voxel_tensor_to_point_clouds(dec, 0.4)
+    assert [len(p) for p in got] == [int(v) for v in (dec > 0.4).reshape(32, -1).sum(1).cpu()]
 
 
 def test_latent_sample2_sample3_and_errors(ldm):

@@ -7,7 +7,7 @@ import torch
 
 from oracle import torch_oracle as O
 from shapegen_amd import specs
-from helpers import point_sd, latent_sd, sab_sd, una_sd, rel_l2, voxels_from_idx
+from helpers import point_sd, latent_sd, sab_sd, una_sd, rel_l2, voxels_from_idx, synth_voxels
 
 torch.set_grad_enabled(False)
 
@@ -130,6 +130,25 @@ def test_latent_ddim(golden):
     pcs = O.voxel_tensor_to_point_clouds(O.vae_decode(sd, "vae.", z0, specs.VAE_DEC), 0.4)
     assert [len(p) for p in pcs] == list(g["ldm_T5_counts"])
     assert np.array_equal(pcs[0].numpy(), g["ldm_T5_pc0"])
+
+
+def test_cfg4_launch_shape_rows(golden):
+    """G17 (`make_golden.py cfg4`): the reference at BASELINE configs[3]'s shape, B = 32, T = 1000.  Every sample is
+    independent (GroupNorm per sample, eval BatchNorm3d), so the oracle runs the four decoded rows only."""
+    g = golden("cfg4.npz")
+    sd = latent_sd()
+    rows = g["dec_rows"]
+    vox = synth_voxels(32, 4)
+    assert np.array_equal(vox.reshape(32, -1).sum(1).numpy().astype(np.int64), g["vox_counts"])
+    mu, logvar = O.vae_encode(sd, "vae.", vox[rows], specs.VAE_ENC)
+    assert rel_l2(mu, g["enc_mu"][rows]) < 1e-5 and rel_l2(logvar, g["enc_logvar"][rows]) < 1e-5
+    z0 = O.ddim_sample(lambda z, t: O.latent_unet(sd, "model.", z, t), torch.from_numpy(g["zT"][rows]), 1000)
+    assert rel_l2(z0, g["z0"][rows]) < 1e-4                      # 1000 dependent fp32 steps, row-batched differently
+    dec = O.vae_decode(sd, "vae.", torch.from_numpy(g["z0"][rows]), specs.VAE_DEC)
+    assert float((dec - torch.from_numpy(g["dec"]).float()).abs().max()) < 1e-3          # golden stored as fp16
+    assert [int((d > 0.4).sum()) for d in dec] == list(g["counts"][rows])
+    dm = O.vae_decode(sd, "vae.", torch.from_numpy(g["enc_mu"][rows]), specs.VAE_DEC)
+    assert float((dm - torch.from_numpy(g["dec_of_mu"]).float()).abs().max()) < 1e-3
 
 
 def test_metrics_units_known_answers(golden):
