@@ -1,0 +1,862 @@
+// a11 as ONE launch: whole timesteps of the latent sampler (SimpleLatentUNetPointNet.forward, reference
+// networks.py:1051-1086, + the DDIM loop body diffusion.py:637-645) inside one persistent kernel.
+//
+// Why.  At B <= 32 the step is 12 dependent Linear(+GroupNorm+ReLU) layers over 38 MB of fp16 weights; as one launch
+// per layer (+ a finishing launch for the five big ones) every dependent launch costs ~3.8 us (boundary + kernel
+// fill + two or three dependent memory round trips for weights that do not depend on anything), 19 launches = 72.8 us
+// per step against a 4.8 us weight-streaming roofline.  Here:
+//   * 256 workgroups (one per CU) stay resident for all the steps of a call; the chip's LDS (256 x 160 KB = 41.9 MB)
+//     holds ALL 38.2 MB of weights: every workgroup stages its share once per call by LDS-DMA and keeps it, so
+//     no weight byte is on any step's critical path;
+//   * a layer = units (32 batch rows x 32 columns x a K slice, v_mfma_f32_32x32x16_f16, 4 waves split the slice) that
+//     publish fp32 partial tiles, + finish units (one GroupNorm group x 8 rows: slab sum in slice order, bias,
+//     GroupNorm, ReLU) that publish fp16 activations; layers whose 32-column unit holds whole GroupNorm groups over the
+//     full K (enc1-3, dec1, the output head) finish inside the unit;
+//   * there are NO flags, counters, atomics or fences between layers: the exchanged data carries its own validity.
+//     Activations are post-ReLU fp16 (sign bit clear), partial sums and eps are finite fp32; the buffers are poisoned
+//     with 0xFF bytes (sign bit set / NaN) and a consumer simply loads its operands with sc1 (L1-bypassing) loads
+//     until no element is poison: one memory round trip per layer boundary.  Stores are sc1 write-through.  Two
+//     buffer sets alternate by step parity; a workgroup re-poisons its own output regions of the other set after its
+//     first successful load of a step (by then every reader of that set's previous contents has finished: each
+//     step's first layer needs the previous step's complete eps, which needs every output of every unit);
+//   * activations are stored in MFMA-fragment order ([64-k chunk][j][lane][8 halfs]), so a consumer's operand loads are
+//     1-KB coalesced instructions straight into the registers the MFMA reads: no LDS staging of activations;
+//   * the four workgroups that own enc1 keep the latent state z (fp32, registers) and apply the DDIM update
+//     (same fp32 operation order as pcd_ddim_update, FMA contraction off) redundantly: bit-identical copies, no
+//     broadcast step.
+// Every wait is bounded (s_memrealtime) and reports through a status word; the grid is exactly the number of CUs and
+// the host refuses to launch on a device with fewer (pcd_latent_persist_supported).
+#include <new>
+#include <vector>
+#include <algorithm>
+#include "common.h"
+
+namespace pcd {
+
+constexpr int LP_WGS = 256, LP_THREADS = 256, LP_LAYERS = 12, LP_MAX_UNITS = 8;
+constexpr int LP_LDS_BYTES = 160 * 1024;
+constexpr int LP_RED_BYTES = 4 * 32 * 33 * 4;          // cross-wave reduction scratch
+constexpr int LP_Z16_BYTES = 32 * 256 * 2;             // fp16 image of the latent state (enc1's operand)
+constexpr int LP_CTRL_BYTES = 256;
+constexpr unsigned LP_TIMEOUT_TICKS = 20000000u;       // 0.2 s of the 100 MHz s_memrealtime clock
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+struct LpLayer {
+    const half_t* w; int ldw;          // fp16 [C][K1+K2]
+    const float* bias; const float* gamma; const float* beta;
+    int k1, k2;                        // widths of the two input sources (K2 = 0: one source)
+    int src1_off, src2_off;            // byte offsets (inside a set) of the sources' fp16 fragment-major buffers; -1: the latent state
+    int c, gsz, mode;                  // mode 0: GroupNorm(gsz)+ReLU -> fp16; 1: ReLU -> fp16; 2: identity -> fp32 eps
+    int slabs;                         // 0: the unit finishes the layer itself; S >= 1: S K-slices of fp32 partial tiles + finish units
+    int out_off;                       // byte offset (inside a set) of this layer's output: fp16 fragment-major, or eps fp32 [32][256]
+    int slab_off;                      // byte offset (inside a set) of the fp32 slabs [S][32][C]
+    int pad;
+};
+
+enum { LP_END = 0, LP_GEMM = 1, LP_FINISH = 2 };
+
+struct LpUnit {
+    int kind, layer;
+    int col0, ct;                      // gemm: first output column, number of 32-column tiles (1 or 2)
+    int chunk0, nchunks;               // gemm: K slice in 64-k chunks of the concatenated input
+    int slice;                         // gemm: slab index
+    int lds_w;                         // gemm: byte offset of the unit's weight images in LDS
+    int group, row0;                   // finish: GroupNorm group, first row
+    int head;                          // gemm on the latent state: this workgroup keeps z
+    int pad[5];
+};
+
+struct LpArgs {
+    const LpLayer* layers;             // [LP_LAYERS]
+    const LpUnit* units;               // [LP_WGS][LP_MAX_UNITS]
+    char* ws;                          // ctrl | set 0 | set 1
+    int set_bytes;
+    float* z;                          // fp32 [batch][256], in/out (DDIM mode) or in (forward mode)
+    float* x0;                         // fp32 [batch][256] or null
+    float* eps_out;                    // forward mode: fp32 [batch][256]
+    int batch;
+    const float* tb_table; int tb_elems;      // [T][128] (or one row in forward mode)
+    const float* rates; int rate_width, rate_stride, T;     // (4, T, R) fp32
+    int* counter;                      // device step counter (pcd_step_select semantics), or null: k = 0
+    int nsteps;
+    int forward_only;
+    int sleep;                         // s_sleep argument between polls
+};
+
+// ------------------------------------------------------------------------------------------------ device helpers
+__device__ __forceinline__ int lp_swz(int row, int ch) { return ch ^ ((row >> 1) & 7); }
+
+// LDS-DMA of rows [row0, row0 + 32) x 128 bytes at halfs column k0 of w[rows][ld] into a swizzled 4-KiB image
+// (instruction i of 4 covers rows 8 i .. 8 i + 7); same image format as csrc/skinny.hip
+__device__ __forceinline__ void lp_stage(const half_t* base, int64_t ld, int row0, int k0, char* img, int i, int lane) {
+    const int row = 8 * i + (lane >> 3), ch = lane & 7;
+    lds_dma16(base + (int64_t)(row0 + row) * ld + k0 + lp_swz(row, ch) * 8, img + i * 1024);
+}
+
+__device__ __forceinline__ half8 lp_wfrag(const char* img, int row, int hh, int j) {
+    return *(const half8*)(img + row * 128 + (lp_swz(row, 4 * hh + j) << 4));
+}
+
+__device__ __forceinline__ bool lp_poison16(u32x4 v) { return ((v.x | v.y | v.z | v.w) & 0x80008000u) != 0u; }
+__device__ __forceinline__ bool lp_nan(unsigned b) { return (b & 0x7fffffffu) > 0x7f800000u; }
+__device__ __forceinline__ bool lp_nan4(u32x4 v) { return (int)lp_nan(v.x) | (int)lp_nan(v.y) | (int)lp_nan(v.z) | (int)lp_nan(v.w); }
+
+__device__ __forceinline__ void lp_sleep(int n) { for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1); }
+
+__device__ __forceinline__ unsigned lp_now() { return (unsigned)__builtin_amdgcn_s_memrealtime(); }
+
+// fragment-major byte offset of (row, col) in an fp16 activation buffer: [chunk = col / 64][j][hh * 32 + row][e]
+__device__ __forceinline__ int lp_frag_off(int row, int col) {
+    const int within = col & 63;
+    return (col >> 6) * 4096 + ((within & 31) >> 3) * 1024 + (((within >> 5) << 5) + row) * 16 + (within & 7) * 2;
+}
+
+__device__ __forceinline__ unsigned lp_pack_relu_f16(float a, float b) {
+    // post-ReLU values: saturate, round to fp16, sign bit cleared (the validity bit of the exchange)
+    const half_t ha = to_half_sat(fmaxf(a, 0.f)), hb = to_half_sat(fmaxf(b, 0.f));
+    return ((unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16)) & 0x7fff7fffu;
+}
+
+struct LpCtx {
+    __amdgpu_buffer_rsrc_t rs;         // the whole workspace
+    unsigned* ctrl;                    // ctrl[0]: status (0 ok; else code << 16 | workgroup)
+    char* smem;
+    int* lds_flag;                     // [0]: abort seen by some wave of this workgroup
+    int tid, lane, wave, r, hh;
+    int sleep;
+    unsigned t_start;
+};
+
+__device__ __forceinline__ u32x4 lp_ld16(const LpCtx& c, int off) { return __builtin_amdgcn_raw_buffer_load_b128(c.rs, off, 0, 16); }
+__device__ __forceinline__ void lp_st16(const LpCtx& c, u32x4 v, int off) { __builtin_amdgcn_raw_buffer_store_b128(v, c.rs, off, 0, 16); }
+__device__ __forceinline__ void lp_st8(const LpCtx& c, u32x2 v, int off) { __builtin_amdgcn_raw_buffer_store_b64(v, c.rs, off, 0, 16); }
+__device__ __forceinline__ void lp_st4(const LpCtx& c, unsigned v, int off) { __builtin_amdgcn_raw_buffer_store_b32(v, c.rs, off, 0, 16); }
+
+// called every 64 unsuccessful polls: true = give up (somebody aborted, or this wait exceeded the limit)
+__device__ __forceinline__ bool lp_give_up(const LpCtx& c, unsigned t0, unsigned code) {
+    const unsigned st = __hip_atomic_load(c.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (st != 0u) return true;
+    if (lp_now() - t0 > LP_TIMEOUT_TICKS) {
+        if (c.lane == 0) {
+            unsigned expected = 0u;
+            __hip_atomic_compare_exchange_strong(c.ctrl, &expected, (code << 16) | (unsigned)blockIdx.x, __ATOMIC_RELAXED,
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return true;
+    }
+    return false;
+}
+
+// --------------------------------------------------------------------------------------------- gemm unit
+// Operand fetch of one wave: its chunks (wave, wave + 4, ...) of the unit's K slice, 4 x 16 B per lane and chunk, polled
+// until no fp16 carries the poison bit.  Returns false when the wait was abandoned.
+template <int MAXCH>
+__device__ __forceinline__ bool lp_fetch(const LpCtx& c, const LpLayer& L, const LpUnit& U, int set_off, u32x4 (&pc)[MAXCH][4]) {
+    int off[MAXCH];
+    unsigned need = 0u;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int cl = c.wave + 4 * i;                   // chunk of the slice
+        const int kc = U.chunk0 + cl;                    // chunk of the concatenated K
+        const int n1 = L.k1 >> 6;
+        off[i] = set_off + (kc < n1 ? L.src1_off + kc * 4096 : L.src2_off + (kc - n1) * 4096) + c.lane * 16;
+        if (cl < U.nchunks) need |= 1u << i;
+    }
+    const unsigned t0 = lp_now();
+    for (unsigned spin = 1;; ++spin) {
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i)
+            if (need & (1u << i)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pc[i][j] = lp_ld16(c, off[i] + j * 1024);
+            }
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i)
+            if (need & (1u << i)) {
+                const bool bad = (int)lp_poison16(pc[i][0]) | (int)lp_poison16(pc[i][1]) | (int)lp_poison16(pc[i][2]) | (int)lp_poison16(pc[i][3]);
+                if (__builtin_amdgcn_ballot_w64(bad) == 0ull) need &= ~(1u << i);
+            }
+        if (need == 0u) return true;
+        if ((spin & 63u) == 0u && lp_give_up(c, t0, 1u)) return false;
+        lp_sleep(c.sleep);
+    }
+}
+
+#pragma clang fp contract(off)
+// DDIM update of one element, the operation order of pcd_ddim_update (diffusion.py:283-287)
+__device__ __forceinline__ void lp_ddim(float z, float e, float n, float s, float n2, float s2, float& x0, float& zn) {
+    const float ne = n * e;
+    x0 = (z - ne) / s;
+    const float a = s2 * x0;
+    const float b = n2 * e;
+    zn = a + b;
+}
+#pragma clang fp contract(fast)
+
+struct LpStep {
+    int k;                 // row of the step tables
+    int set_off;           // byte offset of this step's buffer set in the workspace
+    int other_off;         // ... of the other set (previous step's data; to be poisoned for the next step)
+};
+
+// epilogue stores of a gemm unit (or its poison when `poison`): thread = (row = tid >> 3, q = tid & 7), 4 columns per tile
+template <int CT>
+__device__ __forceinline__ void lp_gemm_store(const LpCtx& c, const LpLayer& L, const LpUnit& U, int set_off, const float (&v)[CT][4],
+                                              bool poison) {
+    const int row = c.tid >> 3, q = c.tid & 7;
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        const int col = U.col0 + 32 * t + 4 * q;
+        if (L.slabs > 0) {                                  // fp32 partial tile -> slab [slice][row][col]
+            const int off = set_off + L.slab_off + ((U.slice * 32 + row) * L.c + col) * 4;
+            u32x4 o = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            if (!poison) o = (u32x4){__float_as_uint(v[t][0]), __float_as_uint(v[t][1]), __float_as_uint(v[t][2]), __float_as_uint(v[t][3])};
+            lp_st16(c, o, off);
+        } else if (L.mode == 2) {                           // eps fp32 [32][C]
+            const int off = set_off + L.out_off + (row * L.c + col) * 4;
+            u32x4 o = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            if (!poison) o = (u32x4){__float_as_uint(v[t][0]), __float_as_uint(v[t][1]), __float_as_uint(v[t][2]), __float_as_uint(v[t][3])};
+            lp_st16(c, o, off);
+        } else {                                            // fp16 activation, fragment-major, 4 columns = 8 bytes
+            const int off = set_off + L.out_off + lp_frag_off(row, col);
+            u32x2 o = {0xffffffffu, 0xffffffffu};
+            if (!poison) o = (u32x2){lp_pack_relu_f16(v[t][0], v[t][1]), lp_pack_relu_f16(v[t][2], v[t][3])};
+            lp_st8(c, o, off);
+        }
+    }
+}
+
+template <int CT, int MAXCH>
+__device__ __forceinline__ bool lp_run_gemm(const LpCtx& c, const LpLayer& L, const LpUnit& U, const LpStep& S, const LpArgs& A,
+                                            bool& polled) {
+    f32x16 acc[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    bool ok = true;
+    const char* wimg = c.smem + U.lds_w;
+    if (U.head) {
+        // operand = the fp16 image of z in LDS (fragment-major, written by the update): chunk = wave
+        const char* z16 = c.smem + LP_RED_BYTES;
+        if (c.wave < U.nchunks) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const half8 a = *(const half8*)(z16 + c.wave * 4096 + j * 1024 + c.lane * 16);
+#pragma unroll
+                for (int t = 0; t < CT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, lp_wfrag(wimg + (t * U.nchunks + c.wave) * 4096, c.r, c.hh, j), acc[t], 0, 0, 0);
+            }
+        }
+    } else {
+        u32x4 pc[MAXCH][4];
+        ok = lp_fetch<MAXCH>(c, L, U, S.set_off, pc);
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < MAXCH; ++i) {
+                const int cl = c.wave + 4 * i;
+                if (cl < U.nchunks) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const half8 a = __builtin_bit_cast(half8, pc[i][j]);
+#pragma unroll
+                        for (int t = 0; t < CT; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, lp_wfrag(wimg + (t * U.nchunks + cl) * 4096, c.r, c.hh, j), acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (!ok) c.lds_flag[0] = 1;
+    polled = true;
+    // cross-wave reduction through LDS, one 32-column tile at a time
+    float (*red)[32][33] = (float (*)[32][33])c.smem;
+    const int row = c.tid >> 3, q = c.tid & 7;
+    float v[CT][4];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[c.wave][(e & 3) + 8 * (e >> 2) + 4 * c.hh][c.r] = acc[t][e];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            v[t][i] = (red[0][row][4 * q + i] + red[1][row][4 * q + i]) + (red[2][row][4 * q + i] + red[3][row][4 * q + i]);
+    }
+    if (c.lds_flag[0]) return false;                        // uniform: written before the barriers above
+    if (L.slabs == 0) {
+        // the unit holds whole GroupNorm groups over the full K: bias, GroupNorm, ReLU here
+        float s1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = U.col0 + 32 * t + 4 * q + i;
+                const float b = U.head ? A.tb_table[(int64_t)S.k * A.tb_elems + col] : L.bias[col];
+                v[t][i] += b;
+                s1 += v[t][i];
+            }
+        if (L.mode == 0) {
+            const int tpg = L.gsz >= 32 ? 8 : L.gsz / 4;       // threads of this row that share a group
+            for (int o = 1; o < tpg; o <<= 1) s1 += __shfl_xor(s1, o);
+            const float mean = s1 / (float)L.gsz;
+            float s2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < CT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const float d = v[t][i] - mean; s2 += d * d; }
+            for (int o = 1; o < tpg; o <<= 1) s2 += __shfl_xor(s2, o);
+            const float rstd = rsqrtf(s2 / (float)L.gsz + 1e-5f);
+#pragma unroll
+            for (int t = 0; t < CT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int col = U.col0 + 32 * t + 4 * q + i;
+                    v[t][i] = (v[t][i] - mean) * rstd * L.gamma[col] + L.beta[col];
+                }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's poison stores are complete before its data stores leave
+    lp_gemm_store<CT>(c, L, U, S.set_off, v, false);
+    if (L.slabs == 0 && L.mode == 2 && A.forward_only && row < A.batch) {
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+            *(float4*)(A.eps_out + (int64_t)row * L.c + U.col0 + 32 * t + 4 * q) = make_float4(v[t][0], v[t][1], v[t][2], v[t][3]);
+    }
+    return true;
+}
+
+// --------------------------------------------------------------------------------------------- finish unit
+// One GroupNorm group x (256 / TPR) rows: slabs added in slice order + bias, two-pass statistics over the TPR threads of
+// a row, affine, ReLU, fp16 fragment-major store.  CPT columns per thread.
+template <int CPT, int TPR>
+__device__ __forceinline__ void lp_finish_store(const LpCtx& c, const LpLayer& L, const LpUnit& U, int set_off, const float (&x)[CPT], bool poison) {
+    const int row = U.row0 + c.tid / TPR, col = U.group * L.gsz + (c.tid % TPR) * CPT;
+    unsigned w[CPT / 2];
+#pragma unroll
+    for (int i = 0; i < CPT / 2; ++i) w[i] = poison ? 0xffffffffu : lp_pack_relu_f16(x[2 * i], x[2 * i + 1]);
+    if constexpr (CPT >= 8) {
+#pragma unroll
+        for (int p = 0; p < CPT / 8; ++p)
+            lp_st16(c, (u32x4){w[4 * p], w[4 * p + 1], w[4 * p + 2], w[4 * p + 3]}, set_off + L.out_off + lp_frag_off(row, col + 8 * p));
+    } else if constexpr (CPT == 4) {
+        lp_st8(c, (u32x2){w[0], w[1]}, set_off + L.out_off + lp_frag_off(row, col));
+    } else {
+        lp_st4(c, w[0], set_off + L.out_off + lp_frag_off(row, col));
+    }
+}
+
+template <int CPT, int TPR, int SMAX>
+__device__ __forceinline__ bool lp_run_finish(const LpCtx& c, const LpLayer& L, const LpUnit& U, const LpStep& S, bool& polled) {
+    const int row = U.row0 + c.tid / TPR, col = U.group * L.gsz + (c.tid % TPR) * CPT;
+    constexpr int V = CPT >= 4 ? CPT / 4 : 1;               // 16-byte loads per slab (CPT = 2: one 8-byte load)
+    u32x4 raw[SMAX][V];
+    const int base = S.set_off + L.slab_off + (row * L.c + col) * 4;
+    const int sstride = 32 * L.c * 4;
+    const unsigned t0 = lp_now();
+    bool ok = true;
+    for (unsigned spin = 1;; ++spin) {
+        bool bad = false;
+#pragma unroll
+        for (int s = 0; s < SMAX; ++s)
+            if (s < L.slabs) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    if constexpr (CPT >= 4) raw[s][i] = lp_ld16(c, base + s * sstride + i * 16);
+                    else {
+                        const u32x2 t2 = __builtin_amdgcn_raw_buffer_load_b64(c.rs, base + s * sstride, 0, 16);
+                        raw[s][i] = (u32x4){t2.x, t2.y, 0u, 0u};
+                    }
+                }
+            }
+#pragma unroll
+        for (int s = 0; s < SMAX; ++s)
+            if (s < L.slabs) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) bad |= lp_nan4(raw[s][i]);
+            }
+        if (__builtin_amdgcn_ballot_w64(bad) == 0ull) break;
+        if ((spin & 63u) == 0u && lp_give_up(c, t0, 2u)) { ok = false; break; }
+        lp_sleep(c.sleep);
+    }
+    if (!ok) c.lds_flag[0] = 1;
+    polled = true;
+    __syncthreads();
+    if (c.lds_flag[0]) return false;
+    float x[CPT];
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        float v = L.bias[col + i];
+#pragma unroll
+        for (int s = 0; s < SMAX; ++s)
+            if (s < L.slabs) v += __uint_as_float(raw[s][CPT >= 4 ? i / 4 : 0][i & 3]);
+        x[i] = v;
+        s1 += v;
+    }
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) s1 += __shfl_xor(s1, o);
+    const float mean = s1 / (float)L.gsz;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) { const float d = x[i] - mean; s2 += d * d; }
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) s2 += __shfl_xor(s2, o);
+    const float rstd = rsqrtf(s2 / (float)L.gsz + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) x[i] = (x[i] - mean) * rstd * L.gamma[col + i] + L.beta[col + i];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lp_finish_store<CPT, TPR>(c, L, U, S.set_off, x, false);
+    return true;
+}
+
+__device__ __forceinline__ bool lp_dispatch_finish(const LpCtx& c, const LpLayer& L, const LpUnit& U, const LpStep& S, bool& polled, bool poison) {
+    const float zero16[16] = {};
+#define LP_FIN(CPT, TPR, SMAX)                                                                              \
+    do {                                                                                                   \
+        if (poison) { lp_finish_store<CPT, TPR>(c, L, U, S.other_off, *(const float (*)[CPT])zero16, true); return true; } \
+        return lp_run_finish<CPT, TPR, SMAX>(c, L, U, S, polled);                                           \
+    } while (0)
+    switch (L.gsz) {
+        case 512: LP_FIN(16, 32, 2);
+        case 256: LP_FIN(8, 32, 2);
+        case 128: LP_FIN(4, 32, 8);
+        case 64: LP_FIN(2, 32, 4);
+        default: LP_FIN(2, 16, 2);       // gsz 32
+    }
+#undef LP_FIN
+}
+
+// --------------------------------------------------------------------------------------------- the kernel
+__global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char lp_smem[];
+    __shared__ int lp_flag[4];
+    LpCtx c;
+    c.rs = __builtin_amdgcn_make_buffer_rsrc(A.ws, 0, LP_CTRL_BYTES + 2 * A.set_bytes, 0x00020000);
+    c.ctrl = (unsigned*)A.ws;
+    c.smem = lp_smem;
+    c.lds_flag = lp_flag;
+    c.tid = threadIdx.x;
+    c.lane = threadIdx.x & 63;
+    c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    c.r = c.lane & 31;
+    c.hh = c.lane >> 5;
+    c.sleep = A.sleep;
+    const LpUnit* units = A.units + (int64_t)blockIdx.x * LP_MAX_UNITS;
+    if (c.tid == 0) lp_flag[0] = 0;
+
+    // ---- stage this workgroup's weights once: every 4-KiB image = 4 LDS-DMA instructions, dealt round-robin to the waves
+    bool is_head = false;
+    {
+        int task = 0;
+        for (int u = 0; u < LP_MAX_UNITS; ++u) {
+            const LpUnit U = units[u];
+            if (U.kind == LP_END) break;
+            if (U.kind != LP_GEMM) continue;
+            is_head |= U.head != 0;
+            const LpLayer& L = A.layers[U.layer];
+            for (int t = 0; t < U.ct; ++t)
+                for (int cl = 0; cl < U.nchunks; ++cl)
+                    for (int i = 0; i < 4; ++i, ++task)
+                        if ((task & 3) == c.wave)
+                            lp_stage(L.w, L.ldw, U.col0 + 32 * t, (U.chunk0 + cl) * 64, lp_smem + U.lds_w + (t * U.nchunks + cl) * 4096, i, c.lane);
+        }
+    }
+    const int k_base = A.counter != nullptr ? A.counter[0] : 0;
+    // the latent state: thread (row = tid >> 3, 32 columns from (tid & 7) * 32); rows >= batch are zero
+    float z[32];
+    const int zrow = c.tid >> 3, zq = c.tid & 7;
+    if (is_head) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (zrow < A.batch) v = *(const float4*)(A.z + (int64_t)zrow * 256 + zq * 32 + 4 * i);
+            z[4 * i] = v.x; z[4 * i + 1] = v.y; z[4 * i + 2] = v.z; z[4 * i + 3] = v.w;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int total = A.forward_only ? 1 : A.nsteps;
+    for (int step = 0; step <= total; ++step) {
+        if (A.forward_only && step == 1) break;             // forward mode: no update pass
+        LpStep S;
+        int k = k_base + step;
+        S.k = k < A.T ? k : A.T - 1;
+        S.set_off = LP_CTRL_BYTES + (step & 1) * A.set_bytes;
+        S.other_off = LP_CTRL_BYTES + ((step & 1) ^ 1) * A.set_bytes;
+        bool polled = false, poisoned = false;
+
+        if (is_head) {
+            if (step > 0) {
+                // eps of the previous step (it lives in the other set) -> DDIM update of z; the last pass also writes x0 / z out
+                const LpLayer& Le = A.layers[LP_LAYERS - 1];
+                u32x4 e4[8];
+                const int eoff = S.other_off + Le.out_off + (zrow * 256 + zq * 32) * 4;
+                const unsigned t0 = lp_now();
+                bool ok = true;
+                for (unsigned spin = 1;; ++spin) {
+                    bool bad = false;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) e4[i] = lp_ld16(c, eoff + 16 * i);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) bad |= lp_nan4(e4[i]);
+                    if (__builtin_amdgcn_ballot_w64(bad) == 0ull) break;
+                    if ((spin & 63u) == 0u && lp_give_up(c, t0, 3u)) { ok = false; break; }
+                    lp_sleep(c.sleep);
+                }
+                if (!ok) lp_flag[0] = 1;
+                __syncthreads();
+                if (lp_flag[0]) return;
+                polled = true;
+                const int kp = (k_base + step - 1) < A.T ? (k_base + step - 1) : A.T - 1;
+                const int rb = zrow * A.rate_stride;
+                const float rn = A.rates[((int64_t)0 * A.T + kp) * A.rate_width + rb], rsg = A.rates[((int64_t)1 * A.T + kp) * A.rate_width + rb];
+                const float rn2 = A.rates[((int64_t)2 * A.T + kp) * A.rate_width + rb], rs2 = A.rates[((int64_t)3 * A.T + kp) * A.rate_width + rb];
+                float x0v[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    float zn;
+                    lp_ddim(z[i], __uint_as_float(e4[i >> 2][i & 3]), rn, rsg, rn2, rs2, x0v[i], zn);
+                    z[i] = zn;
+                }
+                if (step == total && units[0].col0 == 0 && zrow < A.batch) {
+                    // head unit 0 hands the state back: z (next) and x0 of the last step
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        *(float4*)(A.z + (int64_t)zrow * 256 + zq * 32 + 4 * i) = make_float4(z[4 * i], z[4 * i + 1], z[4 * i + 2], z[4 * i + 3]);
+                        if (A.x0 != nullptr)
+                            *(float4*)(A.x0 + (int64_t)zrow * 256 + zq * 32 + 4 * i) = make_float4(x0v[4 * i], x0v[4 * i + 1], x0v[4 * i + 2], x0v[4 * i + 3]);
+                    }
+                }
+            }
+            if (step < total) {
+                // fp16 image of z (saturating round to nearest even, like pcd_skinny_fused_f32in), fragment-major in LDS:
+                // this thread's 32 columns are (chunk = zq >> 1, hh = zq & 1), piece j = columns 8 j .. 8 j + 7
+                char* z16 = lp_smem + LP_RED_BYTES;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    half8 h;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) h[e] = to_half_sat(z[8 * j + e]);
+                    *(half8*)(z16 + (zq >> 1) * 4096 + j * 1024 + (((zq & 1) << 5) + zrow) * 16) = h;
+                }
+                __syncthreads();
+            }
+        }
+        if (step == total) break;
+
+        for (int u = 0; u < LP_MAX_UNITS; ++u) {
+            const LpUnit U = units[u];
+            if (U.kind == LP_END) break;
+            const LpLayer& L = A.layers[U.layer];
+            bool ok;
+            if (U.kind == LP_GEMM) {
+                if (U.ct == 2) ok = lp_run_gemm<2, 1>(c, L, U, S, A, polled);
+                else ok = lp_run_gemm<1, 4>(c, L, U, S, A, polled);
+            } else {
+                ok = lp_dispatch_finish(c, L, U, S, polled, false);
+            }
+            if (!ok) return;
+            if (polled && !poisoned) {
+                // every reader of the other set's contents (the previous step) is done: poison this workgroup's regions there
+                // for the next step.  (A head workgroup at step 0 has not polled anything: the other set holds an earlier
+                // call's data, equally dead.)
+                poisoned = true;
+                for (int p = 0; p < LP_MAX_UNITS; ++p) {
+                    const LpUnit P = units[p];
+                    if (P.kind == LP_END) break;
+                    const LpLayer& LP_ = A.layers[P.layer];
+                    if (P.kind == LP_GEMM) {
+                        const float zero[2][4] = {};
+                        if (P.ct == 2) lp_gemm_store<2>(c, LP_, P, S.other_off, zero, true);
+                        else lp_gemm_store<1>(c, LP_, P, S.other_off, *(const float (*)[1][4])zero, true);
+                    } else {
+                        bool dummy;
+                        lp_dispatch_finish(c, LP_, P, S, dummy, true);
+                    }
+                }
+            }
+        }
+    }
+    if (blockIdx.x == 0 && c.tid == 0 && A.counter != nullptr && !A.forward_only) {
+        const int last = k_base + A.nsteps - 1;
+        A.counter[1] = last < A.T ? last : A.T - 1;
+        A.counter[0] = k_base + A.nsteps;
+    }
+}
+
+}  // namespace pcd
+
+using namespace pcd;
+
+// ------------------------------------------------------------------------------------------------ host side
+namespace {
+
+const int kK1[LP_LAYERS] = {256, 128, 256, 512, 1024, 2048, 4096, 1024, 512, 256, 128, 128};
+const int kK2[LP_LAYERS] = {0, 0, 0, 0, 0, 0, 1024, 512, 256, 128, 0, 0};
+const int kC[LP_LAYERS] = {128, 256, 512, 1024, 2048, 4096, 1024, 512, 256, 128, 128, 256};
+// K-slices of fp32 partial tiles per layer (0: the unit finishes the layer itself)
+const int kSlabs[LP_LAYERS] = {0, 0, 0, 1, 2, 2, 8, 4, 2, 0, 0, 0};
+// input activations: index of the producing layer (-1: the latent state), second source = the skip
+const int kSrc1[LP_LAYERS] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10};
+const int kSrc2[LP_LAYERS] = {-1, -1, -1, -1, -1, -1, 3, 2, 1, 0, -1, -1};
+
+struct LpPlan {
+    LpLayer layers[LP_LAYERS];
+    std::vector<LpUnit> units;         // [LP_WGS * LP_MAX_UNITS]
+    int set_bytes;
+};
+
+int lp_align(int v, int a = 256) { return (v + a - 1) / a * a; }
+
+// the static work assignment described at the top of the file; returns false if it does not fit (never, for this network)
+bool lp_build_plan(const pcd_latent_desc_t& d, LpPlan& plan) {
+    int off = 0;
+    int out_off[LP_LAYERS], slab_off[LP_LAYERS];
+    for (int l = 0; l < LP_LAYERS; ++l) {
+        out_off[l] = off;
+        off += lp_align(l == LP_LAYERS - 1 ? 32 * kC[l] * 4 : 32 * kC[l] * 2);
+    }
+    for (int l = 0; l < LP_LAYERS; ++l) {
+        slab_off[l] = off;
+        off += lp_align(kSlabs[l] * 32 * kC[l] * 4);
+    }
+    plan.set_bytes = lp_align(off, 4096);
+    for (int l = 0; l < LP_LAYERS; ++l) {
+        LpLayer& L = plan.layers[l];
+        L.w = (const half_t*)d.lin[l].w; L.ldw = d.lin[l].k;
+        L.bias = d.lin[l].b; L.gamma = d.gn_gamma[l]; L.beta = d.gn_beta[l];
+        L.k1 = kK1[l]; L.k2 = kK2[l];
+        L.src1_off = kSrc1[l] < 0 ? -1 : out_off[kSrc1[l]];
+        L.src2_off = kSrc2[l] < 0 ? -1 : out_off[kSrc2[l]];
+        L.c = kC[l]; L.gsz = kC[l] / 8; L.mode = l < 10 ? 0 : (l == 10 ? 1 : 2);
+        L.slabs = kSlabs[l]; L.out_off = out_off[l]; L.slab_off = slab_off[l]; L.pad = 0;
+    }
+    struct Item { int wg, phase; LpUnit u; int wbytes; };
+    std::vector<Item> items;
+    auto gemm = [&](int wg, int layer, int col0, int ct, int chunk0, int nch, int slice, int head) {
+        LpUnit u{};
+        u.kind = LP_GEMM; u.layer = layer; u.col0 = col0; u.ct = ct; u.chunk0 = chunk0; u.nchunks = nch; u.slice = slice; u.head = head;
+        items.push_back({wg, 2 * layer, u, ct * nch * 4096});
+    };
+    auto finish = [&](int wg, int layer, int group, int row0) {
+        LpUnit u{};
+        u.kind = LP_FINISH; u.layer = layer; u.group = group; u.row0 = row0;
+        items.push_back({wg, 2 * layer + 1, u, 0});
+    };
+    for (int w = 0; w < LP_WGS; ++w) {
+        gemm(w, 5, 32 * (w >> 1), 1, 16 * (w & 1), 16, w & 1, 0);              // global_feat.3: 128 tiles x 2 slices, 64 KB
+        gemm(w, 6, 32 * (w >> 3), 1, 10 * (w & 7), 10, w & 7, 0);              // dec4: 32 tiles x 8 slices, 40 KB
+        if (w < 128) gemm(w, 4, 32 * (w >> 1), 1, 8 * (w & 1), 8, w & 1, 0);   // global_feat.0: 64 tiles x 2 slices, 32 KB
+        else if (w < 160) gemm(w, 3, 32 * (w - 128), 1, 0, 8, 0, 0);           // enc4: 32 tiles, 32 KB
+        else if (w < 224) {
+            const int u = w - 160;
+            gemm(w, 7, 32 * (u >> 2), 1, 6 * (u & 3), 6, u & 3, 0);            // dec3: 16 tiles x 4 slices, 24 KB
+            if (u < 8) gemm(w, 1, 32 * u, 1, 0, 2, 0, 0);                      // enc2: 8 tiles, 8 KB
+            else if (u < 12) gemm(w, 10, 32 * (u - 8), 1, 0, 2, 0, 0);         // output.0: 4 tiles, 8 KB
+            else if (u < 20) gemm(w, 11, 32 * (u - 12), 1, 0, 2, 0, 0);        // output.2: 8 tiles, 8 KB
+        } else if (w < 232) gemm(w, 2, 64 * (w - 224), 2, 0, 4, 0, 0);         // enc3: 8 units of 2 tiles (one group), 32 KB
+        else if (w < 248) { const int u = w - 232; gemm(w, 8, 32 * (u >> 1), 1, 6 * (u & 1), 6, u & 1, 0); }   // dec2: 8 tiles x 2, 24 KB
+        else if (w < 252) gemm(w, 0, 32 * (w - 248), 1, 0, 4, 0, 1);           // enc1: 4 tiles, 16 KB + the state
+        else gemm(w, 9, 32 * (w - 252), 1, 0, 6, 0, 0);                        // dec1: 4 tiles, 24 KB
+    }
+    const int fin_layers[6] = {3, 4, 5, 6, 7, 8};
+    const int fin_base[6] = {0, 32, 64, 96, 128, 192};
+    for (int f = 0; f < 6; ++f) {
+        const int l = fin_layers[f], gsz = kC[l] / 8;
+        const int rows = gsz >= 64 ? 8 : 16, per_group = 32 / rows;
+        for (int g = 0; g < 8; ++g)
+            for (int rb = 0; rb < per_group; ++rb) finish(fin_base[f] + g * per_group + rb, l, g, rb * rows);
+    }
+    std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.wg != b.wg ? a.wg < b.wg : a.phase < b.phase; });
+    plan.units.assign((size_t)LP_WGS * LP_MAX_UNITS, LpUnit{});
+    std::vector<int> count(LP_WGS, 0), lds(LP_WGS, LP_RED_BYTES);
+    for (const Item& it : items) {
+        if (count[it.wg] >= LP_MAX_UNITS - 1) return false;                  // the last slot stays LP_END
+        LpUnit u = it.u;
+        if (u.kind == LP_GEMM) {
+            if (u.head) lds[it.wg] += LP_Z16_BYTES;                          // the fp16 image of z sits right behind the scratch
+            u.lds_w = lds[it.wg];
+            lds[it.wg] += it.wbytes;
+            const LpLayer& L = plan.layers[u.layer];
+            if (L.slabs == 0 && L.mode == 0 && !((u.ct == 1 && (L.gsz == 16 || L.gsz == 32)) || L.gsz == 32 * u.ct)) return false;
+            if ((u.nchunks + 3) / 4 > (u.ct == 2 ? 1 : 4)) return false;
+        }
+        if (lds[it.wg] > LP_LDS_BYTES - 64) return false;                 // the launch's dynamic LDS (64 bytes left to the static flag word)
+        plan.units[(size_t)it.wg * LP_MAX_UNITS + count[it.wg]++] = u;
+    }
+    // a head unit's z16 image must start at LP_RED_BYTES: it is the workgroup's first allocation
+    for (int w = 0; w < LP_WGS; ++w)
+        for (int i = 0; i < LP_MAX_UNITS; ++i) {
+            const LpUnit& u = plan.units[(size_t)w * LP_MAX_UNITS + i];
+            if (u.kind == LP_GEMM && u.head && u.lds_w != LP_RED_BYTES + LP_Z16_BYTES) return false;
+        }
+    return true;
+}
+
+}  // namespace
+
+// Host-only self check of the static work assignment (no HIP calls; tests/test_abi_cpu.py): every (layer, 32-column tile,
+// 64-k chunk) is computed by exactly one gemm unit, every (layer with slabs, group, row) by exactly one finish unit, no
+// workgroup's LDS plan overflows.  Returns the bytes of one buffer set, or -1.
+extern "C" int pcd_latent_persist_plan_check(void) {
+    pcd_latent_desc_t d{};
+    for (int i = 0; i < LP_LAYERS; ++i) { d.lin[i].k = kK1[i] + kK2[i]; d.lin[i].c = kC[i]; }
+    LpPlan plan;
+    if (!lp_build_plan(d, plan)) return -1;
+    std::vector<std::vector<int>> cover(LP_LAYERS), fin(LP_LAYERS);
+    for (int l = 0; l < LP_LAYERS; ++l) {
+        cover[l].assign((size_t)(kC[l] / 32) * ((kK1[l] + kK2[l]) / 64), 0);
+        fin[l].assign(8 * 32, 0);
+    }
+    for (int w = 0; w < LP_WGS; ++w) {
+        int last_phase = -1;
+        bool ended = false;
+        for (int i = 0; i < LP_MAX_UNITS; ++i) {
+            const LpUnit& u = plan.units[(size_t)w * LP_MAX_UNITS + i];
+            if (u.kind == LP_END) { ended = true; continue; }
+            if (ended) return -1;
+            const int phase = 2 * u.layer + (u.kind == LP_FINISH ? 1 : 0);
+            if (phase <= last_phase) return -1;
+            last_phase = phase;
+            const int nk = (kK1[u.layer] + kK2[u.layer]) / 64;
+            if (u.kind == LP_GEMM) {
+                if (u.col0 % 32 || u.chunk0 + u.nchunks > nk || (kSlabs[u.layer] == 0 && u.nchunks != nk)) return -1;
+                if (kSlabs[u.layer] > 0 && (u.slice < 0 || u.slice >= kSlabs[u.layer])) return -1;
+                for (int t = 0; t < u.ct; ++t)
+                    for (int c = 0; c < u.nchunks; ++c) cover[u.layer][(size_t)(u.col0 / 32 + t) * nk + u.chunk0 + c]++;
+            } else {
+                const int gsz = kC[u.layer] / 8, rows = gsz >= 64 ? 8 : 16;
+                if (kSlabs[u.layer] == 0 || u.group < 0 || u.group >= 8 || u.row0 % rows) return -1;
+                for (int r = 0; r < rows; ++r) fin[u.layer][u.group * 32 + u.row0 + r]++;
+            }
+        }
+        if (!ended) return -1;
+    }
+    for (int l = 0; l < LP_LAYERS; ++l) {
+        for (int v : cover[l]) if (v != 1) return -1;
+        for (int v : fin[l]) if (v != (kSlabs[l] > 0 ? 1 : 0)) return -1;
+        // slices of a slabbed layer partition K in order: slice s covers chunks [s * nk / S, (s + 1) * nk / S)
+    }
+    return plan.set_bytes;
+}
+
+struct pcd_latent_persist {
+    LpPlan plan;
+    LpLayer* d_layers = nullptr;
+    LpUnit* d_units = nullptr;
+    int sleep = 1;
+};
+
+extern "C" int pcd_latent_persist_supported(int batch) {
+    if (batch <= 0 || batch > 32) return 0;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    // one workgroup per CU, all resident for the whole call: exactly the 256 CUs of an MI355X, all of its LDS
+    return (prop.multiProcessorCount == LP_WGS && (int)prop.maxSharedMemoryPerMultiProcessor >= LP_LDS_BYTES) ? 1 : 0;
+}
+
+extern "C" int pcd_latent_persist_create(const pcd_latent_desc_t* desc, pcd_latent_persist_t** out) {
+    PCD_CHECK_ARG(desc != nullptr && out != nullptr);
+    for (int i = 0; i < LP_LAYERS; ++i)
+        PCD_CHECK_ARG(desc->lin[i].w && desc->lin[i].b && desc->lin[i].k == kK1[i] + kK2[i] && desc->lin[i].c == kC[i] &&
+                      (i >= 10 || (desc->gn_gamma[i] && desc->gn_beta[i])));
+    pcd_latent_persist* h = new (std::nothrow) pcd_latent_persist;
+    PCD_CHECK_ARG(h != nullptr);
+    if (!lp_build_plan(*desc, h->plan)) {
+        delete h;
+        set_error("pcd_latent_persist_create: the static work assignment does not fit");
+        return PCD_ERR_ARG;
+    }
+    hipError_t e = hipMalloc(&h->d_layers, sizeof(LpLayer) * LP_LAYERS);
+    if (e == hipSuccess) e = hipMalloc(&h->d_units, sizeof(LpUnit) * h->plan.units.size());
+    if (e == hipSuccess) e = hipMemcpy(h->d_layers, h->plan.layers, sizeof(LpLayer) * LP_LAYERS, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(h->d_units, h->plan.units.data(), sizeof(LpUnit) * h->plan.units.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)latent_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LP_LDS_BYTES - 64);
+    if (e != hipSuccess) {
+        set_error("pcd_latent_persist_create: %s", hipGetErrorString(e));
+        if (h->d_layers) (void)hipFree(h->d_layers);
+        if (h->d_units) (void)hipFree(h->d_units);
+        delete h;
+        return PCD_ERR_HIP;
+    }
+    *out = h;
+    return PCD_OK;
+}
+
+extern "C" void pcd_latent_persist_destroy(pcd_latent_persist_t* h) {
+    if (!h) return;
+    if (h->d_layers) (void)hipFree(h->d_layers);
+    if (h->d_units) (void)hipFree(h->d_units);
+    delete h;
+}
+
+extern "C" size_t pcd_latent_persist_workspace_bytes(const pcd_latent_persist_t* h) {
+    return h ? (size_t)LP_CTRL_BYTES + 2 * (size_t)h->plan.set_bytes : 0;
+}
+
+extern "C" int pcd_latent_persist_config(pcd_latent_persist_t* h, int poll_sleep) {
+    PCD_CHECK_ARG(h != nullptr && poll_sleep >= 0 && poll_sleep <= 127);
+    h->sleep = poll_sleep;
+    return PCD_OK;
+}
+
+static int lp_launch(pcd_latent_persist_t* h, LpArgs& a, void* workspace, size_t workspace_bytes, void* stream) {
+    const size_t need = pcd_latent_persist_workspace_bytes(h);
+    if (workspace_bytes < need) {
+        set_error("pcd_latent_persist: workspace %zu < required %zu", workspace_bytes, need);
+        return PCD_ERR_WORKSPACE;
+    }
+    PCD_CHECK_ARG(((uintptr_t)workspace & 255) == 0);
+    if (!pcd_latent_persist_supported(a.batch)) {
+        set_error("pcd_latent_persist: needs batch <= 32 and a device with exactly %d CUs of %d KB LDS", LP_WGS, LP_LDS_BYTES / 1024);
+        return PCD_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    a.layers = h->d_layers;
+    a.units = h->d_units;
+    a.ws = (char*)workspace;
+    a.set_bytes = h->plan.set_bytes;
+    a.sleep = h->sleep;
+    // status word cleared, set 0 poisoned (set 1 is poisoned by the kernel during its first step)
+    PCD_CHECK_HIP(hipMemsetAsync(workspace, 0, LP_CTRL_BYTES, s));
+    PCD_CHECK_HIP(hipMemsetAsync((char*)workspace + LP_CTRL_BYTES, 0xff, (size_t)h->plan.set_bytes, s));
+    // dynamic LDS = everything but the 16 bytes of the static flag word (rounded)
+    hipLaunchKernelGGL(latent_persist_kernel, dim3(LP_WGS), dim3(LP_THREADS), LP_LDS_BYTES - 64, s, a);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_latent_persist_forward(pcd_latent_persist_t* h, const float* z, int batch, const float* tbias, float* eps,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+    PCD_CHECK_ARG(h && z && tbias && eps && workspace && batch > 0);
+    LpArgs a{};
+    a.z = (float*)z; a.x0 = nullptr; a.eps_out = eps; a.batch = batch;
+    a.tb_table = tbias; a.tb_elems = 128;
+    a.rates = nullptr; a.rate_width = 1; a.rate_stride = 0; a.T = 1;
+    a.counter = nullptr; a.nsteps = 1; a.forward_only = 1;
+    return lp_launch(h, a, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pcd_latent_persist_ddim(pcd_latent_persist_t* h, float* z, float* x0, int batch, const float* tb_table, int tb_elems,
+                                       const float* rate_tables, int rate_width, int n_steps_table, int* counter, int nsteps,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    PCD_CHECK_ARG(h && z && tb_table && rate_tables && counter && workspace && batch > 0 && nsteps > 0 && n_steps_table > 0);
+    PCD_CHECK_ARG(tb_elems == 128 && (rate_width == 1 || rate_width == batch));
+    LpArgs a{};
+    a.z = z; a.x0 = x0; a.eps_out = nullptr; a.batch = batch;
+    a.tb_table = tb_table; a.tb_elems = tb_elems;
+    a.rates = rate_tables; a.rate_width = rate_width; a.rate_stride = rate_width == 1 ? 0 : 1; a.T = n_steps_table;
+    a.counter = counter; a.nsteps = nsteps; a.forward_only = 0;
+    return lp_launch(h, a, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pcd_latent_persist_status(const void* workspace, unsigned* status_host) {
+    PCD_CHECK_ARG(workspace && status_host);
+    PCD_CHECK_HIP(hipMemcpy(status_host, workspace, sizeof(unsigned), hipMemcpyDeviceToHost));
+    return PCD_OK;
+}

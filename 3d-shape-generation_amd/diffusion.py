@@ -9,6 +9,7 @@ per-timestep computation runs in HIP kernels (`_lib`).  The training surface (`t
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -502,6 +503,23 @@ class LatentDiffusion(_DiffusionBase):
 
     def _forward_fn(self):
         return lambda x, tb_cur, eps: self.model.forward_with_bias(x, tb_cur, 0, out=eps)
+
+    # the DDIM loops (`sample`, `sample3`) of a batch <= 32 run as ONE persistent launch for all their steps
+    # (csrc/latent_persist.hip); PCD_LATENT_PERSISTENT=0 (or use_persistent = False) keeps the per-layer launches, which
+    # is also what runs for larger batches, for DDPM (`sample2`) and when several processes share one GPU
+    use_persistent = os.environ.get("PCD_LATENT_PERSISTENT", "1") != "0"
+
+    def _run(self, x, tab, bias_table, forward, kind, noises=None, skip_last_update=False):
+        if (kind == "ddim" and noises is None and self.use_persistent and x.dim() == 2
+                and self.model.persist_supported(x.shape[0])):
+            rates = torch.stack([tab.n, tab.s, tab.a, tab.b]).contiguous()           # (4, T, R)
+            counter = torch.zeros(2, dtype=torch.int32, device=x.device)
+            x0 = torch.empty_like(x)
+            # the last step's update of z is computed and discarded when `skip_last_update` (sample3): x0 is the result
+            self.model.ddim_steps_persist(x, x0, bias_table.contiguous(), rates, counter, tab.steps)
+            self.model.check_persist_status()
+            return x0
+        return super()._run(x, tab, bias_table, forward, kind, noises, skip_last_update)
 
     # ------------------------------------------------------------------ training surface (diffusion.py:410-443, 522-537)
     def configure_optimizers(self, max_epochs: int = 100):

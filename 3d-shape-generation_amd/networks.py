@@ -390,17 +390,66 @@ class SimpleLatentUNetPointNet(_HipModule):
         self.latent_dim, self.dim, self.time_dim = latent_dim, dim, time_dim
         self._build_from_spec(specs.latent_unet_spec(latent_dim, dim, time_dim))
         self._handle = None
+        self._persist = None
 
     def _release(self):
         if getattr(self, "_handle", None):
             _lib.load().pcd_latent_destroy(self._handle)
+        if getattr(self, "_persist", None):
+            _lib.load().pcd_latent_persist_destroy(self._persist)
         self._handle = None
+        self._persist = None
+        self._persist_ws = None
 
     def __del__(self):
         try:
             self._release()
         except Exception:
             pass
+
+    # ------------------------------------------------------------------ the whole step as one persistent launch
+    def persist_supported(self, batch: int) -> bool:
+        """True when `csrc/latent_persist.hip` can run on this device for this batch (batch <= 32, a 256-CU gfx950)."""
+        self._need_cuda()
+        return bool(_lib.load().pcd_latent_persist_supported(int(batch)))
+
+    def _persist_handle(self):
+        self._ensure_packed()
+        if getattr(self, "_persist", None) is None:
+            handle = C.c_void_p()
+            _lib.check(_lib.load().pcd_latent_persist_create(C.byref(self._desc), C.byref(handle)), "latent_persist_create")
+            self._persist = handle
+        if getattr(self, "_persist_ws", None) is None:                   # its own buffer: the per-layer path keeps `_ws`
+            self._persist_ws = torch.empty(_lib.load().pcd_latent_persist_workspace_bytes(self._persist), dtype=torch.uint8,
+                                           device=self.device)
+        return self._persist, self._persist_ws
+
+    def check_persist_status(self):
+        """Synchronises and raises if a wait inside the last persistent launch gave up (0.2 s bound per wait)."""
+        h, ws = self._persist_handle()
+        st = C.c_uint(0)
+        _lib.check(_lib.load().pcd_latent_persist_status(ws.data_ptr(), C.byref(st)), "latent_persist_status")
+        if st.value:
+            raise RuntimeError(f"persistent latent kernel: wait kind {st.value >> 16} of workgroup {st.value & 0xffff} timed out "
+                               "(is another process holding CUs of this GPU?  set PCD_LATENT_PERSISTENT=0 to use the per-layer launches)")
+
+    def forward_persist(self, z, tbias_row, out=None):
+        """eps = model(z, t) for ONE t shared by the batch (tbias_row = time_bias(t)[0], 128 values), one launch."""
+        h, ws = self._persist_handle()
+        if out is None:
+            out = torch.empty_like(z)
+        _lib.check(_lib.load().pcd_latent_persist_forward(h, z.data_ptr(), z.shape[0], tbias_row.data_ptr(), out.data_ptr(),
+                                                          ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "latent_persist_forward")
+        return out
+
+    def ddim_steps_persist(self, z, x0, bias_table, rates, counter, nsteps):
+        """`nsteps` DDIM steps from table row counter[0] in ONE launch: z updated in place, x0 = the last step's x_0.
+        rates (4, T, R) fp32 = (n, s, n_next, s_next)."""
+        h, ws = self._persist_handle()
+        _lib.check(_lib.load().pcd_latent_persist_ddim(h, z.data_ptr(), x0.data_ptr(), z.shape[0], bias_table.data_ptr(),
+                                                       bias_table.shape[1], rates.data_ptr(), rates.shape[2], rates.shape[1],
+                                                       counter.data_ptr(), int(nsteps), ws.data_ptr(), ws.numel(),
+                                                       _lib.stream_ptr()), "latent_persist_ddim")
 
     def _ensure_packed(self):
         if self._packed is not None:
@@ -424,7 +473,7 @@ class SimpleLatentUNetPointNet(_HipModule):
             desc.gn_gamma[i], desc.gn_beta[i] = keep[f"g{i}"].data_ptr(), keep[f"be{i}"].data_ptr()
         handle = C.c_void_p()
         _lib.check(_lib.load().pcd_latent_create(C.byref(desc), C.byref(handle)), "latent_create")
-        self._handle, self._packed = handle, keep
+        self._handle, self._packed, self._desc = handle, keep, desc
         return keep
 
     def time_bias(self, t: torch.Tensor) -> torch.Tensor:

@@ -253,6 +253,38 @@ int pcd_latent_forward(pcd_latent_t* h, const float* z, int batch, const float* 
                        int tbias_shape_stride, float* eps, void* workspace, size_t workspace_bytes,
                        void* stream);
 
+/* The same network, and whole DDIM timesteps of the latent sampler (the loop body of LatentDiffusion.sample / sample3,
+ * diffusion.py:637-645, 691-700), as ONE persistent launch for batch <= 32 (csrc/latent_persist.hip): 256 workgroups, one
+ * per CU, keep all 38 MB of fp16 weights in LDS for the whole call and exchange activations through self-validating
+ * buffers (no flags or atomics between layers).  pcd_latent_persist_supported(batch) tells (1/0) whether the current
+ * device can run it (exactly 256 CUs with 160 KB LDS, batch <= 32); callers fall back to pcd_latent_forward otherwise.
+ * The handle keeps the descriptor's pointers.  Workspace: pcd_latent_persist_workspace_bytes(h), 256-byte aligned, owned
+ * by the caller, private to one in-flight call.
+ *  - pcd_latent_persist_forward: eps = model(z, t) with tbias = the hoisted time row [128] (one t for the batch).
+ *  - pcd_latent_persist_ddim: `nsteps` consecutive DDIM steps starting at table row counter[0] (pcd_step_select
+ *    semantics: rows clamp at n_steps_table - 1; on return counter[0] += nsteps, counter[1] = last row used): z is
+ *    updated in place, x0 (may be NULL) receives the last step's x0.  rate_tables is (4, n_steps_table, rate_width)
+ *    fp32 = (n, s, n_next, s_next) like pcd_ddim_update's operands, rate_width 1 or batch.  The update is bitwise
+ *    pcd_ddim_update's.
+ *  - every in-kernel wait is bounded (0.2 s); pcd_latent_persist_status copies the status word to the host after the
+ *    caller has synchronised: 0 = ok, otherwise (wait kind << 16 | workgroup) of the first wait that gave up (outputs
+ *    are then undefined).
+ *  - pcd_latent_persist_config: poll back-off (s_sleep count between polls), a tuning hook. */
+typedef struct pcd_latent_persist pcd_latent_persist_t;
+int pcd_latent_persist_supported(int batch);
+int pcd_latent_persist_create(const pcd_latent_desc_t* desc, pcd_latent_persist_t** out);
+void pcd_latent_persist_destroy(pcd_latent_persist_t* h);
+size_t pcd_latent_persist_workspace_bytes(const pcd_latent_persist_t* h);
+int pcd_latent_persist_config(pcd_latent_persist_t* h, int poll_sleep);
+int pcd_latent_persist_forward(pcd_latent_persist_t* h, const float* z, int batch, const float* tbias, float* eps,
+                               void* workspace, size_t workspace_bytes, void* stream);
+int pcd_latent_persist_ddim(pcd_latent_persist_t* h, float* z, float* x0, int batch, const float* tb_table, int tb_elems,
+                            const float* rate_tables, int rate_width, int n_steps_table, int* counter, int nsteps,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int pcd_latent_persist_status(const void* workspace, unsigned* status_host);
+/* host-only self check of the kernel's static work assignment (no device needed): bytes of one buffer set, or -1 */
+int pcd_latent_persist_plan_check(void);
+
 /* ------------------------------------------------------ 3-D convolution (a12, K9)
  * Implicit-GEMM Conv3d on NDHWC fp16 activations (replaces nn.Conv3d / nn.ConvTranspose3d +
  * BatchNorm3d(eval) + ReLU / residual add of networks.py:2225-2264, 471-504; BN folded on the host).

@@ -127,3 +127,12 @@ def test_vectorized_step_tables_equal_the_per_step_loop(T):
         assert a.steps == b.steps == T and a.width == b.width == 1 and a.stride == b.stride
         for f in ("t", "n", "s", "a", "b"):
             assert torch.equal(getattr(a, f), getattr(b, f)), f
+
+
+def test_persistent_latent_plan_is_a_partition():
+    """csrc/latent_persist.hip's static work assignment, checked on the host without a device: every (layer, 32-column tile,
+    64-k chunk) belongs to exactly one gemm unit, every (GroupNorm group, row) of a layer with partial slabs to exactly one
+    finish unit, unit lists are in phase order and every workgroup's LDS plan fits 160 KB."""
+    from shapegen_amd import _lib
+    set_bytes = _lib.load().pcd_latent_persist_plan_check()
+    assert set_bytes > 0 and set_bytes % 4096 == 0 and set_bytes < 8 << 20

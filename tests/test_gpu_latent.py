@@ -311,10 +311,15 @@ def test_cfg4_launch_shapes_vs_reference(ldm, golden):
     assert rel_l2(mu.cpu(), g["enc_mu"]) < 1e-2 and rel_l2(logvar.cpu(), g["enc_logvar"]) < 1e-2
     for i in rows:                                                   # per row too: no sample hides behind the batch norm
         assert rel_l2(mu[i].cpu(), g["enc_mu"][i]) < 1.5e-2, i
-    pcs, z0 = ldm.sample(32, num_steps=1000, z_T=torch.from_numpy(g["zT"]).cuda(), return_latent=True)
-    err = rel_l2(z0.cpu(), g["z0"])
-    assert err < 5e-3, err
-    assert max(rel_l2(z0[i].cpu(), g["z0"][i]) for i in range(32)) < 1e-2
+    for persistent in (True, False):                       # one persistent launch for the 1000 steps / per-layer launches
+        ldm.use_persistent = persistent
+        try:
+            pcs, z0 = ldm.sample(32, num_steps=1000, z_T=torch.from_numpy(g["zT"]).cuda(), return_latent=True)
+        finally:
+            ldm.use_persistent = type(ldm).use_persistent
+        err = rel_l2(z0.cpu(), g["z0"])
+        assert err < 5e-3, (persistent, err)
+        assert max(rel_l2(z0[i].cpu(), g["z0"][i]) for i in range(32)) < 1e-2
     counts = np.array([len(p) for p in pcs])
     assert np.all(np.abs(counts - g["counts"]) <= 0.02 * g["counts"] + 8)
     # decode at B = 32 of the REFERENCE's latents (so the comparison is of the decoder alone), four rows kept in the fixture
@@ -330,6 +335,59 @@ def test_cfg4_launch_shapes_vs_reference(ldm, golden):
     assert float(merr.max()) < 3e-2 and float(merr.mean()) < 3e-3
     got = voxel_tensor_to_point_clouds(dec, 0.4)
     assert [len(p) for p in got] == [int(v) for v in (dec > 0.4).reshape(32, -1).sum(1).cpu()]
+
+
+def test_latent_persistent_forward(ldm):
+    """csrc/latent_persist.hip, forward mode: the whole network in ONE launch (weights resident in LDS, layers exchanged
+    through self-validating buffers) against the per-layer launches and against the oracle, B = 32 / 5 / 1; repeated
+    launches are bitwise identical (fixed summation order, no atomics)."""
+    from oracle import torch_oracle as O
+    if not ldm.model.persist_supported(32):
+        pytest.skip("needs a 256-CU device")
+    sd = latent_sd()
+    g = torch.Generator().manual_seed(11)
+    for b, tval in ((32, 0.73), (5, 0.31), (1, 1.0)):
+        z = (torch.randn(b, 256, generator=g) * 1.2).cuda()
+        t = torch.full((b,), tval)
+        tb = ldm.model.time_bias(t[:1].cuda())
+        eps = ldm.model.forward_persist(z, tb[0])
+        ldm.model.check_persist_status()
+        want_layers = ldm.model.forward_with_bias(z, tb[0], 0)
+        want = O.latent_unet(sd, "model.", z.cpu(), t)
+        assert torch.isfinite(eps).all()
+        assert rel_l2(eps.cpu(), want) < 3e-3, b
+        assert rel_l2(eps.cpu(), want_layers.cpu()) < 2e-3, b
+        again = ldm.model.forward_persist(z, tb[0])
+        assert torch.equal(again, eps)
+
+
+def test_latent_persistent_ddim_steps(ldm):
+    """... DDIM mode: T steps in ONE launch (state and update inside the kernel) against the Stepper over per-layer launches;
+    the in-kernel update is pcd_ddim_update's arithmetic, so with the same eps the states would be bitwise equal -- the eps differ
+    by fp32 summation order only.  Then 1000 steps twice: bitwise equal (a stale exchange read would show as a difference), and
+    B < 32 rows, the linear schedule's per-row rates and `sample3` (last update skipped) take the same path."""
+    from shapegen_amd.diffusion import LatentDiffusion
+    if not ldm.model.persist_supported(32):
+        pytest.skip("needs a 256-CU device")
+    g = torch.Generator().manual_seed(12)
+    zT = torch.randn(32, 256, generator=g).cuda()
+    assert LatentDiffusion.use_persistent or True
+    try:
+        ldm.use_persistent = True
+        _, a = ldm.sample(32, num_steps=20, z_T=zT, return_latent=True)
+        _, a1000 = ldm.sample(32, num_steps=1000, z_T=zT, return_latent=True)
+        _, b1000 = ldm.sample(32, num_steps=1000, z_T=zT, return_latent=True)
+        _, a5 = ldm.sample3(5, z=zT[:5], start_t=torch.ones(5) * 0.4, num_steps=9, return_latent=True)
+        ldm.use_persistent = False
+        _, want = ldm.sample(32, num_steps=20, z_T=zT, return_latent=True)
+        _, want1000 = ldm.sample(32, num_steps=1000, z_T=zT, return_latent=True)
+        _, want5 = ldm.sample3(5, z=zT[:5], start_t=torch.ones(5) * 0.4, num_steps=9, return_latent=True)
+    finally:
+        ldm.use_persistent = LatentDiffusion.use_persistent
+    assert torch.isfinite(a).all() and rel_l2(a.cpu(), want.cpu()) < 2e-3
+    assert torch.equal(a1000, b1000)
+    assert rel_l2(a1000.cpu(), want1000.cpu()) < 5e-3
+    assert rel_l2(a5.cpu(), want5.cpu()) < 2e-3
 
 
 def test_latent_sample2_sample3_and_errors(ldm):
