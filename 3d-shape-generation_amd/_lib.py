@@ -156,10 +156,12 @@ _SIGS = {
     "pcd_latent_persist_destroy": (None, [vp]),
     "pcd_latent_persist_workspace_bytes": (sz, [vp]),
     "pcd_latent_persist_config": (i32, [vp, i32]),
+    "pcd_latent_persist_trace": (i32, [vp, vp, i32]),
     "pcd_latent_persist_forward": (i32, [vp, vp, i32, vp, vp, vp, sz, vp]),
     "pcd_latent_persist_ddim": (i32, [vp, vp, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, sz, vp]),
     "pcd_latent_persist_status": (i32, [vp, C.POINTER(C.c_uint)]),
     "pcd_latent_persist_plan_check": (i32, []),
+    "pcd_latent_persist_plan_dump": (i32, [vp]),
     "pcd_conv3d_f16": (i32, [C.POINTER(Conv3dDesc), vp]),
     "pcd_conv3d_k3s1_supported": (i32, [C.POINTER(Conv3dDesc)]),
     "pcd_conv3d_k3s1_f16": (i32, [C.POINTER(Conv3dDesc), vp]),

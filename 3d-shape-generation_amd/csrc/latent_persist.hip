@@ -65,7 +65,8 @@ struct LpUnit {
     int lds_w;                         // gemm: byte offset of the unit's weight images in LDS
     int group, row0;                   // finish: GroupNorm group, first row
     int head;                          // gemm on the latent state: this workgroup keeps z
-    int pad[5];
+    int lds_p;                         // byte offset in LDS of the unit's bias | gamma | beta rows (its columns only), or -1
+    int pad[4];
 };
 
 struct LpArgs {
@@ -83,6 +84,8 @@ struct LpArgs {
     int nsteps;
     int forward_only;
     int sleep;                         // s_sleep argument between polls
+    unsigned* trace;                   // diagnostic build only: [wg][step][unit][4] s_memrealtime stamps (enter, operands in, stored)
+    int trace_steps;
 };
 
 // ------------------------------------------------------------------------------------------------ device helpers
@@ -126,7 +129,7 @@ struct LpCtx {
     int* lds_flag;                     // [0]: abort seen by some wave of this workgroup
     int tid, lane, wave, r, hh;
     int sleep;
-    unsigned t_start;
+    unsigned* tr;                      // where this unit's stamps go (diagnostic build), else null
 };
 
 __device__ __forceinline__ u32x4 lp_ld16(const LpCtx& c, int off) { return __builtin_amdgcn_raw_buffer_load_b128(c.rs, off, 0, 16); }
@@ -166,6 +169,7 @@ __device__ __forceinline__ bool lp_fetch(const LpCtx& c, const LpLayer& L, const
     }
     const unsigned t0 = lp_now();
     for (unsigned spin = 1;; ++spin) {
+        // all the missing chunks at once (when the producers are done this is the only pass) ...
 #pragma unroll
         for (int i = 0; i < MAXCH; ++i)
             if (need & (1u << i)) {
@@ -179,8 +183,19 @@ __device__ __forceinline__ bool lp_fetch(const LpCtx& c, const LpLayer& L, const
                 if (__builtin_amdgcn_ballot_w64(bad) == 0ull) need &= ~(1u << i);
             }
         if (need == 0u) return true;
+        // ... otherwise wait on ONE 1-KiB piece of the first missing chunk (1/16 of the traffic of a full pass: hundreds of
+        // waves wait here for most of a step, and their polls share the fabric with the stores they are waiting for)
+        int poff = 0;
+#pragma unroll
+        for (int i = MAXCH - 1; i >= 0; --i)
+            if (need & (1u << i)) poff = off[i];
+        for (unsigned probe = 1;; ++probe) {
+            const u32x4 v = lp_ld16(c, poff + 3 * 1024);
+            if (__builtin_amdgcn_ballot_w64(lp_poison16(v)) == 0ull) break;
+            if ((probe & 63u) == 0u && lp_give_up(c, t0, 1u)) return false;
+            lp_sleep(c.sleep);
+        }
         if ((spin & 63u) == 0u && lp_give_up(c, t0, 1u)) return false;
-        lp_sleep(c.sleep);
     }
 }
 
@@ -230,7 +245,7 @@ __device__ __forceinline__ void lp_gemm_store(const LpCtx& c, const LpLayer& L, 
 
 template <int CT, int MAXCH>
 __device__ __forceinline__ bool lp_run_gemm(const LpCtx& c, const LpLayer& L, const LpUnit& U, const LpStep& S, const LpArgs& A,
-                                            bool& polled) {
+                                            bool& polled, const float (&tbv)[4]) {
     f32x16 acc[CT];
 #pragma unroll
     for (int t = 0; t < CT; ++t)
@@ -271,6 +286,7 @@ __device__ __forceinline__ bool lp_run_gemm(const LpCtx& c, const LpLayer& L, co
     }
     if (!ok) c.lds_flag[0] = 1;
     polled = true;
+    if (c.tr != nullptr && c.tid == 0) c.tr[1] = lp_now();
     // cross-wave reduction through LDS, one 32-column tile at a time
     float (*red)[32][33] = (float (*)[32][33])c.smem;
     const int row = c.tid >> 3, q = c.tid & 7;
@@ -287,14 +303,15 @@ __device__ __forceinline__ bool lp_run_gemm(const LpCtx& c, const LpLayer& L, co
     }
     if (c.lds_flag[0]) return false;                        // uniform: written before the barriers above
     if (L.slabs == 0) {
-        // the unit holds whole GroupNorm groups over the full K: bias, GroupNorm, ReLU here
+        // the unit holds whole GroupNorm groups over the full K: bias, GroupNorm, ReLU here; the per-column constants were
+        // copied to LDS when the kernel started (a global load here is a memory round trip on every step's critical path)
+        const float* pst = (const float*)(c.smem + U.lds_p);
         float s1 = 0.f;
 #pragma unroll
         for (int t = 0; t < CT; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int col = U.col0 + 32 * t + 4 * q + i;
-                const float b = U.head ? A.tb_table[(int64_t)S.k * A.tb_elems + col] : L.bias[col];
+                const float b = U.head ? tbv[i] : pst[32 * t + 4 * q + i];
                 v[t][i] += b;
                 s1 += v[t][i];
             }
@@ -313,12 +330,12 @@ __device__ __forceinline__ bool lp_run_gemm(const LpCtx& c, const LpLayer& L, co
             for (int t = 0; t < CT; ++t)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int col = U.col0 + 32 * t + 4 * q + i;
-                    v[t][i] = (v[t][i] - mean) * rstd * L.gamma[col] + L.beta[col];
+                    v[t][i] = (v[t][i] - mean) * rstd * pst[64 + 32 * t + 4 * q + i] + pst[128 + 32 * t + 4 * q + i];
                 }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's poison stores are complete before its data stores leave
+    if (c.tr != nullptr && c.tid == 0) c.tr[3] = lp_now();
     lp_gemm_store<CT>(c, L, U, S.set_off, v, false);
     if (L.slabs == 0 && L.mode == 2 && A.forward_only && row < A.batch) {
 #pragma unroll
@@ -379,17 +396,28 @@ __device__ __forceinline__ bool lp_run_finish(const LpCtx& c, const LpLayer& L, 
             }
         if (__builtin_amdgcn_ballot_w64(bad) == 0ull) break;
         if ((spin & 63u) == 0u && lp_give_up(c, t0, 2u)) { ok = false; break; }
-        lp_sleep(c.sleep);
+        // not there yet: wait on the last slab's first load only, then take the full pass again
+        for (unsigned probe = 1;; ++probe) {
+            unsigned v0;
+            if constexpr (CPT >= 4) v0 = lp_ld16(c, base + (L.slabs - 1) * sstride).x;
+            else v0 = __builtin_amdgcn_raw_buffer_load_b64(c.rs, base + (L.slabs - 1) * sstride, 0, 16)[0];
+            if (__builtin_amdgcn_ballot_w64(lp_nan(v0)) == 0ull) break;
+            if ((probe & 63u) == 0u && lp_give_up(c, t0, 2u)) { ok = false; break; }
+            lp_sleep(c.sleep);
+        }
+        if (!ok) break;
     }
     if (!ok) c.lds_flag[0] = 1;
     polled = true;
+    if (c.tr != nullptr && c.tid == 0) c.tr[1] = lp_now();
     __syncthreads();
     if (c.lds_flag[0]) return false;
+    const float* pst = (const float*)(c.smem + U.lds_p) + (c.tid % TPR) * CPT;      // bias | gamma | beta of this group's columns
     float x[CPT];
     float s1 = 0.f;
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-        float v = L.bias[col + i];
+        float v = pst[i];
 #pragma unroll
         for (int s = 0; s < SMAX; ++s)
             if (s < L.slabs) v += __uint_as_float(raw[s][CPT >= 4 ? i / 4 : 0][i & 3]);
@@ -406,8 +434,9 @@ __device__ __forceinline__ bool lp_run_finish(const LpCtx& c, const LpLayer& L, 
     for (int o = 1; o < TPR; o <<= 1) s2 += __shfl_xor(s2, o);
     const float rstd = rsqrtf(s2 / (float)L.gsz + 1e-5f);
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) x[i] = (x[i] - mean) * rstd * L.gamma[col + i] + L.beta[col + i];
+    for (int i = 0; i < CPT; ++i) x[i] = (x[i] - mean) * rstd * pst[L.gsz + i] + pst[2 * L.gsz + i];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (c.tr != nullptr && c.tid == 0) c.tr[3] = lp_now();
     lp_finish_store<CPT, TPR>(c, L, U, S.set_off, x, false);
     return true;
 }
@@ -430,6 +459,7 @@ __device__ __forceinline__ bool lp_dispatch_finish(const LpCtx& c, const LpLayer
 }
 
 // --------------------------------------------------------------------------------------------- the kernel
+template <bool TRACE>
 __global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A) {
     extern __shared__ __attribute__((aligned(16))) char lp_smem[];
     __shared__ int lp_flag[4];
@@ -444,6 +474,7 @@ __global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A)
     c.r = c.lane & 31;
     c.hh = c.lane >> 5;
     c.sleep = A.sleep;
+    c.tr = nullptr;
     const LpUnit* units = A.units + (int64_t)blockIdx.x * LP_MAX_UNITS;
     if (c.tid == 0) lp_flag[0] = 0;
 
@@ -462,6 +493,21 @@ __global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A)
                     for (int i = 0; i < 4; ++i, ++task)
                         if ((task & 3) == c.wave)
                             lp_stage(L.w, L.ldw, U.col0 + 32 * t, (U.chunk0 + cl) * 64, lp_smem + U.lds_w + (t * U.nchunks + cl) * 4096, i, c.lane);
+        }
+    }
+    // per-column constants of this workgroup's units -> LDS: gemm units that finish their layer [bias | gamma | beta] x 64
+    // columns, finish units x gsz columns
+    for (int u = 0; u < LP_MAX_UNITS; ++u) {
+        const LpUnit U = units[u];
+        if (U.kind == LP_END) break;
+        if (U.lds_p < 0) continue;
+        const LpLayer& L = A.layers[U.layer];
+        float* pst = (float*)(lp_smem + U.lds_p);
+        const int ncol = U.kind == LP_GEMM ? 32 * U.ct : L.gsz, stride = U.kind == LP_GEMM ? 64 : L.gsz;
+        const int c0 = U.kind == LP_GEMM ? U.col0 : U.group * L.gsz;
+        for (int i = c.tid; i < ncol; i += LP_THREADS) {
+            pst[i] = L.bias[c0 + i];
+            if (L.mode == 0) { pst[stride + i] = L.gamma[c0 + i]; pst[2 * stride + i] = L.beta[c0 + i]; }
         }
     }
     const int k_base = A.counter != nullptr ? A.counter[0] : 0;
@@ -488,6 +534,12 @@ __global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A)
         S.set_off = LP_CTRL_BYTES + (step & 1) * A.set_bytes;
         S.other_off = LP_CTRL_BYTES + ((step & 1) ^ 1) * A.set_bytes;
         bool polled = false, poisoned = false;
+        // enc1's bias is the hoisted time row of this step: requested now, used after the update and the product
+        float tbv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (is_head && step < total) {
+            const float4 t4 = *(const float4*)(A.tb_table + (int64_t)S.k * A.tb_elems + units[0].col0 + 4 * (c.tid & 7));
+            tbv[0] = t4.x; tbv[1] = t4.y; tbv[2] = t4.z; tbv[3] = t4.w;
+        }
 
         if (is_head) {
             if (step > 0) {
@@ -553,13 +605,18 @@ __global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A)
             if (U.kind == LP_END) break;
             const LpLayer& L = A.layers[U.layer];
             bool ok;
+            if (TRACE && step < A.trace_steps) {
+                c.tr = A.trace + (((int64_t)blockIdx.x * A.trace_steps + step) * LP_MAX_UNITS + u) * 4;
+                if (c.tid == 0) c.tr[0] = lp_now();
+            } else c.tr = nullptr;
             if (U.kind == LP_GEMM) {
-                if (U.ct == 2) ok = lp_run_gemm<2, 1>(c, L, U, S, A, polled);
-                else ok = lp_run_gemm<1, 4>(c, L, U, S, A, polled);
+                if (U.ct == 2) ok = lp_run_gemm<2, 1>(c, L, U, S, A, polled, tbv);
+                else ok = lp_run_gemm<1, 4>(c, L, U, S, A, polled, tbv);
             } else {
                 ok = lp_dispatch_finish(c, L, U, S, polled, false);
             }
             if (!ok) return;
+            if (TRACE && c.tr != nullptr && c.tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); c.tr[2] = lp_now(); }
             if (polled && !poisoned) {
                 // every reader of the other set's contents (the previous step) is done: poison this workgroup's regions there
                 // for the next step.  (A head workgroup at step 0 has not polled anything: the other set holds an earlier
@@ -684,6 +741,11 @@ bool lp_build_plan(const pcd_latent_desc_t& d, LpPlan& plan) {
             const LpLayer& L = plan.layers[u.layer];
             if (L.slabs == 0 && L.mode == 0 && !((u.ct == 1 && (L.gsz == 16 || L.gsz == 32)) || L.gsz == 32 * u.ct)) return false;
             if ((u.nchunks + 3) / 4 > (u.ct == 2 ? 1 : 4)) return false;
+            u.lds_p = -1;
+            if (L.slabs == 0) { u.lds_p = lds[it.wg]; lds[it.wg] += 3 * 64 * 4; }
+        } else {
+            u.lds_p = lds[it.wg];
+            lds[it.wg] += 3 * plan.layers[u.layer].gsz * 4;
         }
         if (lds[it.wg] > LP_LDS_BYTES - 64) return false;                 // the launch's dynamic LDS (64 bytes left to the static flag word)
         plan.units[(size_t)it.wg * LP_MAX_UNITS + count[it.wg]++] = u;
@@ -744,11 +806,27 @@ extern "C" int pcd_latent_persist_plan_check(void) {
     return plan.set_bytes;
 }
 
+// host-only: phase ids (2 * layer + (finish ? 1 : 0), -1 = none) of every workgroup's unit list, [256][8] ints (tools/trace_latent_persist.py)
+extern "C" int pcd_latent_persist_plan_dump(int* phases_host) {
+    PCD_CHECK_ARG(phases_host != nullptr);
+    pcd_latent_desc_t d{};
+    for (int i = 0; i < LP_LAYERS; ++i) { d.lin[i].k = kK1[i] + kK2[i]; d.lin[i].c = kC[i]; }
+    LpPlan plan;
+    PCD_CHECK_ARG(lp_build_plan(d, plan));
+    for (size_t i = 0; i < plan.units.size(); ++i) {
+        const LpUnit& u = plan.units[i];
+        phases_host[i] = u.kind == LP_END ? -1 : 2 * u.layer + (u.kind == LP_FINISH ? 1 : 0);
+    }
+    return PCD_OK;
+}
+
 struct pcd_latent_persist {
     LpPlan plan;
     LpLayer* d_layers = nullptr;
     LpUnit* d_units = nullptr;
     int sleep = 1;
+    unsigned* trace = nullptr;         // diagnostic: device buffer [256][trace_steps][8][4] u32
+    int trace_steps = 0;
 };
 
 extern "C" int pcd_latent_persist_supported(int batch) {
@@ -776,7 +854,8 @@ extern "C" int pcd_latent_persist_create(const pcd_latent_desc_t* desc, pcd_late
     if (e == hipSuccess) e = hipMalloc(&h->d_units, sizeof(LpUnit) * h->plan.units.size());
     if (e == hipSuccess) e = hipMemcpy(h->d_layers, h->plan.layers, sizeof(LpLayer) * LP_LAYERS, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(h->d_units, h->plan.units.data(), sizeof(LpUnit) * h->plan.units.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)latent_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LP_LDS_BYTES - 64);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)latent_persist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LP_LDS_BYTES - 64);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)latent_persist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LP_LDS_BYTES - 64);
     if (e != hipSuccess) {
         set_error("pcd_latent_persist_create: %s", hipGetErrorString(e));
         if (h->d_layers) (void)hipFree(h->d_layers);
@@ -797,6 +876,15 @@ extern "C" void pcd_latent_persist_destroy(pcd_latent_persist_t* h) {
 
 extern "C" size_t pcd_latent_persist_workspace_bytes(const pcd_latent_persist_t* h) {
     return h ? (size_t)LP_CTRL_BYTES + 2 * (size_t)h->plan.set_bytes : 0;
+}
+
+// diagnostic: the next launches run the instrumented kernel and leave s_memrealtime stamps (100 MHz) of the first
+// `steps` steps in `buf` ([256 workgroups][steps][8 units][4]: enter, operands in, stored, unused); buf = NULL switches it off
+extern "C" int pcd_latent_persist_trace(pcd_latent_persist_t* h, unsigned* buf, int steps) {
+    PCD_CHECK_ARG(h != nullptr && (buf == nullptr || steps > 0));
+    h->trace = buf;
+    h->trace_steps = buf ? steps : 0;
+    return PCD_OK;
 }
 
 extern "C" int pcd_latent_persist_config(pcd_latent_persist_t* h, int poll_sleep) {
@@ -822,11 +910,14 @@ static int lp_launch(pcd_latent_persist_t* h, LpArgs& a, void* workspace, size_t
     a.ws = (char*)workspace;
     a.set_bytes = h->plan.set_bytes;
     a.sleep = h->sleep;
+    a.trace = h->trace;
+    a.trace_steps = h->trace_steps;
     // status word cleared, set 0 poisoned (set 1 is poisoned by the kernel during its first step)
     PCD_CHECK_HIP(hipMemsetAsync(workspace, 0, LP_CTRL_BYTES, s));
     PCD_CHECK_HIP(hipMemsetAsync((char*)workspace + LP_CTRL_BYTES, 0xff, (size_t)h->plan.set_bytes, s));
     // dynamic LDS = everything but the 16 bytes of the static flag word (rounded)
-    hipLaunchKernelGGL(latent_persist_kernel, dim3(LP_WGS), dim3(LP_THREADS), LP_LDS_BYTES - 64, s, a);
+    if (a.trace != nullptr) hipLaunchKernelGGL(latent_persist_kernel<true>, dim3(LP_WGS), dim3(LP_THREADS), LP_LDS_BYTES - 64, s, a);
+    else hipLaunchKernelGGL(latent_persist_kernel<false>, dim3(LP_WGS), dim3(LP_THREADS), LP_LDS_BYTES - 64, s, a);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

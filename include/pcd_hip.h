@@ -276,6 +276,8 @@ int pcd_latent_persist_create(const pcd_latent_desc_t* desc, pcd_latent_persist_
 void pcd_latent_persist_destroy(pcd_latent_persist_t* h);
 size_t pcd_latent_persist_workspace_bytes(const pcd_latent_persist_t* h);
 int pcd_latent_persist_config(pcd_latent_persist_t* h, int poll_sleep);
+/* diagnostic: instrumented kernel for the next launches; buf [256][steps][8][4] u32 of 100 MHz stamps, NULL = off */
+int pcd_latent_persist_trace(pcd_latent_persist_t* h, unsigned* buf, int steps);
 int pcd_latent_persist_forward(pcd_latent_persist_t* h, const float* z, int batch, const float* tbias, float* eps,
                                void* workspace, size_t workspace_bytes, void* stream);
 int pcd_latent_persist_ddim(pcd_latent_persist_t* h, float* z, float* x0, int batch, const float* tb_table, int tb_elems,
@@ -284,6 +286,8 @@ int pcd_latent_persist_ddim(pcd_latent_persist_t* h, float* z, float* x0, int ba
 int pcd_latent_persist_status(const void* workspace, unsigned* status_host);
 /* host-only self check of the kernel's static work assignment (no device needed): bytes of one buffer set, or -1 */
 int pcd_latent_persist_plan_check(void);
+/* host-only: phase id (2 * layer + finish, -1 = none) of every workgroup's units, [256][8] ints */
+int pcd_latent_persist_plan_dump(int* phases_host);
 
 /* ------------------------------------------------------ 3-D convolution (a12, K9)
  * Implicit-GEMM Conv3d on NDHWC fp16 activations (replaces nn.Conv3d / nn.ConvTranspose3d +

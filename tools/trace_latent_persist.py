@@ -1,0 +1,44 @@
+"""Dev tool: timeline of the persistent latent kernel (instrumented build, s_memrealtime stamps at 100 MHz): for every phase of
+one steady-state step, when its units started waiting, when their operands were in, when their stores had been acknowledged.
+Prints, per phase: first / last "operands in" and "stored" relative to the step's start, and the gap to the previous phase."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch
+import shapegen_amd
+from shapegen_amd import _lib
+from shapegen_amd.diffusion import LatentDiffusion
+from shapegen_amd.vae import VAE3DLarge
+from helpers import latent_sd
+torch.set_grad_enabled(False)
+lib = _lib.load()
+m = LatentDiffusion(VAE3DLarge()); m.load_state_dict(latent_sd(), strict=True); m = m.to("cuda").eval()
+B, T, STEPS = 32, 64, 48
+h, _ = m.model._persist_handle()
+buf = torch.zeros(256 * STEPS * 8 * 4, dtype=torch.int32, device="cuda")
+lib.pcd_latent_persist_trace(h, buf.data_ptr(), STEPS)
+zT = torch.randn(B, 256, device="cuda")
+m.sample(B, num_steps=T, z_T=zT)
+m.sample(B, num_steps=T, z_T=zT)
+torch.cuda.synchronize()
+lib.pcd_latent_persist_trace(h, 0, 0)
+tr = buf.cpu().numpy().astype(np.int64).reshape(256, STEPS, 8, 4) & 0xffffffff
+import ctypes
+plan = (ctypes.c_int * (256 * 8))()
+lib.pcd_latent_persist_plan_dump(plan)
+plan = np.array(plan).reshape(256, 8)
+names = ["enc1", "enc2", "enc3", "enc4", "gf0", "gf3", "dec4", "dec3", "dec2", "dec1", "out0", "out2"]
+for step in (40, 41):
+    ent, inn, pre, out = tr[:, step, :, 0], tr[:, step, :, 1], tr[:, step, :, 3], tr[:, step, :, 2]
+    t0 = ent[plan == 0].min()
+    print(f"step {step}: times in us from the first enc1 unit's entry; per phase: units | waiting from (median) | operands in first..last | "
+          f"epilogue computed (median after operands) | stores acknowledged first..last")
+    prev = 0.0
+    for ph in sorted(set(plan[plan >= 0].tolist())):
+        sel = plan == ph
+        e, i, p_, o = (ent[sel] - t0) / 100.0, (inn[sel] - t0) / 100.0, (pre[sel] - t0) / 100.0, (out[sel] - t0) / 100.0
+        print(f"  {names[ph // 2]:5s}{' fin' if ph & 1 else '    '} {sel.sum():4d} | {np.median(e):6.2f} | {i.min():6.2f}..{i.max():6.2f} | +{np.median(p_ - i):4.2f} | "
+              f"{o.min():6.2f}..{o.max():6.2f}   (+{i.max() - prev:5.2f} after the previous phase's last ack)")
+        prev = o.max()
+    t_next = tr[:, step + 1, :, 0][plan == 0].min()
+    print(f"  step length {(t_next - t0) / 100.0:.2f} us")
