@@ -155,7 +155,7 @@ _SIGS = {
     "pcd_latent_persist_create": (i32, [C.POINTER(LatentDesc), C.POINTER(vp)]),
     "pcd_latent_persist_destroy": (None, [vp]),
     "pcd_latent_persist_workspace_bytes": (sz, [vp]),
-    "pcd_latent_persist_config": (i32, [vp, i32]),
+    "pcd_latent_persist_config": (i32, [vp, i32, i32]),
     "pcd_latent_persist_trace": (i32, [vp, vp, i32]),
     "pcd_latent_persist_forward": (i32, [vp, vp, i32, vp, vp, vp, sz, vp]),
     "pcd_latent_persist_ddim": (i32, [vp, vp, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, sz, vp]),

@@ -35,6 +35,7 @@ namespace pcd {
 
 constexpr int LP_WGS = 256, LP_THREADS = 256, LP_LAYERS = 12, LP_MAX_UNITS = 8;
 constexpr int LP_LDS_BYTES = 160 * 1024;
+constexpr int LP_DYN_LDS = LP_LDS_BYTES - 256;         // dynamic part: the kernel's static words (abort flag, wait history) take the rest
 constexpr int LP_RED_BYTES = 4 * 32 * 33 * 4;          // cross-wave reduction scratch
 constexpr int LP_Z16_BYTES = 32 * 256 * 2;             // fp16 image of the latent state (enc1's operand)
 constexpr int LP_CTRL_BYTES = 256;
@@ -84,6 +85,7 @@ struct LpArgs {
     int nsteps;
     int forward_only;
     int sleep;                         // s_sleep argument between polls
+    int predict;                       // sleep through most of the wait the previous step measured before probing
     unsigned* trace;                   // diagnostic build only: [wg][step][unit][4] s_memrealtime stamps (enter, operands in, stored)
     int trace_steps;
 };
@@ -106,9 +108,24 @@ __device__ __forceinline__ bool lp_poison16(u32x4 v) { return ((v.x | v.y | v.z 
 __device__ __forceinline__ bool lp_nan(unsigned b) { return (b & 0x7fffffffu) > 0x7f800000u; }
 __device__ __forceinline__ bool lp_nan4(u32x4 v) { return (int)lp_nan(v.x) | (int)lp_nan(v.y) | (int)lp_nan(v.z) | (int)lp_nan(v.w); }
 
-__device__ __forceinline__ void lp_sleep(int n) { for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1); }
+// between two polls: the back-off, and a compiler barrier so that the next pass's loads are issued again
+__device__ __forceinline__ void lp_sleep(int n) {
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
 
 __device__ __forceinline__ unsigned lp_now() { return (unsigned)__builtin_amdgcn_s_memrealtime(); }
+
+// Steps are periodic: a wait that took `prev` ticks in the previous step will take about as long in this one.  Waits of 8 us and
+// more sleep through a fraction of it (shift: 1 = half, 2 = three quarters) before the first probe: hundreds of waves wait for most of a
+// step, and each probe is a fabric read that competes with the stores everybody is waiting for.  Short waits probe at once (they are
+// the ones close to the critical path; the sleep loop's granularity is ~0.5 us).
+__device__ __forceinline__ void lp_presleep(unsigned t_enter, unsigned prev, int shift) {
+    if (prev < 800u) return;
+    const unsigned until = t_enter + prev - (prev >> shift);
+    while ((int)(until - lp_now()) > 0) __builtin_amdgcn_s_sleep(8);
+    asm volatile("" ::: "memory");
+}
 
 // fragment-major byte offset of (row, col) in an fp16 activation buffer: [chunk = col / 64][j][hh * 32 + row][e]
 __device__ __forceinline__ int lp_frag_off(int row, int col) {
@@ -130,6 +147,8 @@ struct LpCtx {
     int tid, lane, wave, r, hh;
     int sleep;
     unsigned* tr;                      // where this unit's stamps go (diagnostic build), else null
+    unsigned* hist;                    // LDS word of (unit, wave): how long this wait took in the previous step (100 MHz ticks)
+    int predict;                       // 1: sleep through most of the predicted wait before probing
 };
 
 __device__ __forceinline__ u32x4 lp_ld16(const LpCtx& c, int off) { return __builtin_amdgcn_raw_buffer_load_b128(c.rs, off, 0, 16); }
@@ -182,7 +201,11 @@ __device__ __forceinline__ bool lp_fetch(const LpCtx& c, const LpLayer& L, const
                 const bool bad = (int)lp_poison16(pc[i][0]) | (int)lp_poison16(pc[i][1]) | (int)lp_poison16(pc[i][2]) | (int)lp_poison16(pc[i][3]);
                 if (__builtin_amdgcn_ballot_w64(bad) == 0ull) need &= ~(1u << i);
             }
-        if (need == 0u) return true;
+        if (need == 0u) {
+            if (c.hist != nullptr && c.lane == 0) *c.hist = lp_now() - t0;
+            return true;
+        }
+        if (spin == 1u && c.predict && c.hist != nullptr) lp_presleep(t0, __builtin_amdgcn_readfirstlane(*c.hist), c.predict);
         // ... otherwise wait on ONE 1-KiB piece of the first missing chunk (1/16 of the traffic of a full pass: hundreds of
         // waves wait here for most of a step, and their polls share the fabric with the stores they are waiting for)
         int poff = 0;
@@ -243,9 +266,11 @@ __device__ __forceinline__ void lp_gemm_store(const LpCtx& c, const LpLayer& L, 
     }
 }
 
+__device__ __forceinline__ void lp_poison_all(const LpCtx& c, const LpArgs& A, const LpUnit* units, int other_off);
+
 template <int CT, int MAXCH>
 __device__ __forceinline__ bool lp_run_gemm(const LpCtx& c, const LpLayer& L, const LpUnit& U, const LpStep& S, const LpArgs& A,
-                                            bool& polled, const float (&tbv)[4]) {
+                                            bool& poisoned, const LpUnit* units, const float (&tbv)[4]) {
     f32x16 acc[CT];
 #pragma unroll
     for (int t = 0; t < CT; ++t)
@@ -285,7 +310,6 @@ __device__ __forceinline__ bool lp_run_gemm(const LpCtx& c, const LpLayer& L, co
         }
     }
     if (!ok) c.lds_flag[0] = 1;
-    polled = true;
     if (c.tr != nullptr && c.tid == 0) c.tr[1] = lp_now();
     // cross-wave reduction through LDS, one 32-column tile at a time
     float (*red)[32][33] = (float (*)[32][33])c.smem;
@@ -366,7 +390,8 @@ __device__ __forceinline__ void lp_finish_store(const LpCtx& c, const LpLayer& L
 }
 
 template <int CPT, int TPR, int SMAX>
-__device__ __forceinline__ bool lp_run_finish(const LpCtx& c, const LpLayer& L, const LpUnit& U, const LpStep& S, bool& polled) {
+__device__ __forceinline__ bool lp_run_finish(const LpCtx& c, const LpLayer& L, const LpUnit& U, const LpStep& S, const LpArgs& A, bool& poisoned,
+                                              const LpUnit* units) {
     const int row = U.row0 + c.tid / TPR, col = U.group * L.gsz + (c.tid % TPR) * CPT;
     constexpr int V = CPT >= 4 ? CPT / 4 : 1;               // 16-byte loads per slab (CPT = 2: one 8-byte load)
     u32x4 raw[SMAX][V];
@@ -394,8 +419,12 @@ __device__ __forceinline__ bool lp_run_finish(const LpCtx& c, const LpLayer& L, 
 #pragma unroll
                 for (int i = 0; i < V; ++i) bad |= lp_nan4(raw[s][i]);
             }
-        if (__builtin_amdgcn_ballot_w64(bad) == 0ull) break;
+        if (__builtin_amdgcn_ballot_w64(bad) == 0ull) {
+            if (c.hist != nullptr && c.lane == 0) *c.hist = lp_now() - t0;
+            break;
+        }
         if ((spin & 63u) == 0u && lp_give_up(c, t0, 2u)) { ok = false; break; }
+        if (spin == 1u && c.predict && c.hist != nullptr) lp_presleep(t0, __builtin_amdgcn_readfirstlane(*c.hist), c.predict);
         // not there yet: wait on the last slab's first load only, then take the full pass again
         for (unsigned probe = 1;; ++probe) {
             unsigned v0;
@@ -408,7 +437,6 @@ __device__ __forceinline__ bool lp_run_finish(const LpCtx& c, const LpLayer& L, 
         if (!ok) break;
     }
     if (!ok) c.lds_flag[0] = 1;
-    polled = true;
     if (c.tr != nullptr && c.tid == 0) c.tr[1] = lp_now();
     __syncthreads();
     if (c.lds_flag[0]) return false;
@@ -441,21 +469,38 @@ __device__ __forceinline__ bool lp_run_finish(const LpCtx& c, const LpLayer& L, 
     return true;
 }
 
-__device__ __forceinline__ bool lp_dispatch_finish(const LpCtx& c, const LpLayer& L, const LpUnit& U, const LpStep& S, bool& polled, bool poison) {
-    const float zero16[16] = {};
-#define LP_FIN(CPT, TPR, SMAX)                                                                              \
-    do {                                                                                                   \
-        if (poison) { lp_finish_store<CPT, TPR>(c, L, U, S.other_off, *(const float (*)[CPT])zero16, true); return true; } \
-        return lp_run_finish<CPT, TPR, SMAX>(c, L, U, S, polled);                                           \
-    } while (0)
+__device__ __forceinline__ bool lp_dispatch_finish(const LpCtx& c, const LpLayer& L, const LpUnit& U, const LpStep& S, const LpArgs& A, bool& poisoned,
+                                                   const LpUnit* units) {
     switch (L.gsz) {
-        case 512: LP_FIN(16, 32, 2);
-        case 256: LP_FIN(8, 32, 2);
-        case 128: LP_FIN(4, 32, 8);
-        case 64: LP_FIN(2, 32, 4);
-        default: LP_FIN(2, 16, 2);       // gsz 32
+        case 512: return lp_run_finish<16, 32, 2>(c, L, U, S, A, poisoned, units);
+        case 256: return lp_run_finish<8, 32, 2>(c, L, U, S, A, poisoned, units);
+        case 128: return lp_run_finish<4, 32, 8>(c, L, U, S, A, poisoned, units);
+        case 64: return lp_run_finish<2, 32, 4>(c, L, U, S, A, poisoned, units);
+        default: return lp_run_finish<2, 16, 2>(c, L, U, S, A, poisoned, units);       // gsz 32
     }
-#undef LP_FIN
+}
+
+// poison every output region of this workgroup in the buffer set at `other_off` (same addresses and store widths as the data stores)
+__device__ __forceinline__ void lp_poison_all(const LpCtx& c, const LpArgs& A, const LpUnit* units, int other_off) {
+    const float zero[2][4] = {};
+    const float zero16[16] = {};
+    for (int p = 0; p < LP_MAX_UNITS; ++p) {
+        const LpUnit P = units[p];
+        if (P.kind == LP_END) break;
+        const LpLayer& L = A.layers[P.layer];
+        if (P.kind == LP_GEMM) {
+            if (P.ct == 2) lp_gemm_store<2>(c, L, P, other_off, zero, true);
+            else lp_gemm_store<1>(c, L, P, other_off, *(const float (*)[1][4])zero, true);
+        } else {
+            switch (L.gsz) {
+                case 512: lp_finish_store<16, 32>(c, L, P, other_off, zero16, true); break;
+                case 256: lp_finish_store<8, 32>(c, L, P, other_off, *(const float (*)[8])zero16, true); break;
+                case 128: lp_finish_store<4, 32>(c, L, P, other_off, *(const float (*)[4])zero16, true); break;
+                case 64: lp_finish_store<2, 32>(c, L, P, other_off, *(const float (*)[2])zero16, true); break;
+                default: lp_finish_store<2, 16>(c, L, P, other_off, *(const float (*)[2])zero16, true); break;
+            }
+        }
+    }
 }
 
 // --------------------------------------------------------------------------------------------- the kernel
@@ -463,8 +508,9 @@ template <bool TRACE>
 __global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A) {
     extern __shared__ __attribute__((aligned(16))) char lp_smem[];
     __shared__ int lp_flag[4];
+    __shared__ unsigned lp_hist[(LP_MAX_UNITS + 1) * 4];
     LpCtx c;
-    c.rs = __builtin_amdgcn_make_buffer_rsrc(A.ws, 0, LP_CTRL_BYTES + 2 * A.set_bytes, 0x00020000);
+    c.rs = __builtin_amdgcn_make_buffer_rsrc(A.ws, 0, LP_CTRL_BYTES + 3 * A.set_bytes, 0x00020000);
     c.ctrl = (unsigned*)A.ws;
     c.smem = lp_smem;
     c.lds_flag = lp_flag;
@@ -475,6 +521,9 @@ __global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A)
     c.hh = c.lane >> 5;
     c.sleep = A.sleep;
     c.tr = nullptr;
+    c.hist = nullptr;
+    c.predict = A.predict;
+    if (c.tid < (LP_MAX_UNITS + 1) * 4) lp_hist[c.tid] = 0u;
     const LpUnit* units = A.units + (int64_t)blockIdx.x * LP_MAX_UNITS;
     if (c.tid == 0) lp_flag[0] = 0;
 
@@ -531,9 +580,11 @@ __global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A)
         LpStep S;
         int k = k_base + step;
         S.k = k < A.T ? k : A.T - 1;
-        S.set_off = LP_CTRL_BYTES + (step & 1) * A.set_bytes;
-        S.other_off = LP_CTRL_BYTES + ((step & 1) ^ 1) * A.set_bytes;
-        bool polled = false, poisoned = false;
+        // three buffer sets: step s writes / reads set s % 3; the previous step's eps is in set (s + 2) % 3, which is also the set
+        // this workgroup re-poisons during step s (for step s + 2)
+        S.set_off = LP_CTRL_BYTES + (step % 3) * A.set_bytes;
+        S.other_off = LP_CTRL_BYTES + ((step + 2) % 3) * A.set_bytes;
+        bool poisoned = false;
         // enc1's bias is the hoisted time row of this step: requested now, used after the update and the product
         float tbv[4] = {0.f, 0.f, 0.f, 0.f};
         if (is_head && step < total) {
@@ -555,14 +606,17 @@ __global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A)
                     for (int i = 0; i < 8; ++i) e4[i] = lp_ld16(c, eoff + 16 * i);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) bad |= lp_nan4(e4[i]);
-                    if (__builtin_amdgcn_ballot_w64(bad) == 0ull) break;
+                    if (__builtin_amdgcn_ballot_w64(bad) == 0ull) {
+                        if (c.lane == 0) lp_hist[LP_MAX_UNITS * 4 + c.wave] = lp_now() - t0;
+                        break;
+                    }
                     if ((spin & 63u) == 0u && lp_give_up(c, t0, 3u)) { ok = false; break; }
+                    if (spin == 1u && c.predict) lp_presleep(t0, __builtin_amdgcn_readfirstlane(lp_hist[LP_MAX_UNITS * 4 + c.wave]), c.predict);
                     lp_sleep(c.sleep);
                 }
                 if (!ok) lp_flag[0] = 1;
                 __syncthreads();
                 if (lp_flag[0]) return;
-                polled = true;
                 const int kp = (k_base + step - 1) < A.T ? (k_base + step - 1) : A.T - 1;
                 const int rb = zrow * A.rate_stride;
                 const float rn = A.rates[((int64_t)0 * A.T + kp) * A.rate_width + rb], rsg = A.rates[((int64_t)1 * A.T + kp) * A.rate_width + rb];
@@ -609,33 +663,21 @@ __global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A)
                 c.tr = A.trace + (((int64_t)blockIdx.x * A.trace_steps + step) * LP_MAX_UNITS + u) * 4;
                 if (c.tid == 0) c.tr[0] = lp_now();
             } else c.tr = nullptr;
+            c.hist = lp_hist + u * 4 + c.wave;
             if (U.kind == LP_GEMM) {
-                if (U.ct == 2) ok = lp_run_gemm<2, 1>(c, L, U, S, A, polled, tbv);
-                else ok = lp_run_gemm<1, 4>(c, L, U, S, A, polled, tbv);
+                if (U.ct == 2) ok = lp_run_gemm<2, 1>(c, L, U, S, A, poisoned, units, tbv);
+                else ok = lp_run_gemm<1, 4>(c, L, U, S, A, poisoned, units, tbv);
             } else {
-                ok = lp_dispatch_finish(c, L, U, S, polled, false);
+                ok = lp_dispatch_finish(c, L, U, S, A, poisoned, units);
             }
             if (!ok) return;
             if (TRACE && c.tr != nullptr && c.tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); c.tr[2] = lp_now(); }
-            if (polled && !poisoned) {
-                // every reader of the other set's contents (the previous step) is done: poison this workgroup's regions there
-                // for the next step.  (A head workgroup at step 0 has not polled anything: the other set holds an earlier
-                // call's data, equally dead.)
-                poisoned = true;
-                for (int p = 0; p < LP_MAX_UNITS; ++p) {
-                    const LpUnit P = units[p];
-                    if (P.kind == LP_END) break;
-                    const LpLayer& LP_ = A.layers[P.layer];
-                    if (P.kind == LP_GEMM) {
-                        const float zero[2][4] = {};
-                        if (P.ct == 2) lp_gemm_store<2>(c, LP_, P, S.other_off, zero, true);
-                        else lp_gemm_store<1>(c, LP_, P, S.other_off, *(const float (*)[1][4])zero, true);
-                    } else {
-                        bool dummy;
-                        lp_dispatch_finish(c, LP_, P, S, dummy, true);
-                    }
-                }
-            }
+            // This unit's operands were step-s data, so every reader of the previous step's set is done (step s's first layer
+            // needed the complete eps of step s - 1): re-poison this workgroup's regions of that set, which step s + 2 will use.
+            // Issued AFTER the unit's own stores (off the critical path).  Why a reader of step s + 2 cannot see step s - 1's
+            // values: before it polls, it has finished its own dec4 unit of step s + 1, which needed every workgroup's gf3 output
+            // of step s + 1, and every data store waits (s_waitcnt vmcnt(0)) for all earlier stores of its wave, these included.
+            if (!poisoned) { poisoned = true; lp_poison_all(c, A, units, S.other_off); }
         }
     }
     if (blockIdx.x == 0 && c.tid == 0 && A.counter != nullptr && !A.forward_only) {
@@ -747,7 +789,7 @@ bool lp_build_plan(const pcd_latent_desc_t& d, LpPlan& plan) {
             u.lds_p = lds[it.wg];
             lds[it.wg] += 3 * plan.layers[u.layer].gsz * 4;
         }
-        if (lds[it.wg] > LP_LDS_BYTES - 64) return false;                 // the launch's dynamic LDS (64 bytes left to the static flag word)
+        if (lds[it.wg] > LP_DYN_LDS) return false;                 // the launch's dynamic LDS (64 bytes left to the static flag word)
         plan.units[(size_t)it.wg * LP_MAX_UNITS + count[it.wg]++] = u;
     }
     // a head unit's z16 image must start at LP_RED_BYTES: it is the workgroup's first allocation
@@ -825,6 +867,7 @@ struct pcd_latent_persist {
     LpLayer* d_layers = nullptr;
     LpUnit* d_units = nullptr;
     int sleep = 1;
+    int predict = 1;
     unsigned* trace = nullptr;         // diagnostic: device buffer [256][trace_steps][8][4] u32
     int trace_steps = 0;
 };
@@ -854,8 +897,8 @@ extern "C" int pcd_latent_persist_create(const pcd_latent_desc_t* desc, pcd_late
     if (e == hipSuccess) e = hipMalloc(&h->d_units, sizeof(LpUnit) * h->plan.units.size());
     if (e == hipSuccess) e = hipMemcpy(h->d_layers, h->plan.layers, sizeof(LpLayer) * LP_LAYERS, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(h->d_units, h->plan.units.data(), sizeof(LpUnit) * h->plan.units.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)latent_persist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LP_LDS_BYTES - 64);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)latent_persist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LP_LDS_BYTES - 64);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)latent_persist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LP_DYN_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)latent_persist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LP_DYN_LDS);
     if (e != hipSuccess) {
         set_error("pcd_latent_persist_create: %s", hipGetErrorString(e));
         if (h->d_layers) (void)hipFree(h->d_layers);
@@ -875,7 +918,7 @@ extern "C" void pcd_latent_persist_destroy(pcd_latent_persist_t* h) {
 }
 
 extern "C" size_t pcd_latent_persist_workspace_bytes(const pcd_latent_persist_t* h) {
-    return h ? (size_t)LP_CTRL_BYTES + 2 * (size_t)h->plan.set_bytes : 0;
+    return h ? (size_t)LP_CTRL_BYTES + 3 * (size_t)h->plan.set_bytes : 0;
 }
 
 // diagnostic: the next launches run the instrumented kernel and leave s_memrealtime stamps (100 MHz) of the first
@@ -887,9 +930,10 @@ extern "C" int pcd_latent_persist_trace(pcd_latent_persist_t* h, unsigned* buf, 
     return PCD_OK;
 }
 
-extern "C" int pcd_latent_persist_config(pcd_latent_persist_t* h, int poll_sleep) {
+extern "C" int pcd_latent_persist_config(pcd_latent_persist_t* h, int poll_sleep, int predict_waits) {
     PCD_CHECK_ARG(h != nullptr && poll_sleep >= 0 && poll_sleep <= 127);
     h->sleep = poll_sleep;
+    h->predict = predict_waits < 0 ? 0 : (predict_waits > 3 ? 3 : predict_waits);
     return PCD_OK;
 }
 
@@ -910,14 +954,15 @@ static int lp_launch(pcd_latent_persist_t* h, LpArgs& a, void* workspace, size_t
     a.ws = (char*)workspace;
     a.set_bytes = h->plan.set_bytes;
     a.sleep = h->sleep;
+    a.predict = h->predict;
     a.trace = h->trace;
     a.trace_steps = h->trace_steps;
-    // status word cleared, set 0 poisoned (set 1 is poisoned by the kernel during its first step)
+    // status word cleared, sets 0 and 1 poisoned (set 2 is poisoned by the kernel during its first step, two steps before its use)
     PCD_CHECK_HIP(hipMemsetAsync(workspace, 0, LP_CTRL_BYTES, s));
-    PCD_CHECK_HIP(hipMemsetAsync((char*)workspace + LP_CTRL_BYTES, 0xff, (size_t)h->plan.set_bytes, s));
+    PCD_CHECK_HIP(hipMemsetAsync((char*)workspace + LP_CTRL_BYTES, 0xff, 2 * (size_t)h->plan.set_bytes, s));
     // dynamic LDS = everything but the 16 bytes of the static flag word (rounded)
-    if (a.trace != nullptr) hipLaunchKernelGGL(latent_persist_kernel<true>, dim3(LP_WGS), dim3(LP_THREADS), LP_LDS_BYTES - 64, s, a);
-    else hipLaunchKernelGGL(latent_persist_kernel<false>, dim3(LP_WGS), dim3(LP_THREADS), LP_LDS_BYTES - 64, s, a);
+    if (a.trace != nullptr) hipLaunchKernelGGL(latent_persist_kernel<true>, dim3(LP_WGS), dim3(LP_THREADS), LP_DYN_LDS, s, a);
+    else hipLaunchKernelGGL(latent_persist_kernel<false>, dim3(LP_WGS), dim3(LP_THREADS), LP_DYN_LDS, s, a);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

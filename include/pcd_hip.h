@@ -269,13 +269,14 @@ int pcd_latent_forward(pcd_latent_t* h, const float* z, int batch, const float* 
  *  - every in-kernel wait is bounded (0.2 s); pcd_latent_persist_status copies the status word to the host after the
  *    caller has synchronised: 0 = ok, otherwise (wait kind << 16 | workgroup) of the first wait that gave up (outputs
  *    are then undefined).
- *  - pcd_latent_persist_config: poll back-off (s_sleep count between polls), a tuning hook. */
+ *  - pcd_latent_persist_config: tuning hooks: poll back-off (s_sleep count between polls); predict_waits = 1 (default): a wait
+ *    sleeps through 7/8 of the time the same wait took in the previous step before it starts probing. */
 typedef struct pcd_latent_persist pcd_latent_persist_t;
 int pcd_latent_persist_supported(int batch);
 int pcd_latent_persist_create(const pcd_latent_desc_t* desc, pcd_latent_persist_t** out);
 void pcd_latent_persist_destroy(pcd_latent_persist_t* h);
 size_t pcd_latent_persist_workspace_bytes(const pcd_latent_persist_t* h);
-int pcd_latent_persist_config(pcd_latent_persist_t* h, int poll_sleep);
+int pcd_latent_persist_config(pcd_latent_persist_t* h, int poll_sleep, int predict_waits);
 /* diagnostic: instrumented kernel for the next launches; buf [256][steps][8][4] u32 of 100 MHz stamps, NULL = off */
 int pcd_latent_persist_trace(pcd_latent_persist_t* h, unsigned* buf, int steps);
 int pcd_latent_persist_forward(pcd_latent_persist_t* h, const float* z, int batch, const float* tbias, float* eps,

@@ -32,6 +32,8 @@ for rep in range(3):
             print(f"persistent={int(persistent)}: {us:6.1f} us/step  |z0| {float(z0.abs().max()):.3f}", flush=True)
 for sl in [int(v) for v in os.environ.get("SLEEPS", "").split()]:
     h, _ = m.model._persist_handle()
-    lib.pcd_latent_persist_config(h, sl)
-    us = min(loop(True)[0] for _ in range(3))
-    print(f"poll sleep {sl}: {us:6.1f} us/step", flush=True)
+    for pred in (0, 1, 2, 3):
+        lib.pcd_latent_persist_config(h, sl, pred)
+        us = min(loop(True)[0] for _ in range(3))
+        print(f"poll sleep {sl} predict {pred}: {us:6.1f} us/step", flush=True)
+lib.pcd_latent_persist_config(m.model._persist_handle()[0], 1, 1)
