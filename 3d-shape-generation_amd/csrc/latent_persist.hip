@@ -15,17 +15,24 @@
 //   * there are NO flags, counters, atomics or fences between layers: the exchanged data carries its own validity.
 //     Activations are post-ReLU fp16 (sign bit clear), partial sums and eps are finite fp32; the buffers are poisoned
 //     with 0xFF bytes (sign bit set / NaN) and a consumer simply loads its operands with sc1 (L1-bypassing) loads
-//     until no element is poison: one memory round trip per layer boundary.  Stores are sc1 write-through.  Two
-//     buffer sets alternate by step parity; a workgroup re-poisons its own output regions of the other set after its
-//     first successful load of a step (by then every reader of that set's previous contents has finished: each
-//     step's first layer needs the previous step's complete eps, which needs every output of every unit);
+//     until no element is poison: one memory round trip per layer boundary.  THREE buffer sets rotate by step; at the
+//     end of its step s a workgroup re-poisons its own output regions of set (s - 1) % 3 (every reader of that set's
+//     contents has finished: step s's first layer needed the complete eps of step s - 1) for step s + 2; a reader of
+//     step s + 2 has by then finished its own dec4 unit of step s + 1, which needed every workgroup's global_feat.3
+//     tile of step s + 1, whose stores wait (s_waitcnt vmcnt(0)) for all earlier stores of their wave;
 //   * activations are stored in MFMA-fragment order ([64-k chunk][j][lane][8 halfs]), so a consumer's operand loads are
-//     1-KB coalesced instructions straight into the registers the MFMA reads: no LDS staging of activations;
+//     1-KB coalesced instructions straight into the registers the MFMA reads: no LDS staging of activations; stores
+//     are whole 128-byte lines per 8 lanes (finish units transpose through LDS for that);
+//   * work is assigned by (XCD, arrival rank on that XCD) read from HW_REG_XCC_ID, not by blockIdx: the seven small
+//     layers that chain the end of a step to the start of the next (dec2, dec1, output.0, output.2, update + enc1,
+//     enc2, enc3's input) all sit on XCD 0 and exchange through that XCD's L2 with PLAIN stores (tools/ubench_handoff:
+//     0.40 us per hand-off against 0.92 us for write-through stores across XCDs); everything else uses sc1 stores;
 //   * the four workgroups that own enc1 keep the latent state z (fp32, registers) and apply the DDIM update
 //     (same fp32 operation order as pcd_ddim_update, FMA contraction off) redundantly: bit-identical copies, no
 //     broadcast step.
 // Every wait is bounded (s_memrealtime) and reports through a status word; the grid is exactly the number of CUs and
-// the host refuses to launch on a device with fewer (pcd_latent_persist_supported).
+// the host refuses to launch on a device with fewer (pcd_latent_persist_supported).  Timeline tool:
+// tools/trace_latent_persist.py (instrumented build).  Measured, B = 32: 47 us / step against 74 us for the per-layer launches.
 #include <new>
 #include <vector>
 #include <algorithm>
@@ -53,7 +60,8 @@ struct LpLayer {
     int slabs;                         // 0: the unit finishes the layer itself; S >= 1: S K-slices of fp32 partial tiles + finish units
     int out_off;                       // byte offset (inside a set) of this layer's output: fp16 fragment-major, or eps fp32 [32][256]
     int slab_off;                      // byte offset (inside a set) of the fp32 slabs [S][32][C]
-    int pad;
+    int out_local;                     // 1: producers and consumers of this layer's outputs all sit on XCD 0: plain stores (the XCD's L2 is
+                                       //    their meeting point: ~0.4 us per hand-off instead of ~0.9 through the fabric); 0: sc1 write-through
 };
 
 enum { LP_END = 0, LP_GEMM = 1, LP_FINISH = 2 };
@@ -152,9 +160,16 @@ struct LpCtx {
 };
 
 __device__ __forceinline__ u32x4 lp_ld16(const LpCtx& c, int off) { return __builtin_amdgcn_raw_buffer_load_b128(c.rs, off, 0, 16); }
-__device__ __forceinline__ void lp_st16(const LpCtx& c, u32x4 v, int off) { __builtin_amdgcn_raw_buffer_store_b128(v, c.rs, off, 0, 16); }
-__device__ __forceinline__ void lp_st8(const LpCtx& c, u32x2 v, int off) { __builtin_amdgcn_raw_buffer_store_b64(v, c.rs, off, 0, 16); }
-__device__ __forceinline__ void lp_st4(const LpCtx& c, unsigned v, int off) { __builtin_amdgcn_raw_buffer_store_b32(v, c.rs, off, 0, 16); }
+// stores: sc1 (write-through to the fabric: visible to every XCD) or plain (stays in this XCD's L2: visible to the sc1 loads of the same XCD)
+__device__ __forceinline__ void lp_st16(const LpCtx& c, u32x4 v, int off, int local) {
+    if (local) __builtin_amdgcn_raw_buffer_store_b128(v, c.rs, off, 0, 0); else __builtin_amdgcn_raw_buffer_store_b128(v, c.rs, off, 0, 16);
+}
+__device__ __forceinline__ void lp_st8(const LpCtx& c, u32x2 v, int off, int local) {
+    if (local) __builtin_amdgcn_raw_buffer_store_b64(v, c.rs, off, 0, 0); else __builtin_amdgcn_raw_buffer_store_b64(v, c.rs, off, 0, 16);
+}
+__device__ __forceinline__ void lp_st4(const LpCtx& c, unsigned v, int off, int local) {
+    if (local) __builtin_amdgcn_raw_buffer_store_b32(v, c.rs, off, 0, 0); else __builtin_amdgcn_raw_buffer_store_b32(v, c.rs, off, 0, 16);
+}
 
 // called every 64 unsuccessful polls: true = give up (somebody aborted, or this wait exceeded the limit)
 __device__ __forceinline__ bool lp_give_up(const LpCtx& c, unsigned t0, unsigned code) {
@@ -251,17 +266,17 @@ __device__ __forceinline__ void lp_gemm_store(const LpCtx& c, const LpLayer& L, 
             const int off = set_off + L.slab_off + ((U.slice * 32 + row) * L.c + col) * 4;
             u32x4 o = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
             if (!poison) o = (u32x4){__float_as_uint(v[t][0]), __float_as_uint(v[t][1]), __float_as_uint(v[t][2]), __float_as_uint(v[t][3])};
-            lp_st16(c, o, off);
+            lp_st16(c, o, off, L.out_local);
         } else if (L.mode == 2) {                           // eps fp32 [32][C]
             const int off = set_off + L.out_off + (row * L.c + col) * 4;
             u32x4 o = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
             if (!poison) o = (u32x4){__float_as_uint(v[t][0]), __float_as_uint(v[t][1]), __float_as_uint(v[t][2]), __float_as_uint(v[t][3])};
-            lp_st16(c, o, off);
+            lp_st16(c, o, off, L.out_local);
         } else {                                            // fp16 activation, fragment-major, 4 columns = 8 bytes
             const int off = set_off + L.out_off + lp_frag_off(row, col);
             u32x2 o = {0xffffffffu, 0xffffffffu};
             if (!poison) o = (u32x2){lp_pack_relu_f16(v[t][0], v[t][1]), lp_pack_relu_f16(v[t][2], v[t][3])};
-            lp_st8(c, o, off);
+            lp_st8(c, o, off, L.out_local);
         }
     }
 }
@@ -372,20 +387,28 @@ __device__ __forceinline__ bool lp_run_gemm(const LpCtx& c, const LpLayer& L, co
 // --------------------------------------------------------------------------------------------- finish unit
 // One GroupNorm group x (256 / TPR) rows: slabs added in slice order + bias, two-pass statistics over the TPR threads of
 // a row, affine, ReLU, fp16 fragment-major store.  CPT columns per thread.
+// Output of a finish unit: ROWS = 256 / TPR rows x gsz columns of fp16, fragment-major.  The rows of one (chunk, j, hh) piece are 16 bytes
+// apart, so the values go through LDS ([row][gsz] fp16 in the reduction scratch) and leave with consecutive lanes on consecutive rows: 8
+// lanes = one full 128-byte line per store instruction (a thread's own CPT columns of 2 rows per wave would be 32-byte fragments of 32
+// lines: 4x the fabric writes, and the write-through acknowledgement of the big layers' finish phases took 3-5 us).  Poison: same addresses.
 template <int CPT, int TPR>
 __device__ __forceinline__ void lp_finish_store(const LpCtx& c, const LpLayer& L, const LpUnit& U, int set_off, const float (&x)[CPT], bool poison) {
-    const int row = U.row0 + c.tid / TPR, col = U.group * L.gsz + (c.tid % TPR) * CPT;
-    unsigned w[CPT / 2];
+    constexpr int ROWS = LP_THREADS / TPR;
+    const int gsz = TPR * CPT;
+    unsigned* stage = (unsigned*)c.smem;                       // [ROWS][gsz / 2] packed pairs
+    if (!poison) {
+        const int rr = c.tid / TPR, q = c.tid % TPR;
+        __syncthreads();                                       // the scratch may still be read by a previous unit's epilogue
 #pragma unroll
-    for (int i = 0; i < CPT / 2; ++i) w[i] = poison ? 0xffffffffu : lp_pack_relu_f16(x[2 * i], x[2 * i + 1]);
-    if constexpr (CPT >= 8) {
-#pragma unroll
-        for (int p = 0; p < CPT / 8; ++p)
-            lp_st16(c, (u32x4){w[4 * p], w[4 * p + 1], w[4 * p + 2], w[4 * p + 3]}, set_off + L.out_off + lp_frag_off(row, col + 8 * p));
-    } else if constexpr (CPT == 4) {
-        lp_st8(c, (u32x2){w[0], w[1]}, set_off + L.out_off + lp_frag_off(row, col));
-    } else {
-        lp_st4(c, w[0], set_off + L.out_off + lp_frag_off(row, col));
+        for (int i = 0; i < CPT / 2; ++i) stage[rr * (gsz / 2) + q * (CPT / 2) + i] = lp_pack_relu_f16(x[2 * i], x[2 * i + 1]);
+        __syncthreads();
+    }
+    const int npieces = ROWS * (gsz / 8);                      // 16-byte pieces: 8 columns of one row
+    for (int id = c.tid; id < npieces; id += LP_THREADS) {
+        const int rr = id % ROWS, cg = id / ROWS;
+        u32x4 v = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        if (!poison) v = *(const u32x4*)(stage + rr * (gsz / 2) + cg * 4);
+        lp_st16(c, v, set_off + L.out_off + lp_frag_off(U.row0 + rr, U.group * gsz + cg * 8), L.out_local);
     }
 }
 
@@ -524,8 +547,26 @@ __global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A)
     c.hist = nullptr;
     c.predict = A.predict;
     if (c.tid < (LP_MAX_UNITS + 1) * 4) lp_hist[c.tid] = 0u;
-    const LpUnit* units = A.units + (int64_t)blockIdx.x * LP_MAX_UNITS;
-    if (c.tid == 0) lp_flag[0] = 0;
+    // Work is assigned by (XCD, arrival rank on that XCD), not by blockIdx: the 7 small layers that chain the end of one step to the
+    // start of the next all run on XCD 0 and hand their outputs over through that XCD's L2.  256 workgroups on 256 CUs = 32 per XCD
+    // whatever the dispatch order (one per CU: each needs the whole LDS); a rank of 32 or more reports and aborts.
+    if (c.tid == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 7u;
+        const unsigned rank = __hip_atomic_fetch_add(c.ctrl + 4 + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lp_flag[1] = rank < 32u ? (int)(xcc * 32u + rank) : -1;
+        lp_flag[0] = 0;
+        if (rank >= 32u) {
+            unsigned expected = 0u;
+            __hip_atomic_compare_exchange_strong(c.ctrl, &expected, (4u << 16) | (unsigned)blockIdx.x, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    const int vwg = lp_flag[1];
+    if (vwg < 0) return;
+    const LpUnit* units = A.units + (int64_t)vwg * LP_MAX_UNITS;
 
     // ---- stage this workgroup's weights once: every 4-KiB image = 4 LDS-DMA instructions, dealt round-robin to the waves
     bool is_head = false;
@@ -660,7 +701,7 @@ __global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A)
             const LpLayer& L = A.layers[U.layer];
             bool ok;
             if (TRACE && step < A.trace_steps) {
-                c.tr = A.trace + (((int64_t)blockIdx.x * A.trace_steps + step) * LP_MAX_UNITS + u) * 4;
+                c.tr = A.trace + (((int64_t)vwg * A.trace_steps + step) * LP_MAX_UNITS + u) * 4;
                 if (c.tid == 0) c.tr[0] = lp_now();
             } else c.tr = nullptr;
             c.hist = lp_hist + u * 4 + c.wave;
@@ -672,15 +713,16 @@ __global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A)
             }
             if (!ok) return;
             if (TRACE && c.tr != nullptr && c.tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); c.tr[2] = lp_now(); }
-            // This unit's operands were step-s data, so every reader of the previous step's set is done (step s's first layer
-            // needed the complete eps of step s - 1): re-poison this workgroup's regions of that set, which step s + 2 will use.
-            // Issued AFTER the unit's own stores (off the critical path).  Why a reader of step s + 2 cannot see step s - 1's
-            // values: before it polls, it has finished its own dec4 unit of step s + 1, which needed every workgroup's gf3 output
-            // of step s + 1, and every data store waits (s_waitcnt vmcnt(0)) for all earlier stores of its wave, these included.
-            if (!poisoned) { poisoned = true; lp_poison_all(c, A, units, S.other_off); }
         }
+        // End of this workgroup's step s.  Its units consumed step-s data, so every reader of the previous step's set is done (step
+        // s's first layer needed the complete eps of step s - 1): re-poison this workgroup's regions of that set, which step s + 2
+        // will use.  Here, behind the last unit, the stores are off every critical path (issued right behind a unit they delay the
+        // next unit's operand loads: vmcnt retires in order).  Why a reader of step s + 2 cannot see step s - 1's values: before it
+        // polls, it has finished its own dec4 unit of step s + 1, which needed every workgroup's gf3 output of step s + 1, and every
+        // data store waits (s_waitcnt vmcnt(0)) for all earlier stores of its wave, these included.
+        lp_poison_all(c, A, units, S.other_off);
     }
-    if (blockIdx.x == 0 && c.tid == 0 && A.counter != nullptr && !A.forward_only) {
+    if (vwg == 0 && c.tid == 0 && A.counter != nullptr && !A.forward_only) {
         const int last = k_base + A.nsteps - 1;
         A.counter[1] = last < A.T ? last : A.T - 1;
         A.counter[0] = k_base + A.nsteps;
@@ -732,7 +774,8 @@ bool lp_build_plan(const pcd_latent_desc_t& d, LpPlan& plan) {
         L.src1_off = kSrc1[l] < 0 ? -1 : out_off[kSrc1[l]];
         L.src2_off = kSrc2[l] < 0 ? -1 : out_off[kSrc2[l]];
         L.c = kC[l]; L.gsz = kC[l] / 8; L.mode = l < 10 ? 0 : (l == 10 ? 1 : 2);
-        L.slabs = kSlabs[l]; L.out_off = out_off[l]; L.slab_off = slab_off[l]; L.pad = 0;
+        L.slabs = kSlabs[l]; L.out_off = out_off[l]; L.slab_off = slab_off[l];
+        L.out_local = (l == 0 || l == 1 || l == 8 || l == 9 || l == 10 || l == 11) ? 1 : 0;      // producers and consumers all on XCD 0
     }
     struct Item { int wg, phase; LpUnit u; int wbytes; };
     std::vector<Item> items;
@@ -746,24 +789,27 @@ bool lp_build_plan(const pcd_latent_desc_t& d, LpPlan& plan) {
         u.kind = LP_FINISH; u.layer = layer; u.group = group; u.row0 = row0;
         items.push_back({wg, 2 * layer + 1, u, 0});
     };
+    // w = virtual workgroup id = XCD * 32 + rank.  XCD 0 (w < 32) holds the small layers whose outputs stay in its L2.
     for (int w = 0; w < LP_WGS; ++w) {
         gemm(w, 5, 32 * (w >> 1), 1, 16 * (w & 1), 16, w & 1, 0);              // global_feat.3: 128 tiles x 2 slices, 64 KB
         gemm(w, 6, 32 * (w >> 3), 1, 10 * (w & 7), 10, w & 7, 0);              // dec4: 32 tiles x 8 slices, 40 KB
-        if (w < 128) gemm(w, 4, 32 * (w >> 1), 1, 8 * (w & 1), 8, w & 1, 0);   // global_feat.0: 64 tiles x 2 slices, 32 KB
-        else if (w < 160) gemm(w, 3, 32 * (w - 128), 1, 0, 8, 0, 0);           // enc4: 32 tiles, 32 KB
-        else if (w < 224) {
-            const int u = w - 160;
-            gemm(w, 7, 32 * (u >> 2), 1, 6 * (u & 3), 6, u & 3, 0);            // dec3: 16 tiles x 4 slices, 24 KB
+        if (w < 8) gemm(w, 2, 64 * w, 2, 0, 4, 0, 0);                          // enc3: 8 units of 2 tiles (one group), 32 KB
+        else if (w < 12) gemm(w, 0, 32 * (w - 8), 1, 0, 4, 0, 1);              // enc1: 4 tiles, 16 KB + the state
+        else if (w < 28) {
+            const int u = w - 12;
+            gemm(w, 8, 32 * (u >> 1), 1, 6 * (u & 1), 6, u & 1, 0);            // dec2: 8 tiles x 2 slices, 24 KB
             if (u < 8) gemm(w, 1, 32 * u, 1, 0, 2, 0, 0);                      // enc2: 8 tiles, 8 KB
             else if (u < 12) gemm(w, 10, 32 * (u - 8), 1, 0, 2, 0, 0);         // output.0: 4 tiles, 8 KB
-            else if (u < 20) gemm(w, 11, 32 * (u - 12), 1, 0, 2, 0, 0);        // output.2: 8 tiles, 8 KB
-        } else if (w < 232) gemm(w, 2, 64 * (w - 224), 2, 0, 4, 0, 0);         // enc3: 8 units of 2 tiles (one group), 32 KB
-        else if (w < 248) { const int u = w - 232; gemm(w, 8, 32 * (u >> 1), 1, 6 * (u & 1), 6, u & 1, 0); }   // dec2: 8 tiles x 2, 24 KB
-        else if (w < 252) gemm(w, 0, 32 * (w - 248), 1, 0, 4, 0, 1);           // enc1: 4 tiles, 16 KB + the state
-        else gemm(w, 9, 32 * (w - 252), 1, 0, 6, 0, 0);                        // dec1: 4 tiles, 24 KB
+            else gemm(w, 11, 32 * (u - 12), 1, 0, 2, 0, 0);                    // output.2: tiles 0..3, 8 KB
+        } else if (w < 32) {
+            gemm(w, 9, 32 * (w - 28), 1, 0, 6, 0, 0);                          // dec1: 4 tiles, 24 KB
+            gemm(w, 11, 32 * (w - 28 + 4), 1, 0, 2, 0, 0);                     // output.2: tiles 4..7, 8 KB
+        } else if (w < 160) { const int u = w - 32; gemm(w, 4, 32 * (u >> 1), 1, 8 * (u & 1), 8, u & 1, 0); }   // global_feat.0: 64 tiles x 2, 32 KB
+        else if (w < 192) gemm(w, 3, 32 * (w - 160), 1, 0, 8, 0, 0);           // enc4: 32 tiles, 32 KB
+        else { const int u = w - 192; gemm(w, 7, 32 * (u >> 2), 1, 6 * (u & 3), 6, u & 3, 0); }                  // dec3: 16 tiles x 4, 24 KB
     }
     const int fin_layers[6] = {3, 4, 5, 6, 7, 8};
-    const int fin_base[6] = {0, 32, 64, 96, 128, 192};
+    const int fin_base[6] = {32, 64, 96, 128, 160, 0};       // dec2's finish units on XCD 0, the others anywhere else
     for (int f = 0; f < 6; ++f) {
         const int l = fin_layers[f], gsz = kC[l] / 8;
         const int rows = gsz >= 64 ? 8 : 16, per_group = 32 / rows;
@@ -826,6 +872,16 @@ extern "C" int pcd_latent_persist_plan_check(void) {
             const int phase = 2 * u.layer + (u.kind == LP_FINISH ? 1 : 0);
             if (phase <= last_phase) return -1;
             last_phase = phase;
+            // a layer whose outputs are stored plain (XCD-local) must be produced AND consumed on XCD 0 only (virtual ids < 32)
+            if (plan.layers[u.layer].out_local && w >= 32) return -1;
+            if (u.kind == LP_GEMM) {
+                const int s1 = kSrc1[u.layer], s2 = kSrc2[u.layer];
+                const int n1 = kK1[u.layer] / 64;
+                for (int c = u.chunk0; c < u.chunk0 + u.nchunks; ++c) {
+                    const int src = c < n1 ? s1 : s2;
+                    if (src >= 0 && plan.layers[src].out_local && w >= 32) return -1;
+                }
+            }
             const int nk = (kK1[u.layer] + kK2[u.layer]) / 64;
             if (u.kind == LP_GEMM) {
                 if (u.col0 % 32 || u.chunk0 + u.nchunks > nk || (kSlabs[u.layer] == 0 && u.nchunks != nk)) return -1;

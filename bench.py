@@ -699,6 +699,10 @@ def run_cfg4(args, R: Ranks):
 
 def main():
     args = parse_args()
+    if os.environ.get("PCD_BENCH_SHARE_GPU") == "1":
+        # several ranks on ONE GPU (the one-GPU rehearsal of the multi-rank path): the persistent latent kernel needs every
+        # CU of its device, two of them cannot be resident together -> the per-layer launches
+        os.environ.setdefault("PCD_LATENT_PERSISTENT", "0")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_children(args))           # the parent stays GPU-free
 

@@ -40,5 +40,9 @@ for step in (40, 41):
         print(f"  {names[ph // 2]:5s}{' fin' if ph & 1 else '    '} {sel.sum():4d} | {np.median(e):6.2f} | {i.min():6.2f}..{i.max():6.2f} | +{np.median(p_ - i):4.2f} | "
               f"{o.min():6.2f}..{o.max():6.2f}   (+{i.max() - prev:5.2f} after the previous phase's last ack)")
         prev = o.max()
+        if i.max() - i.min() > 2.0 and step == 41:
+            ws = np.argwhere(sel)
+            late = sorted(((inn[w, u] - t0) / 100.0, (ent[w, u] - t0) / 100.0, int(w)) for w, u in ws)
+            print("      late operands (in, entered, vwg):", " ".join(f"{a:.1f}/{b:.1f}/{w}" for a, b, w in late[::max(1, len(late) // 24)]))
     t_next = tr[:, step + 1, :, 0][plan == 0].min()
     print(f"  step length {(t_next - t0) / 100.0:.2f} us")
