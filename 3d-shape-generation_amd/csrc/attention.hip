@@ -682,6 +682,187 @@ __global__ __launch_bounds__(256, 2) void set_attention_sp_kernel(const half_t* 
     store(oB, lB + (float)tB.x, q0 + 32 + qr);                 // B's last tile sum is still pending (A's went in with B's last phase)
 }
 
+
+// ------------------------------------------------------------ generic kernel without the running max (d = 16 / 32 / 64, any n)
+// set_attention_kernel above spends 66 VALU instructions per 32 x 32 score tile, 50 of them around the 16 v_exp_f32 (row max chain,
+// half-wave exchange, compare, fp32 row sums); at d = 32 / 16 a tile is only 4 / 3 MFMAs (128 / 96 matrix cycles), so the kernel is VALU
+// bound at 25.6 % / 14.2 % of the MFMA peak.  This kernel keeps its structure (one 32-query block per wave, 2-deep K/V ring, masked last
+// tile: any n) and takes the softmax of set_attention_sp_kernel: m is fixed exactly by the first 32 keys (every row then has a P = 1 term);
+// afterwards a tile is exponentiated against the old m, its lane-partial row sum is formed from the fp16 P by a packed-fp16 tree and only a
+// sum >= 2^13 (or inf) sends the wave down the rare path (exact maxima, rescale O / l, redo the tile).  Softmax is invariant to m: the same
+// function as the reference's.  ~36 VALU instructions per tile.  The bound that remains is the exponentials themselves: 16 v_exp_f32
+// (8 cycles each) + 8 packs + 8 packed adds = ~200 issue cycles per tile and wave against 128 / 96 cycles of MFMA, i.e. <= ~42 % / ~21 % of
+// the MFMA peak for d = 32 / 16 however the rest is arranged.
+template <int D>
+__global__ __launch_bounds__(256, 2) void set_attention_om_kernel(const half_t* __restrict__ qkv, int n, int c, int heads,
+                                                                   float scale_log2e, half_t* __restrict__ out) {
+    constexpr int DP = (D < 32) ? 32 : D;
+    constexpr int KSTEPS = D / 16;
+    constexpr int OT = DP / 32;
+    constexpr int KRB = D * 2;
+    constexpr int KBYTES = KT * KRB, STAGE = 2 * KBYTES;
+    constexpr int ZERO_OFF = 2 * STAGE;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + 64];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qr = lane & 31, hh = lane >> 5;
+    const int bh = blockIdx.y, b = bh / heads, head = bh - b * heads;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int64_t row_base = (int64_t)b * n;
+    const int ld = 3 * c;
+
+    half8 qf[KSTEPS];
+    {
+        int qi = q0 + qr;
+        qi = qi < n ? qi : n - 1;
+        const half_t* qp = qkv + (row_base + qi) * ld + head * D;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            const half8 raw = *(const half8*)(qp + 16 * s + 8 * hh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[s][e] = (half_t)((float)raw[e] * scale_log2e);
+        }
+    }
+    f32x16 oacc[OT], negm;
+    float l = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+#pragma unroll
+    for (int o = 0; o < OT; ++o)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[o][r] = 0.f;
+    if (tid < 16) *(float*)(smem + ZERO_OFF + tid * 4) = 0.f;
+
+    const half_t* kbase = qkv + row_base * ld + c + head * D;
+    const half_t* vbase = qkv + row_base * ld + 2 * c + head * D;
+    const int ntiles = (n + KT - 1) / KT;
+    const int tq = (lane >> 2) & 3, tp = lane & 3, tg = lane >> 4;
+    const int tr_dd0 = 16 * (tg & 1);
+
+    auto stage = [&](int kt, int buf) {
+        char* base = smem + buf * STAGE;
+        stage_tile<KT, KRB, false, 4, true>(kbase, ld, kt * KT, n, base, wave, lane);
+        stage_tile<KT, KRB, true, 4, true>(vbase, ld, kt * KT, n, base + KBYTES, wave, lane);
+    };
+
+    auto tile_body = [&](int kt, auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
+        const char* kb = smem + (kt & 1) * STAGE;
+        const char* vb = kb + KBYTES;
+#pragma unroll
+        for (int sub = 0; sub < KT / 32; ++sub) {
+            half8 kf[KSTEPS];
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                const int row = sub * 32 + qr;
+                kf[s] = *(const half8*)(kb + row * KRB + (k_swz<KRB>(row, 2 * s + hh) << 4));
+            }
+            half8 vf[2][OT];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int o = 0; o < OT; ++o) {
+                    const int dd0 = o * 32 + tr_dd0;
+                    fp16x4 lo, hi;
+                    if (D >= 32 || dd0 < D) {
+                        const int key = sub * 32 + 16 * s2 + 4 * (tg >> 1) + tq;
+                        const int ch = (dd0 >> 3) + (tp >> 1);
+                        const char* a0 = vb + key * KRB + (v_swz<KRB>(key, ch) << 4) + (tp & 1) * 8;
+                        const char* a1 = vb + (key + 8) * KRB + (v_swz<KRB>(key + 8, ch) << 4) + (tp & 1) * 8;
+                        lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)a0);
+                        hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)a1);
+                    } else {
+                        const char* z = smem + ZERO_OFF + (tp & 1) * 8;
+                        lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)z);
+                        hi = lo;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { vf[s2][o][e] = (half_t)lo[e]; vf[s2][o][4 + e] = (half_t)hi[e]; }
+                }
+            f32x16 sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[0], negm, 0, 0, 0);
+#pragma unroll
+            for (int s = 1; s < KSTEPS; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[s], qf[s], sacc, 0, 0, 0);
+            if constexpr (MASK) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * KT + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (key >= n) sacc[r] = -INFINITY;
+                }
+            }
+            if (kt == 0 && sub == 0) {                       // the first 32 keys fix the running max exactly
+                const float mx = sp_rowmax(sacc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { negm[r] = -mx; sacc[r] -= mx; }
+            }
+            half8 p0, p1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                p0[j] = (half_t)__builtin_amdgcn_exp2f(sacc[j]);
+                p1[j] = (half_t)__builtin_amdgcn_exp2f(sacc[8 + j]);
+            }
+            half2_ tt = sp_tile_sum(p0, p1);
+            if (__builtin_expect(__any(__builtin_bit_cast(unsigned, tt) > SP_BIG_BITS), 0)) {
+                // rare: some score is ~9 or more above the running max (or P overflowed fp16): exact maxima, rescale, redo the tile
+                const float delta = fmaxf(sp_rowmax(sacc), 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                l *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { negm[r] -= delta; sacc[r] -= delta; }
+#pragma unroll
+                for (int o = 0; o < OT; ++o)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[o][r] *= alpha;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    p0[j] = (half_t)__builtin_amdgcn_exp2f(sacc[j]);
+                    p1[j] = (half_t)__builtin_amdgcn_exp2f(sacc[8 + j]);
+                }
+                tt = sp_tile_sum(p0, p1);
+            }
+            l += (float)tt.x;
+#pragma unroll
+            for (int o = 0; o < OT; ++o) {
+                oacc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][o], p0, oacc[o], 0, 0, 0);
+                oacc[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][o], p1, oacc[o], 0, 0, 0);
+            }
+        }
+    };
+
+    const int full_tiles = n / KT;
+    stage(0, 0);
+    for (int kt = 0; kt < full_tiles; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < ntiles) stage(kt + 1, (kt + 1) & 1);
+        tile_body(kt, std::false_type{});
+    }
+    if (full_tiles < ntiles) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        tile_body(full_tiles, std::true_type{});
+    }
+
+    const int qi = q0 + qr;
+    const float l_tot = l + __shfl_xor(l, 32);
+    if (qi < n) {
+        const float inv = 1.f / l_tot;
+        half_t* orow = out + (row_base + qi) * c + head * D;
+#pragma unroll
+        for (int o = 0; o < OT; ++o)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dd = o * 32 + 8 * g + 4 * hh;
+                if (dd < D) {
+                    half4 ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ov[e] = to_half_sat(oacc[o][4 * g + e] * inv);
+                    *(half4*)(orow + dd) = ov;
+                }
+            }
+    }
+}
+
 }  // namespace pcd
 
 using namespace pcd;
@@ -704,10 +885,10 @@ extern "C" size_t pcd_set_attention_workspace_bytes(int batch, int n_points, int
     return 0;   // V is transposed on the fly by ds_read_b64_tr_b16: no workspace needed any more
 }
 
-static int g_attn_force_generic = 0;   // tuning/testing hook: 1 = always the generic kernel
+static int g_attn_force_generic = 0;   // tuning/testing hook: 1 = always the round-1 generic kernel, 2 = always the max-free generic kernel
 
 extern "C" int pcd_set_attention_config(int force_generic) {
-    g_attn_force_generic = force_generic ? 1 : 0;
+    g_attn_force_generic = force_generic < 0 ? 0 : (force_generic > 2 ? 2 : force_generic);
     return PCD_OK;
 }
 
@@ -723,7 +904,7 @@ extern "C" int pcd_set_attention_f16(const void* qkv, int batch, int n_points, i
     // 32*QT queries per wave.  QT = 1 measured fastest (836 vs 764 TFLOP/s at d = 64): at QT = 2 the kernel
     // sits at 256 VGPRs (2 waves/SIMD) and the shared K/V fragments do not pay for the lost occupancy.
     constexpr int QT = 1;
-    if (d == 64 && n_points % 256 == 0 && !g_attn_force_generic) {   // software-pipelined kernel: 64 queries per wave, 256 per workgroup
+    if (d == 64 && n_points % 256 == 0 && g_attn_force_generic == 0) {   // software-pipelined kernel: 64 queries per wave, 256 per workgroup
         dim3 sgrid((unsigned)((n_points / 256) * batch * heads));
         hipLaunchKernelGGL(set_attention_sp_kernel, sgrid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads,
                            scale_log2e, (half_t*)out);
@@ -731,6 +912,14 @@ extern "C" int pcd_set_attention_f16(const void* qkv, int batch, int n_points, i
         return PCD_OK;
     }
     dim3 grid((unsigned)ceil_div(n_points, 128 * QT), (unsigned)(batch * heads));
+    if (g_attn_force_generic != 1) {
+        // every other shape (d = 16 / 32, or n not a multiple of 256): the generic structure with the max-free softmax
+        if (d == 16) hipLaunchKernelGGL((set_attention_om_kernel<16>), grid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads, scale_log2e, (half_t*)out);
+        else if (d == 32) hipLaunchKernelGGL((set_attention_om_kernel<32>), grid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads, scale_log2e, (half_t*)out);
+        else hipLaunchKernelGGL((set_attention_om_kernel<64>), grid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads, scale_log2e, (half_t*)out);
+        PCD_CHECK_LAUNCH();
+        return PCD_OK;
+    }
     if (d == 16)
         hipLaunchKernelGGL((set_attention_kernel<16, QT>), grid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads,
                            scale_log2e, (half_t*)out);

@@ -315,6 +315,13 @@ __global__ __launch_bounds__(256) void pair_bce_kernel(const unsigned* __restric
 }
 #pragma clang fp contract(fast)
 
+// a pair with an empty cloud has no metrics (the reference's compute_metrics would raise on it): its row is NaN, explicitly --
+// otherwise the Chamfer mean is 0/0 but the Sinkhorn scale divides by a zero cost maximum and the BCE of an empty grid is a number
+__global__ void pair_empty_rows_kernel(const int* __restrict__ na, const int* __restrict__ nb, int P, float* __restrict__ rows) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < P && (na[p] <= 0 || nb[p] <= 0)) rows[p * 3 + 0] = rows[p * 3 + 1] = rows[p * 3 + 2] = __builtin_nanf("");
+}
+
 static inline size_t pm_align(size_t v) { return (v + 255) / 256 * 256; }
 struct PmWs { size_t an, bn, mins, alpha, beta, rowc, cmax, err, bits, total; };
 static PmWs pm_carve(int P, int NA, int NB) {
@@ -395,5 +402,7 @@ extern "C" int pcd_pair_metrics(const float* a, const int* na, int na_max, const
         hipLaunchKernelGGL(pair_row_sum_kernel, dim3(P), dim3(256), 0, s, rowc, na, NA, rows);
         PCD_CHECK_LAUNCH();
     }
+    hipLaunchKernelGGL(pair_empty_rows_kernel, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, s, na, nb, P, rows);
+    PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

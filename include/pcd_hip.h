@@ -481,7 +481,7 @@ int pcd_sinkhorn_cost(const float* x, const float* y, int batch, int n, int m, c
 
 /* ---- a batch of independent cloud pairs in one enqueue (the evaluation loop of test_point_ddpm.py:85-92) ----
  * Pair p = a[p][0..na[p]) vs b[p][0..nb[p]) inside padded fp32 arrays [P][na_max][3] / [P][nb_max][3]; na, nb device
- * int32 [P], every count >= 1.  rows fp32 [P][3] = (Chamfer with scaling 1 (metrics.py:23-47), Sinkhorn EMD
+ * int32 [P]; a pair with a count of 0 gets a NaN row (the reference's compute_metrics would raise on an empty cloud).  rows fp32 [P][3] = (Chamfer with scaling 1 (metrics.py:23-47), Sinkhorn EMD
  * (metrics.py:94-158, only when with_sinkhorn, else 0), voxel BCE (metrics.py:177-181)), each computed exactly as
  * compute_metrics(a_p, b_p) would for that pair alone: per-pair normalize_to_cube, per-pair cost normalisation, per-pair
  * convergence test (kept on the device: all max_iter iterations are enqueued, converged pairs skip theirs; no host

@@ -94,6 +94,43 @@ def test_attention_pipelined_kernel_d64(pattern):
     assert rel_l2(got, gen) < 2e-3
 
 
+@pytest.mark.parametrize("pattern", ["plain", "late_spike", "rising", "falling", "huge_first"])
+@pytest.mark.parametrize("C,N", [(64, 512), (128, 512), (256, 448), (128, 333)])
+def test_attention_max_free_generic_kernel(pattern, C, N):
+    """d = 16 / 32 (and d = 64 at lengths the pipelined kernel does not take) run the generic structure with the same max-free
+    softmax: the same five score patterns at d = 16, 32, 64 and at a ragged length (masked last tile), against fp64 and against
+    the round-1 kernel that tracks the running max per tile."""
+    from shapegen_amd import _lib, ops
+    B, H = 2, 4
+    g = torch.Generator().manual_seed(3 + C + N)
+    qkv = torch.randn(B * N, 3 * C, generator=g)
+    k = qkv[:, C:2 * C]
+    if pattern == "late_spike":
+        k[N + N - 40] *= 14.0                    # shape 1, one of the last keys (inside the masked tile when N is ragged)
+        k[37] *= 9.0
+    elif pattern == "rising":
+        k *= torch.linspace(0.2, 6.0, N).repeat(B)[:, None]
+    elif pattern == "falling":
+        k *= torch.linspace(8.0, 0.1, N).repeat(B)[:, None]
+    elif pattern == "huge_first":
+        k[:32] *= 20.0
+    qkv16 = qkv.half()
+    want = _attention_fp64(qkv16, B, N, C, H)
+    lib = _lib.load()
+    outs = {}
+    for mode in (2, 1):                                         # 2: max-free generic kernel, 1: round-1 generic kernel
+        _lib.check(lib.pcd_set_attention_config(mode))
+        try:
+            outs[mode] = ops.set_attention_f16(qkv16.cuda(), B, N, C, H).float().cpu()
+        finally:
+            _lib.check(lib.pcd_set_attention_config(0))
+    assert torch.isfinite(outs[2]).all()
+    assert rel_l2(outs[2], want) < 2e-3, (pattern, C, N)
+    assert rel_l2(outs[2], outs[1]) < 2e-3
+    if not (C == 256 and N % 256 == 0):                         # the default dispatch is this kernel for these shapes
+        assert torch.equal(ops.set_attention_f16(qkv16.cuda(), B, N, C, H).float().cpu(), outs[2])
+
+
 @pytest.mark.parametrize("rows,c", [(4096 + 5, 64), (1000, 128), (777, 256), (64, 96), (3, 256)])
 def test_layernorm_rows(rows, c):
     """nn.LayerNorm over the channel axis (reference networks.py:66-67, eps 1e-5, biased variance) on fp16 rows: the vectorised

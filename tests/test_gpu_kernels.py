@@ -260,3 +260,25 @@ def test_pair_metrics_batched_equals_per_pair_calls():
     # exact (Hungarian) EMD column comes from the host solve, like the reference
     ex = M.pair_metrics(x[:1], y[:1], False).cpu()
     assert abs(float(ex[0, 1]) - float(M.earth_mover_distance_cpu(x[0], y[0]))) < 1e-6
+
+
+def test_pair_metrics_c_entry_point_with_an_empty_cloud():
+    """the C entry point itself (not only the Python wrapper, which filters such pairs) answers a zero count with a
+    NaN row and leaves the other pairs untouched."""
+    from shapegen_amd import _lib, metrics as M
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    a, b = torch.rand(3, 96, 3, generator=g).cuda(), torch.rand(3, 80, 3, generator=g).cuda()
+    na = torch.tensor([96, 0, 50], dtype=torch.int32, device="cuda")
+    nb = torch.tensor([80, 80, 0], dtype=torch.int32, device="cuda")
+    log_mu = torch.log(1.0 / na.clamp_min(1).float().cpu() + 1e-10).cuda()
+    log_nu = torch.log(1.0 / nb.clamp_min(1).float().cpu() + 1e-10).cuda()
+    rows = torch.empty(3, 3, device="cuda")
+    need = int(lib.pcd_pair_metrics_workspace_bytes(3, 96, 80))
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.pcd_pair_metrics(a.data_ptr(), na.data_ptr(), 96, b.data_ptr(), nb.data_ptr(), 80, 3, 1, 1e-2, 1e-5, 100,
+                                    log_mu.data_ptr(), log_nu.data_ptr(), rows.data_ptr(), ws.data_ptr(), need, _lib.stream_ptr()))
+    rows = rows.cpu()
+    assert torch.isnan(rows[1]).all() and torch.isnan(rows[2]).all() and torch.isfinite(rows[0]).all()
+    cd, emd, bce = M.compute_metrics(a[0], b[0], True)
+    assert abs(float(rows[0, 0]) * 1e3 - float(cd)) <= 2e-6 * float(cd) and float(rows[0, 2]) == float(bce)

@@ -7,7 +7,7 @@ import shapegen_amd
 from shapegen_amd import _lib
 lib = _lib.load()
 B, N, H = 64, 2048, 4
-for generic in ([0, 1] if os.environ.get("PCD_ATTN_BOTH", "1") == "1" else [0]):
+for generic in ([0, 1, 2] if os.environ.get("PCD_ATTN_BOTH", "1") == "1" else [0]):      # 0 default dispatch, 1 round-1 generic, 2 max-free generic
     _lib.check(lib.pcd_set_attention_config(generic))
     for C in (256, 128, 64):
         for sigma in (1.0, 0.7):
