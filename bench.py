@@ -286,40 +286,52 @@ class Ranks:
 
 
 def attention_roofline(device, launches=100):
-    """HIP events (torch's current stream is the stream the kernel is launched on) around
-    pcd_set_attention_f16 at B=64, N=2048, C=256, 4 heads."""
+    """HIP events (torch's current stream is the stream the kernel is launched on) around pcd_set_attention_f16 at B=64, N=2048,
+    4 heads: C = 256 (d_head 64, the north-star shape: the headline numbers) and, under `by_d`, C = 128 / 64 (d_head 32 / 16: the
+    other widths of the attention U-Net, reference networks.py:628-646)."""
     import torch
     from shapegen_amd import _lib
     lib = _lib.load()
-    g = torch.Generator(device="cpu").manual_seed(7)
-    qkv = torch.randn(B_PER_GPU * N_POINTS, 3 * ATT_C, generator=g).to(device, torch.float16)     # unit-variance q, k, v
-    out = torch.empty(B_PER_GPU * N_POINTS, ATT_C, dtype=torch.float16, device=device)
 
-    def launch():
-        _lib.check(lib.pcd_set_attention_f16(qkv.data_ptr(), B_PER_GPU, N_POINTS, ATT_C, ATT_HEADS, out.data_ptr(), 0, 0,
-                                             _lib.stream_ptr()), "set_attention")
-    # warm-up: the chip takes ~100 launches (27 ms) from idle to its running clocks (tools/bench_attn_sustained.py: the first
-    # 100-launch chunk measures 10 % below the following nine); the timed train starts after that ramp
-    for _ in range(200):
-        launch()
-    # one event pair around the whole train of launches (an event record between kernels costs tens of microseconds of
-    # its own, comparable to the kernel)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(launches):
-        launch()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / launches
-    if not torch.isfinite(out.float()).all():
-        raise SystemExit("set attention produced non-finite values")
-    achieved = ATT_FLOP_PER_LAUNCH / (ms * 1e-3) / 1e12
+    def run(chan, count, warm):
+        g = torch.Generator(device="cpu").manual_seed(7)
+        qkv = torch.randn(B_PER_GPU * N_POINTS, 3 * chan, generator=g).to(device, torch.float16)     # unit-variance q, k, v
+        out = torch.empty(B_PER_GPU * N_POINTS, chan, dtype=torch.float16, device=device)
+
+        def launch():
+            _lib.check(lib.pcd_set_attention_f16(qkv.data_ptr(), B_PER_GPU, N_POINTS, chan, ATT_HEADS, out.data_ptr(), 0, 0,
+                                                 _lib.stream_ptr()), "set_attention")
+        # warm-up: the chip takes ~100 launches (27 ms) from idle to its running clocks (tools/bench_attn_sustained.py: the first
+        # 100-launch chunk measures 10 % below the following nine); the timed train starts after that ramp
+        for _ in range(warm):
+            launch()
+        # one event pair around the whole train of launches (an event record between kernels costs tens of microseconds of
+        # its own, comparable to the kernel)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(count):
+            launch()
+        e1.record()
+        torch.cuda.synchronize()
+        if not torch.isfinite(out.float()).all():
+            raise SystemExit("set attention produced non-finite values")
+        ms = e0.elapsed_time(e1) / count
+        flop = 4.0 * B_PER_GPU * N_POINTS * N_POINTS * chan
+        return ms, flop / (ms * 1e-3) / 1e12
+
+    ms, achieved = run(ATT_C, launches, 200)
+    by_d = {str(ATT_C // ATT_HEADS): {"achieved": achieved, "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS, "avg_launch_ms": ms,
+                                      "kernel": "set_attention_sp_kernel"}}
+    for chan in (128, 64):
+        m2, a2 = run(chan, 50, 20)
+        by_d[str(chan // ATT_HEADS)] = {"achieved": a2, "frac": a2 / MFMA_F16_DENSE_PEAK_TFLOPS, "avg_launch_ms": m2,
+                                        "kernel": "set_attention_om_kernel (max-free generic; exp-issue bound: <= ~42 % / ~21 % at d 32 / 16)"}
     return {"bound": "mfma", "kernel": "set_attention_sp_kernel (QK^T, softmax, PV; d_head 64; software-pipelined, 2 query blocks per wave)",
             "achieved": achieved, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": None,
             "avg_launch_ms": ms, "launches_timed": launches, "flop_per_launch": ATT_FLOP_PER_LAUNCH,
-            "shape": {"batch": B_PER_GPU, "points": N_POINTS, "channels": ATT_C, "heads": ATT_HEADS}}
+            "shape": {"batch": B_PER_GPU, "points": N_POINTS, "channels": ATT_C, "heads": ATT_HEADS}, "by_d": by_d}
 
 
 def _sha16(path):
