@@ -130,6 +130,9 @@ _SIGS = {
     "pcd_pw_chain_128": (i32, [vp, i64, vp, vp, vp, vp, vp, vp]),
     "pcd_pw_chain_tail": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "pcd_unet_config": (i32, [i32]),
+    "pcd_pw_wide_packed_bytes": (sz, [i32]),
+    "pcd_pw_wide_pack": (i32, [i32, vp, vp, vp, vp]),
+    "pcd_pw_wide_chain": (i32, [i32, vp, vp, i64, vp, vp, vp]),
     "pcd_conv1x1_supported": (i32, [i32, i32]),
     "pcd_conv1x1_f16": (i32, [vp, i64, i32, vp, i64, vp, i32, i32, vp, vp]),
     "pcd_unet_create": (i32, [C.POINTER(UnetDesc), C.POINTER(vp)]),

@@ -36,6 +36,8 @@ struct pcd_unet {
     hipEvent_t ev0[kMaxEv];
     hipEvent_t ev1[kMaxEv];
     int ev_created = 0;
+    // packed stage images + biases of the two 256-channel chains (csrc/widechain.hip): enc3 and dec2
+    void* wide[2] = {nullptr, nullptr};
 };
 
 namespace pcd {
@@ -72,10 +74,11 @@ static const int kLinK[PCD_UNET_NLIN] = {64, 64, 128, 128, 128, 256, 256, 256, 5
 static const int kLinC[PCD_UNET_NLIN] = {64, 128, 128, 128, 256, 256, 256, 512, 512, 512, 1024, 2048, 4096,
                                          1024, 1024, 512, 512, 512, 256, 256, 256, 128, 128, 128, 64, 64};
 
-static int g_unet_chains = 1;        // tuning / testing hook (pcd_unet_config): 0 = one GEMM launch per layer
+static int g_unet_chains = 3;        // tuning / testing hook (pcd_unet_config): bit 0 = the narrow chains (csrc/chain.hip), bit 1 = the
+                                     // 256-channel chains enc3 / dec2 (csrc/widechain.hip); 0 = one GEMM launch per layer
 
 extern "C" int pcd_unet_config(int use_chains) {
-    g_unet_chains = use_chains ? 1 : 0;
+    g_unet_chains = use_chains & 3;
     return PCD_OK;
 }
 
@@ -95,12 +98,28 @@ extern "C" int pcd_unet_create(const pcd_unet_desc_t* desc, pcd_unet_t** out) {
     pcd_unet* h = new (std::nothrow) pcd_unet;
     PCD_CHECK_ARG(h != nullptr);
     h->d = *desc;
+    // the two 256-channel chains read their weights as packed stage images: built once, here (the descriptor's weights are final)
+    const int first[2] = {5, 19};
+    for (int c = 0; c < 2; ++c) {
+        const void* w[3] = {desc->lin[first[c]].w, desc->lin[first[c] + 1].w, desc->lin[first[c] + 2].w};
+        const float* b[3] = {desc->lin[first[c]].b, desc->lin[first[c] + 1].b, desc->lin[first[c] + 2].b};
+        hipError_t e = hipMalloc(&h->wide[c], pcd_pw_wide_packed_bytes(c));
+        int rc = e == hipSuccess ? pcd_pw_wide_pack(c, w, b, h->wide[c], nullptr) : PCD_ERR_HIP;
+        if (rc == PCD_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = PCD_ERR_HIP;
+        if (rc != PCD_OK) {
+            if (e != hipSuccess) set_error("pcd_unet_create: %s", hipGetErrorString(e));
+            for (int k = 0; k < 2; ++k) if (h->wide[k]) (void)hipFree(h->wide[k]);
+            delete h;
+            return rc;
+        }
+    }
     *out = h;
     return PCD_OK;
 }
 
 extern "C" void pcd_unet_destroy(pcd_unet_t* h) {
     if (h == nullptr) return;
+    for (int k = 0; k < 2; ++k) if (h->wide[k]) (void)hipFree(h->wide[k]);
     for (int i = 0; i < h->ev_created; ++i) { (void)hipEventDestroy(h->ev0[i]); (void)hipEventDestroy(h->ev1[i]); }
     delete h;
 }
@@ -165,7 +184,8 @@ extern "C" int pcd_unet_forward(pcd_unet_t* h, const float* x, int batch, int n_
     const pcd_unet_desc_t& d = h->d;
     int rc;
 #define RUN(expr) do { rc = (expr); if (rc) return rc; } while (0)
-    const bool chains = g_unet_chains != 0;
+    const bool chains = (g_unet_chains & 1) != 0;
+    const bool wide = (g_unet_chains & 2) != 0 && m % 256 == 0;     // enc3 / dec2 as register-resident chains (whole 256-point tiles only)
     if (chains) {
         // enc1 (xyz -> 64 -> 64 -> 128) and enc2.conv1-2 (128 -> 128 -> 128): one launch each, intermediates in LDS
         RUN(pcd_pw_chain_enc1(x, m, n_points, d.e1w_xyz, tbias, tbias_shape_stride, d.lin[0].w, d.lin[0].b, d.lin[1].w,
@@ -179,9 +199,13 @@ extern "C" int pcd_unet_forward(pcd_unet_t* h, const float* x, int batch, int n_
         RUN(run_lin(d, 3, m, s0, nullptr, 0, nullptr, 0, s1, s));
     }
     RUN(run_lin(d, 4, m, s1, nullptr, 0, nullptr, 0, x2, s));
-    RUN(run_lin(d, 5, m, x2, nullptr, 0, nullptr, 0, s0, s));
-    RUN(run_lin(d, 6, m, s0, nullptr, 0, nullptr, 0, s1, s));
-    RUN(run_lin(d, 7, m, s1, nullptr, 0, nullptr, 0, x3, s));
+    if (wide) {
+        RUN(pcd_pw_wide_chain(0, x2, nullptr, m, h->wide[0], x3, s));
+    } else {
+        RUN(run_lin(d, 5, m, x2, nullptr, 0, nullptr, 0, s0, s));
+        RUN(run_lin(d, 6, m, s0, nullptr, 0, nullptr, 0, s1, s));
+        RUN(run_lin(d, 7, m, s1, nullptr, 0, nullptr, 0, x3, s));
+    }
     RUN(run_lin(d, 8, m, x3, nullptr, 0, nullptr, 0, s0, s));
     RUN(run_lin(d, 9, m, s0, nullptr, 0, nullptr, 0, s1, s));
     RUN(run_lin(d, 10, m, s1, nullptr, 0, nullptr, 0, x4, s));
@@ -223,9 +247,13 @@ extern "C" int pcd_unet_forward(pcd_unet_t* h, const float* x, int batch, int n_
     RUN(run_lin(d, 16, m, s1, x3, 512, nullptr, 0, s0, s));
     RUN(run_lin(d, 17, m, s0, nullptr, 0, nullptr, 0, s1, s));
     RUN(run_lin(d, 18, m, s1, nullptr, 0, nullptr, 0, s0, s));
-    RUN(run_lin(d, 19, m, s0, x2, 256, nullptr, 0, s1, s));
-    RUN(run_lin(d, 20, m, s1, nullptr, 0, nullptr, 0, s0, s));
-    RUN(run_lin(d, 21, m, s0, nullptr, 0, nullptr, 0, s1, s));
+    if (wide) {
+        RUN(pcd_pw_wide_chain(1, s0, x2, m, h->wide[1], s1, s));
+    } else {
+        RUN(run_lin(d, 19, m, s0, x2, 256, nullptr, 0, s1, s));
+        RUN(run_lin(d, 20, m, s1, nullptr, 0, nullptr, 0, s0, s));
+        RUN(run_lin(d, 21, m, s0, nullptr, 0, nullptr, 0, s1, s));
+    }
     RUN(run_lin(d, 22, m, s1, x1, 128, nullptr, 0, s0, s));
     if (chains) {
         // dec1.conv2 -> conv3 -> output.0 -> output.3 (128 -> 128 -> 64 -> 64 -> 3): one launch

@@ -1,0 +1,249 @@
+// Chains of 256-channel pointwise layers of UNetPointNetLarge (reference networks.py:16-49, 779-818) as one launch each:
+//   E3: x2 [M][256] -> enc3.conv1 256->256 -> conv2 256->256 -> conv3 256->512 -> x3
+//   D2: [dec3 out [M][256] | x2 [M][256]] -> dec2.conv1 512->256 -> conv2 256->256 -> conv3 256->128
+// As separate GEMMs these layers are HBM / latency bound (K = 256: four K tiles per output tile; 33-57 us per layer against a
+// 22 us traffic floor) and write + re-read a 67 MB intermediate each.  Here a wave owns 32 points for the whole chain and the
+// activations never leave its REGISTERS between layers:
+//   * every layer is the transposed product D[channel][point] = W[channel][k] . act[point][k] on v_mfma_f32_32x32x16_f16 (weights
+//     = A operand, activations = B operand); the B fragments of all 16 k-steps of a 256-wide input are 64 registers per lane;
+//   * an accumulator group holds 4 consecutive channels of one point; after bias + ReLU + fp16 rounding, one v_permlane32_swap per
+//     register turns two such groups of the two lane halves into the 8 consecutive k of the NEXT layer's B fragment: no LDS, no
+//     barrier, no memory traffic between layers;
+//   * only the weights stream: packed once into 32-KB stage images ([8 channel tiles][4 k-steps][64 lanes][16 B] = 256 channels x
+//     64 k in fragment order), they arrive by LDS-DMA into a 3-deep ring, one barrier per 64-deep K tile for the 8 waves
+//     (256 points) of a workgroup; a 256 x 256 tile of work per 32 KB of LDS fill = 256 FLOP per filled byte, twice the GEMM's.
+// Output rows leave as 16-byte pieces (8 consecutive channels per lane after the same swap).  M must be a multiple of 256.
+#include "common.h"
+
+namespace pcd {
+
+constexpr int WC_WAVES = 8, WC_THREADS = 64 * WC_WAVES, WC_TILE = 32 * WC_WAVES;
+constexpr int WC_STAGE = 32768, WC_RING = 3;
+constexpr int WC_MAXSEG = 8;
+
+// one 256-channel output pass: 4 K tiles of the current B fragments (accumulating onto the previous segment when `cont`)
+struct WcSeg {
+    int src;          // 0: the registers hold the previous layer's output; 1 / 2: load the B fragments from in1 / in2
+    int cont;         // 1: keep accumulating (second K half of a two-source layer), 0: start from zero
+    int finish;       // 0: more K to come; 1: epilogue -> next layer's fragments (registers); 2: epilogue -> global at channel offset `coff`
+    int coff;         // finish 2: first output channel of this pass
+    int cvalid;       // finish 2: channels of this pass that exist (256, or 128 for a padded last layer)
+    int bias_off;     // offset into the bias array
+    int keep_b;       // 1: the B fragments are needed by the next segment too (second output pass of a 512-channel layer)
+    int pad;
+};
+
+struct WcParams {
+    const half_t* in1; const half_t* in2;     // [M][256]
+    const char* wpacked;                       // stage images, segment after segment, 4 per segment
+    const float* bias;                         // fp32, indexed by bias_off + channel
+    half_t* out; int ldo;                      // [M][ldo]
+    int64_t m;
+    int nseg;
+    WcSeg seg[WC_MAXSEG];
+};
+
+__device__ __forceinline__ void wc_dma(const char* g, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory", "m0");
+}
+
+// two accumulator groups (same channel tile, g = 2 gp and 2 gp + 1) -> the 8 consecutive channels a lane needs as the next B fragment /
+// as one 16-byte output piece: lane half 0 ends with channels 16 s .. + 7, lane half 1 with 16 s + 8 .. + 15 (s = 2 t + gp)
+__device__ __forceinline__ half8 wc_regroup(const f32x16& acc, int gp, const float* bias_t, int hh) {
+    // group g holds channels 8 g + 4 hh + e of the 32-channel tile
+    unsigned p[2], q[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int g0 = 2 * gp, g1 = 2 * gp + 1;
+        const float a0 = acc[4 * g0 + 2 * h] + bias_t[8 * g0 + 4 * hh + 2 * h], a1 = acc[4 * g0 + 2 * h + 1] + bias_t[8 * g0 + 4 * hh + 2 * h + 1];
+        const float b0 = acc[4 * g1 + 2 * h] + bias_t[8 * g1 + 4 * hh + 2 * h], b1 = acc[4 * g1 + 2 * h + 1] + bias_t[8 * g1 + 4 * hh + 2 * h + 1];
+        half2_ pa, pb;
+        pa.x = (half_t)__builtin_amdgcn_fmed3f(a0, 0.f, 65504.f); pa.y = (half_t)__builtin_amdgcn_fmed3f(a1, 0.f, 65504.f);
+        pb.x = (half_t)__builtin_amdgcn_fmed3f(b0, 0.f, 65504.f); pb.y = (half_t)__builtin_amdgcn_fmed3f(b1, 0.f, 65504.f);
+        p[h] = __builtin_bit_cast(unsigned, pa);
+        q[h] = __builtin_bit_cast(unsigned, pb);
+    }
+    // registers P = (half 0: X0, half 1: X1), Q = (half 0: Y0, half 1: Y1)  ->  (X0, Y0) and (X1, Y1): swap P's upper lanes with Q's lower lanes
+    unsigned f[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const auto r = __builtin_amdgcn_permlane32_swap(p[h], q[h], false, false);
+        f[h] = r[0];            // half 0: X0[h], half 1: Y0[h]
+        f[2 + h] = r[1];        // half 0: X1[h], half 1: Y1[h]
+    }
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(half8, (u4){f[0], f[1], f[2], f[3]});
+}
+
+__global__ __launch_bounds__(WC_THREADS, 2) void pw_wide_chain_kernel(WcParams p) {
+    extern __shared__ __attribute__((aligned(16))) char wc_smem[];          // [WC_RING][WC_STAGE] | bias copy
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pnt = lane & 31, hh = lane >> 5;
+    float* bias_lds = (float*)(wc_smem + WC_RING * WC_STAGE);
+    const int nbias = p.nseg * 256;
+    for (int i = threadIdx.x; i < nbias; i += WC_THREADS) bias_lds[i] = p.bias[i];
+    const unsigned lds0 = (unsigned)(size_t)wc_smem;
+    const int64_t ntiles = p.m / WC_TILE;
+    const int my_tiles = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
+    const int nstage_seq = p.nseg * 4;                         // stages per tile of points
+    const int total_stages = my_tiles * nstage_seq;
+    // stage n of this workgroup's run = image (n % nstage_seq); wave w moves pieces 4 w .. 4 w + 3 of its 32
+    auto issue = [&](int n) __attribute__((always_inline)) {
+        if (n < total_stages) {
+            const char* src = p.wpacked + (size_t)(n % nstage_seq) * WC_STAGE + (size_t)(4 * wave) * 1024 + lane * 16;
+            const unsigned dst = lds0 + (n % WC_RING) * WC_STAGE + (4 * wave) * 1024;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wc_dma(src + i * 1024, dst + i * 1024);
+        }
+    };
+    issue(0);
+    issue(1);
+    int n = 0;                                                 // next stage to consume
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        const int64_t tile = blockIdx.x + (int64_t)ti * gridDim.x;
+        const int64_t pt = tile * WC_TILE + wave * 32 + pnt;
+        half8 bf[16];
+        f32x16 acc[8];
+#pragma unroll 1
+        for (int sg = 0; sg < p.nseg; ++sg) {
+            const WcSeg S = p.seg[sg];
+            if (S.src != 0) {
+                // B fragments straight from the [point][256] rows: lane (point, half) takes the 8 channels 16 s + 8 half of every k-step
+                const half_t* row = (S.src == 1 ? p.in1 : p.in2) + pt * 256 + 8 * hh;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) bf[s] = *(const half8*)(row + 16 * s);
+            }
+            if (!S.cont) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+            }
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                // stage n has landed (all but this wave's 4 youngest LDS-DMA pieces), every wave is done with stage n - 1: its
+                // slot takes stage n + 2
+                if (n + 1 < total_stages) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                issue(n + 2);
+                const char* img = wc_smem + (n % WC_RING) * WC_STAGE + lane * 16;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    half8 af[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) af[t] = *(const half8*)(img + (t * 4 + q) * 1024);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t], bf[4 * kt + q], acc[t], 0, 0, 0);
+                }
+                ++n;
+            }
+            if (S.finish == 0) continue;
+            const float* bseg = bias_lds + S.bias_off;
+            if (S.finish == 1) {
+                // -> the next layer's B fragments: k-step s = 2 t + gp of the new input
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) bf[2 * t + gp] = wc_regroup(acc[t], gp, bseg + 32 * t, hh);
+            } else {
+                half_t* orow = p.out + pt * p.ldo + S.coff + 8 * hh;
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        const half8 v = wc_regroup(acc[t], gp, bseg + 32 * t, hh);
+                        if (32 * t + 16 * gp < S.cvalid) *(half8*)(orow + 32 * t + 16 * gp) = v;
+                    }
+            }
+        }
+    }
+}
+
+// W [C][ldw] fp16 (columns k0 .. k0 + 63 of channels c0 .. c0 + 255, rows >= c_limit read as zero) -> one stage image
+__global__ __launch_bounds__(256) void wc_pack_kernel(const half_t* __restrict__ w, int64_t ldw, int c0, int c_limit, int k0, char* __restrict__ img) {
+    // piece id = (t * 4 + q) * 64 + lane: 8 halfs W[c0 + 32 t + (lane & 31)][k0 + 16 q + 8 (lane >> 5) .. + 7]
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= 8 * 4 * 64) return;
+    const int lane = id & 63, tq = id >> 6, t = tq >> 2, q = tq & 3;
+    const int ch = c0 + 32 * t + (lane & 31);
+    half8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (half_t)0.f;
+    if (ch < c_limit) v = *(const half8*)(w + (int64_t)ch * ldw + k0 + 16 * q + 8 * (lane >> 5));
+    *(half8*)(img + (size_t)id * 16) = v;
+}
+
+}  // namespace pcd
+
+using namespace pcd;
+
+extern "C" size_t pcd_pw_wide_packed_bytes(int chain) {
+    return (chain == 0 || chain == 1) ? (size_t)16 * WC_STAGE + (size_t)4 * 256 * sizeof(float) : 0;
+}
+
+// chain 0 (E3): w[0..2] = enc3.conv1 [256][256], conv2 [256][256], conv3 [512][256]; chain 1 (D2): dec2.conv1 [256][512], conv2 [256][256],
+// conv3 [128][256].  Writes the stage images followed by the per-pass bias rows (4 x 256 fp32) into `packed`.
+extern "C" int pcd_pw_wide_pack(int chain, const void* const* w, const float* const* b, void* packed, void* stream) {
+    PCD_CHECK_ARG((chain == 0 || chain == 1) && w && b && packed && w[0] && w[1] && w[2] && b[0] && b[1] && b[2]);
+    hipStream_t s = (hipStream_t)stream;
+    char* img = (char*)packed;
+    float* bias = (float*)(img + (size_t)16 * WC_STAGE);
+    // passes in execution order: (weights, ldw, first channel, channel limit, first k, bias source, bias channels)
+    struct Pass { int layer; int ldw; int c0; int climit; int k0; };
+    const Pass e3[4] = {{0, 256, 0, 256, 0}, {1, 256, 0, 256, 0}, {2, 256, 0, 512, 0}, {2, 256, 256, 512, 0}};
+    const Pass d2[4] = {{0, 512, 0, 256, 0}, {0, 512, 0, 256, 256}, {1, 256, 0, 256, 0}, {2, 256, 0, 128, 0}};
+    const Pass* ps = chain == 0 ? e3 : d2;
+    for (int i = 0; i < 4; ++i)
+        for (int kt = 0; kt < 4; ++kt)
+            hipLaunchKernelGGL(wc_pack_kernel, dim3(8), dim3(256), 0, s, (const half_t*)w[ps[i].layer], (int64_t)ps[i].ldw, ps[i].c0, ps[i].climit,
+                               ps[i].k0 + 64 * kt, img + (size_t)(4 * i + kt) * WC_STAGE);
+    PCD_CHECK_LAUNCH();
+    PCD_CHECK_HIP(hipMemsetAsync(bias, 0, 4 * 256 * sizeof(float), s));
+    if (chain == 0) {
+        PCD_CHECK_HIP(hipMemcpyAsync(bias, b[0], 256 * 4, hipMemcpyDeviceToDevice, s));
+        PCD_CHECK_HIP(hipMemcpyAsync(bias + 256, b[1], 256 * 4, hipMemcpyDeviceToDevice, s));
+        PCD_CHECK_HIP(hipMemcpyAsync(bias + 512, b[2], 512 * 4, hipMemcpyDeviceToDevice, s));
+    } else {
+        PCD_CHECK_HIP(hipMemcpyAsync(bias + 256, b[0], 256 * 4, hipMemcpyDeviceToDevice, s));      // pass 1 finishes dec2.conv1 (pass 0 has no epilogue)
+        PCD_CHECK_HIP(hipMemcpyAsync(bias + 512, b[1], 256 * 4, hipMemcpyDeviceToDevice, s));
+        PCD_CHECK_HIP(hipMemcpyAsync(bias + 768, b[2], 128 * 4, hipMemcpyDeviceToDevice, s));
+    }
+    return PCD_OK;
+}
+
+extern "C" int pcd_pw_wide_chain(int chain, const void* in1, const void* in2, int64_t m, const void* packed, void* out, void* stream) {
+    PCD_CHECK_ARG((chain == 0 || chain == 1) && in1 && packed && out && m > 0 && m % WC_TILE == 0);
+    PCD_CHECK_ARG(chain == 0 || in2 != nullptr);
+    WcParams p{};
+    p.in1 = (const half_t*)in1; p.in2 = (const half_t*)in2; p.m = m;
+    p.wpacked = (const char*)packed;
+    p.bias = (const float*)((const char*)packed + (size_t)16 * WC_STAGE);
+    p.out = (half_t*)out;
+    p.nseg = 4;
+    if (chain == 0) {
+        p.ldo = 512;
+        p.seg[0] = WcSeg{1, 0, 1, 0, 256, 0, 0, 0};
+        p.seg[1] = WcSeg{0, 0, 1, 0, 256, 256, 0, 0};
+        p.seg[2] = WcSeg{0, 0, 2, 0, 256, 512, 1, 0};
+        p.seg[3] = WcSeg{0, 0, 2, 256, 256, 768, 0, 0};
+    } else {
+        p.ldo = 128;
+        p.seg[0] = WcSeg{1, 0, 0, 0, 256, 0, 0, 0};
+        p.seg[1] = WcSeg{2, 1, 1, 0, 256, 256, 0, 0};
+        p.seg[2] = WcSeg{0, 0, 1, 0, 256, 512, 0, 0};
+        p.seg[3] = WcSeg{0, 0, 2, 0, 128, 768, 0, 0};
+    }
+    static bool attr_set = false;
+    const size_t lds = (size_t)WC_RING * WC_STAGE + 4 * 256 * sizeof(float);
+    if (!attr_set) {
+        PCD_CHECK_HIP(hipFuncSetAttribute((const void*)pw_wide_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int64_t tiles = m / WC_TILE;
+    const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+    hipLaunchKernelGGL(pw_wide_chain_kernel, dim3(grid), dim3(WC_THREADS), lds, (hipStream_t)stream, p);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}

@@ -186,6 +186,15 @@ int pcd_conv1x1_f16(const void* in, int64_t m, int k, const void* w, int64_t ldw
                     void* out, void* stream);
 /* testing / tuning hook for pcd_unet_forward: 0 = one GEMM launch per layer, 1 (default) = the chained kernels above */
 int pcd_unet_config(int use_chains);
+/* The 256-channel chains of the same network as one launch each (csrc/widechain.hip): chain 0 = enc3.conv1-3 (x2 [M][256] -> x3 [M][512]),
+ * chain 1 = dec2.conv1-3 ([in1 [M][256] | in2 [M][256]] -> [M][128]).  A wave carries 32 points through the chain with the activations
+ * in registers (the layer-to-layer hand-over is a v_permlane32_swap per register); only the weights stream, as 32-KB stage images that
+ * pcd_pw_wide_pack builds once from the three layers' [C][K] fp16 weights and fp32 biases (BatchNorm folded, as for pcd_gemm_f16) into a
+ * caller-owned buffer of pcd_pw_wide_packed_bytes(chain) bytes.  M must be a multiple of 256.  pcd_unet_config bit 1 switches
+ * pcd_unet_forward between these chains and one GEMM launch per layer (bit 0: the narrow chains above). */
+size_t pcd_pw_wide_packed_bytes(int chain);
+int pcd_pw_wide_pack(int chain, const void* const* w, const float* const* b, void* packed, void* stream);
+int pcd_pw_wide_chain(int chain, const void* in1, const void* in2, int64_t m, const void* packed, void* out, void* stream);
 
 typedef struct pcd_unet pcd_unet_t;
 int pcd_unet_create(const pcd_unet_desc_t* desc, pcd_unet_t** out);

@@ -65,17 +65,73 @@ def test_chained_narrow_layers_match_per_layer_launches(model, B, N):
     g = torch.Generator().manual_seed(B * 1000 + N)
     x = torch.randn(B, N, 3, generator=g).cuda()
     t = torch.randint(0, 1000, (B,), generator=g).cuda()
-    eps_chain = model.model(x, t).clone()
-    x1_chain = model.model.tap("x1", B, N).clone()
-    _lib.check(lib.pcd_unet_config(0))
+    _lib.check(lib.pcd_unet_config(1))                  # narrow chains only (the 256-channel chains sum in another order)
     try:
+        eps_chain = model.model(x, t).clone()
+        x1_chain = model.model.tap("x1", B, N).clone()
+        _lib.check(lib.pcd_unet_config(0))
         eps_layers = model.model(x, t).clone()
         x1_layers = model.model.tap("x1", B, N).clone()
     finally:
-        _lib.check(lib.pcd_unet_config(1))
+        _lib.check(lib.pcd_unet_config(3))
     assert torch.isfinite(eps_chain).all()
     assert torch.equal(x1_chain, x1_layers)
     assert torch.equal(eps_chain, eps_layers)
+
+
+@pytest.mark.parametrize("chain", [0, 1])
+def test_wide_chain_exact_on_integers(chain):
+    """csrc/widechain.hip: enc3 (256 -> 256 -> 256 -> 512) and dec2 ([256 | 256] -> 256 -> 256 -> 128) with the activations in
+    registers between the layers.  Small-integer weights, biases and inputs make every product and sum exact in fp16 / fp32,
+    so the result must equal the float64 chain of relu(x W^T + b) exactly -- any mistake in the fragment regrouping
+    (v_permlane32_swap), the packed stage order or the ring shows as a wrong integer."""
+    from shapegen_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(40 + chain)
+    m = 1024 + 256
+    shapes = [(256, 256), (256, 256), (512, 256)] if chain == 0 else [(256, 512), (256, 256), (128, 256)]
+    ws = [torch.randint(-1, 2, s_, generator=g).float() * (torch.rand(s_, generator=g) < 0.06).float() for s_ in shapes]
+    bs = [torch.randint(-2, 3, (s_[0],), generator=g).float() for s_ in shapes]
+    x1 = torch.randint(0, 3, (m, 256), generator=g).float()
+    x2 = torch.randint(0, 3, (m, 256), generator=g).float()
+    a = torch.cat([x1, x2], 1).double() if chain == 1 else x1.double()
+    for w, b in zip(ws, bs):
+        a = torch.relu(a @ w.double().T + b.double())
+        assert float(a.max()) < 2048                                   # exactly representable in fp16
+    dw = [w.half().cuda().contiguous() for w in ws]
+    db = [b.cuda().contiguous() for b in bs]
+    packed = torch.empty(int(lib.pcd_pw_wide_packed_bytes(chain)), dtype=torch.uint8, device="cuda")
+    import ctypes as C
+    wp = (C.c_void_p * 3)(*[t.data_ptr() for t in dw])
+    bp = (C.c_void_p * 3)(*[t.data_ptr() for t in db])
+    _lib.check(lib.pcd_pw_wide_pack(chain, wp, bp, packed.data_ptr(), _lib.stream_ptr()))
+    out = torch.full((m, shapes[2][0]), -1.0, dtype=torch.float16, device="cuda")
+    d1, d2 = x1.half().cuda(), x2.half().cuda()
+    _lib.check(lib.pcd_pw_wide_chain(chain, d1.data_ptr(), d2.data_ptr() if chain == 1 else 0, m, packed.data_ptr(), out.data_ptr(),
+                                     _lib.stream_ptr()))
+    assert torch.equal(out.double().cpu(), a)
+    assert lib.pcd_pw_wide_chain(chain, d1.data_ptr(), d2.data_ptr(), 100, packed.data_ptr(), out.data_ptr(), _lib.stream_ptr()) != 0
+
+
+def test_wide_chains_in_the_forward(model):
+    """pcd_unet_forward with the 256-channel chains on (default) against one GEMM launch per layer for the same six layers: the same
+    fp16 operands, fp32 sums in another order, one fp16 rounding per layer either way."""
+    from shapegen_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(2, 512, 3, generator=g).cuda()
+    t = torch.rand(2, generator=g).cuda()
+    eps_wide = model.model(x, t).clone()
+    x3_wide = model.model.tap("x3", 2, 512).clone()
+    _lib.check(lib.pcd_unet_config(1))
+    try:
+        eps_layers = model.model(x, t).clone()
+        x3_layers = model.model.tap("x3", 2, 512).clone()
+    finally:
+        _lib.check(lib.pcd_unet_config(3))
+    assert torch.isfinite(eps_wide).all()
+    assert rel_l2(x3_wide.float().cpu(), x3_layers.float().cpu()) < 1e-3
+    assert rel_l2(eps_wide.cpu(), eps_layers.cpu()) < 1e-3
 
 
 def test_forward_ragged_sizes(model):
