@@ -60,6 +60,7 @@ struct LpLayer {
     int slabs;                         // 0: the unit finishes the layer itself; S >= 1: S K-slices of fp32 partial tiles + finish units
     int out_off;                       // byte offset (inside a set) of this layer's output: fp16 fragment-major, or eps fp32 [32][256]
     int slab_off;                      // byte offset (inside a set) of the fp32 slabs [S][32][C]
+    int slab_local;                    // 1: every GroupNorm group's partial tiles are produced and finished on ONE XCD: plain stores for them too
     int out_local;                     // 1: producers and consumers of this layer's outputs all sit on XCD 0: plain stores (the XCD's L2 is
                                        //    their meeting point: ~0.4 us per hand-off instead of ~0.9 through the fabric); 0: sc1 write-through
 };
@@ -266,7 +267,7 @@ __device__ __forceinline__ void lp_gemm_store(const LpCtx& c, const LpLayer& L, 
             const int off = set_off + L.slab_off + ((U.slice * 32 + row) * L.c + col) * 4;
             u32x4 o = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
             if (!poison) o = (u32x4){__float_as_uint(v[t][0]), __float_as_uint(v[t][1]), __float_as_uint(v[t][2]), __float_as_uint(v[t][3])};
-            lp_st16(c, o, off, L.out_local);
+            lp_st16(c, o, off, L.slab_local);
         } else if (L.mode == 2) {                           // eps fp32 [32][C]
             const int off = set_off + L.out_off + (row * L.c + col) * 4;
             u32x4 o = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
@@ -776,6 +777,7 @@ bool lp_build_plan(const pcd_latent_desc_t& d, LpPlan& plan) {
         L.c = kC[l]; L.gsz = kC[l] / 8; L.mode = l < 10 ? 0 : (l == 10 ? 1 : 2);
         L.slabs = kSlabs[l]; L.out_off = out_off[l]; L.slab_off = slab_off[l];
         L.out_local = (l == 0 || l == 1 || l == 8 || l == 9 || l == 10 || l == 11) ? 1 : 0;      // producers and consumers all on XCD 0
+        L.slab_local = kSlabs[l] > 0 ? 1 : 0;          // finish units are placed on the XCD that produces their group (checked below)
     }
     struct Item { int wg, phase; LpUnit u; int wbytes; };
     std::vector<Item> items;
@@ -808,13 +810,36 @@ bool lp_build_plan(const pcd_latent_desc_t& d, LpPlan& plan) {
         else if (w < 192) gemm(w, 3, 32 * (w - 160), 1, 0, 8, 0, 0);           // enc4: 32 tiles, 32 KB
         else { const int u = w - 192; gemm(w, 7, 32 * (u >> 2), 1, 6 * (u & 3), 6, u & 3, 0); }                  // dec3: 16 tiles x 4, 24 KB
     }
-    const int fin_layers[6] = {3, 4, 5, 6, 7, 8};
-    const int fin_base[6] = {32, 64, 96, 128, 160, 0};       // dec2's finish units on XCD 0, the others anywhere else
-    for (int f = 0; f < 6; ++f) {
-        const int l = fin_layers[f], gsz = kC[l] / 8;
-        const int rows = gsz >= 64 ? 8 : 16, per_group = 32 / rows;
-        for (int g = 0; g < 8; ++g)
-            for (int rb = 0; rb < per_group; ++rb) finish(fin_base[f] + g * per_group + rb, l, g, rb * rows);
+    // Finish units go to the XCD whose workgroups produce their group's partial tiles (all K slices of all its column tiles: true for every
+    // layer of this assignment, verified here), so that hand-over too stays in one L2; inside the XCD, to the workgroup with the most LDS left
+    // for the unit's constants.
+    {
+        std::vector<int> used(LP_WGS, LP_RED_BYTES);
+        for (const Item& it : items) used[it.wg] += it.wbytes + (it.u.head ? LP_Z16_BYTES : 0) + (kSlabs[it.u.layer] == 0 ? 768 : 0);
+        const int fin_layers[6] = {5, 4, 3, 6, 7, 8};         // largest constants first
+        for (int f = 0; f < 6; ++f) {
+            const int l = fin_layers[f], gsz = kC[l] / 8;
+            const int rows = gsz >= 64 ? 8 : 16, per_group = 32 / rows;
+            for (int g = 0; g < 8; ++g) {
+                int xcd = -1;
+                for (const Item& it : items)
+                    if (it.u.kind == LP_GEMM && it.u.layer == l && it.u.col0 / gsz == g) {
+                        if (it.u.col0 / gsz != (it.u.col0 + 32 * it.u.ct - 1) / gsz) return false;
+                        if (xcd >= 0 && xcd != it.wg / 32) return false;
+                        xcd = it.wg / 32;
+                    }
+                if (xcd < 0) return false;
+                for (int rb = 0; rb < per_group; ++rb) {
+                    int best = -1;
+                    for (int r = 0; r < 32; ++r) {
+                        const int w = xcd * 32 + r;
+                        if (best < 0 || used[w] < used[best]) best = w;
+                    }
+                    used[best] += 3 * gsz * 4;
+                    finish(best, l, g, rb * rows);
+                }
+            }
+        }
     }
     std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.wg != b.wg ? a.wg < b.wg : a.phase < b.phase; });
     plan.units.assign((size_t)LP_WGS * LP_MAX_UNITS, LpUnit{});
@@ -870,8 +895,17 @@ extern "C" int pcd_latent_persist_plan_check(void) {
             if (u.kind == LP_END) { ended = true; continue; }
             if (ended) return -1;
             const int phase = 2 * u.layer + (u.kind == LP_FINISH ? 1 : 0);
-            if (phase <= last_phase) return -1;
+            if (phase < last_phase || (phase == last_phase && u.kind != LP_FINISH)) return -1;     // (two finish units of a layer may share a workgroup)
             last_phase = phase;
+            // partial tiles stored plain: the finish unit of a group sits on the XCD of that group's gemm units
+            if (u.kind == LP_FINISH && plan.layers[u.layer].slab_local) {
+                const int gsz = kC[u.layer] / 8;
+                for (int w2 = 0; w2 < LP_WGS; ++w2)
+                    for (int i2 = 0; i2 < LP_MAX_UNITS; ++i2) {
+                        const LpUnit& v = plan.units[(size_t)w2 * LP_MAX_UNITS + i2];
+                        if (v.kind == LP_GEMM && v.layer == u.layer && v.col0 / gsz == u.group && w2 / 32 != w / 32) return -1;
+                    }
+            }
             // a layer whose outputs are stored plain (XCD-local) must be produced AND consumed on XCD 0 only (virtual ids < 32)
             if (plan.layers[u.layer].out_local && w >= 32) return -1;
             if (u.kind == LP_GEMM) {
