@@ -194,6 +194,7 @@ _SIGS = {
     "pcd_attn_unet_workspace_bytes": (sz, [i32, i32]),
     "pcd_attn_unet_time_bias": (i32, [vp, vp, i32, vp, vp, vp]),
     "pcd_attn_unet_forward": (i32, [vp, vp, i32, i32, vp, i32, vp, vp, sz, vp]),
+    "pcd_attn_unet_tap": (i32, [vp, C.c_char_p, i32, i32, vp, vp, sz, vp]),
     "pcd_normalize_to_cube": (i32, [vp, i32, i32, vp, vp]),
     "pcd_chamfer_sums": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "pcd_voxelize": (i32, [vp, i32, i32, i32, vp, vp]),

@@ -236,3 +236,19 @@ extern "C" int pcd_attn_unet_forward(pcd_attn_unet_t* h, const float* x, int bat
 #undef RUN
     return PCD_OK;
 }
+
+// parity taps: the three skip tensors of the last forward (x1 = att1 + emb2 [m][64], x2 = att2 + emb3 [m][128], x3 = att3 [m][256], fp16)
+extern "C" int pcd_attn_unet_tap(pcd_attn_unet_t* h, const char* name, int batch, int n_points, const void* workspace, void* dst,
+                                 size_t dst_bytes, void* stream) {
+    PCD_CHECK_ARG(h && name && workspace && dst && batch > 0 && n_points > 0);
+    const AuWs w = au_carve(batch, n_points);
+    const size_t m = (size_t)batch * n_points;
+    size_t off = 0, bytes = 0;
+    if (name[0] == 'x' && name[1] == '1' && !name[2]) { off = w.x1; bytes = m * 64 * 2; }
+    else if (name[0] == 'x' && name[1] == '2' && !name[2]) { off = w.x2; bytes = m * 128 * 2; }
+    else if (name[0] == 'x' && name[1] == '3' && !name[2]) { off = w.x3; bytes = m * 256 * 2; }
+    else { set_error("pcd_attn_unet_tap: unknown tap '%s'", name); return PCD_ERR_ARG; }
+    PCD_CHECK_ARG(dst_bytes >= bytes);
+    PCD_CHECK_HIP(hipMemcpyAsync(dst, (const char*)workspace + off, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return PCD_OK;
+}

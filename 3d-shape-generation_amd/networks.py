@@ -379,6 +379,14 @@ class UNetAttentionPointExperimental(_HipModule):
         x = x.to(torch.float32).contiguous()
         return self.forward_with_bias(x, self.time_bias(t), 1)
 
+    def tap(self, name: str, batch: int, n_points: int) -> torch.Tensor:
+        """Skip tensor of the last forward (parity tests): x1 / x2 / x3 as (B, N, 64 / 128 / 256) fp16."""
+        ws = self._ws[(batch, n_points)]
+        dst = torch.empty(batch, n_points, {"x1": 64, "x2": 128, "x3": 256}[name], dtype=torch.float16, device=self.device)
+        _lib.check(_lib.load().pcd_attn_unet_tap(self._handle, name.encode(), batch, n_points, ws.data_ptr(), dst.data_ptr(),
+                                                 dst.numel() * 2, _lib.stream_ptr()), "attn_unet_tap")
+        return dst
+
 
 # ------------------------------------------------------------------ latent denoiser
 class SimpleLatentUNetPointNet(_HipModule):

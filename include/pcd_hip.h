@@ -456,6 +456,9 @@ int pcd_attn_unet_time_bias(pcd_attn_unet_t* h, const float* t, int n_t, float* 
 /* eps = model(x, t) given the time-bias rows: tbias row (b * tbias_shape_stride), stride 0 = one t for every shape */
 int pcd_attn_unet_forward(pcd_attn_unet_t* h, const float* x, int batch, int n_points, const float* tbias,
                           int tbias_shape_stride, float* eps, void* workspace, size_t workspace_bytes, void* stream);
+/* parity taps of the last forward: "x1" [B*N][64], "x2" [B*N][128], "x3" [B*N][256] fp16 (the skip tensors, networks.py:663-672) */
+int pcd_attn_unet_tap(pcd_attn_unet_t* h, const char* name, int batch, int n_points, const void* workspace, void* dst,
+                      size_t dst_bytes, void* stream);
 
 /* ------------------------------------------------------------- metrics (K10-K12)
  * normalize_to_cube (metrics.py:7-21) for B clouds of N points, fp32 in/out. */

@@ -165,8 +165,9 @@ def set_attention_block(sd: SD, p: str, x: torch.Tensor, heads: int = 4) -> torc
 
 
 def unet_attention(sd: SD, p: str, x: torch.Tensor, t: torch.Tensor,
-                   time_dim: int = 256, heads: int = 4) -> torch.Tensor:
-    """networks.py:652-704 (UNetAttentionPointExperimental.forward)."""
+                   time_dim: int = 256, heads: int = 4, taps: dict = None) -> torch.Tensor:
+    """networks.py:652-704 (UNetAttentionPointExperimental.forward).  `taps` (optional dict) receives the three skip tensors
+    x1 / x2 / x3 as (B, N, C): the values after att1 + emb2, att2 + emb3 and att3 (networks.py:663-672)."""
     te = time_mlp(sd, p, timestep_embedding(t, time_dim).float())
 
     def emb(name):
@@ -181,6 +182,8 @@ def unet_attention(sd: SD, p: str, x: torch.Tensor, t: torch.Tensor,
     x2 = att("att2", pointnet_layer(sd, p + "enc2", x1))
     x2 = x2 + emb("emb3")
     x3 = att("att3", pointnet_layer(sd, p + "enc3", x2))
+    if taps is not None:
+        taps.update(x1=x1.transpose(2, 1), x2=x2.transpose(2, 1), x3=x3.transpose(2, 1))
     xb = att("bottleneck", x3)
     xb = att("att_dec3", xb + emb("emb_dec3"))
     h = pointnet_layer(sd, p + "dec3", torch.cat([xb, x3], dim=1))

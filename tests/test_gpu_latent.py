@@ -1,7 +1,7 @@
 """Latent path parity: SimpleLatentUNetPointNet, VAE3DLarge encode/decode (implicit-GEMM 3-D
 convolutions), LatentDiffusion samplers -- HIP through the C ABI vs reference goldens / oracle.
-Tolerances: fp16 operands + fp32 accumulate.  latent eps rel-L2 <= 3e-3; VAE mu/logvar <= 1e-2
-(11 conv layers deep), decoded occupancy probabilities max-abs <= 2e-2."""
+Tolerances: fp16 operands + fp32 accumulate.  latent eps rel-L2 <= 3e-3; VAE mu/logvar <= 3e-3
+(11 conv layers deep), decoded occupancy probabilities max-abs <= 5e-3 on in-distribution latents."""
 import numpy as np
 import pytest
 import torch
@@ -247,11 +247,11 @@ def test_vae_encode_decode(ldm, golden):
     g = golden("latent.npz")
     vox = voxels_from_idx([g["vae_occ_idx"], g["vae_occ_idx1"]]).cuda()
     mu, logvar = ldm.vae.encode(vox)
-    assert rel_l2(mu.cpu(), g["vae_mu"]) < 1e-2 and rel_l2(logvar.cpu(), g["vae_logvar"]) < 1e-2
+    assert rel_l2(mu.cpu(), g["vae_mu"]) < 3e-3 and rel_l2(logvar.cpu(), g["vae_logvar"]) < 3e-3    # measured 1.1e-3 / 1.0e-3
     dec = ldm.vae.decode(torch.from_numpy(g["vae_mu"]).cuda())
     assert dec.shape == (2, 1, 32, 32, 32)
     err = (dec.cpu() - torch.from_numpy(g["vae_dec"])).abs()
-    assert float(err.max()) < 2e-2 and float(err.mean()) < 2e-3
+    assert float(err.max()) < 5e-3 and float(err.mean()) < 5e-4                                      # measured 1.4e-3 / 1.9e-4
     # voxel->points on the HIP-decoded grid: the occupied set may differ from the reference only where
     # the probability is within the decode tolerance of the threshold
     want = torch.from_numpy(g["vae_dec"])
@@ -308,9 +308,9 @@ def test_cfg4_launch_shapes_vs_reference(ldm, golden):
     vox = synth_voxels(32, 4).cuda()
     mu, logvar = ldm.vae.encode(vox)
     assert mu.shape == (32, 256)
-    assert rel_l2(mu.cpu(), g["enc_mu"]) < 1e-2 and rel_l2(logvar.cpu(), g["enc_logvar"]) < 1e-2
+    assert rel_l2(mu.cpu(), g["enc_mu"]) < 3e-3 and rel_l2(logvar.cpu(), g["enc_logvar"]) < 3e-3
     for i in rows:                                                   # per row too: no sample hides behind the batch norm
-        assert rel_l2(mu[i].cpu(), g["enc_mu"][i]) < 1.5e-2, i
+        assert rel_l2(mu[i].cpu(), g["enc_mu"][i]) < 5e-3, i
     for persistent in (True, False):                       # one persistent launch for the 1000 steps / per-layer launches
         ldm.use_persistent = persistent
         try:
@@ -431,10 +431,10 @@ def test_vae3d_small(golden):
     vae = vae.to("cuda").eval()
     vox = voxels_from_idx([g["occ_idx0"], g["occ_idx1"]]).cuda()
     mu, logvar = vae.encode(vox)
-    assert rel_l2(mu.cpu(), g["mu"]) < 1e-2 and rel_l2(logvar.cpu(), g["logvar"]) < 1e-2
+    assert rel_l2(mu.cpu(), g["mu"]) < 3e-3 and rel_l2(logvar.cpu(), g["logvar"]) < 3e-3
     dec = vae.decode(torch.from_numpy(g["mu"]).cuda())
     err = (dec.cpu() - torch.from_numpy(g["dec"])).abs()
-    assert dec.shape == (2, 1, 32, 32, 32) and float(err.max()) < 2e-2 and float(err.mean()) < 2e-3
+    assert dec.shape == (2, 1, 32, 32, 32) and float(err.max()) < 5e-3 and float(err.mean()) < 5e-4
     pcs = vae.sample(2, threshold=0.4, z=torch.from_numpy(g["mu"]).cuda())
     assert len(pcs) == 2 and all(p.shape[1] == 3 for p in pcs)
 
