@@ -14,6 +14,7 @@ G5-G7 point_samplers.npz, G8 latent.npz, G9 metrics.npz, G10 attention.npz; beyo
 G11 vae3d_small.npz (`make_golden.py vae3d`), G12 data.npz (`make_golden.py data`), G13 train.npz
 (`make_golden.py train`), G14 train_latent.npz (`make_golden.py train_latent`), G15 train_vae.npz (`make_golden.py train_vae`),
 G16 linear.npz (`make_golden.py linear`: the linear schedule's per-shape rate tables and sampler outputs),
+G18 point_n2048.npz (`make_golden.py n2048`: `PointCloudDiffusion.sample(2, 2048, num_steps=50)` at the BASELINE point count, start noise recorded),
 G17 cfg4.npz (`make_golden.py cfg4`: BASELINE configs[3] at its real launch shape -- 32 grids through `VAE3DLarge.encode`,
 `LatentDiffusion.sample(32, num_steps=1000)` with the start noise recorded, the decoded grids of four rows).
 """
@@ -121,6 +122,22 @@ def capture_linear_schedule(rd):
     g["s3_out"] = pcd.sample3(B, N, x=noisy, start_t=tt, num_steps=Tn).numpy()
     np.savez_compressed(os.path.join(OUT, "linear.npz"), **g)
     print("linear done: |sample| max", float(out.abs().max()), "|sample2| max", float(out2.abs().max()))
+
+
+def capture_n2048(rd):
+    """G18: the DDIM sampler at BASELINE's N = 2048 (diffusion.py:261-289), 2 shapes, 50 steps: the Chamfer gate of the north star
+    needs a reference cloud at the full point count, not only at (4, 512)."""
+    pspec = specs.unet_pointnet_large_spec(prefix="model.")
+    pcd = rd.PointCloudDiffusion(num_points=2048).eval()
+    pcd.load_state_dict(T(specs.synth_state_dict(pspec, seed=0, gain=POINT_GAIN)), strict=True)
+    t0 = time.time()
+    torch.manual_seed(24)
+    out = pcd.sample(2, 2048, num_steps=50)
+    torch.manual_seed(24)
+    xT = torch.randn(2, 2048, 3)
+    print("n2048 sample", time.time() - t0, "|out| max", float(out.abs().max()))
+    np.savez_compressed(os.path.join(OUT, "point_n2048.npz"), xT=xT.numpy(), out=out.numpy())
+    print("point_n2048.npz", os.path.getsize(os.path.join(OUT, "point_n2048.npz")))
 
 
 def capture_cfg4(rd, rn, ru):
@@ -397,6 +414,9 @@ def main():
         return
     if "cfg4" in sys.argv[1:]:
         capture_cfg4(rd, rn, ru)
+        return
+    if "n2048" in sys.argv[1:]:
+        capture_n2048(rd)
         return
     if "linear" in sys.argv[1:]:
         capture_linear_schedule(rd)

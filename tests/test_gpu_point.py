@@ -165,6 +165,28 @@ def test_ddim_sample(model, golden, T):
     assert cd_pair < 2e-3
 
 
+def test_ddim_sample_chamfer_gate_at_2048_points(golden):
+    """The north star's quality gate at BASELINE's point count (G18: the reference's `sample(2, 2048, num_steps=50)`):
+    |CD_build - CD_ref| <= 1e-4 (scaling 1) against the same third cloud, cloud rel-L2 <= 5e-3; CD(gpu cloud, reference
+    cloud) itself is printed (fp16 operands put it at a few 1e-4, above the oracle's own cdist floor of 8e-5)."""
+    from shapegen_amd import metrics as M
+    from shapegen_amd.diffusion import PointCloudDiffusion
+    g = golden("point_n2048.npz")
+    m = PointCloudDiffusion(num_points=2048)
+    m.load_state_dict(point_sd(), strict=True)
+    m = m.to("cuda").eval()
+    out = m.sample(2, 2048, num_steps=50, x_T=torch.from_numpy(g["xT"]).cuda())
+    want = torch.from_numpy(g["out"])
+    assert rel_l2(out.cpu(), want) < 5e-3
+    other = torch.from_numpy(g["xT"]).cuda()
+    cd_build = float(M.chamfer_distance(out, other, 1))
+    cd_ref = float(M.chamfer_distance(want.cuda(), other, 1))
+    cd_pair = float(M.chamfer_distance(out, want.cuda(), 1))
+    print(f"N=2048 T=50: CD(gpu,ref)={cd_pair:.3e}  CD_build={cd_build:.6f} CD_ref={cd_ref:.6f}")
+    assert abs(cd_build - cd_ref) < 1e-4, (cd_build, cd_ref)
+    assert cd_pair < 2e-3
+
+
 def test_ddpm_sample2(model, golden):
     g = golden("point_samplers.npz")
     out = model.sample2(2, 64, num_steps=20, x_T=torch.from_numpy(g["s2_xT"]).cuda(),

@@ -132,6 +132,14 @@ def test_latent_ddim(golden):
     assert np.array_equal(pcs[0].numpy(), g["ldm_T5_pc0"])
 
 
+def test_ddim_sampler_at_baseline_point_count(golden):
+    """G18 (`make_golden.py n2048`): `sample(2, 2048, num_steps=50)` of the reference at BASELINE's N = 2048."""
+    g = golden("point_n2048.npz")
+    sd = point_sd()
+    out = O.ddim_sample(lambda x, t: O.unet_pointnet_large(sd, "model.", x, t), torch.from_numpy(g["xT"]), 50)
+    assert rel_l2(out, g["out"]) < 1e-5
+
+
 def test_cfg4_launch_shape_rows(golden):
     """G17 (`make_golden.py cfg4`): the reference at BASELINE configs[3]'s shape, B = 32, T = 1000.  Every sample is
     independent (GroupNorm per sample, eval BatchNorm3d), so the oracle runs the four decoded rows only."""
