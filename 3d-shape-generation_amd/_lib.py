@@ -204,7 +204,6 @@ _SIGS = {
     "pcd_sinkhorn_dual_update": (i32, [vp, vp, i32, i32, i32, vp, f32, f32, vp, vp, vp, vp]),
     "pcd_sinkhorn_cost": (i32, [vp, vp, i32, i32, i32, vp, f32, vp, vp, vp, vp, vp]),
     "pcd_pair_metrics_workspace_bytes": (sz, [i32, i32, i32]),
-    "pcd_pair_metrics_config": (i32, [i32]),
     "pcd_pair_metrics": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, f32, f32, i32, vp, vp, vp, vp, sz, vp]),
     "pcd_colsum_f16": (i32, [vp, i64, i32, i32, vp, vp]),
     "pcd_bn_batch_stats": (i32, [vp, i64, i32, f32, vp, vp, vp, vp, vp, vp]),

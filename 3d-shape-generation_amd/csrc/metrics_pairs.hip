@@ -118,84 +118,6 @@ __global__ __launch_bounds__(256) void pair_chamfer_min_kernel(const float* __re
     }
 }
 
-// Both directions in ONE pass: every distance is evaluated once.  grid (query blocks of 256 * CQ over cloud a, target splits over cloud b, P).
-// A thread keeps CQ queries of a in registers and their running minima (the a -> b direction, as above); for the b -> a direction the minimum
-// over the workgroup's 1024 queries of every target j is formed where it is cheapest: 3 v_min over the thread's CQ distances, a 6-step DPP
-// reduction across the wave (v_min_f32 with quad_perm / row_mirror / row_bcast modifiers: no LDS traffic), one ds_min_u32 per wave into an LDS
-// slot of the tile (d^2 >= 0, so the float bits order as unsigned ints), one global atomicMin per target and tile.  ~42 VALU instructions per target
-// and thread against 2 x 32 for two one-direction passes; minima are order independent, so the result is bit-identical to theirs.
-__device__ __forceinline__ float pm_wave_min_dpp(float v) {
-    // after the six steps lane 63 holds the minimum of the wave (every lane holds the minimum of a growing neighbourhood)
-#define PM_DPP(ctrl, rmask)                                                                                             \
-    v = fminf(v, __uint_as_float((unsigned)__builtin_amdgcn_update_dpp((int)__float_as_uint(v), (int)__float_as_uint(v), ctrl, rmask, 0xf, false)))
-    PM_DPP(0xB1, 0xf);          // quad_perm [1,0,3,2]
-    PM_DPP(0x4E, 0xf);          // quad_perm [2,3,0,1]
-    PM_DPP(0x141, 0xf);         // row_half_mirror
-    PM_DPP(0x140, 0xf);         // row_mirror
-    PM_DPP(0x142, 0xa);         // row_bcast15 into rows 1 and 3
-    PM_DPP(0x143, 0xc);         // row_bcast31 into rows 2 and 3
-#undef PM_DPP
-    return v;
-}
-
-__global__ __launch_bounds__(256) void pair_chamfer_both_kernel(const float* __restrict__ an, const int* __restrict__ na, int NA,
-                                                                 const float* __restrict__ bn, const int* __restrict__ nb, int NB,
-                                                                 int NQ, unsigned* __restrict__ mins) {
-    __shared__ float4 tile[PT];
-    __shared__ unsigned colmin[PT];
-    const int p = blockIdx.z;
-    const float* q = an + (int64_t)p * NA * 3;
-    const float* r = bn + (int64_t)p * NB * 3;
-    const int nq = na[p], nr = nb[p];
-    const int q0 = blockIdx.x * (256 * CQ);
-    if (q0 >= nq) return;
-    const int per = (nr + gridDim.y - 1) / gridDim.y;
-    const int r_lo = blockIdx.y * per, r_hi = min(nr, r_lo + per);
-    if (r_lo >= r_hi) return;
-    const int lane = threadIdx.x & 63;
-    float qx[CQ], qy[CQ], qz[CQ], best[CQ];
-#pragma unroll
-    for (int c = 0; c < CQ; ++c) {
-        int qi = q0 + c * 256 + threadIdx.x;
-        qi = qi < nq ? qi : nq - 1;                          // clamped duplicates: same distances as a real query, harmless in a minimum
-        qx[c] = q[qi * 3]; qy[c] = q[qi * 3 + 1]; qz[c] = q[qi * 3 + 2];
-        best[c] = INFINITY;
-    }
-    unsigned* mins_a = mins + (int64_t)(2 * p) * NQ;
-    unsigned* mins_b = mins + (int64_t)(2 * p + 1) * NQ;
-    for (int r0 = r_lo; r0 < r_hi; r0 += PT) {
-        const int cnt = min(PT, r_hi - r0);
-        __syncthreads();
-        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
-            const float* t = r + (int64_t)(r0 + i) * 3;
-            tile[i] = make_float4(t[0], t[1], t[2], 0.f);
-            colmin[i] = 0x7f7f7f7fu;
-        }
-        __syncthreads();
-#pragma unroll 2
-        for (int j = 0; j < cnt; ++j) {
-            const float4 t = tile[j];
-            float m = INFINITY;
-#pragma unroll
-            for (int c = 0; c < CQ; ++c) {
-                const float dx = qx[c] - t.x, dy = qy[c] - t.y, dz = qz[c] - t.z;
-                const float d2 = dx * dx + dy * dy + dz * dz;
-                best[c] = fminf(best[c], d2);
-                m = fminf(m, d2);
-            }
-            m = pm_wave_min_dpp(m);
-            if (lane == 63) atomicMin(&colmin[j], __float_as_uint(m));
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < cnt; i += blockDim.x) atomicMin(mins_b + r0 + i, colmin[i]);
-    }
-#pragma unroll
-    for (int c = 0; c < CQ; ++c) {
-        const int qi = q0 + c * 256 + threadIdx.x;
-        if (qi < nq) atomicMin(mins_a + qi, __float_as_uint(best[c]));
-    }
-}
-
 // grid (P): cd[p] = sum_i sqrt(min_a[i]) / na + sum_j sqrt(min_b[j]) / nb, fixed summation order (metrics.py:41-46)
 __global__ __launch_bounds__(256) void pair_chamfer_sum_kernel(const unsigned* __restrict__ mins, const int* __restrict__ na,
                                                                 const int* __restrict__ nb, int NQ, float* __restrict__ rows) {
@@ -423,12 +345,6 @@ static PmWs pm_carve(int P, int NA, int NB) {
 
 using namespace pcd;
 
-static int g_pair_chamfer_two_pass = 0;       // testing hook: 1 = the round-2 form (each direction its own pass)
-extern "C" int pcd_pair_metrics_config(int chamfer_two_pass) {
-    g_pair_chamfer_two_pass = chamfer_two_pass ? 1 : 0;
-    return PCD_OK;
-}
-
 extern "C" size_t pcd_pair_metrics_workspace_bytes(int pairs, int na_max, int nb_max) {
     if (pairs <= 0 || na_max <= 0 || nb_max <= 0) return 0;
     return pm_carve(pairs, na_max, nb_max).total;
@@ -461,17 +377,7 @@ extern "C" int pcd_pair_metrics(const float* a, const int* na, int na_max, const
     int tsplit = (int)ceil_div(1024, (int64_t)cqblocks * 2 * P);
     const int max_split = (int)ceil_div(NQ, 128);
     tsplit = tsplit < 1 ? 1 : (tsplit > max_split ? max_split : tsplit);
-    if (g_pair_chamfer_two_pass) {
-        hipLaunchKernelGGL(pair_chamfer_min_kernel, dim3(cqblocks, tsplit, 2 * P), dim3(256), 0, s, an, na, NA, bn, nb, NB, NQ, mins);
-    } else {
-        // one pass, every distance once: query blocks over cloud a, target splits over cloud b (twice the splits of one direction of the
-        // two-pass form, so that a single pair still spreads over the chip)
-        const int ablocks = (int)ceil_div(NA, 256 * CQ);
-        int bsplit = (int)ceil_div(1024, (int64_t)ablocks * P);
-        const int bmax = (int)ceil_div(NB, 128);
-        bsplit = bsplit < 1 ? 1 : (bsplit > bmax ? bmax : bsplit);
-        hipLaunchKernelGGL(pair_chamfer_both_kernel, dim3(ablocks, bsplit, P), dim3(256), 0, s, an, na, NA, bn, nb, NB, NQ, mins);
-    }
+    hipLaunchKernelGGL(pair_chamfer_min_kernel, dim3(cqblocks, tsplit, 2 * P), dim3(256), 0, s, an, na, NA, bn, nb, NB, NQ, mins);
     hipLaunchKernelGGL(pair_chamfer_sum_kernel, dim3(P), dim3(256), 0, s, mins, na, nb, NQ, rows);
     hipLaunchKernelGGL(pair_voxelize_bits_kernel, dim3(qblocks, P, 2), dim3(256), 0, s, a, na, NA, b, nb, NB, bits);   // the RAW clouds (metrics.py:181)
     hipLaunchKernelGGL(pair_bce_kernel, dim3(P), dim3(256), 0, s, bits, rows);

@@ -499,8 +499,6 @@ int pcd_sinkhorn_cost(const float* x, const float* y, int batch, int n, int m, c
  * convergence test (kept on the device: all max_iter iterations are enqueued, converged pairs skip theirs; no host
  * synchronisation).  log_mu[p] = log(1/na[p] + 1e-10), log_nu likewise, fp32 device arrays from the host's torch ops. */
 size_t pcd_pair_metrics_workspace_bytes(int pairs, int na_max, int nb_max);
-/* testing hook: 1 = Chamfer as two one-direction passes (the round-2 form), 0 (default) = one pass that evaluates every distance once */
-int pcd_pair_metrics_config(int chamfer_two_pass);
 int pcd_pair_metrics(const float* a, const int* na, int na_max, const float* b, const int* nb, int nb_max, int pairs,
                      int with_sinkhorn, float epsilon, float thresh, int max_iter, const float* log_mu,
                      const float* log_nu, float* rows, void* workspace, size_t workspace_bytes, void* stream);
