@@ -9,8 +9,8 @@
 //     holds ALL 38.2 MB of weights: every workgroup stages its share once per call by LDS-DMA and keeps it, so
 //     no weight byte is on any step's critical path;
 //   * a layer = units (32 batch rows x 32 columns x a K slice, v_mfma_f32_32x32x16_f16, 4 waves split the slice) that
-//     publish fp32 partial tiles, + finish units (one GroupNorm group x 8 rows: slab sum in slice order, bias,
-//     GroupNorm, ReLU) that publish fp16 activations; layers whose 32-column unit holds whole GroupNorm groups over the
+//     publish fp32 partial tiles (the first slice's carries the bias), + finish units (one GroupNorm group x 8 rows: slab sum in
+//     slice order, GroupNorm, ReLU) that publish fp16 activations; layers whose 32-column unit holds whole GroupNorm groups over the
 //     full K (enc1-3, dec1, the output head) finish inside the unit;
 //   * there are NO flags, counters, atomics or fences between layers: the exchanged data carries its own validity.
 //     Activations are post-ReLU fp16 (sign bit clear), partial sums and eps are finite fp32; the buffers are poisoned
@@ -75,7 +75,8 @@ struct LpUnit {
     int lds_w;                         // gemm: byte offset of the unit's weight images in LDS
     int group, row0;                   // finish: GroupNorm group, first row
     int head;                          // gemm on the latent state: this workgroup keeps z
-    int lds_p;                         // byte offset in LDS of the unit's bias | gamma | beta rows (its columns only), or -1
+    int lds_p;                         // byte offset in LDS of the unit's constants (its columns only): gemm that finishes its layer
+                                       // bias | gamma | beta, slice-0 gemm of a layer with partial tiles bias, finish gamma | beta; or -1
     int pad[4];
 };
 
@@ -95,7 +96,7 @@ struct LpArgs {
     int forward_only;
     int sleep;                         // s_sleep argument between polls
     int predict;                       // sleep through most of the wait the previous step measured before probing
-    unsigned* trace;                   // diagnostic build only: [wg][step][unit][4] s_memrealtime stamps (enter, operands in, stored)
+    unsigned* trace;                   // diagnostic build only: [wg][step][unit][8] s_memrealtime stamps (enter, operands in, stored, epilogue computed, operands in of waves 0..3)
     int trace_steps;
 };
 
@@ -146,6 +147,28 @@ __device__ __forceinline__ unsigned lp_pack_relu_f16(float a, float b) {
     // post-ReLU values: saturate, round to fp16, sign bit cleared (the validity bit of the exchange)
     const half_t ha = to_half_sat(fmaxf(a, 0.f)), hb = to_half_sat(fmaxf(b, 0.f));
     return ((unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16)) & 0x7fff7fffu;
+}
+
+// Sum over the W consecutive lanes a lane belongs to (W = 2 .. 32, aligned groups), result in every lane: DPP quad permutes, half-row and
+// row mirrors (VALU, a few cycles each) and one v_permlane16_swap for the last step, instead of a chain of ds_bpermute round trips through
+// the LDS crossbar (~60 ns each, two dependent chains of up to five per GroupNorm: 0.3-0.5 us on every phase's critical path).  Both
+// partners of a pair add the same two numbers, so all lanes of a group end with identical bits.
+template <int CTRL>
+__device__ __forceinline__ float lp_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int W>
+__device__ __forceinline__ float lp_group_sum(float v) {
+    if constexpr (W >= 2) v += lp_dpp<0xB1>(v);              // quad_perm [1,0,3,2]
+    if constexpr (W >= 4) v += lp_dpp<0x4E>(v);              // quad_perm [2,3,0,1]
+    if constexpr (W >= 8) v += lp_dpp<0x141>(v);             // row_half_mirror: lane i <-> 7 - i of each 8
+    if constexpr (W >= 16) v += lp_dpp<0x140>(v);            // row_mirror: lane i <-> 15 - i of each 16
+    if constexpr (W >= 32) {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);     // rows (16 lanes) 0 <-> 1, 2 <-> 3
+        v = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    }
+    return v;
 }
 
 struct LpCtx {
@@ -326,7 +349,7 @@ __device__ __forceinline__ bool lp_run_gemm(const LpCtx& c, const LpLayer& L, co
         }
     }
     if (!ok) c.lds_flag[0] = 1;
-    if (c.tr != nullptr && c.tid == 0) c.tr[1] = lp_now();
+    if (c.tr != nullptr && c.lane == 0) { c.tr[4 + c.wave] = lp_now(); if (c.wave == 0) c.tr[1] = lp_now(); }
     // cross-wave reduction through LDS, one 32-column tile at a time
     float (*red)[32][33] = (float (*)[32][33])c.smem;
     const int row = c.tid >> 3, q = c.tid & 7;
@@ -342,6 +365,15 @@ __device__ __forceinline__ bool lp_run_gemm(const LpCtx& c, const LpLayer& L, co
             v[t][i] = (red[0][row][4 * q + i] + red[1][row][4 * q + i]) + (red[2][row][4 * q + i] + red[3][row][4 * q + i]);
     }
     if (c.lds_flag[0]) return false;                        // uniform: written before the barriers above
+    if (L.slabs > 0 && U.slice == 0) {
+        // partial tile of the first K slice: + bias here, so that the finish unit keeps only gamma | beta (its sum (s0 + b) + s1 + ...
+        // has the order of csrc/skinny.hip's finish)
+        const float* pst = (const float*)(c.smem + U.lds_p);
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[t][i] += pst[32 * t + 4 * q + i];
+    }
     if (L.slabs == 0) {
         // the unit holds whole GroupNorm groups over the full K: bias, GroupNorm, ReLU here; the per-column constants were
         // copied to LDS when the kernel started (a global load here is a memory round trip on every step's critical path)
@@ -356,15 +388,15 @@ __device__ __forceinline__ bool lp_run_gemm(const LpCtx& c, const LpLayer& L, co
                 s1 += v[t][i];
             }
         if (L.mode == 0) {
-            const int tpg = L.gsz >= 32 ? 8 : L.gsz / 4;       // threads of this row that share a group
-            for (int o = 1; o < tpg; o <<= 1) s1 += __shfl_xor(s1, o);
+            const bool g8 = L.gsz >= 32;                       // threads of this row that share a group: 8, or 4 (groups of 16)
+            s1 = g8 ? lp_group_sum<8>(s1) : lp_group_sum<4>(s1);
             const float mean = s1 / (float)L.gsz;
             float s2 = 0.f;
 #pragma unroll
             for (int t = 0; t < CT; ++t)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { const float d = v[t][i] - mean; s2 += d * d; }
-            for (int o = 1; o < tpg; o <<= 1) s2 += __shfl_xor(s2, o);
+            s2 = g8 ? lp_group_sum<8>(s2) : lp_group_sum<4>(s2);
             const float rstd = rsqrtf(s2 / (float)L.gsz + 1e-5f);
 #pragma unroll
             for (int t = 0; t < CT; ++t)
@@ -392,6 +424,12 @@ __device__ __forceinline__ bool lp_run_gemm(const LpCtx& c, const LpLayer& L, co
 // apart, so the values go through LDS ([row][gsz] fp16 in the reduction scratch) and leave with consecutive lanes on consecutive rows: 8
 // lanes = one full 128-byte line per store instruction (a thread's own CPT columns of 2 rows per wave would be 32-byte fragments of 32
 // lines: 4x the fabric writes, and the write-through acknowledgement of the big layers' finish phases took 3-5 us).  Poison: same addresses.
+// column (inside the group) of element i of thread q of a row: 4-column pieces dealt round-robin to the TPR threads (piece p of thread q =
+// columns 4 (p TPR + q) ..): a wave-wide 16-byte access then covers consecutive addresses, in the slabs and in LDS (16 columns per thread in
+// one run made every LDS read of the per-column constants a 16-way bank conflict and every slab load touch 32 lines for a quarter each)
+template <int CPT, int TPR>
+__device__ __forceinline__ int lp_fin_col(int q, int i) { return CPT >= 4 ? (((i >> 2) * TPR + q) << 2) + (i & 3) : q * CPT + i; }
+
 template <int CPT, int TPR>
 __device__ __forceinline__ void lp_finish_store(const LpCtx& c, const LpLayer& L, const LpUnit& U, int set_off, const float (&x)[CPT], bool poison) {
     constexpr int ROWS = LP_THREADS / TPR;
@@ -400,8 +438,15 @@ __device__ __forceinline__ void lp_finish_store(const LpCtx& c, const LpLayer& L
     if (!poison) {
         const int rr = c.tid / TPR, q = c.tid % TPR;
         __syncthreads();                                       // the scratch may still be read by a previous unit's epilogue
+        if constexpr (CPT >= 4) {
 #pragma unroll
-        for (int i = 0; i < CPT / 2; ++i) stage[rr * (gsz / 2) + q * (CPT / 2) + i] = lp_pack_relu_f16(x[2 * i], x[2 * i + 1]);
+            for (int p = 0; p < CPT / 4; ++p)
+                *(u32x2*)(stage + rr * (gsz / 2) + (lp_fin_col<CPT, TPR>(q, 4 * p) >> 1)) =
+                    (u32x2){lp_pack_relu_f16(x[4 * p], x[4 * p + 1]), lp_pack_relu_f16(x[4 * p + 2], x[4 * p + 3])};
+        } else {
+#pragma unroll
+            for (int i = 0; i < CPT / 2; ++i) stage[rr * (gsz / 2) + q * (CPT / 2) + i] = lp_pack_relu_f16(x[2 * i], x[2 * i + 1]);
+        }
         __syncthreads();
     }
     const int npieces = ROWS * (gsz / 8);                      // 16-byte pieces: 8 columns of one row
@@ -416,10 +461,11 @@ __device__ __forceinline__ void lp_finish_store(const LpCtx& c, const LpLayer& L
 template <int CPT, int TPR, int SMAX>
 __device__ __forceinline__ bool lp_run_finish(const LpCtx& c, const LpLayer& L, const LpUnit& U, const LpStep& S, const LpArgs& A, bool& poisoned,
                                               const LpUnit* units) {
-    const int row = U.row0 + c.tid / TPR, col = U.group * L.gsz + (c.tid % TPR) * CPT;
+    const int row = U.row0 + c.tid / TPR, q = c.tid % TPR;
     constexpr int V = CPT >= 4 ? CPT / 4 : 1;               // 16-byte loads per slab (CPT = 2: one 8-byte load)
     u32x4 raw[SMAX][V];
-    const int base = S.set_off + L.slab_off + (row * L.c + col) * 4;
+    const int base = S.set_off + L.slab_off + (row * L.c + U.group * L.gsz + lp_fin_col<CPT, TPR>(q, 0)) * 4;
+    constexpr int PSTEP = TPR * 16;                         // bytes between a thread's consecutive 4-column pieces
     const int sstride = 32 * L.c * 4;
     const unsigned t0 = lp_now();
     bool ok = true;
@@ -430,7 +476,7 @@ __device__ __forceinline__ bool lp_run_finish(const LpCtx& c, const LpLayer& L, 
             if (s < L.slabs) {
 #pragma unroll
                 for (int i = 0; i < V; ++i) {
-                    if constexpr (CPT >= 4) raw[s][i] = lp_ld16(c, base + s * sstride + i * 16);
+                    if constexpr (CPT >= 4) raw[s][i] = lp_ld16(c, base + s * sstride + i * PSTEP);
                     else {
                         const u32x2 t2 = __builtin_amdgcn_raw_buffer_load_b64(c.rs, base + s * sstride, 0, 16);
                         raw[s][i] = (u32x4){t2.x, t2.y, 0u, 0u};
@@ -461,32 +507,43 @@ __device__ __forceinline__ bool lp_run_finish(const LpCtx& c, const LpLayer& L, 
         if (!ok) break;
     }
     if (!ok) c.lds_flag[0] = 1;
-    if (c.tr != nullptr && c.tid == 0) c.tr[1] = lp_now();
+    if (c.tr != nullptr && c.lane == 0) { c.tr[4 + c.wave] = lp_now(); if (c.wave == 0) c.tr[1] = lp_now(); }
     __syncthreads();
     if (c.lds_flag[0]) return false;
-    const float* pst = (const float*)(c.smem + U.lds_p) + (c.tid % TPR) * CPT;      // bias | gamma | beta of this group's columns
+    // slab 0 already carries the bias (added by the slice-0 gemm unit): x = ((s0 + b) + s1) + ..., the order of csrc/skinny.hip's finish
+    const float* pst = (const float*)(c.smem + U.lds_p);    // gamma | beta of this group's columns
     float x[CPT];
     float s1 = 0.f;
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-        float v = pst[i];
+        float v = __uint_as_float(raw[0][CPT >= 4 ? i / 4 : 0][i & 3]);
 #pragma unroll
-        for (int s = 0; s < SMAX; ++s)
+        for (int s = 1; s < SMAX; ++s)
             if (s < L.slabs) v += __uint_as_float(raw[s][CPT >= 4 ? i / 4 : 0][i & 3]);
         x[i] = v;
         s1 += v;
     }
-#pragma unroll
-    for (int o = 1; o < TPR; o <<= 1) s1 += __shfl_xor(s1, o);
+    s1 = lp_group_sum<TPR>(s1);
     const float mean = s1 / (float)L.gsz;
     float s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < CPT; ++i) { const float d = x[i] - mean; s2 += d * d; }
-#pragma unroll
-    for (int o = 1; o < TPR; o <<= 1) s2 += __shfl_xor(s2, o);
+    s2 = lp_group_sum<TPR>(s2);
     const float rstd = rsqrtf(s2 / (float)L.gsz + 1e-5f);
+    if constexpr (CPT >= 4) {
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) x[i] = (x[i] - mean) * rstd * pst[L.gsz + i] + pst[2 * L.gsz + i];
+        for (int p = 0; p < CPT / 4; ++p) {
+            const float4 ga = *(const float4*)(pst + lp_fin_col<CPT, TPR>(q, 4 * p));
+            const float4 be = *(const float4*)(pst + L.gsz + lp_fin_col<CPT, TPR>(q, 4 * p));
+            x[4 * p] = (x[4 * p] - mean) * rstd * ga.x + be.x;
+            x[4 * p + 1] = (x[4 * p + 1] - mean) * rstd * ga.y + be.y;
+            x[4 * p + 2] = (x[4 * p + 2] - mean) * rstd * ga.z + be.z;
+            x[4 * p + 3] = (x[4 * p + 3] - mean) * rstd * ga.w + be.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) x[i] = (x[i] - mean) * rstd * pst[q * CPT + i] + pst[L.gsz + q * CPT + i];
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (c.tr != nullptr && c.tid == 0) c.tr[3] = lp_now();
     lp_finish_store<CPT, TPR>(c, L, U, S.set_off, x, false);
@@ -586,19 +643,24 @@ __global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A)
                             lp_stage(L.w, L.ldw, U.col0 + 32 * t, (U.chunk0 + cl) * 64, lp_smem + U.lds_w + (t * U.nchunks + cl) * 4096, i, c.lane);
         }
     }
-    // per-column constants of this workgroup's units -> LDS: gemm units that finish their layer [bias | gamma | beta] x 64
-    // columns, finish units x gsz columns
+    // per-column constants of this workgroup's units -> LDS: gemm units that finish their layer [bias | gamma | beta] x 64 columns,
+    // slice-0 gemm units of a layer with partial tiles [bias] x their columns, finish units [gamma | beta] x gsz columns
     for (int u = 0; u < LP_MAX_UNITS; ++u) {
         const LpUnit U = units[u];
         if (U.kind == LP_END) break;
         if (U.lds_p < 0) continue;
         const LpLayer& L = A.layers[U.layer];
         float* pst = (float*)(lp_smem + U.lds_p);
-        const int ncol = U.kind == LP_GEMM ? 32 * U.ct : L.gsz, stride = U.kind == LP_GEMM ? 64 : L.gsz;
-        const int c0 = U.kind == LP_GEMM ? U.col0 : U.group * L.gsz;
-        for (int i = c.tid; i < ncol; i += LP_THREADS) {
-            pst[i] = L.bias[c0 + i];
-            if (L.mode == 0) { pst[stride + i] = L.gamma[c0 + i]; pst[2 * stride + i] = L.beta[c0 + i]; }
+        if (U.kind == LP_GEMM) {
+            for (int i = c.tid; i < 32 * U.ct; i += LP_THREADS) {
+                pst[i] = L.bias[U.col0 + i];
+                if (L.slabs == 0 && L.mode == 0) { pst[64 + i] = L.gamma[U.col0 + i]; pst[128 + i] = L.beta[U.col0 + i]; }
+            }
+        } else {
+            for (int i = c.tid; i < L.gsz; i += LP_THREADS) {
+                pst[i] = L.gamma[U.group * L.gsz + i];
+                pst[L.gsz + i] = L.beta[U.group * L.gsz + i];
+            }
         }
     }
     const int k_base = A.counter != nullptr ? A.counter[0] : 0;
@@ -702,7 +764,7 @@ __global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A)
             const LpLayer& L = A.layers[U.layer];
             bool ok;
             if (TRACE && step < A.trace_steps) {
-                c.tr = A.trace + (((int64_t)vwg * A.trace_steps + step) * LP_MAX_UNITS + u) * 4;
+                c.tr = A.trace + (((int64_t)vwg * A.trace_steps + step) * LP_MAX_UNITS + u) * 8;
                 if (c.tid == 0) c.tr[0] = lp_now();
             } else c.tr = nullptr;
             c.hist = lp_hist + u * 4 + c.wave;
@@ -815,11 +877,15 @@ bool lp_build_plan(const pcd_latent_desc_t& d, LpPlan& plan) {
     // for the unit's constants.
     {
         std::vector<int> used(LP_WGS, LP_RED_BYTES);
-        for (const Item& it : items) used[it.wg] += it.wbytes + (it.u.head ? LP_Z16_BYTES : 0) + (kSlabs[it.u.layer] == 0 ? 768 : 0);
+        for (const Item& it : items)
+            used[it.wg] += it.wbytes + (it.u.head ? LP_Z16_BYTES : 0) +
+                           (kSlabs[it.u.layer] == 0 ? 768 : (it.u.slice == 0 ? 128 * it.u.ct : 0));
         const int fin_layers[6] = {5, 4, 3, 6, 7, 8};         // largest constants first
         for (int f = 0; f < 6; ++f) {
             const int l = fin_layers[f], gsz = kC[l] / 8;
             const int rows = gsz >= 64 ? 8 : 16, per_group = 32 / rows;
+            std::vector<int> mine(LP_WGS, 0);                 // finish units of THIS layer already on a workgroup: they would run one after
+                                                              // the other, and the second one's consumers wait a whole unit longer
             for (int g = 0; g < 8; ++g) {
                 int xcd = -1;
                 for (const Item& it : items)
@@ -833,9 +899,12 @@ bool lp_build_plan(const pcd_latent_desc_t& d, LpPlan& plan) {
                     int best = -1;
                     for (int r = 0; r < 32; ++r) {
                         const int w = xcd * 32 + r;
-                        if (best < 0 || used[w] < used[best]) best = w;
+                        if (used[w] + 2 * gsz * 4 > LP_DYN_LDS) continue;
+                        if (best < 0 || mine[w] < mine[best] || (mine[w] == mine[best] && used[w] < used[best])) best = w;
                     }
-                    used[best] += 3 * gsz * 4;
+                    if (best < 0) return false;
+                    used[best] += 2 * gsz * 4;
+                    mine[best]++;
                     finish(best, l, g, rb * rows);
                 }
             }
@@ -856,9 +925,10 @@ bool lp_build_plan(const pcd_latent_desc_t& d, LpPlan& plan) {
             if ((u.nchunks + 3) / 4 > (u.ct == 2 ? 1 : 4)) return false;
             u.lds_p = -1;
             if (L.slabs == 0) { u.lds_p = lds[it.wg]; lds[it.wg] += 3 * 64 * 4; }
+            else if (u.slice == 0) { u.lds_p = lds[it.wg]; lds[it.wg] += 128 * u.ct; }      // bias of its columns
         } else {
             u.lds_p = lds[it.wg];
-            lds[it.wg] += 3 * plan.layers[u.layer].gsz * 4;
+            lds[it.wg] += 2 * plan.layers[u.layer].gsz * 4;                                  // gamma | beta
         }
         if (lds[it.wg] > LP_DYN_LDS) return false;                 // the launch's dynamic LDS (64 bytes left to the static flag word)
         plan.units[(size_t)it.wg * LP_MAX_UNITS + count[it.wg]++] = u;
@@ -895,7 +965,7 @@ extern "C" int pcd_latent_persist_plan_check(void) {
             if (u.kind == LP_END) { ended = true; continue; }
             if (ended) return -1;
             const int phase = 2 * u.layer + (u.kind == LP_FINISH ? 1 : 0);
-            if (phase < last_phase || (phase == last_phase && u.kind != LP_FINISH)) return -1;     // (two finish units of a layer may share a workgroup)
+            if (phase <= last_phase) return -1;                 // at most one unit of a phase per workgroup (two would run one after the other)
             last_phase = phase;
             // partial tiles stored plain: the finish unit of a group sits on the XCD of that group's gemm units
             if (u.kind == LP_FINISH && plan.layers[u.layer].slab_local) {
@@ -958,7 +1028,7 @@ struct pcd_latent_persist {
     LpUnit* d_units = nullptr;
     int sleep = 1;
     int predict = 1;
-    unsigned* trace = nullptr;         // diagnostic: device buffer [256][trace_steps][8][4] u32
+    unsigned* trace = nullptr;         // diagnostic: device buffer [256][trace_steps][8][8] u32
     int trace_steps = 0;
 };
 
@@ -1012,7 +1082,7 @@ extern "C" size_t pcd_latent_persist_workspace_bytes(const pcd_latent_persist_t*
 }
 
 // diagnostic: the next launches run the instrumented kernel and leave s_memrealtime stamps (100 MHz) of the first
-// `steps` steps in `buf` ([256 workgroups][steps][8 units][4]: enter, operands in, stored, unused); buf = NULL switches it off
+// `steps` steps in `buf` ([256 workgroups][steps][8 units][8]: enter, operands in, stored, epilogue computed, operands in of waves 0..3); buf = NULL switches it off
 extern "C" int pcd_latent_persist_trace(pcd_latent_persist_t* h, unsigned* buf, int steps) {
     PCD_CHECK_ARG(h != nullptr && (buf == nullptr || steps > 0));
     h->trace = buf;

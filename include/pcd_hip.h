@@ -286,7 +286,7 @@ int pcd_latent_persist_create(const pcd_latent_desc_t* desc, pcd_latent_persist_
 void pcd_latent_persist_destroy(pcd_latent_persist_t* h);
 size_t pcd_latent_persist_workspace_bytes(const pcd_latent_persist_t* h);
 int pcd_latent_persist_config(pcd_latent_persist_t* h, int poll_sleep, int predict_waits);
-/* diagnostic: instrumented kernel for the next launches; buf [256][steps][8][4] u32 of 100 MHz stamps, NULL = off */
+/* diagnostic: instrumented kernel for the next launches; buf [256][steps][8 units][8] u32 of 100 MHz stamps, NULL = off */
 int pcd_latent_persist_trace(pcd_latent_persist_t* h, unsigned* buf, int steps);
 int pcd_latent_persist_forward(pcd_latent_persist_t* h, const float* z, int batch, const float* tbias, float* eps,
                                void* workspace, size_t workspace_bytes, void* stream);

@@ -15,14 +15,14 @@ lib = _lib.load()
 m = LatentDiffusion(VAE3DLarge()); m.load_state_dict(latent_sd(), strict=True); m = m.to("cuda").eval()
 B, T, STEPS = 32, 64, 48
 h, _ = m.model._persist_handle()
-buf = torch.zeros(256 * STEPS * 8 * 4, dtype=torch.int32, device="cuda")
+buf = torch.zeros(256 * STEPS * 8 * 8, dtype=torch.int32, device="cuda")
 lib.pcd_latent_persist_trace(h, buf.data_ptr(), STEPS)
 zT = torch.randn(B, 256, device="cuda")
 m.sample(B, num_steps=T, z_T=zT)
 m.sample(B, num_steps=T, z_T=zT)
 torch.cuda.synchronize()
 lib.pcd_latent_persist_trace(h, 0, 0)
-tr = buf.cpu().numpy().astype(np.int64).reshape(256, STEPS, 8, 4) & 0xffffffff
+tr = buf.cpu().numpy().astype(np.int64).reshape(256, STEPS, 8, 8) & 0xffffffff
 import ctypes
 plan = (ctypes.c_int * (256 * 8))()
 lib.pcd_latent_persist_plan_dump(plan)
@@ -40,6 +40,9 @@ for step in (40, 41):
         print(f"  {names[ph // 2]:5s}{' fin' if ph & 1 else '    '} {sel.sum():4d} | {np.median(e):6.2f} | {i.min():6.2f}..{i.max():6.2f} | +{np.median(p_ - i):4.2f} | "
               f"{o.min():6.2f}..{o.max():6.2f}   (+{i.max() - prev:5.2f} after the previous phase's last ack)")
         prev = o.max()
+        wv = (tr[:, step, :, 4:8][sel] - t0) / 100.0            # operands in, per wave
+        print(f"        per wave operands in (median over units): " + " ".join(f"{np.median(wv[:, k]):6.2f}" for k in range(4)) +
+              f" | slowest wave - fastest wave, median {np.median(wv.max(1) - wv.min(1)):.2f} max {(wv.max(1) - wv.min(1)).max():.2f}")
         if i.max() - i.min() > 2.0 and step == 41:
             ws = np.argwhere(sel)
             late = sorted(((inn[w, u] - t0) / 100.0, (ent[w, u] - t0) / 100.0, int(w)) for w, u in ws)
