@@ -127,9 +127,9 @@ __device__ __forceinline__ void lp_sleep(int n) {
 __device__ __forceinline__ unsigned lp_now() { return (unsigned)__builtin_amdgcn_s_memrealtime(); }
 
 // Steps are periodic: a wait that took `prev` ticks in the previous step will take about as long in this one.  Waits of 8 us and
-// more sleep through a fraction of it (shift: 1 = half, 2 = three quarters) before the first probe: hundreds of waves wait for most of a
-// step, and each probe is a fabric read that competes with the stores everybody is waiting for.  Short waits probe at once (they are
-// the ones close to the critical path; the sleep loop's granularity is ~0.5 us).
+// more sleep through a fraction of it (shift: 1 = half, 2 = three quarters) before the second polling pass: hundreds of waves wait for most
+// of a step, and each pass is a set of fabric reads that competes with the stores everybody is waiting for.  Short waits poll at once
+// (they are the ones close to the critical path; the sleep loop's granularity is ~0.5 us).
 __device__ __forceinline__ void lp_presleep(unsigned t_enter, unsigned prev, int shift) {
     if (prev < 800u) return;
     const unsigned until = t_enter + prev - (prev >> shift);
@@ -245,18 +245,9 @@ __device__ __forceinline__ bool lp_fetch(const LpCtx& c, const LpLayer& L, const
             return true;
         }
         if (spin == 1u && c.predict && c.hist != nullptr) lp_presleep(t0, __builtin_amdgcn_readfirstlane(*c.hist), c.predict);
-        // ... otherwise wait on ONE 1-KiB piece of the first missing chunk (1/16 of the traffic of a full pass: hundreds of
-        // waves wait here for most of a step, and their polls share the fabric with the stores they are waiting for)
-        int poff = 0;
-#pragma unroll
-        for (int i = MAXCH - 1; i >= 0; --i)
-            if (need & (1u << i)) poff = off[i];
-        for (unsigned probe = 1;; ++probe) {
-            const u32x4 v = lp_ld16(c, poff + 3 * 1024);
-            if (__builtin_amdgcn_ballot_w64(lp_poison16(v)) == 0ull) break;
-            if ((probe & 63u) == 0u && lp_give_up(c, t0, 1u)) return false;
-            lp_sleep(c.sleep);
-        }
+        // ... otherwise again, after the back-off.  (Waiting on a single 1-KiB probe piece and fetching after it -- 1/16 of the polling
+        // traffic -- was measured 1.4 us/step slower: the fetch after the probe is one more dependent round trip on every edge.)
+        lp_sleep(c.sleep);
         if ((spin & 63u) == 0u && lp_give_up(c, t0, 1u)) return false;
     }
 }
@@ -495,16 +486,7 @@ __device__ __forceinline__ bool lp_run_finish(const LpCtx& c, const LpLayer& L, 
         }
         if ((spin & 63u) == 0u && lp_give_up(c, t0, 2u)) { ok = false; break; }
         if (spin == 1u && c.predict && c.hist != nullptr) lp_presleep(t0, __builtin_amdgcn_readfirstlane(*c.hist), c.predict);
-        // not there yet: wait on the last slab's first load only, then take the full pass again
-        for (unsigned probe = 1;; ++probe) {
-            unsigned v0;
-            if constexpr (CPT >= 4) v0 = lp_ld16(c, base + (L.slabs - 1) * sstride).x;
-            else v0 = __builtin_amdgcn_raw_buffer_load_b64(c.rs, base + (L.slabs - 1) * sstride, 0, 16)[0];
-            if (__builtin_amdgcn_ballot_w64(lp_nan(v0)) == 0ull) break;
-            if ((probe & 63u) == 0u && lp_give_up(c, t0, 2u)) { ok = false; break; }
-            lp_sleep(c.sleep);
-        }
-        if (!ok) break;
+        lp_sleep(c.sleep);
     }
     if (!ok) c.lds_flag[0] = 1;
     if (c.tr != nullptr && c.lane == 0) { c.tr[4 + c.wave] = lp_now(); if (c.wave == 0) c.tr[1] = lp_now(); }
@@ -702,6 +684,12 @@ __global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A)
                 const LpLayer& Le = A.layers[LP_LAYERS - 1];
                 u32x4 e4[8];
                 const int eoff = S.other_off + Le.out_off + (zrow * 256 + zq * 32) * 4;
+                // the step's rates do not depend on eps: requested before the wait (four dependent-free loads that were a memory
+                // round trip between eps and the next step's first layer)
+                const int kp = (k_base + step - 1) < A.T ? (k_base + step - 1) : A.T - 1;
+                const int rb = zrow * A.rate_stride;
+                const float rn = A.rates[((int64_t)0 * A.T + kp) * A.rate_width + rb], rsg = A.rates[((int64_t)1 * A.T + kp) * A.rate_width + rb];
+                const float rn2 = A.rates[((int64_t)2 * A.T + kp) * A.rate_width + rb], rs2 = A.rates[((int64_t)3 * A.T + kp) * A.rate_width + rb];
                 const unsigned t0 = lp_now();
                 bool ok = true;
                 for (unsigned spin = 1;; ++spin) {
@@ -721,10 +709,6 @@ __global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A)
                 if (!ok) lp_flag[0] = 1;
                 __syncthreads();
                 if (lp_flag[0]) return;
-                const int kp = (k_base + step - 1) < A.T ? (k_base + step - 1) : A.T - 1;
-                const int rb = zrow * A.rate_stride;
-                const float rn = A.rates[((int64_t)0 * A.T + kp) * A.rate_width + rb], rsg = A.rates[((int64_t)1 * A.T + kp) * A.rate_width + rb];
-                const float rn2 = A.rates[((int64_t)2 * A.T + kp) * A.rate_width + rb], rs2 = A.rates[((int64_t)3 * A.T + kp) * A.rate_width + rb];
                 float x0v[32];
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
@@ -1026,7 +1010,7 @@ struct pcd_latent_persist {
     LpPlan plan;
     LpLayer* d_layers = nullptr;
     LpUnit* d_units = nullptr;
-    int sleep = 1;
+    int sleep = 0;                     // back-off between polling passes (s_sleep count): 0 measured best (37.1 v. 37.3 / 37.5 / 37.9 us at 1 / 2 / 4)
     int predict = 1;
     unsigned* trace = nullptr;         // diagnostic: device buffer [256][trace_steps][8][8] u32
     int trace_steps = 0;

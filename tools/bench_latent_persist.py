@@ -36,4 +36,9 @@ for sl in [int(v) for v in os.environ.get("SLEEPS", "").split()]:
         lib.pcd_latent_persist_config(h, sl, pred)
         us = min(loop(True)[0] for _ in range(3))
         print(f"poll sleep {sl} predict {pred}: {us:6.1f} us/step", flush=True)
-lib.pcd_latent_persist_config(m.model._persist_handle()[0], 1, 1)
+for pol in [int(v, 0) for v in os.environ.get("POLICIES", "").split()]:      # predict | probe_chunks << 4 | finish_full_pass << 8
+    h, _ = m.model._persist_handle()
+    lib.pcd_latent_persist_config(h, 1, pol)
+    us = min(loop(True)[0] for _ in range(3))
+    print(f"policy {pol:#x}: {us:6.1f} us/step", flush=True)
+lib.pcd_latent_persist_config(m.model._persist_handle()[0], 0, 1)
