@@ -13,11 +13,11 @@
 //     slice order, GroupNorm, ReLU) that publish fp16 activations; layers whose 32-column unit holds whole GroupNorm groups over the
 //     full K (enc1-3, dec1, the output head) finish inside the unit;
 //   * there are NO flags, counters, atomics or fences between layers: the exchanged data carries its own validity.
-//     Activations are post-ReLU fp16 (sign bit clear), partial sums and eps are finite fp32; the buffers are poisoned
+//     Activations are post-ReLU fp16 (sign bit clear), partial sums are finite fp32, the state is finite fp16; the buffers are poisoned
 //     with 0xFF bytes (sign bit set / NaN) and a consumer simply loads its operands with sc1 (L1-bypassing) loads
 //     until no element is poison: one memory round trip per layer boundary.  THREE buffer sets rotate by step; at the
 //     end of its step s a workgroup re-poisons its own output regions of set (s - 1) % 3 (every reader of that set's
-//     contents has finished: step s's first layer needed the complete eps of step s - 1) for step s + 2; a reader of
+//     contents has finished: step s's first layer needed the complete state published by step s - 1) for step s + 2; a reader of
 //     step s + 2 has by then finished its own dec4 unit of step s + 1, which needed every workgroup's global_feat.3
 //     tile of step s + 1, whose stores wait (s_waitcnt vmcnt(0)) for all earlier stores of their wave;
 //   * activations are stored in MFMA-fragment order ([64-k chunk][j][lane][8 halfs]), so a consumer's operand loads are
@@ -27,9 +27,10 @@
 //     layers that chain the end of a step to the start of the next (dec2, dec1, output.0, output.2, update + enc1,
 //     enc2, enc3's input) all sit on XCD 0 and exchange through that XCD's L2 with PLAIN stores (tools/ubench_handoff:
 //     0.40 us per hand-off against 0.92 us for write-through stores across XCDs); everything else uses sc1 stores;
-//   * the four workgroups that own enc1 keep the latent state z (fp32, registers) and apply the DDIM update
-//     (same fp32 operation order as pcd_ddim_update, FMA contraction off) redundantly: bit-identical copies, no
-//     broadcast step.
+//   * the eight workgroups that own output.2's tiles keep their 32 columns of the latent state z (fp32, registers: 4 values per
+//     thread) and apply the DDIM update to them in the tile's epilogue (same fp32 operation order as pcd_ddim_update, FMA
+//     contraction off): what they publish is the NEXT step's enc1 operand, z rounded to fp16 in fragment order (poison = fp16 NaN,
+//     the state is signed), so the update is 4 divisions per thread instead of a separate 32-per-thread stage between two layers.
 // Every wait is bounded (s_memrealtime) and reports through a status word; the grid is exactly the number of CUs and
 // the host refuses to launch on a device with fewer (pcd_latent_persist_supported).  Timeline tool:
 // tools/trace_latent_persist.py (instrumented build).  Measured, B = 32: 47 us / step against 74 us for the per-layer launches.
@@ -44,7 +45,6 @@ constexpr int LP_WGS = 256, LP_THREADS = 256, LP_LAYERS = 12, LP_MAX_UNITS = 8;
 constexpr int LP_LDS_BYTES = 160 * 1024;
 constexpr int LP_DYN_LDS = LP_LDS_BYTES - 256;         // dynamic part: the kernel's static words (abort flag, wait history) take the rest
 constexpr int LP_RED_BYTES = 4 * 32 * 33 * 4;          // cross-wave reduction scratch
-constexpr int LP_Z16_BYTES = 32 * 256 * 2;             // fp16 image of the latent state (enc1's operand)
 constexpr int LP_CTRL_BYTES = 256;
 constexpr unsigned LP_TIMEOUT_TICKS = 20000000u;       // 0.2 s of the 100 MHz s_memrealtime clock
 
@@ -55,10 +55,10 @@ struct LpLayer {
     const half_t* w; int ldw;          // fp16 [C][K1+K2]
     const float* bias; const float* gamma; const float* beta;
     int k1, k2;                        // widths of the two input sources (K2 = 0: one source)
-    int src1_off, src2_off;            // byte offsets (inside a set) of the sources' fp16 fragment-major buffers; -1: the latent state
-    int c, gsz, mode;                  // mode 0: GroupNorm(gsz)+ReLU -> fp16; 1: ReLU -> fp16; 2: identity -> fp32 eps
+    int src1_off, src2_off;            // byte offsets (inside a set) of the sources' fp16 fragment-major buffers (src2: -1 = none)
+    int c, gsz, mode;                  // mode 0: GroupNorm(gsz)+ReLU -> fp16; 1: ReLU -> fp16; 2: identity = eps -> DDIM update -> next state, signed fp16
     int slabs;                         // 0: the unit finishes the layer itself; S >= 1: S K-slices of fp32 partial tiles + finish units
-    int out_off;                       // byte offset (inside a set) of this layer's output: fp16 fragment-major, or eps fp32 [32][256]
+    int out_off;                       // byte offset (inside a set) of this layer's output, fp16 fragment-major
     int slab_off;                      // byte offset (inside a set) of the fp32 slabs [S][32][C]
     int slab_local;                    // 1: every GroupNorm group's partial tiles are produced and finished on ONE XCD: plain stores for them too
     int out_local;                     // 1: producers and consumers of this layer's outputs all sit on XCD 0: plain stores (the XCD's L2 is
@@ -74,7 +74,7 @@ struct LpUnit {
     int slice;                         // gemm: slab index
     int lds_w;                         // gemm: byte offset of the unit's weight images in LDS
     int group, row0;                   // finish: GroupNorm group, first row
-    int head;                          // gemm on the latent state: this workgroup keeps z
+    int head;                          // gemm on the latent state (enc1): operand = the previous step's z16, bias = the step's time row
     int lds_p;                         // byte offset in LDS of the unit's constants (its columns only): gemm that finishes its layer
                                        // bias | gamma | beta, slice-0 gemm of a layer with partial tiles bias, finish gamma | beta; or -1
     int pad[4];
@@ -115,6 +115,11 @@ __device__ __forceinline__ half8 lp_wfrag(const char* img, int row, int hh, int 
 }
 
 __device__ __forceinline__ bool lp_poison16(u32x4 v) { return ((v.x | v.y | v.z | v.w) & 0x80008000u) != 0u; }
+// signed fp16 data (the latent state): poison = NaN halves.  (h & 0x7fff) > 0x7c00 <=> bit 15 of (h & 0x7fff) + 0x03ff, per half, no carry
+__device__ __forceinline__ bool lp_nan16(u32x4 v) {
+    const unsigned m = 0x7fff7fffu, a = 0x03ff03ffu;
+    return ((((v.x & m) + a) | ((v.y & m) + a) | ((v.z & m) + a) | ((v.w & m) + a)) & 0x80008000u) != 0u;
+}
 __device__ __forceinline__ bool lp_nan(unsigned b) { return (b & 0x7fffffffu) > 0x7f800000u; }
 __device__ __forceinline__ bool lp_nan4(u32x4 v) { return (int)lp_nan(v.x) | (int)lp_nan(v.y) | (int)lp_nan(v.z) | (int)lp_nan(v.w); }
 
@@ -215,6 +220,7 @@ __device__ __forceinline__ bool lp_give_up(const LpCtx& c, unsigned t0, unsigned
 // until no fp16 carries the poison bit.  Returns false when the wait was abandoned.
 template <int MAXCH>
 __device__ __forceinline__ bool lp_fetch(const LpCtx& c, const LpLayer& L, const LpUnit& U, int set_off, u32x4 (&pc)[MAXCH][4]) {
+    const bool sgn = U.head != 0;                        // enc1 reads the signed state: NaN poison instead of the sign bit
     int off[MAXCH];
     unsigned need = 0u;
 #pragma unroll
@@ -237,7 +243,8 @@ __device__ __forceinline__ bool lp_fetch(const LpCtx& c, const LpLayer& L, const
 #pragma unroll
         for (int i = 0; i < MAXCH; ++i)
             if (need & (1u << i)) {
-                const bool bad = (int)lp_poison16(pc[i][0]) | (int)lp_poison16(pc[i][1]) | (int)lp_poison16(pc[i][2]) | (int)lp_poison16(pc[i][3]);
+                const bool bad = sgn ? (bool)((int)lp_nan16(pc[i][0]) | (int)lp_nan16(pc[i][1]) | (int)lp_nan16(pc[i][2]) | (int)lp_nan16(pc[i][3]))
+                                     : (bool)((int)lp_poison16(pc[i][0]) | (int)lp_poison16(pc[i][1]) | (int)lp_poison16(pc[i][2]) | (int)lp_poison16(pc[i][3]));
                 if (__builtin_amdgcn_ballot_w64(bad) == 0ull) need &= ~(1u << i);
             }
         if (need == 0u) {
@@ -282,11 +289,15 @@ __device__ __forceinline__ void lp_gemm_store(const LpCtx& c, const LpLayer& L, 
             u32x4 o = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
             if (!poison) o = (u32x4){__float_as_uint(v[t][0]), __float_as_uint(v[t][1]), __float_as_uint(v[t][2]), __float_as_uint(v[t][3])};
             lp_st16(c, o, off, L.slab_local);
-        } else if (L.mode == 2) {                           // eps fp32 [32][C]
-            const int off = set_off + L.out_off + (row * L.c + col) * 4;
-            u32x4 o = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-            if (!poison) o = (u32x4){__float_as_uint(v[t][0]), __float_as_uint(v[t][1]), __float_as_uint(v[t][2]), __float_as_uint(v[t][3])};
-            lp_st16(c, o, off, L.out_local);
+        } else if (L.mode == 2) {                           // the next step's state, signed fp16 (saturating, like pcd_skinny_fused_f32in), fragment-major
+            const int off = set_off + L.out_off + lp_frag_off(row, col);
+            u32x2 o = {0xffffffffu, 0xffffffffu};           // fp16 NaN halves
+            if (!poison) {
+                const half_t h0 = to_half_sat(v[t][0]), h1 = to_half_sat(v[t][1]), h2 = to_half_sat(v[t][2]), h3 = to_half_sat(v[t][3]);
+                o = (u32x2){(unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16),
+                            (unsigned)__builtin_bit_cast(unsigned short, h2) | ((unsigned)__builtin_bit_cast(unsigned short, h3) << 16)};
+            }
+            lp_st8(c, o, off, L.out_local);
         } else {                                            // fp16 activation, fragment-major, 4 columns = 8 bytes
             const int off = set_off + L.out_off + lp_frag_off(row, col);
             u32x2 o = {0xffffffffu, 0xffffffffu};
@@ -300,7 +311,8 @@ __device__ __forceinline__ void lp_poison_all(const LpCtx& c, const LpArgs& A, c
 
 template <int CT, int MAXCH>
 __device__ __forceinline__ bool lp_run_gemm(const LpCtx& c, const LpLayer& L, const LpUnit& U, const LpStep& S, const LpArgs& A,
-                                            bool& poisoned, const LpUnit* units, const float (&tbv)[4]) {
+                                            bool& poisoned, const LpUnit* units, const float (&tbv)[4], float (&zs)[4], const float (&rates)[4],
+                                            bool last_step) {
     f32x16 acc[CT];
 #pragma unroll
     for (int t = 0; t < CT; ++t)
@@ -308,21 +320,10 @@ __device__ __forceinline__ bool lp_run_gemm(const LpCtx& c, const LpLayer& L, co
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
     bool ok = true;
     const char* wimg = c.smem + U.lds_w;
-    if (U.head) {
-        // operand = the fp16 image of z in LDS (fragment-major, written by the update): chunk = wave
-        const char* z16 = c.smem + LP_RED_BYTES;
-        if (c.wave < U.nchunks) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const half8 a = *(const half8*)(z16 + c.wave * 4096 + j * 1024 + c.lane * 16);
-#pragma unroll
-                for (int t = 0; t < CT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, lp_wfrag(wimg + (t * U.nchunks + c.wave) * 4096, c.r, c.hh, j), acc[t], 0, 0, 0);
-            }
-        }
-    } else {
+    {
         u32x4 pc[MAXCH][4];
-        ok = lp_fetch<MAXCH>(c, L, U, S.set_off, pc);
+        // enc1's operand is the state the previous step's output.2 units published (in that step's set)
+        ok = lp_fetch<MAXCH>(c, L, U, U.head ? S.other_off : S.set_off, pc);
         if (ok) {
 #pragma unroll
             for (int i = 0; i < MAXCH; ++i) {
@@ -397,14 +398,29 @@ __device__ __forceinline__ bool lp_run_gemm(const LpCtx& c, const LpLayer& L, co
                 }
         }
     }
+    if (L.slabs == 0 && L.mode == 2) {
+        // output.2: v = eps of this thread's 4 columns.  Forward mode hands eps back; the sampler applies the DDIM update to the
+        // thread's piece of the state and publishes the new state as the next step's enc1 operand
+        if (A.forward_only) {
+            if (row < A.batch) *(float4*)(A.eps_out + (int64_t)row * L.c + U.col0 + 4 * q) = make_float4(v[0][0], v[0][1], v[0][2], v[0][3]);
+            return true;
+        }
+        float x0v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float zn;
+            lp_ddim(zs[i], v[0][i], rates[0], rates[1], rates[2], rates[3], x0v[i], zn);
+            zs[i] = row < A.batch ? zn : 0.f;
+            v[0][i] = zs[i];
+        }
+        if (last_step && row < A.batch) {
+            *(float4*)(A.z + (int64_t)row * 256 + U.col0 + 4 * q) = make_float4(zs[0], zs[1], zs[2], zs[3]);
+            if (A.x0 != nullptr) *(float4*)(A.x0 + (int64_t)row * 256 + U.col0 + 4 * q) = make_float4(x0v[0], x0v[1], x0v[2], x0v[3]);
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's poison stores are complete before its data stores leave
     if (c.tr != nullptr && c.tid == 0) c.tr[3] = lp_now();
     lp_gemm_store<CT>(c, L, U, S.set_off, v, false);
-    if (L.slabs == 0 && L.mode == 2 && A.forward_only && row < A.batch) {
-#pragma unroll
-        for (int t = 0; t < CT; ++t)
-            *(float4*)(A.eps_out + (int64_t)row * L.c + U.col0 + 32 * t + 4 * q) = make_float4(v[t][0], v[t][1], v[t][2], v[t][3]);
-    }
     return true;
 }
 
@@ -609,7 +625,8 @@ __global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A)
     const LpUnit* units = A.units + (int64_t)vwg * LP_MAX_UNITS;
 
     // ---- stage this workgroup's weights once: every 4-KiB image = 4 LDS-DMA instructions, dealt round-robin to the waves
-    bool is_head = false;
+    bool is_head = false;                                   // an enc1 unit: its bias is the step's time row
+    int zu = -1;                                            // this workgroup's output.2 unit (it keeps 32 columns of the state), or -1
     {
         int task = 0;
         for (int u = 0; u < LP_MAX_UNITS; ++u) {
@@ -618,6 +635,7 @@ __global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A)
             if (U.kind != LP_GEMM) continue;
             is_head |= U.head != 0;
             const LpLayer& L = A.layers[U.layer];
+            if (L.mode == 2) zu = u;
             for (int t = 0; t < U.ct; ++t)
                 for (int cl = 0; cl < U.nchunks; ++cl)
                     for (int i = 0; i < 4; ++i, ++task)
@@ -646,101 +664,47 @@ __global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A)
         }
     }
     const int k_base = A.counter != nullptr ? A.counter[0] : 0;
-    // the latent state: thread (row = tid >> 3, 32 columns from (tid & 7) * 32); rows >= batch are zero
-    float z[32];
-    const int zrow = c.tid >> 3, zq = c.tid & 7;
-    if (is_head) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (zrow < A.batch) v = *(const float4*)(A.z + (int64_t)zrow * 256 + zq * 32 + 4 * i);
-            z[4 * i] = v.x; z[4 * i + 1] = v.y; z[4 * i + 2] = v.z; z[4 * i + 3] = v.w;
+    // the latent state: the thread (row = tid >> 3, q = tid & 7) of an output.2 unit keeps columns col0 + 4 q .. + 3 of its row (rows >=
+    // batch are zero) and publishes the initial state the way every later step's epilogue does: fp16, fragment order, into the set
+    // "before" step 0 (set 2; the host poisoned all three sets)
+    float zs[4] = {0.f, 0.f, 0.f, 0.f};
+    const int zrow = c.tid >> 3;
+    if (zu >= 0) {
+        const LpUnit U = units[zu];
+        const LpLayer& L = A.layers[U.layer];
+        if (zrow < A.batch) {
+            const float4 v = *(const float4*)(A.z + (int64_t)zrow * 256 + U.col0 + 4 * (c.tid & 7));
+            zs[0] = v.x; zs[1] = v.y; zs[2] = v.z; zs[3] = v.w;
         }
+        const float v1[1][4] = {{zs[0], zs[1], zs[2], zs[3]}};
+        lp_gemm_store<1>(c, L, U, LP_CTRL_BYTES + 2 * A.set_bytes, v1, false);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int total = A.forward_only ? 1 : A.nsteps;
-    for (int step = 0; step <= total; ++step) {
-        if (A.forward_only && step == 1) break;             // forward mode: no update pass
+    for (int step = 0; step < total; ++step) {
         LpStep S;
         int k = k_base + step;
         S.k = k < A.T ? k : A.T - 1;
-        // three buffer sets: step s writes / reads set s % 3; the previous step's eps is in set (s + 2) % 3, which is also the set
-        // this workgroup re-poisons during step s (for step s + 2)
+        // three buffer sets: step s writes / reads set s % 3; the previous step's state (enc1's operand) is in set (s + 2) % 3, which is
+        // also the set this workgroup re-poisons at the end of step s (for step s + 2)
         S.set_off = LP_CTRL_BYTES + (step % 3) * A.set_bytes;
         S.other_off = LP_CTRL_BYTES + ((step + 2) % 3) * A.set_bytes;
         bool poisoned = false;
-        // enc1's bias is the hoisted time row of this step: requested now, used after the update and the product
+        // per-step constants, requested now and used behind the waits: enc1's bias is the hoisted time row of this step; the update's
+        // four rates of this thread's row
         float tbv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (is_head && step < total) {
+        if (is_head) {
             const float4 t4 = *(const float4*)(A.tb_table + (int64_t)S.k * A.tb_elems + units[0].col0 + 4 * (c.tid & 7));
             tbv[0] = t4.x; tbv[1] = t4.y; tbv[2] = t4.z; tbv[3] = t4.w;
         }
-
-        if (is_head) {
-            if (step > 0) {
-                // eps of the previous step (it lives in the other set) -> DDIM update of z; the last pass also writes x0 / z out
-                const LpLayer& Le = A.layers[LP_LAYERS - 1];
-                u32x4 e4[8];
-                const int eoff = S.other_off + Le.out_off + (zrow * 256 + zq * 32) * 4;
-                // the step's rates do not depend on eps: requested before the wait (four dependent-free loads that were a memory
-                // round trip between eps and the next step's first layer)
-                const int kp = (k_base + step - 1) < A.T ? (k_base + step - 1) : A.T - 1;
-                const int rb = zrow * A.rate_stride;
-                const float rn = A.rates[((int64_t)0 * A.T + kp) * A.rate_width + rb], rsg = A.rates[((int64_t)1 * A.T + kp) * A.rate_width + rb];
-                const float rn2 = A.rates[((int64_t)2 * A.T + kp) * A.rate_width + rb], rs2 = A.rates[((int64_t)3 * A.T + kp) * A.rate_width + rb];
-                const unsigned t0 = lp_now();
-                bool ok = true;
-                for (unsigned spin = 1;; ++spin) {
-                    bool bad = false;
+        float rates[4] = {0.f, 1.f, 0.f, 0.f};
+        if (zu >= 0 && !A.forward_only && zrow < A.batch) {
+            const int rb = zrow * A.rate_stride;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) e4[i] = lp_ld16(c, eoff + 16 * i);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) bad |= lp_nan4(e4[i]);
-                    if (__builtin_amdgcn_ballot_w64(bad) == 0ull) {
-                        if (c.lane == 0) lp_hist[LP_MAX_UNITS * 4 + c.wave] = lp_now() - t0;
-                        break;
-                    }
-                    if ((spin & 63u) == 0u && lp_give_up(c, t0, 3u)) { ok = false; break; }
-                    if (spin == 1u && c.predict) lp_presleep(t0, __builtin_amdgcn_readfirstlane(lp_hist[LP_MAX_UNITS * 4 + c.wave]), c.predict);
-                    lp_sleep(c.sleep);
-                }
-                if (!ok) lp_flag[0] = 1;
-                __syncthreads();
-                if (lp_flag[0]) return;
-                float x0v[32];
-#pragma unroll
-                for (int i = 0; i < 32; ++i) {
-                    float zn;
-                    lp_ddim(z[i], __uint_as_float(e4[i >> 2][i & 3]), rn, rsg, rn2, rs2, x0v[i], zn);
-                    z[i] = zn;
-                }
-                if (step == total && units[0].col0 == 0 && zrow < A.batch) {
-                    // head unit 0 hands the state back: z (next) and x0 of the last step
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        *(float4*)(A.z + (int64_t)zrow * 256 + zq * 32 + 4 * i) = make_float4(z[4 * i], z[4 * i + 1], z[4 * i + 2], z[4 * i + 3]);
-                        if (A.x0 != nullptr)
-                            *(float4*)(A.x0 + (int64_t)zrow * 256 + zq * 32 + 4 * i) = make_float4(x0v[4 * i], x0v[4 * i + 1], x0v[4 * i + 2], x0v[4 * i + 3]);
-                    }
-                }
-            }
-            if (step < total) {
-                // fp16 image of z (saturating round to nearest even, like pcd_skinny_fused_f32in), fragment-major in LDS:
-                // this thread's 32 columns are (chunk = zq >> 1, hh = zq & 1), piece j = columns 8 j .. 8 j + 7
-                char* z16 = lp_smem + LP_RED_BYTES;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    half8 h;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) h[e] = to_half_sat(z[8 * j + e]);
-                    *(half8*)(z16 + (zq >> 1) * 4096 + j * 1024 + (((zq & 1) << 5) + zrow) * 16) = h;
-                }
-                __syncthreads();
-            }
+            for (int i = 0; i < 4; ++i) rates[i] = A.rates[((int64_t)i * A.T + S.k) * A.rate_width + rb];
         }
-        if (step == total) break;
 
         for (int u = 0; u < LP_MAX_UNITS; ++u) {
             const LpUnit U = units[u];
@@ -753,8 +717,8 @@ __global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A)
             } else c.tr = nullptr;
             c.hist = lp_hist + u * 4 + c.wave;
             if (U.kind == LP_GEMM) {
-                if (U.ct == 2) ok = lp_run_gemm<2, 1>(c, L, U, S, A, poisoned, units, tbv);
-                else ok = lp_run_gemm<1, 4>(c, L, U, S, A, poisoned, units, tbv);
+                if (U.ct == 2) ok = lp_run_gemm<2, 1>(c, L, U, S, A, poisoned, units, tbv, zs, rates, step == total - 1);
+                else ok = lp_run_gemm<1, 4>(c, L, U, S, A, poisoned, units, tbv, zs, rates, step == total - 1);
             } else {
                 ok = lp_dispatch_finish(c, L, U, S, A, poisoned, units);
             }
@@ -762,7 +726,7 @@ __global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A)
             if (TRACE && c.tr != nullptr && c.tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); c.tr[2] = lp_now(); }
         }
         // End of this workgroup's step s.  Its units consumed step-s data, so every reader of the previous step's set is done (step
-        // s's first layer needed the complete eps of step s - 1): re-poison this workgroup's regions of that set, which step s + 2
+        // s's first layer needed the complete state published by step s - 1): re-poison this workgroup's regions of that set, which step s + 2
         // will use.  Here, behind the last unit, the stores are off every critical path (issued right behind a unit they delay the
         // next unit's operand loads: vmcnt retires in order).  Why a reader of step s + 2 cannot see step s - 1's values: before it
         // polls, it has finished its own dec4 unit of step s + 1, which needed every workgroup's gf3 output of step s + 1, and every
@@ -806,7 +770,7 @@ bool lp_build_plan(const pcd_latent_desc_t& d, LpPlan& plan) {
     int out_off[LP_LAYERS], slab_off[LP_LAYERS];
     for (int l = 0; l < LP_LAYERS; ++l) {
         out_off[l] = off;
-        off += lp_align(l == LP_LAYERS - 1 ? 32 * kC[l] * 4 : 32 * kC[l] * 2);
+        off += lp_align(32 * kC[l] * 2);                  // fp16, fragment-major (the last layer's output is the next state)
     }
     for (int l = 0; l < LP_LAYERS; ++l) {
         slab_off[l] = off;
@@ -818,7 +782,7 @@ bool lp_build_plan(const pcd_latent_desc_t& d, LpPlan& plan) {
         L.w = (const half_t*)d.lin[l].w; L.ldw = d.lin[l].k;
         L.bias = d.lin[l].b; L.gamma = d.gn_gamma[l]; L.beta = d.gn_beta[l];
         L.k1 = kK1[l]; L.k2 = kK2[l];
-        L.src1_off = kSrc1[l] < 0 ? -1 : out_off[kSrc1[l]];
+        L.src1_off = out_off[kSrc1[l] < 0 ? LP_LAYERS - 1 : kSrc1[l]];      // enc1 reads the state output.2 published (previous step's set)
         L.src2_off = kSrc2[l] < 0 ? -1 : out_off[kSrc2[l]];
         L.c = kC[l]; L.gsz = kC[l] / 8; L.mode = l < 10 ? 0 : (l == 10 ? 1 : 2);
         L.slabs = kSlabs[l]; L.out_off = out_off[l]; L.slab_off = slab_off[l];
@@ -862,7 +826,7 @@ bool lp_build_plan(const pcd_latent_desc_t& d, LpPlan& plan) {
     {
         std::vector<int> used(LP_WGS, LP_RED_BYTES);
         for (const Item& it : items)
-            used[it.wg] += it.wbytes + (it.u.head ? LP_Z16_BYTES : 0) +
+            used[it.wg] += it.wbytes +
                            (kSlabs[it.u.layer] == 0 ? 768 : (it.u.slice == 0 ? 128 * it.u.ct : 0));
         const int fin_layers[6] = {5, 4, 3, 6, 7, 8};         // largest constants first
         for (int f = 0; f < 6; ++f) {
@@ -901,7 +865,6 @@ bool lp_build_plan(const pcd_latent_desc_t& d, LpPlan& plan) {
         if (count[it.wg] >= LP_MAX_UNITS - 1) return false;                  // the last slot stays LP_END
         LpUnit u = it.u;
         if (u.kind == LP_GEMM) {
-            if (u.head) lds[it.wg] += LP_Z16_BYTES;                          // the fp16 image of z sits right behind the scratch
             u.lds_w = lds[it.wg];
             lds[it.wg] += it.wbytes;
             const LpLayer& L = plan.layers[u.layer];
@@ -917,12 +880,15 @@ bool lp_build_plan(const pcd_latent_desc_t& d, LpPlan& plan) {
         if (lds[it.wg] > LP_DYN_LDS) return false;                 // the launch's dynamic LDS (64 bytes left to the static flag word)
         plan.units[(size_t)it.wg * LP_MAX_UNITS + count[it.wg]++] = u;
     }
-    // a head unit's z16 image must start at LP_RED_BYTES: it is the workgroup's first allocation
-    for (int w = 0; w < LP_WGS; ++w)
+    // at most one output.2 unit per workgroup (it keeps its piece of the state in registers)
+    for (int w = 0; w < LP_WGS; ++w) {
+        int n = 0;
         for (int i = 0; i < LP_MAX_UNITS; ++i) {
             const LpUnit& u = plan.units[(size_t)w * LP_MAX_UNITS + i];
-            if (u.kind == LP_GEMM && u.head && u.lds_w != LP_RED_BYTES + LP_Z16_BYTES) return false;
+            if (u.kind == LP_GEMM && u.layer == LP_LAYERS - 1) { ++n; if (u.ct != 1) return false; }
         }
+        if (n > 1) return false;
+    }
     return true;
 }
 
@@ -966,7 +932,8 @@ extern "C" int pcd_latent_persist_plan_check(void) {
                 const int s1 = kSrc1[u.layer], s2 = kSrc2[u.layer];
                 const int n1 = kK1[u.layer] / 64;
                 for (int c = u.chunk0; c < u.chunk0 + u.nchunks; ++c) {
-                    const int src = c < n1 ? s1 : s2;
+                    int src = c < n1 ? s1 : s2;
+                    if (c < n1 && src < 0) src = LP_LAYERS - 1;       // enc1 reads the state published by output.2
                     if (src >= 0 && plan.layers[src].out_local && w >= 32) return -1;
                 }
             }
@@ -1101,9 +1068,9 @@ static int lp_launch(pcd_latent_persist_t* h, LpArgs& a, void* workspace, size_t
     a.predict = h->predict;
     a.trace = h->trace;
     a.trace_steps = h->trace_steps;
-    // status word cleared, sets 0 and 1 poisoned (set 2 is poisoned by the kernel during its first step, two steps before its use)
+    // status word cleared, all three sets poisoned (set 2 receives the initial state before step 0 and is re-poisoned at the end of step 0)
     PCD_CHECK_HIP(hipMemsetAsync(workspace, 0, LP_CTRL_BYTES, s));
-    PCD_CHECK_HIP(hipMemsetAsync((char*)workspace + LP_CTRL_BYTES, 0xff, 2 * (size_t)h->plan.set_bytes, s));
+    PCD_CHECK_HIP(hipMemsetAsync((char*)workspace + LP_CTRL_BYTES, 0xff, 3 * (size_t)h->plan.set_bytes, s));
     // dynamic LDS = everything but the 16 bytes of the static flag word (rounded)
     if (a.trace != nullptr) hipLaunchKernelGGL(latent_persist_kernel<true>, dim3(LP_WGS), dim3(LP_THREADS), LP_DYN_LDS, s, a);
     else hipLaunchKernelGGL(latent_persist_kernel<false>, dim3(LP_WGS), dim3(LP_THREADS), LP_DYN_LDS, s, a);
