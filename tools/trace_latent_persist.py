@@ -30,8 +30,9 @@ plan = np.array(plan).reshape(256, 8)
 names = ["enc1", "enc2", "enc3", "enc4", "gf0", "gf3", "dec4", "dec3", "dec2", "dec1", "out0", "out2"]
 for step in (40, 41):
     ent, inn, pre, out = tr[:, step, :, 0], tr[:, step, :, 1], tr[:, step, :, 3], tr[:, step, :, 2]
-    t0 = ent[plan == 0].min()
-    print(f"step {step}: times in us from the first enc1 unit's entry; per phase: units | waiting from (median) | operands in first..last | "
+    first = int(plan[plan >= 0].min())                     # the step's first phase (the enc1 -> enc2 -> enc3 chain)
+    t0 = ent[plan == first].min()
+    print(f"step {step}: times in us from the first unit's entry; per phase: units | waiting from (median) | operands in first..last | "
           f"epilogue computed (median after operands) | stores acknowledged first..last")
     prev = 0.0
     for ph in sorted(set(plan[plan >= 0].tolist())):
@@ -40,12 +41,16 @@ for step in (40, 41):
         print(f"  {names[ph // 2]:5s}{' fin' if ph & 1 else '    '} {sel.sum():4d} | {np.median(e):6.2f} | {i.min():6.2f}..{i.max():6.2f} | +{np.median(p_ - i):4.2f} | "
               f"{o.min():6.2f}..{o.max():6.2f}   (+{i.max() - prev:5.2f} after the previous phase's last ack)")
         prev = o.max()
-        wv = (tr[:, step, :, 4:8][sel] - t0) / 100.0            # operands in, per wave
+        wv = (tr[:, step, :, 4:8][sel] - t0) / 100.0            # operands in, per wave (chains: stage stamps in 5 .. 7)
+        if ph in (4, 22) and first != 0:                       # (an experimental build fused enc1-enc3 / dec1-output.2 into chain units)
+            print(f"        chain stages (median): operands in {np.median(wv[:, 0]):6.2f} | first layer done {np.median(wv[:, 1]):6.2f} | second {np.median(wv[:, 2]):6.2f} | "
+                  f"last layer's products {np.median(wv[:, 3]):6.2f} | epilogue computed {np.median(p_):6.2f}")
+            continue
         print(f"        per wave operands in (median over units): " + " ".join(f"{np.median(wv[:, k]):6.2f}" for k in range(4)) +
               f" | slowest wave - fastest wave, median {np.median(wv.max(1) - wv.min(1)):.2f} max {(wv.max(1) - wv.min(1)).max():.2f}")
         if i.max() - i.min() > 2.0 and step == 41:
             ws = np.argwhere(sel)
             late = sorted(((inn[w, u] - t0) / 100.0, (ent[w, u] - t0) / 100.0, int(w)) for w, u in ws)
             print("      late operands (in, entered, vwg):", " ".join(f"{a:.1f}/{b:.1f}/{w}" for a, b, w in late[::max(1, len(late) // 24)]))
-    t_next = tr[:, step + 1, :, 0][plan == 0].min()
+    t_next = tr[:, step + 1, :, 0][plan == first].min()
     print(f"  step length {(t_next - t0) / 100.0:.2f} us")
