@@ -31,6 +31,7 @@ struct GemmParams {
     // split-K (EPI_F32 only): `splits` independent products over consecutive k1-deep slices of the reduction;
     // slice s reads A and W at column offset s*k1 and writes the fp32 slab out32 + s*split_out
     int splits; int64_t split_out;
+    int xp_depth;             // gemm_xp_kernel: K tiles of the next tile requested before the epilogue's stores (1 or 2)
 };
 
 constexpr int BK = 64;          // K granularity required by the API (k1, k2 multiples of 64)
@@ -376,6 +377,218 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
     }   // tile loop
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 store-epilogue tile, whole tiles only, with the NEXT tile's first two K tiles requested BEFORE the epilogue's
+// stores.  Why: a round of tiles ends in a 32 MB store burst that the chip drains in ~6 us (5.1-5.5 TB/s whatever the access
+// pattern), and a load issued behind a wave's stores waits for that drain: in the generic kernel the first K tile of every tile
+// does (timeline in profiles/r01_c_gemm_tile_sweep.txt: 7-12 % "wait for the first K tile" + the epilogue).  Here both LDS
+// stages are refilled for the next tile while the accumulators are still being converted, the stores go out behind those loads,
+// and the next tile computes two K tiles (3.2 us at K tile 64) under the drain.  What makes that affordable in registers: the
+// LDS-DMA takes an SGPR base (tile and K-tile dependent, scalar) + a 32-bit VGPR offset (row-in-tile x ld + swizzled chunk,
+// tile-INVARIANT), so staging for another tile costs no vector registers and no address arithmetic (the generic kernel keeps
+// sixteen 64-bit pointers and spills 59 registers with a cross-tile prefetch).  Requires m % 256 == 0, c % 256 == 0, one K
+// source layout (k2 == 0 or lda2 == lda1), a per-shape bias only with rows_per_shape % 256 == 0; launch() falls back otherwise.
+__device__ __forceinline__ void glds16_s(unsigned voff, const half_t* sbase, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+
+// 64 lanes x 4 bytes: lane l's dword lands at lds_addr + 4 l
+__device__ __forceinline__ void glds4_s(unsigned voff, const float* sbase, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+
+// bias / per-shape bias arrive by LDS-DMA as well (both pointers non-null: the host substitutes a zero row): a compiler-visible
+// vector load in the epilogue would make the compiler wait for vmcnt(0), i.e. for the prefetched K tiles it knows nothing about
+// EPI_F16: fp16 store epilogue (16 stores per thread); EPI_COLMAX: max over the rows of a shape (4 atomics per wave; cm_rps % 128 == 0)
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_xp_kernel(GemmParams p) {
+    constexpr int NST = EPI == EPI_F16 ? 16 : 4;           // vector-memory operations of one epilogue, per wave (they count in vmcnt)
+    constexpr int BM = 256, BN = 256, BKT = 64, ROWB = 128, KS = 2, WGN = 4;
+    constexpr int WM = 128, WN = 64, MI = 8, NI = 4;
+    constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) float bias_lds[2][2][BN];      // [tile parity][bias | per-shape bias][column of the tile]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave - wm * WGN;
+    const int tiles_mn = p.tiles_m * p.tiles_n;
+    const int nk1 = p.k1 / BKT, nk = (p.k1 + p.k2) / BKT;
+
+    // staging: round r covers rows r * 64 + wave * 8 + lane / 8 of the 256-row operand panel, 16-byte chunk swz(row, lane % 8)
+    unsigned voa[4], vow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = r * 64 + wave * 8 + (lane >> 3);
+        const int chunk = swz<BKT>(row, lane & 7);
+        voa[r] = (unsigned)(row * (int)p.lda1 * 2 + chunk * 16);
+        vow[r] = (unsigned)(row * (int)p.ldw * 2 + chunk * 16);
+    }
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    auto stage = [&](int m0, int n0, int kt, int buf) __attribute__((always_inline)) {
+        const half_t* ab = kt < nk1 ? p.a1 + (int64_t)m0 * p.lda1 + kt * BKT : p.a2 + (int64_t)m0 * p.lda2 + (kt - nk1) * BKT;
+        const half_t* wb = p.w + (int64_t)n0 * p.ldw + kt * BKT;
+        const unsigned la = lds0 + buf * STAGE_BYTES + wave * 8 * ROWB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) glds16_s(voa[r], ab, la + r * 64 * ROWB);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) glds16_s(vow[r], wb, la + BM * ROWB + r * 64 * ROWB);
+    };
+    // the tile's bias columns of this wave's column quarter (waves with the same wn write the same 256 bytes: benign) -> LDS, 2 pieces
+    const unsigned lds_b = (unsigned)(size_t)&bias_lds[0][0][0];
+    auto stage_bias = [&](int m0, int n0, int par) __attribute__((always_inline)) {
+        const unsigned dst = lds_b + par * (2 * BN * 4) + wn * WN * 4;
+        glds4_s((unsigned)(lane * 4), p.bias + n0 + wn * WN, dst);
+        glds4_s((unsigned)(lane * 4), p.shape_bias + (int64_t)(m0 / p.rows_per_shape) * p.c + n0 + wn * WN, dst + BN * 4);
+    };
+    auto tile_coords = [&](int tile, int& tm, int& tn) {
+        if (p.patch_pn > 0) {
+            const int pn = p.patch_pn, pm = 32 / pn, xn = p.patch_xn, xm = 8 / xn;
+            const int round = tile >> 8, b = tile & 255;
+            const int xcd = b & 7, slot = b >> 3;
+            const int sbn = p.tiles_n / (xn * pn);
+            const int sb_m = round / sbn, sb_n = round - sb_m * sbn;
+            tm = (sb_m * xm + xcd / xn) * pm + slot / pn;
+            tn = (sb_n * xn + xcd % xn) * pn + slot % pn;
+        } else {
+            tm = tile / p.tiles_n;
+            tn = tile - tm * p.tiles_n;
+        }
+    };
+
+    // fragment read offsets (as in gemm_f16_kernel)
+    const int ra = wm * WM + (lane & 15), rb = wn * WN + (lane & 15), q = lane >> 4;
+    int offa[KS], offb[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        offa[ks] = ra * ROWB + (swz<BKT>(ra, ks * 4 + q) << 4);
+        offb[ks] = BM * ROWB + rb * ROWB + (swz<BKT>(rb, ks * 4 + q) << 4);
+    }
+    f32x4 acc[MI][NI];
+    auto compute = [&](const char* base) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            half8 af[MI], bf[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *(const half8*)(base + offa[ks] + i * 16 * ROWB);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bf[j] = *(const half8*)(base + offb[ks] + j * 16 * ROWB);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = EPI == EPI_F16 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0)
+                                               : __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= tiles_mn) return;
+    int tm, tn;
+    tile_coords(tile, tm, tn);
+    int m0 = tm * BM, n0 = tn * BN;
+    stage(m0, n0, 0, 0);
+    stage_bias(m0, n0, 0);
+    stage(m0, n0, 1, 1);                                   // nk >= 2 (checked by the host)
+    int it = 0;                                            // K tiles consumed by this block: tile `it` lives in stage it & 1
+    int par = 0;                                           // parity of this block's tile count: which bias slot the tile uses
+    bool behind_stores = false;                            // the staged K tiles are followed by the previous tile's 16 stores
+    bool pre1 = true;                                      // K tile 1 of the current tile was staged ahead (prologue / before the stores)
+    const bool deep = p.xp_depth >= 2;
+    for (;;) {
+        const int next = tile + (int)gridDim.x;
+        const bool has_next = next < tiles_mn;
+        int m1 = 0, n1 = 0;
+        if (has_next) { int tm1, tn1; tile_coords(next, tm1, tn1); m1 = tm1 * BM; n1 = tn1 * BN; }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nk; ++kt) {
+            // vmcnt counts loads and stores in issue order: K tile kt's loads are older than K tile kt + 1's (8 per thread) and than the
+            // previous tile's stores (16 per thread) when those were issued behind the prefetch
+            // (issue order around a tile boundary: K tile 0 x 8, bias x 2, [K tile 1 x 8,] the epilogue's NST stores / atomics)
+            if (kt == 0) { if (!behind_stores) wait_vmcnt<10>(); else if (pre1) wait_vmcnt<10 + NST>(); else wait_vmcnt<2 + NST>(); }
+            else if (kt == 1 && behind_stores && pre1) wait_vmcnt<NST>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            // stage it & 1 is about to be read; the other one held K tile kt - 1 and is free now (every wave passed the barrier), except at
+            // kt == 0, where it already holds K tile 1
+            if (kt >= 1 || !pre1) {
+                if (kt + 1 < nk) stage(m0, n0, kt + 1, (it + 1) & 1);
+                else if (has_next) { stage(m1, n1, 0, (it + 1) & 1); stage_bias(m1, n1, par ^ 1); }
+            }
+            compute(smem + (it & 1) * STAGE_BYTES);
+            ++it;
+        }
+        if (has_next && deep) {
+            __builtin_amdgcn_s_barrier();                  // every wave is done with the last K tile's stage: it takes the next tile's K tile 1
+            stage(m1, n1, 1, (it + 1) & 1);
+        }
+        if constexpr (EPI == EPI_COLMAX) {
+            // values are post-ReLU (>= 0): float bits order like unsigned ints, colmax pre-zeroed; the wave's 128 rows lie in one shape
+            unsigned* cm = reinterpret_cast<unsigned*>(p.colmax);
+            const int shape = (m0 + wm * WM) / p.cm_rps, colq = lane & 15;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int cl = wn * WN + j * 16 + colq;
+                const float b = bias_lds[par][0][cl] + bias_lds[par][1][cl];
+                float mx = 0.f;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[i][j][r] + b);
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                if (q == 0) atomicMax(cm + (int64_t)shape * p.c + n0 + cl, __float_as_uint(mx));
+            }
+        } else {
+        // ---- store epilogue (whole tile): accumulator element (i, j, r) = point row wm*WM + i*16 + (lane & 15), channel wn*WN + j*16 + 4 (lane >> 4) + r
+        {
+            const int q4 = (lane >> 4) * 4, pr = lane & 15, qq = lane >> 4;
+            f32x4 bv[NI];
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                bv[j] = *(const f32x4*)&bias_lds[par][0][wn * WN + j * 16 + q4] + *(const f32x4*)&bias_lds[par][1][wn * WN + j * 16 + q4];
+            const float lo = p.relu ? 0.f : -65504.f;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                half_t* orow = p.out16 + (int64_t)(m0 + wm * WM + i * 16 + pr) * p.ldo;
+#pragma unroll
+                for (int j = 0; j < NI; j += 2) {
+                    unsigned pk[2][2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const f32x4 v = acc[i][j + t] + bv[j + t];
+                        half2_ lo2, hi2;
+                        lo2[0] = (half_t)__builtin_amdgcn_fmed3f(v[0], lo, 65504.f);
+                        lo2[1] = (half_t)__builtin_amdgcn_fmed3f(v[1], lo, 65504.f);
+                        hi2[0] = (half_t)__builtin_amdgcn_fmed3f(v[2], lo, 65504.f);
+                        hi2[1] = (half_t)__builtin_amdgcn_fmed3f(v[3], lo, 65504.f);
+                        pk[t][0] = __builtin_bit_cast(unsigned, lo2);
+                        pk[t][1] = __builtin_bit_cast(unsigned, hi2);
+                    }
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                    const int col = n0 + wn * WN + (j + (qq & 1)) * 16 + (qq >> 1) * 8;
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    *(u32x4*)(orow + col) = (u32x4){s0[0], s1[0], s0[1], s1[1]};
+                }
+            }
+        }
+        }
+        if (!has_next) break;
+        behind_stores = true;
+        pre1 = deep;
+        par ^= 1;
+        tile = next; m0 = m1; n0 = n1;
+    }
+}
+
+static int g_xp = 1;            // tuning hook (pcd_gemm_set_config(5) / (6) / (7)): the cross-tile prefetching store kernel off / 2 K tiles ahead / 1
+
 static int num_cus() {
     static int n = 0;
     if (n == 0) {
@@ -404,6 +617,32 @@ static int launch(const GemmParams& p0, hipStream_t s, int blocks_per_cu) {
         const int xn = p.tiles_n >= 16 ? 2 : 1;
         if ((pn & (pn - 1)) == 0 && p.tiles_n % (xn * pn) == 0 && p.tiles_m % ((8 / xn) * (32 / pn)) == 0) {
             p.patch_pn = pn; p.patch_xn = xn;
+        }
+    }
+    if constexpr (BM == 256 && BN == 256 && (EPI == EPI_F16 || EPI == EPI_COLMAX) && STAGES == 2 && BKT == 64) {
+        // whole tiles, one A layout, per-shape bias only if a tile lies in one shape: the variant that refills both LDS stages for
+        // the next tile before the epilogue's stores (gemm_xp_kernel)
+        const bool ok = g_xp && p.m % 256 == 0 && p.c % 256 == 0 && p.splits == 1 && (p.k1 + p.k2) >= 128 &&
+                        (p.k2 == 0 || p.lda2 == p.lda1) && (p.shape_bias == nullptr || p.rows_per_shape % 256 == 0) &&
+                        (EPI != EPI_COLMAX || p.cm_rps % 128 == 0) &&
+                        (int64_t)255 * p.lda1 * 2 + 128 < 0x7fffffffLL && (int64_t)255 * p.ldw * 2 + 128 < 0x7fffffffLL;
+        if (ok && (p.bias == nullptr || p.shape_bias == nullptr)) {
+            // a zero row stands in for a missing bias (fixed number of LDS-DMA pieces per tile: the waits are counted)
+            static float* zeros = nullptr;
+            constexpr int kZeroCols = 16384;
+            if (zeros == nullptr && p.c <= kZeroCols) {
+                if (hipMalloc(&zeros, kZeroCols * sizeof(float)) != hipSuccess || hipMemset(zeros, 0, kZeroCols * sizeof(float)) != hipSuccess) zeros = nullptr;
+            }
+            if (zeros != nullptr && p.c <= kZeroCols) {
+                if (p.bias == nullptr) p.bias = zeros;
+                if (p.shape_bias == nullptr) { p.shape_bias = zeros; p.rows_per_shape = p.m; }       // shape 0 for every tile
+            }
+        }
+        if (ok && p.bias != nullptr && p.shape_bias != nullptr) {
+            p.xp_depth = EPI == EPI_COLMAX ? 1 : g_xp;
+            hipLaunchKernelGGL(gemm_xp_kernel<EPI>, dim3(grid), dim3(512), 0, s, p);
+            PCD_CHECK_LAUNCH();
+            return PCD_OK;
         }
     }
     hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WGM, WGN, STAGES, EPI, BKT>), dim3(grid), dim3(64 * WGM * WGN), 0, s, p);
@@ -537,7 +776,8 @@ extern "C" int pcd_gemm_f16_colmax(const pcd_gemm_desc_t* d, float* colmax, int 
 }
 
 extern "C" int pcd_gemm_set_config(int cfg) {
-    PCD_CHECK_ARG(cfg >= -1 && cfg <= 4);
+    PCD_CHECK_ARG(cfg >= -1 && cfg <= 7);
+    if (cfg >= 5) { g_xp = cfg == 5 ? 0 : (cfg == 6 ? 2 : 1); return PCD_OK; }      // A/B switch of gemm_xp_kernel; the tile choice is left as it is
     g_force_cfg = cfg;
     return PCD_OK;
 }

@@ -77,7 +77,9 @@ int pcd_gemm_f16_residual(const pcd_gemm_desc_t* d, const void* resid, int64_t l
 int pcd_gemm_f16_colmax(const pcd_gemm_desc_t* d, float* colmax, int rows_per_shape, void* stream);
 
 /* tuning/benchmark hook: force a tile configuration for every following GEMM launch of this
- * process (-1 = shape heuristic; 0: 128x64, 1: 128x128, 2: 256x128 3-stage, 3: 256x256, 4: 128x128 3-stage) */
+ * process (-1 = shape heuristic; 0: 128x64, 1: 128x128, 2: 256x128 3-stage, 3: 256x256, 4: 128x128 3-stage).
+ * 5 / 7 / 6 leave the tile choice alone and switch the 256x256 store / column-max kernel that requests the next tile's first
+ * K tile(s) before the epilogue's stores (whole tiles only): off / one K tile ahead (default) / two (store epilogue only). */
 int pcd_gemm_set_config(int cfg);
 
 int pcd_fill_zero(void* p, size_t bytes, void* stream);

@@ -54,6 +54,48 @@ def test_gemm_persistent_tile_mappings_exact(ops, m, k, c):
     assert torch.equal(cm, want_cm)
 
 
+@pytest.mark.parametrize("depth_cfg", [7, 6])
+def test_gemm_cross_tile_prefetch_kernel_exact(ops, depth_cfg):
+    """gemm_xp_kernel (whole 256 x 256 tiles; the next tile's first K tile(s) requested before the epilogue's stores, bias by LDS-DMA,
+    counted vmcnt waits): several tiles per workgroup, two K sources, a per-shape bias, no bias at all, no ReLU, the column-max
+    epilogue -- exact on small integers, and bitwise equal to the generic kernel."""
+    from shapegen_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    try:
+        for m, k1, k2, c, use_bias, use_sb, relu in [(65536, 256, 0, 512, True, False, True), (32768, 128, 128, 1024, True, True, True),
+                                                     (65536, 192, 0, 256, False, False, False), (16384 + 512, 192, 192, 768, False, True, True)]:
+            a1 = torch.randint(-3, 4, (m, k1), generator=g, device="cuda").half()
+            a2 = torch.randint(-3, 4, (m, k2), generator=g, device="cuda").half() if k2 else None
+            w = torch.randint(-2, 3, (c, k1 + k2), generator=g, device="cuda").half()
+            bias = torch.randint(-3, 4, (c,), generator=g, device="cuda").float() if use_bias else None
+            rps = 256 if m % 2048 else 2048
+            sb = torch.randint(-3, 4, (m // rps, c), generator=g, device="cuda").float() if use_sb else None
+            want = (torch.cat([a1, a2], 1) if k2 else a1).float() @ w.float().t()
+            if use_bias: want = want + bias
+            if use_sb: want = want + sb.repeat_interleave(rps, 0)
+            if relu: want = want.clamp_min(0)
+            outs = {}
+            for cfg in (depth_cfg, 5):
+                lib.pcd_gemm_set_config(cfg)
+                d = ops._desc(a1, w, bias, a2, sb, rps if use_sb else 0, relu)      # (two sources: equal row strides, the kernel's condition)
+                out = torch.empty(m, c, dtype=torch.float16, device="cuda")
+                _lib.check(lib.pcd_gemm_f16(d, out.data_ptr(), c, _lib.stream_ptr()), "gemm_f16")
+                outs[cfg] = out
+            assert torch.equal(outs[depth_cfg].float(), want.half().float()), (m, k1, k2, c)
+            assert torch.equal(outs[depth_cfg], outs[5])
+        # column max, several tiles per workgroup (65536 x 512 / 256^2 = 512 tiles)
+        a = torch.randint(-3, 4, (65536, 256), generator=g, device="cuda").half()
+        w = torch.randint(-2, 3, (512, 256), generator=g, device="cuda").half()
+        bias = torch.randint(-3, 4, (512,), generator=g, device="cuda").float()
+        want = (a.float() @ w.float().t() + bias).clamp_min(0).reshape(-1, 2048, 512).max(1)[0]
+        for cfg in (depth_cfg, 5):
+            lib.pcd_gemm_set_config(cfg)
+            assert torch.equal(ops.gemm_f16_colmax(a, w, bias, 2048), want), cfg
+    finally:
+        lib.pcd_gemm_set_config(7)
+
+
 def test_gemm_dual_source_shape_bias_residual(ops):
     m, k1, k2, c, rps = 384, 128, 64, 136, 96
     a1, a2, w = _int_mat(m, k1, 4), _int_mat(m, k2, 5), _int_mat(c, k1 + k2, 6)
