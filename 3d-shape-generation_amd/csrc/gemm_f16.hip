@@ -386,7 +386,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
 // and the next tile computes two K tiles (3.2 us at K tile 64) under the drain.  What makes that affordable in registers: the
 // LDS-DMA takes an SGPR base (tile and K-tile dependent, scalar) + a 32-bit VGPR offset (row-in-tile x ld + swizzled chunk,
 // tile-INVARIANT), so staging for another tile costs no vector registers and no address arithmetic (the generic kernel keeps
-// sixteen 64-bit pointers and spills 59 registers with a cross-tile prefetch).  Requires m % 256 == 0, c % 256 == 0, one K
+// sixteen 64-bit pointers and spills 59 registers with a cross-tile prefetch).  Measured (tools/bench_gemm_xp.py, profiles/r03_k): one K tile
+// ahead beats the generic kernel on every store shape (+3 ... +15 %) and on the column-max GEMM (+4 %); two K tiles ahead (the second
+// one behind an extra barrier) is better only at K = 1024, C = 512 and worse on the wide layers; converting the tile to fp16 and
+// storing it in pieces during the next tile's first four K tiles (64 more live registers, A fragments in two halves) ran 12-30 % SLOWER.
+// Requires m % 256 == 0, c % 256 == 0, one K
 // source layout (k2 == 0 or lda2 == lda1), a per-shape bias only with rows_per_shape % 256 == 0; launch() falls back otherwise.
 __device__ __forceinline__ void glds16_s(unsigned voff, const half_t* sbase, unsigned lds_addr) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");

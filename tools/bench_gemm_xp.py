@@ -60,6 +60,6 @@ for rep in range(3):
         lib.pcd_gemm_set_config(cfg)
         ms = ev(lambda: model.model(x, tt), 20) / 1e3
         res[cfg] = model.model(x, tt).clone()
-        if rep: print(f"forward, xp {'2' if cfg == 6 else ('1' if cfg == 7 else 'off')}: {ms:.3f} ms", flush=True)
-print("forward outputs bitwise equal:", torch.equal(res[5], res[6]))
+        if rep: print(f"forward, {'xp 2' if cfg == 6 else ('xp 1' if cfg == 7 else 'generic')}: {ms:.3f} ms", flush=True)
+print("forward outputs bitwise equal:", torch.equal(res[5], res[6]) and torch.equal(res[5], res[7]))
 lib.pcd_gemm_set_config(7)
