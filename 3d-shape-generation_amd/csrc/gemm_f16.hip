@@ -403,10 +403,12 @@ __device__ __forceinline__ void glds4_s(unsigned voff, const float* sbase, unsig
 
 // bias / per-shape bias arrive by LDS-DMA as well (both pointers non-null: the host substitutes a zero row): a compiler-visible
 // vector load in the epilogue would make the compiler wait for vmcnt(0), i.e. for the prefetched K tiles it knows nothing about
-// EPI_F16: fp16 store epilogue (16 stores per thread); EPI_COLMAX: max over the rows of a shape (4 atomics per wave; cm_rps % 128 == 0)
+// EPI_F16 / EPI_RESID: fp16 store epilogue (16 stores per thread, + 16 residual loads); EPI_COLMAX: max over the rows of a shape
+// (4 atomics per wave; cm_rps % 128 == 0)
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_xp_kernel(GemmParams p) {
-    constexpr int NST = EPI == EPI_F16 ? 16 : 4;           // vector-memory operations of one epilogue, per wave (they count in vmcnt)
+    // vector-memory operations of one epilogue, per wave (they count in vmcnt): 16 stores (+ 16 residual loads), or 4 atomics
+    constexpr int NST = EPI == EPI_F16 ? 16 : (EPI == EPI_RESID ? 32 : 4);
     constexpr int BM = 256, BN = 256, BKT = 64, ROWB = 128, KS = 2, WGN = 4;
     constexpr int WM = 128, WN = 64, MI = 8, NI = 4;
     constexpr int STAGE_BYTES = (BM + BN) * ROWB;
@@ -482,8 +484,8 @@ __global__ __launch_bounds__(512) void gemm_xp_kernel(GemmParams p) {
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = EPI == EPI_F16 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0)
-                                               : __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = EPI != EPI_COLMAX ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0)
+                                                  : __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         }
     };
@@ -578,7 +580,16 @@ __global__ __launch_bounds__(512) void gemm_xp_kernel(GemmParams p) {
                     const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
                     const int col = n0 + wn * WN + (j + (qq & 1)) * 16 + (qq >> 1) * 8;
                     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                    *(u32x4*)(orow + col) = (u32x4){s0[0], s1[0], s0[1], s1[1]};
+                    u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                    if constexpr (EPI == EPI_RESID) {
+                        // (a compiler-visible load: the compiler's own wait for it also waits for the older prefetch, which is at most early)
+                        half8 ov = __builtin_bit_cast(half8, o);
+                        const half8 rs = *(const half8*)(p.resid + (int64_t)(m0 + wm * WM + i * 16 + pr) * p.ldr + col);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ov[e] = to_half_sat((float)ov[e] + (float)rs[e]);
+                        o = __builtin_bit_cast(u32x4, ov);
+                    }
+                    *(u32x4*)(orow + col) = o;
                 }
             }
         }
@@ -623,7 +634,7 @@ static int launch(const GemmParams& p0, hipStream_t s, int blocks_per_cu) {
             p.patch_pn = pn; p.patch_xn = xn;
         }
     }
-    if constexpr (BM == 256 && BN == 256 && (EPI == EPI_F16 || EPI == EPI_COLMAX) && STAGES == 2 && BKT == 64) {
+    if constexpr (BM == 256 && BN == 256 && (EPI == EPI_F16 || EPI == EPI_COLMAX || EPI == EPI_RESID) && STAGES == 2 && BKT == 64) {
         // whole tiles, one A layout, per-shape bias only if a tile lies in one shape: the variant that refills both LDS stages for
         // the next tile before the epilogue's stores (gemm_xp_kernel)
         const bool ok = g_xp && p.m % 256 == 0 && p.c % 256 == 0 && p.splits == 1 && (p.k1 + p.k2) >= 128 &&
@@ -643,7 +654,7 @@ static int launch(const GemmParams& p0, hipStream_t s, int blocks_per_cu) {
             }
         }
         if (ok && p.bias != nullptr && p.shape_bias != nullptr) {
-            p.xp_depth = EPI == EPI_COLMAX ? 1 : g_xp;
+            p.xp_depth = EPI == EPI_F16 ? g_xp : 1;
             hipLaunchKernelGGL(gemm_xp_kernel<EPI>, dim3(grid), dim3(512), 0, s, p);
             PCD_CHECK_LAUNCH();
             return PCD_OK;

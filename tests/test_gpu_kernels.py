@@ -57,8 +57,8 @@ def test_gemm_persistent_tile_mappings_exact(ops, m, k, c):
 @pytest.mark.parametrize("depth_cfg", [7, 6])
 def test_gemm_cross_tile_prefetch_kernel_exact(ops, depth_cfg):
     """gemm_xp_kernel (whole 256 x 256 tiles; the next tile's first K tile(s) requested before the epilogue's stores, bias by LDS-DMA,
-    counted vmcnt waits): several tiles per workgroup, two K sources, a per-shape bias, no bias at all, no ReLU, the column-max
-    epilogue -- exact on small integers, and bitwise equal to the generic kernel."""
+    counted vmcnt waits): several tiles per workgroup, two K sources, a per-shape bias, no bias at all, no ReLU, the residual and the
+    column-max epilogues -- exact on small integers, and bitwise equal to the generic kernel."""
     from shapegen_amd import _lib
     lib = _lib.load()
     g = torch.Generator(device="cuda").manual_seed(5)
@@ -84,6 +84,17 @@ def test_gemm_cross_tile_prefetch_kernel_exact(ops, depth_cfg):
                 outs[cfg] = out
             assert torch.equal(outs[depth_cfg].float(), want.half().float()), (m, k1, k2, c)
             assert torch.equal(outs[depth_cfg], outs[5])
+        # residual epilogue (the attention blocks' out_proj / FFN.2): out = fp16(fp16(acc + bias) + resid), 2 tiles per workgroup
+        a = torch.randint(-3, 4, (65536, 256), generator=g, device="cuda").half()
+        w = torch.randint(-2, 3, (512, 256), generator=g, device="cuda").half()
+        bias = torch.randint(-3, 4, (512,), generator=g, device="cuda").float()
+        resid = torch.randint(-5, 6, (65536, 512), generator=g, device="cuda").half()
+        want = ((a.float() @ w.float().t() + bias).half().float() + resid.float()).half()
+        res = {}
+        for cfg in (depth_cfg, 5):
+            lib.pcd_gemm_set_config(cfg)
+            res[cfg] = ops.gemm_f16_residual(a, w, bias, resid)
+        assert torch.equal(res[depth_cfg], want) and torch.equal(res[depth_cfg], res[5])
         # column max, several tiles per workgroup (65536 x 512 / 256^2 = 512 tiles)
         a = torch.randint(-3, 4, (65536, 256), generator=g, device="cuda").half()
         w = torch.randint(-2, 3, (512, 256), generator=g, device="cuda").half()
