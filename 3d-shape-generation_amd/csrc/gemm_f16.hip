@@ -389,7 +389,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
 // sixteen 64-bit pointers and spills 59 registers with a cross-tile prefetch).  Measured (tools/bench_gemm_xp.py, profiles/r03_k): one K tile
 // ahead beats the generic kernel on every store shape (+3 ... +15 %) and on the column-max GEMM (+4 %); two K tiles ahead (the second
 // one behind an extra barrier) is better only at K = 1024, C = 512 and worse on the wide layers; converting the tile to fp16 and
-// storing it in pieces during the next tile's first four K tiles (64 more live registers, A fragments in two halves) ran 12-30 % SLOWER.
+// storing it in pieces during the next tile's first four K tiles (64 more live registers, A fragments in two halves) ran 12-30 % SLOWER;
+// non-temporal output stores change nothing (forward 3.67-3.71 v. 3.63-3.65 ms).
 // Requires m % 256 == 0, c % 256 == 0, one K
 // source layout (k2 == 0 or lda2 == lda1), a per-shape bias only with rows_per_shape % 256 == 0; launch() falls back otherwise.
 __device__ __forceinline__ void glds16_s(unsigned voff, const half_t* sbase, unsigned lds_addr) {
