@@ -647,7 +647,12 @@ static int launch(const GemmParams& p0, hipStream_t s, int blocks_per_cu) {
             static float* zeros = nullptr;
             constexpr int kZeroCols = 16384;
             if (zeros == nullptr && p.c <= kZeroCols) {
-                if (hipMalloc(&zeros, kZeroCols * sizeof(float)) != hipSuccess || hipMemset(zeros, 0, kZeroCols * sizeof(float)) != hipSuccess) zeros = nullptr;
+                // one-time allocation: never inside a stream capture (a launch that is being captured takes the generic kernel instead)
+                hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+                if (hipStreamIsCapturing(s, &cap) != hipSuccess) { cap = hipStreamCaptureStatusActive; (void)hipGetLastError(); }
+                if (cap == hipStreamCaptureStatusNone &&
+                    (hipMalloc(&zeros, kZeroCols * sizeof(float)) != hipSuccess || hipMemset(zeros, 0, kZeroCols * sizeof(float)) != hipSuccess))
+                    zeros = nullptr;
             }
             if (zeros != nullptr && p.c <= kZeroCols) {
                 if (p.bias == nullptr) p.bias = zeros;
