@@ -42,6 +42,7 @@
 namespace pcd {
 
 constexpr int LP_WGS = 256, LP_THREADS = 256, LP_LAYERS = 12, LP_MAX_UNITS = 8;
+constexpr int LP_SCHED = 16;                           // two streams: entries of a workgroup's merged unit order (one period)
 constexpr int LP_LDS_BYTES = 160 * 1024;
 constexpr int LP_DYN_LDS = LP_LDS_BYTES - 256;         // dynamic part: the kernel's static words (abort flag, wait history) take the rest
 constexpr int LP_RED_BYTES = 4 * 32 * 33 * 4;          // cross-wave reduction scratch
@@ -83,7 +84,7 @@ struct LpUnit {
 struct LpArgs {
     const LpLayer* layers;             // [LP_LAYERS]
     const LpUnit* units;               // [LP_WGS][LP_MAX_UNITS]
-    char* ws;                          // ctrl | set 0 | set 1
+    char* ws;                          // ctrl | stream 0: sets 0, 1, 2 | stream 1: sets 0, 1, 2
     int set_bytes;
     float* z;                          // fp32 [batch][256], in/out (DDIM mode) or in (forward mode)
     float* x0;                         // fp32 [batch][256] or null
@@ -94,6 +95,7 @@ struct LpArgs {
     int* counter;                      // device step counter (pcd_step_select semantics), or null: k = 0
     int nsteps;
     int forward_only;
+    const int* sched;                  // two streams (batch > 32): [LP_WGS][LP_SCHED] merged unit order of one period, else null
     int sleep;                         // s_sleep argument between polls
     int predict;                       // sleep through most of the wait the previous step measured before probing
     unsigned* trace;                   // diagnostic build only: [wg][step][unit][8] s_memrealtime stamps (enter, operands in, stored, epilogue computed, operands in of waves 0..3)
@@ -274,6 +276,7 @@ struct LpStep {
     int k;                 // row of the step tables
     int set_off;           // byte offset of this step's buffer set in the workspace
     int other_off;         // ... of the other set (previous step's data; to be poisoned for the next step)
+    int r0, nb;            // the rows of the batch this stream carries: global row r0 + local row, local rows < nb exist
 };
 
 // epilogue stores of a gemm unit (or its poison when `poison`): thread = (row = tid >> 3, q = tid & 7), 4 columns per tile
@@ -402,7 +405,7 @@ __device__ __forceinline__ bool lp_run_gemm(const LpCtx& c, const LpLayer& L, co
         // output.2: v = eps of this thread's 4 columns.  Forward mode hands eps back; the sampler applies the DDIM update to the
         // thread's piece of the state and publishes the new state as the next step's enc1 operand
         if (A.forward_only) {
-            if (row < A.batch) *(float4*)(A.eps_out + (int64_t)row * L.c + U.col0 + 4 * q) = make_float4(v[0][0], v[0][1], v[0][2], v[0][3]);
+            if (row < S.nb) *(float4*)(A.eps_out + (int64_t)(S.r0 + row) * L.c + U.col0 + 4 * q) = make_float4(v[0][0], v[0][1], v[0][2], v[0][3]);
             return true;
         }
         float x0v[4];
@@ -410,12 +413,12 @@ __device__ __forceinline__ bool lp_run_gemm(const LpCtx& c, const LpLayer& L, co
         for (int i = 0; i < 4; ++i) {
             float zn;
             lp_ddim(zs[i], v[0][i], rates[0], rates[1], rates[2], rates[3], x0v[i], zn);
-            zs[i] = row < A.batch ? zn : 0.f;
+            zs[i] = row < S.nb ? zn : 0.f;
             v[0][i] = zs[i];
         }
-        if (last_step && row < A.batch) {
-            *(float4*)(A.z + (int64_t)row * 256 + U.col0 + 4 * q) = make_float4(zs[0], zs[1], zs[2], zs[3]);
-            if (A.x0 != nullptr) *(float4*)(A.x0 + (int64_t)row * 256 + U.col0 + 4 * q) = make_float4(x0v[0], x0v[1], x0v[2], x0v[3]);
+        if (last_step && row < S.nb) {
+            *(float4*)(A.z + (int64_t)(S.r0 + row) * 256 + U.col0 + 4 * q) = make_float4(zs[0], zs[1], zs[2], zs[3]);
+            if (A.x0 != nullptr) *(float4*)(A.x0 + (int64_t)(S.r0 + row) * 256 + U.col0 + 4 * q) = make_float4(x0v[0], x0v[1], x0v[2], x0v[3]);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's poison stores are complete before its data stores leave
@@ -583,13 +586,22 @@ __device__ __forceinline__ void lp_poison_all(const LpCtx& c, const LpArgs& A, c
 }
 
 // --------------------------------------------------------------------------------------------- the kernel
-template <bool TRACE>
+// NS = 1: a batch of up to 32 rows as one stream of steps.  NS = 2 (batches of 33 .. 64): rows 0 .. 31 and the rest as TWO independent
+// streams (GroupNorm is per row: they never meet), each with its own three buffer sets, that every workgroup interleaves in a FIXED order:
+// a step is 18 dependent exchanges of ~2 us during which a workgroup works ~20 % of the time, so stream 1 runs about half a step behind
+// stream 0 and its units fill stream 0's waits.  The order is the same total order on every workgroup -- key = the time a phase becomes
+// runnable in a step + the lag for stream 1 (host: lp_upload_sched); a unit depends only on units of its own stream with smaller keys --
+// so blocking waits in that order cannot deadlock (the unfinished unit with the smallest key is always runnable), and every wait stays the
+// per-wave spin of the single-stream loop.  51-53 us per step of the pair (26 per 32 rows) against 2 x 35 for one stream after the other.
+// (Trying both streams' next units in turn, or one probe load per stream in flight, were both slower than running the streams one after
+// the other: a poll that involves the whole workgroup delays the other stream's detection by its round trip: 71 and 103 us per step.)
+template <bool TRACE, int NS>
 __global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A) {
     extern __shared__ __attribute__((aligned(16))) char lp_smem[];
     __shared__ int lp_flag[4];
     __shared__ unsigned lp_hist[(LP_MAX_UNITS + 1) * 4];
     LpCtx c;
-    c.rs = __builtin_amdgcn_make_buffer_rsrc(A.ws, 0, LP_CTRL_BYTES + 3 * A.set_bytes, 0x00020000);
+    c.rs = __builtin_amdgcn_make_buffer_rsrc(A.ws, 0, LP_CTRL_BYTES + NS * 3 * A.set_bytes, 0x00020000);
     c.ctrl = (unsigned*)A.ws;
     c.smem = lp_smem;
     c.lds_flag = lp_flag;
@@ -664,74 +676,123 @@ __global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A)
         }
     }
     const int k_base = A.counter != nullptr ? A.counter[0] : 0;
-    // the latent state: the thread (row = tid >> 3, q = tid & 7) of an output.2 unit keeps columns col0 + 4 q .. + 3 of its row (rows >=
-    // batch are zero) and publishes the initial state the way every later step's epilogue does: fp16, fragment order, into the set
-    // "before" step 0 (set 2; the host poisoned all three sets)
-    float zs[4] = {0.f, 0.f, 0.f, 0.f};
+    // rows of the batch per stream: stream s carries global rows sr0[s] .. sr0[s] + snb[s] - 1 as its local rows 0 ..
+    int sr0[NS], snb[NS];
+    sr0[0] = 0; snb[0] = NS == 1 ? A.batch : 32;
+    if constexpr (NS == 2) { sr0[1] = 32; snb[1] = A.batch - 32; }
+    // the latent state: the thread (row = tid >> 3, q = tid & 7) of an output.2 unit keeps columns col0 + 4 q .. + 3 of its row (rows past
+    // the stream's are zero) and publishes the initial state the way every later step's epilogue does: fp16, fragment order, into the set
+    // "before" step 0 (the stream's set 2; the host poisoned all the sets)
+    float zs[NS][4];
     const int zrow = c.tid >> 3;
-    if (zu >= 0) {
-        const LpUnit U = units[zu];
-        const LpLayer& L = A.layers[U.layer];
-        if (zrow < A.batch) {
-            const float4 v = *(const float4*)(A.z + (int64_t)zrow * 256 + U.col0 + 4 * (c.tid & 7));
-            zs[0] = v.x; zs[1] = v.y; zs[2] = v.z; zs[3] = v.w;
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+        zs[st][0] = zs[st][1] = zs[st][2] = zs[st][3] = 0.f;
+        if (zu >= 0) {
+            const LpUnit U = units[zu];
+            const LpLayer& L = A.layers[U.layer];
+            if (zrow < snb[st]) {
+                const float4 v = *(const float4*)(A.z + (int64_t)(sr0[st] + zrow) * 256 + U.col0 + 4 * (c.tid & 7));
+                zs[st][0] = v.x; zs[st][1] = v.y; zs[st][2] = v.z; zs[st][3] = v.w;
+            }
+            const float v1[1][4] = {{zs[st][0], zs[st][1], zs[st][2], zs[st][3]}};
+            lp_gemm_store<1>(c, L, U, LP_CTRL_BYTES + (st * 3 + 2) * A.set_bytes, v1, false);
         }
-        const float v1[1][4] = {{zs[0], zs[1], zs[2], zs[3]}};
-        lp_gemm_store<1>(c, L, U, LP_CTRL_BYTES + 2 * A.set_bytes, v1, false);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int total = A.forward_only ? 1 : A.nsteps;
-    for (int step = 0; step < total; ++step) {
+    // one step's constants of a stream: its buffer sets (three per stream, rotating by step: the previous step's state -- enc1's operand --
+    // is in set (step + 2) % 3, which is also the set re-poisoned at the end of the step, for step + 2), the row of the step tables
+    auto step_of = [&](int st, int step) {
         LpStep S;
-        int k = k_base + step;
+        const int k = k_base + step;
         S.k = k < A.T ? k : A.T - 1;
-        // three buffer sets: step s writes / reads set s % 3; the previous step's state (enc1's operand) is in set (s + 2) % 3, which is
-        // also the set this workgroup re-poisons at the end of step s (for step s + 2)
-        S.set_off = LP_CTRL_BYTES + (step % 3) * A.set_bytes;
-        S.other_off = LP_CTRL_BYTES + ((step + 2) % 3) * A.set_bytes;
-        bool poisoned = false;
-        // per-step constants, requested now and used behind the waits: enc1's bias is the hoisted time row of this step; the update's
-        // four rates of this thread's row
-        float tbv[4] = {0.f, 0.f, 0.f, 0.f};
+        S.set_off = LP_CTRL_BYTES + (st * 3 + step % 3) * A.set_bytes;
+        S.other_off = LP_CTRL_BYTES + (st * 3 + (step + 2) % 3) * A.set_bytes;
+        S.r0 = sr0[st]; S.nb = snb[st];
+        return S;
+    };
+    // per-step constants, requested at the start of a step and used behind the waits: enc1's bias is the hoisted time row of the step;
+    // the update's four rates of this thread's row
+    auto step_consts = [&](const LpStep& S, float (&tbv)[4], float (&rates)[4]) __attribute__((always_inline)) {
+        tbv[0] = tbv[1] = tbv[2] = tbv[3] = 0.f;
         if (is_head) {
             const float4 t4 = *(const float4*)(A.tb_table + (int64_t)S.k * A.tb_elems + units[0].col0 + 4 * (c.tid & 7));
             tbv[0] = t4.x; tbv[1] = t4.y; tbv[2] = t4.z; tbv[3] = t4.w;
         }
-        float rates[4] = {0.f, 1.f, 0.f, 0.f};
-        if (zu >= 0 && !A.forward_only && zrow < A.batch) {
-            const int rb = zrow * A.rate_stride;
+        rates[0] = 0.f; rates[1] = 1.f; rates[2] = 0.f; rates[3] = 0.f;
+        if (zu >= 0 && !A.forward_only && zrow < S.nb) {
+            const int rb = (S.r0 + zrow) * A.rate_stride;
 #pragma unroll
             for (int i = 0; i < 4; ++i) rates[i] = A.rates[((int64_t)i * A.T + S.k) * A.rate_width + rb];
         }
-
-        for (int u = 0; u < LP_MAX_UNITS; ++u) {
-            const LpUnit U = units[u];
-            if (U.kind == LP_END) break;
-            const LpLayer& L = A.layers[U.layer];
-            bool ok;
-            if (TRACE && step < A.trace_steps) {
-                c.tr = A.trace + (((int64_t)vwg * A.trace_steps + step) * LP_MAX_UNITS + u) * 8;
-                if (c.tid == 0) c.tr[0] = lp_now();
-            } else c.tr = nullptr;
-            c.hist = lp_hist + u * 4 + c.wave;
-            if (U.kind == LP_GEMM) {
-                if (U.ct == 2) ok = lp_run_gemm<2, 1>(c, L, U, S, A, poisoned, units, tbv, zs, rates, step == total - 1);
-                else ok = lp_run_gemm<1, 4>(c, L, U, S, A, poisoned, units, tbv, zs, rates, step == total - 1);
-            } else {
-                ok = lp_dispatch_finish(c, L, U, S, A, poisoned, units);
-            }
-            if (!ok) return;
-            if (TRACE && c.tr != nullptr && c.tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); c.tr[2] = lp_now(); }
+    };
+    bool poisoned = false;
+    // one unit of (stream, step), blocking
+    auto run_unit = [&](const LpStep& S, int u, int step, bool traced, const float (&tbv)[4], float (&zst)[4], const float (&rates)[4]) __attribute__((always_inline)) {
+        const LpUnit U = units[u];
+        const LpLayer& L = A.layers[U.layer];
+        if (TRACE && traced && step < A.trace_steps) {
+            c.tr = A.trace + (((int64_t)vwg * A.trace_steps + step) * LP_MAX_UNITS + u) * 8;
+            if (c.tid == 0) c.tr[0] = lp_now();
+        } else c.tr = nullptr;
+        bool ok;
+        if (U.kind == LP_GEMM) {
+            if (U.ct == 2) ok = lp_run_gemm<2, 1>(c, L, U, S, A, poisoned, units, tbv, zst, rates, step == total - 1);
+            else ok = lp_run_gemm<1, 4>(c, L, U, S, A, poisoned, units, tbv, zst, rates, step == total - 1);
+        } else {
+            ok = lp_dispatch_finish(c, L, U, S, A, poisoned, units);
         }
-        // End of this workgroup's step s.  Its units consumed step-s data, so every reader of the previous step's set is done (step
-        // s's first layer needed the complete state published by step s - 1): re-poison this workgroup's regions of that set, which step s + 2
-        // will use.  Here, behind the last unit, the stores are off every critical path (issued right behind a unit they delay the
-        // next unit's operand loads: vmcnt retires in order).  Why a reader of step s + 2 cannot see step s - 1's values: before it
-        // polls, it has finished its own dec4 unit of step s + 1, which needed every workgroup's gf3 output of step s + 1, and every
-        // data store waits (s_waitcnt vmcnt(0)) for all earlier stores of its wave, these included.
-        lp_poison_all(c, A, units, S.other_off);
+        if (ok && TRACE && c.tr != nullptr && c.tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); c.tr[2] = lp_now(); }
+        return ok;
+    };
+    if constexpr (NS == 1) {
+        for (int step = 0; step < total; ++step) {
+            const LpStep S = step_of(0, step);
+            float tbv[4], rates[4];
+            step_consts(S, tbv, rates);
+            for (int u = 0; u < LP_MAX_UNITS; ++u) {
+                if (units[u].kind == LP_END) break;
+                c.hist = lp_hist + u * 4 + c.wave;
+                if (!run_unit(S, u, step, true, tbv, zs[0], rates)) return;
+            }
+            // End of this workgroup's step s.  Its units consumed step-s data, so every reader of the previous step's set is done (step
+            // s's first layer needed the complete state published by step s - 1): re-poison this workgroup's regions of that set, which step s + 2
+            // will use.  Here, behind the last unit, the stores are off every critical path (issued right behind a unit they delay the
+            // next unit's operand loads: vmcnt retires in order).  Why a reader of step s + 2 cannot see step s - 1's values: before it
+            // polls, it has finished its own dec4 unit of step s + 1, which needed every workgroup's gf3 output of step s + 1, and every
+            // data store waits (s_waitcnt vmcnt(0)) for all earlier stores of its wave, these included.
+            lp_poison_all(c, A, units, S.other_off);
+        }
+    } else {
+        // two streams in the fixed merged order of this workgroup (A.sched: per period, entries sorted by key; an entry = unit index |
+        // stream << 8 | (its step is the period's - 1) << 9 | (last unit of the stream's step on this workgroup) << 10; -1 ends the list).
+        // Period t: stream 0 runs its step t, stream 1 the late part of its step t - 1 and then the early part of its step t.
+        const int* sched = A.sched + (int64_t)vwg * LP_SCHED;
+        float tbv_[NS][4], rates_[NS][4];
+        c.hist = nullptr;                                    // (no wait prediction: a wait's length depends on the other stream too)
+        for (int t = 0; t <= total; ++t) {
+            for (int e = 0; e < LP_SCHED; ++e) {
+                const int ent = sched[e];
+                if (ent < 0) break;
+                const int u = ent & 255, st = (ent >> 8) & 1, step = t - ((ent >> 9) & 1);
+                if (step < 0 || step >= total) continue;
+                const LpStep S = step_of(st, step);
+                bool ok;
+                if (st == 0) {
+                    if (u == 0) step_consts(S, tbv_[0], rates_[0]);
+                    ok = run_unit(S, u, step, true, tbv_[0], zs[0], rates_[0]);
+                } else {
+                    if (u == 0) step_consts(S, tbv_[NS - 1], rates_[NS - 1]);
+                    ok = run_unit(S, u, step, false, tbv_[NS - 1], zs[NS - 1], rates_[NS - 1]);
+                }
+                if (!ok) return;
+                // end of a stream's step on this workgroup: the ordering argument of the single-stream loop holds inside a stream
+                if ((ent >> 10) & 1) lp_poison_all(c, A, units, S.other_off);
+            }
+        }
     }
     if (vwg == 0 && c.tid == 0 && A.counter != nullptr && !A.forward_only) {
         const int last = k_base + A.nsteps - 1;
@@ -977,14 +1038,45 @@ struct pcd_latent_persist {
     LpPlan plan;
     LpLayer* d_layers = nullptr;
     LpUnit* d_units = nullptr;
+    int* d_sched = nullptr;            // [LP_WGS][LP_SCHED]: the merged unit order of the two interleaved streams (batch > 32)
     int sleep = 0;                     // back-off between polling passes (s_sleep count): 0 measured best (37.1 v. 37.3 / 37.5 / 37.9 us at 1 / 2 / 4)
     int predict = 1;
     unsigned* trace = nullptr;         // diagnostic: device buffer [256][trace_steps][8][8] u32
     int trace_steps = 0;
 };
 
+// Merged order of the two streams per workgroup (one period = one step of stream 0).  Key of a unit = when its phase becomes runnable in
+// a step, in 1/100 us (single-stream timeline, profiles/r03_c), + the lag for stream 1 (units whose key passes the period belong to the
+// PREVIOUS step of stream 1 and come first); ties go to stream 0: the same total order on every workgroup.  Lag 15 us: the best of a sweep
+// (10 ... 40 us: 55.8, 51.2, 52.7, 52.9, 56.6, 54.9, 60.8 us per step of the pair).
+static hipError_t lp_upload_sched(pcd_latent_persist* h) {
+    static const int kWhen[2 * LP_LAYERS] = {190, 190, 400, 400, 620, 620, 960, 1150, 1390, 1580, 1900, 2080, 2450, 2680, 2920, 3110, 3310, 3470,
+                                             3610, 3610, 3800, 3800, 3960, 3960};
+    const int period = 3970, lag = 1500;
+    std::vector<int> sched((size_t)LP_WGS * LP_SCHED, -1);
+    for (int w = 0; w < LP_WGS; ++w) {
+        struct Ent { int key, st, u, prev; };
+        std::vector<Ent> ents;
+        int nunits = 0;
+        for (int i = 0; i < LP_MAX_UNITS; ++i) {
+            const LpUnit& u = h->plan.units[(size_t)w * LP_MAX_UNITS + i];
+            if (u.kind == LP_END) break;
+            const int when = kWhen[2 * u.layer + (u.kind == LP_FINISH ? 1 : 0)];
+            ents.push_back({when, 0, i, 0});
+            const int k1 = when + lag;
+            if (k1 >= period) ents.push_back({k1 - period, 1, i, 1}); else ents.push_back({k1, 1, i, 0});
+            ++nunits;
+        }
+        if ((int)ents.size() > LP_SCHED) return hipErrorInvalidValue;
+        std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.key != b.key ? a.key < b.key : a.st < b.st; });
+        for (size_t i = 0; i < ents.size(); ++i)
+            sched[(size_t)w * LP_SCHED + i] = ents[i].u | ents[i].st << 8 | ents[i].prev << 9 | (ents[i].u == nunits - 1 ? 1 << 10 : 0);
+    }
+    return hipMemcpy(h->d_sched, sched.data(), sched.size() * sizeof(int), hipMemcpyHostToDevice);
+}
+
 extern "C" int pcd_latent_persist_supported(int batch) {
-    if (batch <= 0 || batch > 32) return 0;
+    if (batch <= 0 || batch > 64) return 0;
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
@@ -1008,12 +1100,17 @@ extern "C" int pcd_latent_persist_create(const pcd_latent_desc_t* desc, pcd_late
     if (e == hipSuccess) e = hipMalloc(&h->d_units, sizeof(LpUnit) * h->plan.units.size());
     if (e == hipSuccess) e = hipMemcpy(h->d_layers, h->plan.layers, sizeof(LpLayer) * LP_LAYERS, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(h->d_units, h->plan.units.data(), sizeof(LpUnit) * h->plan.units.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)latent_persist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LP_DYN_LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)latent_persist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LP_DYN_LDS);
+    if (e == hipSuccess) e = hipMalloc(&h->d_sched, (size_t)LP_WGS * LP_SCHED * sizeof(int));
+    if (e == hipSuccess) e = lp_upload_sched(h);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)latent_persist_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LP_DYN_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)latent_persist_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LP_DYN_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)latent_persist_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LP_DYN_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)latent_persist_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LP_DYN_LDS);
     if (e != hipSuccess) {
         set_error("pcd_latent_persist_create: %s", hipGetErrorString(e));
         if (h->d_layers) (void)hipFree(h->d_layers);
         if (h->d_units) (void)hipFree(h->d_units);
+        if (h->d_sched) (void)hipFree(h->d_sched);
         delete h;
         return PCD_ERR_HIP;
     }
@@ -1025,11 +1122,12 @@ extern "C" void pcd_latent_persist_destroy(pcd_latent_persist_t* h) {
     if (!h) return;
     if (h->d_layers) (void)hipFree(h->d_layers);
     if (h->d_units) (void)hipFree(h->d_units);
+    if (h->d_sched) (void)hipFree(h->d_sched);
     delete h;
 }
 
 extern "C" size_t pcd_latent_persist_workspace_bytes(const pcd_latent_persist_t* h) {
-    return h ? (size_t)LP_CTRL_BYTES + 3 * (size_t)h->plan.set_bytes : 0;
+    return h ? (size_t)LP_CTRL_BYTES + 2 * 3 * (size_t)h->plan.set_bytes : 0;          // two streams x three sets
 }
 
 // diagnostic: the next launches run the instrumented kernel and leave s_memrealtime stamps (100 MHz) of the first
@@ -1056,7 +1154,7 @@ static int lp_launch(pcd_latent_persist_t* h, LpArgs& a, void* workspace, size_t
     }
     PCD_CHECK_ARG(((uintptr_t)workspace & 255) == 0);
     if (!pcd_latent_persist_supported(a.batch)) {
-        set_error("pcd_latent_persist: needs batch <= 32 and a device with exactly %d CUs of %d KB LDS", LP_WGS, LP_LDS_BYTES / 1024);
+        set_error("pcd_latent_persist: needs batch <= 64 and a device with exactly %d CUs of %d KB LDS", LP_WGS, LP_LDS_BYTES / 1024);
         return PCD_ERR_ARG;
     }
     hipStream_t s = (hipStream_t)stream;
@@ -1068,12 +1166,20 @@ static int lp_launch(pcd_latent_persist_t* h, LpArgs& a, void* workspace, size_t
     a.predict = h->predict;
     a.trace = h->trace;
     a.trace_steps = h->trace_steps;
-    // status word cleared, all three sets poisoned (set 2 receives the initial state before step 0 and is re-poisoned at the end of step 0)
+    // a batch of more than 32 rows: two interleaved streams (rows 0 .. 31 | the rest)
+    const int ns = a.batch > 32 ? 2 : 1;
+    a.sched = ns == 2 ? h->d_sched : nullptr;
+    // status word cleared, every set poisoned (a stream's set 2 receives its initial state before step 0 and is re-poisoned at the end of step 0)
     PCD_CHECK_HIP(hipMemsetAsync(workspace, 0, LP_CTRL_BYTES, s));
-    PCD_CHECK_HIP(hipMemsetAsync((char*)workspace + LP_CTRL_BYTES, 0xff, 3 * (size_t)h->plan.set_bytes, s));
-    // dynamic LDS = everything but the 16 bytes of the static flag word (rounded)
-    if (a.trace != nullptr) hipLaunchKernelGGL(latent_persist_kernel<true>, dim3(LP_WGS), dim3(LP_THREADS), LP_DYN_LDS, s, a);
-    else hipLaunchKernelGGL(latent_persist_kernel<false>, dim3(LP_WGS), dim3(LP_THREADS), LP_DYN_LDS, s, a);
+    PCD_CHECK_HIP(hipMemsetAsync((char*)workspace + LP_CTRL_BYTES, 0xff, (size_t)ns * 3 * (size_t)h->plan.set_bytes, s));
+    // dynamic LDS = everything but the static flag words (rounded)
+    if (ns == 2) {
+        if (a.trace != nullptr) hipLaunchKernelGGL((latent_persist_kernel<true, 2>), dim3(LP_WGS), dim3(LP_THREADS), LP_DYN_LDS, s, a);
+        else hipLaunchKernelGGL((latent_persist_kernel<false, 2>), dim3(LP_WGS), dim3(LP_THREADS), LP_DYN_LDS, s, a);
+    } else {
+        if (a.trace != nullptr) hipLaunchKernelGGL((latent_persist_kernel<true, 1>), dim3(LP_WGS), dim3(LP_THREADS), LP_DYN_LDS, s, a);
+        else hipLaunchKernelGGL((latent_persist_kernel<false, 1>), dim3(LP_WGS), dim3(LP_THREADS), LP_DYN_LDS, s, a);
+    }
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

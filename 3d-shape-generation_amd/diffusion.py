@@ -504,7 +504,7 @@ class LatentDiffusion(_DiffusionBase):
     def _forward_fn(self):
         return lambda x, tb_cur, eps: self.model.forward_with_bias(x, tb_cur, 0, out=eps)
 
-    # the DDIM loops (`sample`, `sample3`) of a batch <= 32 run as ONE persistent launch for all their steps
+    # the DDIM loops (`sample`, `sample3`) of a batch <= 64 run as ONE persistent launch for all their steps
     # (csrc/latent_persist.hip); PCD_LATENT_PERSISTENT=0 (or use_persistent = False) keeps the per-layer launches, which
     # is also what runs for larger batches, for DDPM (`sample2`) and when several processes share one GPU
     use_persistent = os.environ.get("PCD_LATENT_PERSISTENT", "1") != "0"

@@ -417,7 +417,7 @@ class SimpleLatentUNetPointNet(_HipModule):
 
     # ------------------------------------------------------------------ the whole step as one persistent launch
     def persist_supported(self, batch: int) -> bool:
-        """True when `csrc/latent_persist.hip` can run on this device for this batch (batch <= 32, a 256-CU gfx950)."""
+        """True when `csrc/latent_persist.hip` can run on this device for this batch (batch <= 64, a 256-CU gfx950)."""
         self._need_cuda()
         return bool(_lib.load().pcd_latent_persist_supported(int(batch)))
 

@@ -265,10 +265,10 @@ int pcd_latent_forward(pcd_latent_t* h, const float* z, int batch, const float* 
                        void* stream);
 
 /* The same network, and whole DDIM timesteps of the latent sampler (the loop body of LatentDiffusion.sample / sample3,
- * diffusion.py:637-645, 691-700), as ONE persistent launch for batch <= 32 (csrc/latent_persist.hip): 256 workgroups, one
+ * diffusion.py:637-645, 691-700), as ONE persistent launch for batch <= 64 (csrc/latent_persist.hip; 33 .. 64 rows run as two interleaved streams of <= 32): 256 workgroups, one
  * per CU, keep all 38 MB of fp16 weights in LDS for the whole call and exchange activations through self-validating
  * buffers (no flags or atomics between layers).  pcd_latent_persist_supported(batch) tells (1/0) whether the current
- * device can run it (exactly 256 CUs with 160 KB LDS, batch <= 32); callers fall back to pcd_latent_forward otherwise.
+ * device can run it (exactly 256 CUs with 160 KB LDS, batch <= 64); callers fall back to pcd_latent_forward otherwise.
  * The handle keeps the descriptor's pointers.  Workspace: pcd_latent_persist_workspace_bytes(h), 256-byte aligned, owned
  * by the caller, private to one in-flight call.
  *  - pcd_latent_persist_forward: eps = model(z, t) with tbias = the hoisted time row [128] (one t for the batch).

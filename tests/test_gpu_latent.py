@@ -356,7 +356,7 @@ def test_latent_persistent_forward(ldm):
         pytest.skip("needs a 256-CU device")
     sd = latent_sd()
     g = torch.Generator().manual_seed(11)
-    for b, tval in ((32, 0.73), (5, 0.31), (1, 1.0)):
+    for b, tval in ((32, 0.73), (5, 0.31), (1, 1.0), (64, 0.5), (41, 0.2)):      # > 32 rows: two interleaved streams (rows 0 .. 31 | the rest)
         z = (torch.randn(b, 256, generator=g) * 1.2).cuda()
         t = torch.full((b,), tval)
         tb = ldm.model.time_bias(t[:1].cuda())
@@ -395,6 +395,23 @@ def test_latent_persistent_ddim_steps(ldm):
     finally:
         ldm.use_persistent = LatentDiffusion.use_persistent
     assert torch.isfinite(a).all() and rel_l2(a.cpu(), want.cpu()) < 2e-3
+    # 33 .. 64 rows: two streams interleaved by every workgroup in a fixed order; rows 0 .. 31 must come out as a 32-row call's
+    g2 = torch.Generator().manual_seed(13)
+    z64 = torch.randn(64, 256, generator=g2).cuda()
+    try:
+        ldm.use_persistent = True
+        _, p64 = ldm.sample(64, num_steps=200, z_T=z64, return_latent=True)
+        _, p64b = ldm.sample(64, num_steps=200, z_T=z64, return_latent=True)
+        _, p45 = ldm.sample(45, num_steps=30, z_T=z64[:45], return_latent=True)
+        _, p32 = ldm.sample(32, num_steps=200, z_T=z64[:32], return_latent=True)
+        ldm.use_persistent = False
+        _, w64 = ldm.sample(64, num_steps=200, z_T=z64, return_latent=True)
+        _, w45 = ldm.sample(45, num_steps=30, z_T=z64[:45], return_latent=True)
+    finally:
+        ldm.use_persistent = LatentDiffusion.use_persistent
+    assert torch.equal(p64, p64b)
+    assert torch.equal(p64[:32], p32)                     # a stream's rows do not depend on the other stream
+    assert rel_l2(p64.cpu(), w64.cpu()) < 3e-3 and rel_l2(p45.cpu(), w45.cpu()) < 2e-3
     assert torch.equal(a1000, b1000)
     assert rel_l2(a1000.cpu(), want1000.cpu()) < 5e-3
     assert rel_l2(a5.cpu(), want5.cpu()) < 2e-3
