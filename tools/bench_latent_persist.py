@@ -1,4 +1,4 @@
-"""Dev tool: latent DDIM loop, B = 32, T = 1000: one persistent launch (csrc/latent_persist.hip) against the per-layer
+"""Dev tool: latent DDIM loop, B = 32 (env B: up to 64 = two interleaved streams), T = 1000: one persistent launch (csrc/latent_persist.hip) against the per-layer
 launches replayed as 8-step graphs, A/B in one process; optional poll back-off sweep (SLEEPS="0 1 2 4")."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -36,9 +36,4 @@ for sl in [int(v) for v in os.environ.get("SLEEPS", "").split()]:
         lib.pcd_latent_persist_config(h, sl, pred)
         us = min(loop(True)[0] for _ in range(3))
         print(f"poll sleep {sl} predict {pred}: {us:6.1f} us/step", flush=True)
-for pol in [int(v, 0) for v in os.environ.get("POLICIES", "").split()]:      # predict | probe_chunks << 4 | finish_full_pass << 8
-    h, _ = m.model._persist_handle()
-    lib.pcd_latent_persist_config(h, 1, pol)
-    us = min(loop(True)[0] for _ in range(3))
-    print(f"policy {pol:#x}: {us:6.1f} us/step", flush=True)
 lib.pcd_latent_persist_config(m.model._persist_handle()[0], 0, 1)
