@@ -142,6 +142,14 @@ _SIGS = {
     "pcd_unet_profile": (i32, [vp, i32]),
     "pcd_unet_profile_read": (i32, [vp, C.POINTER(C.c_double), C.POINTER(i32)]),
     "pcd_unet_tap": (i32, [vp, C.c_char_p, i32, i32, vp, vp, sz, vp]),
+    "pcd_unet_capture": (i32, [vp, vp, vp, vp, vp]),
+    "pcd_gemm_f32": (i32, [vp, i64, i32, vp, i64, i32, vp, i64, vp, vp, i32, i32, i32, i32, vp, i64, vp]),
+    "pcd_gemm_f32_colmax": (i32, [vp, i64, i32, vp, i64, vp, i32, i32, vp, i32, vp]),
+    "pcd_unet_f32_create": (i32, [C.POINTER(UnetDesc), C.POINTER(vp)]),
+    "pcd_unet_f32_destroy": (None, [vp]),
+    "pcd_unet_f32_workspace_bytes": (sz, [i32, i32]),
+    "pcd_unet_f32_forward": (i32, [vp, vp, i32, i32, vp, i32, vp, vp, sz, vp]),
+    "pcd_unet_f32_tap": (i32, [vp, C.c_char_p, i32, i32, vp, vp, sz, vp]),
     "pcd_groupnorm_relu_f16": (i32, [vp, i32, i32, i32, vp, vp, vp, vp]),
     "pcd_skinny_slabs": (i32, [i32, i32]),
     "pcd_skinny_gemm_f16": (i32, [vp, i32, vp, i32, vp, i64, i32, i32, vp, vp]),

@@ -38,6 +38,8 @@ struct pcd_unet {
     int ev_created = 0;
     // packed stage images + biases of the two 256-channel chains (csrc/widechain.hip): enc3 and dec2
     void* wide[2] = {nullptr, nullptr};
+    // parity-test capture of the decoder blocks' outputs (pcd_unet_capture): dec4 [M][512], dec3 [M][256], dec2 [M][128], dec1 [M][64]
+    void* dec_tap[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace pcd {
@@ -145,6 +147,12 @@ extern "C" int pcd_unet_profile_read(pcd_unet_t* h, double* total_ms, int* launc
     return PCD_OK;
 }
 
+extern "C" int pcd_unet_capture(pcd_unet_t* h, void* d4, void* d3, void* d2, void* d1) {
+    PCD_CHECK_ARG(h != nullptr);
+    h->dec_tap[0] = d4; h->dec_tap[1] = d3; h->dec_tap[2] = d2; h->dec_tap[3] = d1;
+    return PCD_OK;
+}
+
 extern "C" size_t pcd_unet_workspace_bytes(int batch, int n_points) {
     if (batch <= 0 || n_points <= 0) return 0;
     return carve(batch, n_points).total;
@@ -244,9 +252,13 @@ extern "C" int pcd_unet_forward(pcd_unet_t* h, const float* x, int batch, int n_
     RUN(run_lin(d, 13, m, x4, nullptr, 0, gbias, n_points, s1, s));
     RUN(run_lin(d, 14, m, s1, nullptr, 0, nullptr, 0, s0, s));
     RUN(run_lin(d, 15, m, s0, nullptr, 0, nullptr, 0, s1, s));
+#define TAP(i, buf, ch) do { if (h->dec_tap[i]) PCD_CHECK_HIP(hipMemcpyAsync(h->dec_tap[i], buf, (size_t)m * (ch) * 2, \
+                                                                             hipMemcpyDeviceToDevice, s)); } while (0)
+    TAP(0, s1, 512);
     RUN(run_lin(d, 16, m, s1, x3, 512, nullptr, 0, s0, s));
     RUN(run_lin(d, 17, m, s0, nullptr, 0, nullptr, 0, s1, s));
     RUN(run_lin(d, 18, m, s1, nullptr, 0, nullptr, 0, s0, s));
+    TAP(1, s0, 256);
     if (wide) {
         RUN(pcd_pw_wide_chain(1, s0, x2, m, h->wide[1], s1, s));
     } else {
@@ -254,17 +266,20 @@ extern "C" int pcd_unet_forward(pcd_unet_t* h, const float* x, int batch, int n_
         RUN(run_lin(d, 20, m, s1, nullptr, 0, nullptr, 0, s0, s));
         RUN(run_lin(d, 21, m, s0, nullptr, 0, nullptr, 0, s1, s));
     }
+    TAP(2, s1, 128);
     RUN(run_lin(d, 22, m, s1, x1, 128, nullptr, 0, s0, s));
-    if (chains) {
+    if (chains && h->dec_tap[3] == nullptr) {
         // dec1.conv2 -> conv3 -> output.0 -> output.3 (128 -> 128 -> 64 -> 64 -> 3): one launch
         RUN(pcd_pw_chain_tail(s0, m, d.lin[23].w, d.lin[23].b, d.lin[24].w, d.lin[24].b, d.lin[25].w, d.lin[25].b, d.head_w,
                               d.head_b, eps, s));
     } else {
         RUN(run_lin(d, 23, m, s0, nullptr, 0, nullptr, 0, s1, s));
         RUN(run_lin(d, 24, m, s1, nullptr, 0, nullptr, 0, s0, s));
+        TAP(3, s0, 64);       // dec1's output exists only inside the chained tail: a capture runs the tail as per-layer launches (same bits)
         RUN(run_lin(d, 25, m, s0, nullptr, 0, nullptr, 0, s1, s));
         RUN(pcd_head3(s1, m, 64, d.head_w, d.head_b, eps, s));
     }
+#undef TAP
 #undef RUN
     return PCD_OK;
 }

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -116,19 +117,41 @@ def _dev32(a: np.ndarray, dev) -> torch.Tensor:
 
 # ------------------------------------------------------------------ UNetPointNetLarge
 class UNetPointNetLarge(_HipModule):
-    """Drop-in for reference networks.py:724-838: eps = model(x (B,N,3), t (B,))."""
+    """Drop-in for reference networks.py:724-838: eps = model(x (B,N,3), t (B,)).
+
+    `precision`: "fp16" (default; fp16 operands on the fp16 matrix cores, fp32 accumulation: csrc/unet.hip) or "fp32"
+    (SURVEY 8(c)'s parity mode: fp32 weights, activations and products, csrc/unet_f32.hip -- the reference's own
+    arithmetic type, held to eps rel-L2 <= 1e-4).  Chosen per module with `set_precision`, or for every module created
+    afterwards with the environment variable PCD_PARITY=fp32.  The constructor signature stays the reference's."""
+
+    PRECISIONS = ("fp16", "fp32")
 
     def __init__(self, dim: int = 512, time_dim: int = 256):
         super().__init__()
         self.dim, self.time_dim = dim, time_dim
         self._build_from_spec(specs.unet_pointnet_large_spec(dim, time_dim))
         self._handle = None
+        self._handle_f32 = False
+        self._capture = None
+        self.precision = os.environ.get("PCD_PARITY", "fp16")
+        if self.precision not in self.PRECISIONS:
+            raise ValueError(f"PCD_PARITY must be one of {self.PRECISIONS}, got {self.precision!r}")
+
+    def set_precision(self, precision: str) -> "UNetPointNetLarge":
+        if precision not in self.PRECISIONS:
+            raise ValueError(f"precision must be one of {self.PRECISIONS}, got {precision!r}")
+        if precision != self.precision:
+            self.invalidate()
+            self.precision = precision
+        return self
 
     # -- packing -----------------------------------------------------------------
     def _release(self):
         if getattr(self, "_handle", None):
-            _lib.load().pcd_unet_destroy(self._handle)
+            lib = _lib.load()
+            (lib.pcd_unet_f32_destroy if self._handle_f32 else lib.pcd_unet_destroy)(self._handle)
         self._handle = None
+        self._capture = None
 
     def __del__(self):
         try:
@@ -142,23 +165,28 @@ class UNetPointNetLarge(_HipModule):
         dev = self._need_cuda()
         _lib.require_gpu()
         lib = _lib.load()
+        f32 = self.precision == "fp32"
+        devw = _dev32 if f32 else _dev16
         lin, ex = packing.pack_point_unet(self.state_dict(), "", self.time_dim, self.dim)
         keep = {"freqs": packing.timestep_freqs(self.time_dim).to(dev)}
         for k in ("tw0", "tb0", "tw2", "tb2", "e1w_xyz", "e1w_t", "e1b", "head_w", "head_b"):
             keep[k] = _dev32(ex[k], dev)
-        keep["wg"] = _dev16(ex["wg"], dev)
+        keep["wg"] = devw(ex["wg"], dev)
         desc = _lib.UnetDesc()
         desc.time_dim, desc.dim = self.time_dim, self.dim
         for k in ("freqs", "tw0", "tb0", "tw2", "tb2", "e1w_xyz", "e1w_t", "e1b", "head_w", "head_b", "wg"):
             setattr(desc, k, keep[k].data_ptr())
         desc.wg_k, desc.wg_c = 4096, 1024
         for i, (w, b) in enumerate(lin):
-            keep[f"w{i}"], keep[f"b{i}"] = _dev16(w, dev), _dev32(b, dev)
+            keep[f"w{i}"], keep[f"b{i}"] = devw(w, dev), _dev32(b, dev)
             desc.lin[i].w, desc.lin[i].b = keep[f"w{i}"].data_ptr(), keep[f"b{i}"].data_ptr()
             desc.lin[i].c, desc.lin[i].k = w.shape
         handle = C.c_void_p()
-        _lib.check(lib.pcd_unet_create(C.byref(desc), C.byref(handle)), "unet_create")
-        self._handle = handle
+        if f32:
+            _lib.check(lib.pcd_unet_f32_create(C.byref(desc), C.byref(handle)), "unet_f32_create")
+        else:
+            _lib.check(lib.pcd_unet_create(C.byref(desc), C.byref(handle)), "unet_create")
+        self._handle, self._handle_f32 = handle, f32
         self._packed = keep
         return keep
 
@@ -191,10 +219,14 @@ class UNetPointNetLarge(_HipModule):
         self._ensure_packed()
         b, n, _ = x.shape
         lib = _lib.load()
-        nbytes = lib.pcd_unet_workspace_bytes(b, n)
-        ws = self._workspace((b, n), nbytes)
         if out is None:
             out = torch.empty_like(x)
+        if self._handle_f32:
+            ws = self._workspace((b, n), lib.pcd_unet_f32_workspace_bytes(b, n))
+            _lib.check(lib.pcd_unet_f32_forward(self._handle, x.data_ptr(), b, n, tbias.data_ptr(), shape_stride,
+                                                out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "unet_f32_forward")
+            return out
+        ws = self._workspace((b, n), lib.pcd_unet_workspace_bytes(b, n))
         _lib.check(lib.pcd_unet_forward(self._handle, x.data_ptr(), b, n, tbias.data_ptr(), shape_stride,
                                         out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "unet_forward")
         return out
@@ -208,16 +240,40 @@ class UNetPointNetLarge(_HipModule):
         x = x.to(torch.float32).contiguous()
         return self.forward_with_bias(x, self.time_bias(t), 1)
 
+    _TAP_WIDTHS = {"x1": 128, "x2": 256, "x3": 512, "x4": 1024, "d4": 512, "d3": 256, "d2": 128, "d1": 64}
+
+    def capture_decoder(self, batch: int, n_points: int, on: bool = True) -> None:
+        """fp16 path, parity tests: make the following forwards of this shape keep the decoder blocks' outputs
+        (dec4..dec1, networks.py:811-814) for `tap("d4".."d1")`; they otherwise live in ping-pong buffers and inside
+        the chained tail.  The fp32 path always keeps them."""
+        self._ensure_packed()
+        if self._handle_f32:
+            return
+        if on:
+            self._capture = {k: torch.empty(batch, n_points, self._TAP_WIDTHS[k], dtype=torch.float16, device=self.device)
+                             for k in ("d4", "d3", "d2", "d1")}
+            ptrs = [self._capture[k].data_ptr() for k in ("d4", "d3", "d2", "d1")]
+        else:
+            self._capture, ptrs = None, [0, 0, 0, 0]
+        _lib.check(_lib.load().pcd_unet_capture(self._handle, *ptrs), "unet_capture")
+
     def tap(self, name: str, batch: int, n_points: int) -> torch.Tensor:
-        """Intermediate of the last forward (parity tests): x1..x4 (B,N,C) fp16, pooled/gbias fp32."""
-        widths = {"x1": 128, "x2": 256, "x3": 512, "x4": 1024}
+        """Intermediate of the last forward (parity tests): x1..x4 / d4..d1 as (B,N,C) (fp16, or fp32 in the fp32 mode),
+        pooled / gbias fp32."""
         ws = self._ws[(batch, n_points)]
-        if name in widths:
-            dst = torch.empty(batch, n_points, widths[name], dtype=torch.float16, device=self.device)
+        lib = _lib.load()
+        if name in self._TAP_WIDTHS:
+            if not self._handle_f32 and name.startswith("d"):
+                if self._capture is None or tuple(self._capture[name].shape[:2]) != (batch, n_points):
+                    raise RuntimeError("decoder taps of the fp16 path need capture_decoder(batch, n_points) before the forward")
+                return self._capture[name].clone()
+            dst = torch.empty(batch, n_points, self._TAP_WIDTHS[name], device=self.device,
+                              dtype=torch.float32 if self._handle_f32 else torch.float16)
         else:
             dst = torch.empty(batch, {"pooled": 4096, "gbias": 1024}[name], dtype=torch.float32, device=self.device)
-        _lib.check(_lib.load().pcd_unet_tap(self._handle, name.encode(), batch, n_points, ws.data_ptr(),
-                                            dst.data_ptr(), dst.numel() * dst.element_size(), _lib.stream_ptr()), "tap")
+        fn = lib.pcd_unet_f32_tap if self._handle_f32 else lib.pcd_unet_tap
+        _lib.check(fn(self._handle, name.encode(), batch, n_points, ws.data_ptr(),
+                      dst.data_ptr(), dst.numel() * dst.element_size(), _lib.stream_ptr()), "tap")
         return dst
 
 

@@ -247,6 +247,17 @@ def hash_uniform(name: str, n: int, seed: int = 0) -> np.ndarray:
     return (h >> np.uint64(11)).astype(np.float64) * (2.0 / 9007199254740992.0) - 1.0
 
 
+def hash_normal(name: str, n: int, seed: int = 0) -> np.ndarray:
+    """n float64 values, approximately N(0, 1): half the sum of twelve `hash_uniform` draws (Irwin-Hall; variance
+    12 / 3 / 4 = 1).  Elementwise additions in a fixed order and one exact halving only, so every platform rebuilds the same bits: this is how the
+    T = 1000 DDPM fixtures regenerate their 1000 per-step noise tensors instead of storing them."""
+    u = hash_uniform(name, 12 * n, seed).reshape(n, 12)
+    acc = u[:, 0].copy()
+    for j in range(1, 12):          # fixed left-to-right order (a library reduction may pair the terms differently)
+        acc += u[:, j]
+    return acc * 0.5
+
+
 def _fan_in(shape: Tuple[int, ...], role: str) -> int:
     if role == "wT":  # ConvTranspose3d (cin, cout, k,k,k): each output sees cin*k^3/stride^3
         return shape[0] * int(np.prod(shape[2:])) // 8

@@ -211,9 +211,35 @@ int pcd_unet_forward(pcd_unet_t* h, const float* x, int batch, int n_points,
  * enable, run forwards, then read the summed duration and launch count (bench.py roofline). */
 int pcd_unet_profile(pcd_unet_t* h, int enable);
 int pcd_unet_profile_read(pcd_unet_t* h, double* total_ms, int* launches);
-/* optional taps for parity tests: copies of x1..x4 (fp16), pooled (fp32), d4..d1 (fp16) */
+/* optional taps for parity tests: copies of x1..x4 (fp16), pooled / gbias (fp32) out of the last forward's workspace */
 int pcd_unet_tap(pcd_unet_t* h, const char* name, int batch, int n_points,
                  const void* workspace, void* dst, size_t dst_bytes, void* stream);
+/* The decoder blocks' outputs (reference networks.py:811-814: dec4 [M][512], dec3 [M][256], dec2 [M][128], dec1 [M][64], fp16)
+ * live in ping-pong buffers / inside the chained tail; while capture buffers are set, every forward copies them out
+ * (dec1: the tail runs as per-layer launches, bit-identical).  Null pointers switch the capture off. */
+int pcd_unet_capture(pcd_unet_t* h, void* d4, void* d3, void* d2, void* d1);
+
+/* ------------------------------------------------ fp32 parity mode of the point denoiser (csrc/unet_f32.hip)
+ * SURVEY 8(c) "HIP fp32 parity mode": the network of pcd_unet_forward with fp32 weights, fp32 activations and fp32
+ * products (v_mfma_f32_32x32x2_f32); same descriptor layout and lin[] order, but EVERY weight pointer (lin[i].w, wg) is
+ * fp32 [C][K].  Held to eps rel-L2 <= 1e-4 per forward against the reference's fp32 arithmetic (networks.py:779-818).
+ * pcd_gemm_f32: out[m][c] = act([A1 | A2][m][k1 + k2] . W[c][k]^T + bias[c] (or shape_bias[row / rows_per_shape][c]));
+ * k1, k2 multiples of 16.  pcd_gemm_f32_colmax: pooled[row / rows_per_shape][c] = max(pooled, relu(A . W^T + bias)), the
+ * `torch.max(x, 2)` of networks.py:807 fused (pooled zero-initialised by the caller).
+ * Taps of the last forward (all fp32): x1..x4, pooled, gbias, d4..d1. */
+int pcd_gemm_f32(const float* a1, int64_t lda1, int k1, const float* a2, int64_t lda2, int k2, const float* w, int64_t ldw,
+                 const float* bias, const float* shape_bias, int rows_per_shape, int relu, int m, int c, float* out,
+                 int64_t ldo, void* stream);
+int pcd_gemm_f32_colmax(const float* a, int64_t lda, int k, const float* w, int64_t ldw, const float* bias, int m, int c,
+                        float* pooled, int rows_per_shape, void* stream);
+typedef struct pcd_unet_f32 pcd_unet_f32_t;
+int pcd_unet_f32_create(const pcd_unet_desc_t* desc, pcd_unet_f32_t** out);
+void pcd_unet_f32_destroy(pcd_unet_f32_t* h);
+size_t pcd_unet_f32_workspace_bytes(int batch, int n_points);
+int pcd_unet_f32_forward(pcd_unet_f32_t* h, const float* x, int batch, int n_points, const float* tbias,
+                         int tbias_shape_stride, float* eps, void* workspace, size_t workspace_bytes, void* stream);
+int pcd_unet_f32_tap(pcd_unet_f32_t* h, const char* name, int batch, int n_points, const void* workspace, void* dst,
+                     size_t dst_bytes, void* stream);
 
 /* ------------------------------------------------ latent denoiser (a11, K8)
  * GroupNorm(groups, C, eps 1e-5, biased var) + affine + ReLU on rows of x fp32 [rows][c] -> fp16

@@ -16,7 +16,9 @@ G11 vae3d_small.npz (`make_golden.py vae3d`), G12 data.npz (`make_golden.py data
 G16 linear.npz (`make_golden.py linear`: the linear schedule's per-shape rate tables and sampler outputs),
 G18 point_n2048.npz (`make_golden.py n2048`: `PointCloudDiffusion.sample(2, 2048, num_steps=50)` at the BASELINE point count, start noise recorded),
 G17 cfg4.npz (`make_golden.py cfg4`: BASELINE configs[3] at its real launch shape -- 32 grids through `VAE3DLarge.encode`,
-`LatentDiffusion.sample(32, num_steps=1000)` with the start noise recorded, the decoded grids of four rows).
+`LatentDiffusion.sample(32, num_steps=1000)` with the start noise recorded, the decoded grids of four rows),
+G19-G21 point_t1000_{ddim,ddpm,recon}.npz (`make_golden.py g19|g20|g21`: the three point samplers at N = 2048 over the full
+1000-step horizon, see `capture_t1000`).
 """
 from __future__ import annotations
 
@@ -138,6 +140,98 @@ def capture_n2048(rd):
     print("n2048 sample", time.time() - t0, "|out| max", float(out.abs().max()))
     np.savez_compressed(os.path.join(OUT, "point_n2048.npz"), xT=xT.numpy(), out=out.numpy())
     print("point_n2048.npz", os.path.getsize(os.path.join(OUT, "point_n2048.npz")))
+
+
+T1000_CHECKPOINTS = (0, 100, 250, 500, 750, 900, 990, 999)       # model-call indices whose INPUT state is stored
+
+
+def _spy_states(model, keep_rows):
+    """Record the state tensor the reference hands its denoiser at the T1000_CHECKPOINTS calls (a forward pre-hook:
+    the loops of diffusion.py:241-257, 277-287, 326-335 expose nothing else)."""
+    rec, n = {}, [0]
+
+    def pre(mod, args):
+        if n[0] in T1000_CHECKPOINTS:
+            rec[n[0]] = args[0][:keep_rows].detach().clone().numpy()
+        n[0] += 1
+
+    h = model.register_forward_pre_hook(pre)
+    return rec, h
+
+
+def capture_t1000(rd, rm, which):
+    """G19-G21: the point path at the horizon BASELINE configs[1] names (N = 2048, 1000 steps) -> tests/golden/point_t1000_*.npz.
+    G19 `sample(2, 2048)` (DDIM, diffusion.py:261-289, default num_steps = 1000 as test_point_ddpm.py:36 calls it), x_T recorded;
+    G20 `sample2(2, 2048)` (DDPM, diffusion.py:225-259): the 999 per-step draws of `torch.randn_like` are replaced during
+    the capture by `specs.hash_normal("g20.z<k>")`, so the test rebuilds them instead of loading 49 MB;
+    G21 the reconstruction flow of test_point_ddpm.py:74-92 at (4, 2048): `add_noise(t = 0.01)` -> `sample3` 1000 steps ->
+    `compute_metrics` per sample (Hungarian EMD)."""
+    pspec = specs.unet_pointnet_large_spec(prefix="model.")
+    pcd = rd.PointCloudDiffusion(num_points=2048).eval()
+    pcd.load_state_dict(T(specs.synth_state_dict(pspec, seed=0, gain=POINT_GAIN)), strict=True)
+    t0 = time.time()
+    if which == "g19":
+        rec, h = _spy_states(pcd.model, 2)
+        torch.manual_seed(24)
+        out = pcd.sample(2, 2048)
+        h.remove()
+        torch.manual_seed(24)
+        xT = torch.randn(2, 2048, 3)
+        assert np.array_equal(rec[0], xT.numpy())
+        g = {"xT": xT.numpy(), "out": out.numpy(), "ckpt_calls": np.array(sorted(rec), np.int64),
+             "ckpt_x": np.stack([rec[k] for k in sorted(rec)])}
+        name = "point_t1000_ddim.npz"
+    elif which == "g20":
+        real_randn_like = torch.randn_like
+        count = [0]
+
+        def hashed_randn_like(x, *a, **k):
+            z = specs.hash_normal(f"g20.z{count[0]}", x.numel(), 0).astype(np.float32).reshape(tuple(x.shape))
+            count[0] += 1
+            return torch.from_numpy(z)
+
+        rec, h = _spy_states(pcd.model, 2)
+        torch.manual_seed(11)
+        torch.randn_like = hashed_randn_like
+        try:
+            out = pcd.sample2(2, 2048)
+        finally:
+            torch.randn_like = real_randn_like
+        h.remove()
+        assert count[0] == 999
+        torch.manual_seed(11)
+        xT = torch.randn(2, 2048, 3)
+        assert np.array_equal(rec[0], xT.numpy())
+        g = {"xT": xT.numpy(), "out": out.numpy(), "ckpt_calls": np.array(sorted(rec), np.int64),
+             "ckpt_x": np.stack([rec[k] for k in sorted(rec)]), "n_draws": np.int64(count[0])}
+        name = "point_t1000_ddpm.npz"
+    else:
+        B = 4
+        x0c = torch.from_numpy(synth_cloud(B, 2048, 31))
+        tt = torch.ones(B) * 0.010
+        real_randn_like = torch.randn_like
+        torch.randn_like = lambda x, *a, **k: torch.from_numpy(
+            specs.hash_normal("g21.eps", x.numel(), 0).astype(np.float32).reshape(tuple(x.shape)))
+        try:
+            noisy, noise, nr, sr = pcd.add_noise(x0c, tt)
+        finally:
+            torch.randn_like = real_randn_like
+        rec, h = _spy_states(pcd.model, 1)
+        out = pcd.sample3(num_samples=B, num_points=2048, x=noisy, start_t=tt)
+        h.remove()
+        trip = [rm.compute_metrics(a, b) for a, b in zip(x0c, out)]
+        trip_s = [rm.compute_metrics(a, b, use_approximate_gpu_emd=True) for a, b in zip(x0c, out)]
+        g = {"seed_cloud": np.int64(31), "noisy": noisy.numpy(), "out": out.numpy(),
+             "add_rates": np.array([nr[0].item(), sr[0].item()], np.float32),
+             "triples": np.array([[float(v) for v in tr] for tr in trip], np.float64),
+             "triples_sinkhorn": np.array([[float(v) for v in tr] for tr in trip_s], np.float64),
+             "cd_s1": np.array([float(rm.chamfer_distance(a, b, scaling_factor=1)) for a, b in zip(x0c, out)], np.float64),
+             "ckpt_calls": np.array(sorted(rec), np.int64), "ckpt_x": np.stack([rec[k] for k in sorted(rec)])}
+        name = "point_t1000_recon.npz"
+        print("triples", g["triples"], "sinkhorn", g["triples_sinkhorn"])
+    print(which, "seconds", time.time() - t0, "|out| max", float(out.abs().max()), "finite", bool(torch.isfinite(out).all()))
+    np.savez_compressed(os.path.join(OUT, name), **g)
+    print(name, os.path.getsize(os.path.join(OUT, name)))
 
 
 def capture_cfg4(rd, rn, ru):
@@ -415,6 +509,10 @@ def main():
     if "cfg4" in sys.argv[1:]:
         capture_cfg4(rd, rn, ru)
         return
+    for which in ("g19", "g20", "g21"):
+        if which in sys.argv[1:]:
+            capture_t1000(rd, rm, which)
+            return
     if "n2048" in sys.argv[1:]:
         capture_n2048(rd)
         return

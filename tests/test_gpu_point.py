@@ -40,12 +40,21 @@ def test_time_embedding(model, golden):
 def test_forward_small_with_taps(model, golden):
     g = golden("point_unet.npz")
     x, t = torch.from_numpy(g["fw_small_x"]).cuda(), torch.from_numpy(g["fw_small_t"]).cuda()
-    eps = model.model(x, t).cpu()
-    for name, ref in (("x1", "enc1"), ("x2", "enc2"), ("x3", "enc3"), ("x4", "enc4")):
-        tap = model.model.tap(name, 2, 64).float().cpu().transpose(1, 2)   # (B,C,N) like the reference
-        assert rel_l2(tap, g["fw_small_" + ref]) < 2e-3, name
+    eps_plain = model.model(x, t).cpu()
+    model.model.capture_decoder(2, 64)                  # keep dec4..dec1 (ping-pong buffers / inside the chained tail otherwise)
+    try:
+        eps = model.model(x, t).cpu()
+        for name, ref in (("x1", "enc1"), ("x2", "enc2"), ("x3", "enc3"), ("x4", "enc4"), ("d4", "dec4"), ("d3", "dec3"),
+                          ("d2", "dec2"), ("d1", "dec1")):
+            tap = model.model.tap(name, 2, 64).float().cpu().transpose(1, 2)   # (B,C,N) like the reference
+            assert rel_l2(tap, g["fw_small_" + ref]) < 2e-3, name
+    finally:
+        model.model.capture_decoder(2, 64, on=False)
+    assert torch.equal(eps, eps_plain)                  # the capture changes nothing (the unchained tail is bit-identical)
     assert rel_l2(model.model.tap("pooled", 2, 64).cpu(), g["fw_small_pooled"]) < 2e-3
     assert rel_l2(eps, g["fw_small_eps"]) < EPS_TOL
+    with pytest.raises(RuntimeError):
+        model.model.tap("d4", 2, 64)
 
 
 def test_forward_mid_per_shape_time(model, golden):
@@ -252,6 +261,34 @@ def test_full_size_properties(model):
     perm = torch.randperm(2048, generator=gen).cuda()
     eps_p = model.model(x[:2, perm].contiguous(), t[:2].contiguous())
     assert rel_l2(eps_p.cpu(), eps[:2, perm].cpu()) < 1e-6
+
+
+def test_full_size_forward_next_to_the_oracle(model):
+    """The launch bench.py times (B = 64, N = 2048: `gemm_xp_kernel` on 512 whole tiles per layer with the XCD patch map,
+    the wide chains at full grid, the fused column max over 64 shapes) checked against the ORACLE, not against itself:
+    shapes are independent, so rows 5..8 of the full batch must equal the oracle on those four shapes --
+    eps and the x3 / x4 / pooled / d4 / d2 taps."""
+    from oracle import torch_oracle as O
+    sd = point_sd()
+    gen = torch.Generator().manual_seed(64)
+    x = torch.randn(64, 2048, 3, generator=gen)
+    t = torch.rand(64, generator=gen)
+    model.model.capture_decoder(64, 2048)
+    try:
+        eps = model.model(x.cuda(), t.cuda()).cpu()
+        taps_hip = {k: model.model.tap(k, 64, 2048)[5:9].float().cpu() for k in ("x3", "x4", "d4", "d2")}
+        pooled = model.model.tap("pooled", 64, 2048)[5:9].cpu()
+    finally:
+        model.model.capture_decoder(64, 2048, on=False)
+    taps = {}
+    want = O.unet_pointnet_large(sd, "model.", x[5:9], t[5:9], taps=taps)
+    assert rel_l2(eps[5:9], want) < EPS_TOL
+    assert rel_l2(pooled, taps["pooled"]) < 2e-3
+    for k, v in taps_hip.items():
+        assert rel_l2(v.transpose(1, 2), taps[k]) < 2.5e-3, k
+    # and two more shapes at the far end of the batch (last XCD patch, last tiles)
+    want = O.unet_pointnet_large(sd, "model.", x[62:64], t[62:64])
+    assert rel_l2(eps[62:64], want) < EPS_TOL
 
 
 def test_cpu_module_fails_loudly():
