@@ -171,6 +171,7 @@ _SIGS = {
     "pcd_latent_persist_forward": (i32, [vp, vp, i32, vp, vp, vp, sz, vp]),
     "pcd_latent_persist_ddim": (i32, [vp, vp, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, sz, vp]),
     "pcd_latent_persist_status": (i32, [vp, C.POINTER(C.c_uint)]),
+    "pcd_latent_persist_inject_fault": (i32, [vp, i32, i32]),
     "pcd_latent_persist_plan_check": (i32, []),
     "pcd_latent_persist_plan_dump": (i32, [vp]),
     "pcd_conv3d_f16": (i32, [C.POINTER(Conv3dDesc), vp]),

@@ -37,6 +37,7 @@
 #include <new>
 #include <vector>
 #include <algorithm>
+#include <stdlib.h>
 #include "common.h"
 
 namespace pcd {
@@ -98,6 +99,7 @@ struct LpArgs {
     const int* sched;                  // two streams (batch > 32): [LP_WGS][LP_SCHED] merged unit order of one period, else null
     int sleep;                         // s_sleep argument between polls
     int predict;                       // sleep through most of the wait the previous step measured before probing
+    int fault_wg, fault_step;          // fault injection (tests): workgroup `fault_wg` leaves at the start of step `fault_step` (-1: off)
     unsigned* trace;                   // diagnostic build only: [wg][step][unit][8] s_memrealtime stamps (enter, operands in, stored, epilogue computed, operands in of waves 0..3)
     int trace_steps;
 };
@@ -750,6 +752,7 @@ __global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A)
     };
     if constexpr (NS == 1) {
         for (int step = 0; step < total; ++step) {
+            if (step == A.fault_step && vwg == A.fault_wg) return;      // injected fault: this workgroup's publishes of the step never happen
             const LpStep S = step_of(0, step);
             float tbv[4], rates[4];
             step_consts(S, tbv, rates);
@@ -774,6 +777,7 @@ __global__ __launch_bounds__(LP_THREADS, 1) void latent_persist_kernel(LpArgs A)
         float tbv_[NS][4], rates_[NS][4];
         c.hist = nullptr;                                    // (no wait prediction: a wait's length depends on the other stream too)
         for (int t = 0; t <= total; ++t) {
+            if (t == A.fault_step && vwg == A.fault_wg) return;
             for (int e = 0; e < LP_SCHED; ++e) {
                 const int ent = sched[e];
                 if (ent < 0) break;
@@ -1043,6 +1047,7 @@ struct pcd_latent_persist {
     int predict = 1;
     unsigned* trace = nullptr;         // diagnostic: device buffer [256][trace_steps][8][8] u32
     int trace_steps = 0;
+    int fault_wg = -1, fault_step = -1;        // pcd_latent_persist_inject_fault
 };
 
 // Merged order of the two streams per workgroup (one period = one step of stream 0).  Key of a unit = when its phase becomes runnable in
@@ -1080,6 +1085,9 @@ extern "C" int pcd_latent_persist_supported(int batch) {
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    // a CU mask takes CUs away from this process: the 256 co-resident workgroups would never all be scheduled
+    for (const char* name : {"HSA_CU_MASK", "ROC_GLOBAL_CU_MASK", "HSA_CU_MASK_SKIP_INIT"})
+        if (const char* v = getenv(name); v != nullptr && v[0] != '\0') return 0;
     // one workgroup per CU, all resident for the whole call: exactly the 256 CUs of an MI355X, all of its LDS
     return (prop.multiProcessorCount == LP_WGS && (int)prop.maxSharedMemoryPerMultiProcessor >= LP_LDS_BYTES) ? 1 : 0;
 }
@@ -1146,6 +1154,13 @@ extern "C" int pcd_latent_persist_config(pcd_latent_persist_t* h, int poll_sleep
     return PCD_OK;
 }
 
+extern "C" int pcd_latent_persist_inject_fault(pcd_latent_persist_t* h, int workgroup, int step) {
+    PCD_CHECK_ARG(h != nullptr && workgroup < LP_WGS);
+    h->fault_wg = workgroup;
+    h->fault_step = workgroup < 0 ? -1 : step;
+    return PCD_OK;
+}
+
 static int lp_launch(pcd_latent_persist_t* h, LpArgs& a, void* workspace, size_t workspace_bytes, void* stream) {
     const size_t need = pcd_latent_persist_workspace_bytes(h);
     if (workspace_bytes < need) {
@@ -1166,6 +1181,8 @@ static int lp_launch(pcd_latent_persist_t* h, LpArgs& a, void* workspace, size_t
     a.predict = h->predict;
     a.trace = h->trace;
     a.trace_steps = h->trace_steps;
+    a.fault_wg = h->fault_wg;
+    a.fault_step = h->fault_step;
     // a batch of more than 32 rows: two interleaved streams (rows 0 .. 31 | the rest)
     const int ns = a.batch > 32 ? 2 : 1;
     a.sched = ns == 2 ? h->d_sched : nullptr;
@@ -1210,6 +1227,8 @@ extern "C" int pcd_latent_persist_ddim(pcd_latent_persist_t* h, float* z, float*
 
 extern "C" int pcd_latent_persist_status(const void* workspace, unsigned* status_host) {
     PCD_CHECK_ARG(workspace && status_host);
+    // the launch may sit on a non-blocking stream, which a null-stream copy does not wait for: drain the device first
+    PCD_CHECK_HIP(hipDeviceSynchronize());
     PCD_CHECK_HIP(hipMemcpy(status_host, workspace, sizeof(unsigned), hipMemcpyDeviceToHost));
     return PCD_OK;
 }

@@ -504,21 +504,45 @@ class LatentDiffusion(_DiffusionBase):
     def _forward_fn(self):
         return lambda x, tb_cur, eps: self.model.forward_with_bias(x, tb_cur, 0, out=eps)
 
-    # the DDIM loops (`sample`, `sample3`) of a batch <= 64 run as ONE persistent launch for all their steps
-    # (csrc/latent_persist.hip); PCD_LATENT_PERSISTENT=0 (or use_persistent = False) keeps the per-layer launches, which
-    # is also what runs for larger batches, for DDPM (`sample2`) and when several processes share one GPU
+    # The DDIM loops (`sample`, `sample3`) of a batch <= 64 run as ONE persistent launch for all their steps
+    # (csrc/latent_persist.hip) when this process can have the whole GPU: 256 workgroups, one per CU, each with the whole LDS,
+    # must be co-resident.  Otherwise -- larger batches, DDPM (`sample2`), PCD_LATENT_PERSISTENT=0 / use_persistent = False, a CU
+    # mask, several ranks of this job on one device -- the per-layer launches run.  A persistent launch that still cannot
+    # complete (a foreign process holding CUs: every wait inside is bounded) is not an error: the loop is re-run from the saved
+    # start state on the per-layer launches, with one warning, and the module stays on them.
     use_persistent = os.environ.get("PCD_LATENT_PERSISTENT", "1") != "0"
 
+    def _persistent_allowed(self, x) -> bool:
+        if not self.use_persistent or x.dim() != 2:
+            return False
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            # ranks of one job sharing a device (a one-GPU rehearsal of the multi-rank path): two persistent grids cannot be resident together
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", dist.get_world_size()))
+            if local_world > max(torch.cuda.device_count(), 1):
+                return False
+        return self.model.persist_supported(x.shape[0])
+
     def _run(self, x, tab, bias_table, forward, kind, noises=None, skip_last_update=False):
-        if (kind == "ddim" and noises is None and self.use_persistent and x.dim() == 2
-                and self.model.persist_supported(x.shape[0])):
-            rates = torch.stack([tab.n, tab.s, tab.a, tab.b]).contiguous()           # (4, T, R)
-            counter = torch.zeros(2, dtype=torch.int32, device=x.device)
-            x0 = torch.empty_like(x)
-            # the last step's update of z is computed and discarded when `skip_last_update` (sample3): x0 is the result
-            self.model.ddim_steps_persist(x, x0, bias_table.contiguous(), rates, counter, tab.steps)
-            self.model.check_persist_status()
-            return x0
+        if kind == "ddim" and noises is None and self._persistent_allowed(x):
+            # A non-finite start state cannot go through the kernel's exchange (a value IS its own ready flag: NaN / set sign bits
+            # mean "not written yet"), so such a call takes the per-layer launches, where GroupNorm keeps the damage inside its row.
+            if bool(torch.isfinite(x).all()):
+                start = x.clone()                                                        # <= 64 KB: the launch updates x in place
+                rates = torch.stack([tab.n, tab.s, tab.a, tab.b]).contiguous()           # (4, T, R)
+                counter = torch.zeros(2, dtype=torch.int32, device=x.device)
+                x0 = torch.empty_like(x)
+                # the last step's update of z is computed and discarded when `skip_last_update` (sample3): x0 is the result
+                self.model.ddim_steps_persist(x, x0, bias_table.contiguous(), rates, counter, tab.steps)
+                status = self.model.persist_status()
+                if status == 0:
+                    return x0
+                import warnings
+                warnings.warn(f"persistent latent kernel abandoned its launch (wait kind {status >> 16}, workgroup {status & 0xffff}: "
+                              "CUs of this GPU are not all available to this process); re-running on the per-layer launches and "
+                              "staying there (LatentDiffusion.use_persistent = False)", RuntimeWarning, stacklevel=3)
+                self.use_persistent = False
+                x.copy_(start)
         return super()._run(x, tab, bias_table, forward, kind, noises, skip_last_update)
 
     # ------------------------------------------------------------------ training surface (diffusion.py:410-443, 522-537)

@@ -24,10 +24,22 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
         torch.cuda.set_device(local)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_collective()) and not dist.is_initialized():
         kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, local
+
+
+def force_collective() -> bool:
+    """PCD_DIST_FORCE_COLLECTIVE=1: a world of ONE rank still initialises its process group and runs every gather through
+    the backend (no `world == 1` shortcut).  This is how the production branch -- RCCL on device tensors -- executes on
+    the single GPU a test box has (`tests/test_gpu_dist.py::test_rccl_branch_on_one_gpu`); it moves no data between
+    devices and says nothing about scaling."""
+    return os.environ.get("PCD_DIST_FORCE_COLLECTIVE") == "1"
+
+
+def _no_collective(ws: int) -> bool:
+    return ws == 1 and not (force_collective() and dist.is_available() and dist.is_initialized())
 
 
 def world() -> Tuple[int, int]:
@@ -53,7 +65,7 @@ def all_gather_rows(rows: torch.Tensor, counts: Optional[Sequence[int]] = None) 
     """Concatenate per-rank row blocks (r_i, ...) in rank order.  Uneven blocks are padded to the
     largest block for one `all_gather_into_tensor` and trimmed afterwards."""
     rank, ws = world()
-    if ws == 1:
+    if _no_collective(ws):
         return rows
     dev = rows.device
     staged = _host_staged() and dev.type != "cpu"
@@ -76,7 +88,7 @@ def all_gather_clouds(clouds: List[torch.Tensor]) -> List[torch.Tensor]:
     """All-gather a ragged python list of (n_i, 3) clouds (LatentDiffusion outputs): sizes first,
     then one padded payload; returns the global list in rank order."""
     rank, ws = world()
-    if ws == 1:
+    if _no_collective(ws):
         return clouds
     dev = clouds[0].device if clouds else torch.device("cpu")
     sizes = torch.tensor([c.shape[0] for c in clouds], dtype=torch.int64, device=dev)

@@ -488,14 +488,25 @@ class SimpleLatentUNetPointNet(_HipModule):
                                            device=self.device)
         return self._persist, self._persist_ws
 
-    def check_persist_status(self):
-        """Synchronises and raises if a wait inside the last persistent launch gave up (0.2 s bound per wait)."""
+    def persist_status(self) -> int:
+        """Drains the device and returns the status word of the last persistent launch: 0 = every wait was met, else
+        (wait kind << 16) | workgroup -- the launch was abandoned (0.2 s bound per wait) and its outputs are undefined."""
         h, ws = self._persist_handle()
         st = C.c_uint(0)
         _lib.check(_lib.load().pcd_latent_persist_status(ws.data_ptr(), C.byref(st)), "latent_persist_status")
-        if st.value:
-            raise RuntimeError(f"persistent latent kernel: wait kind {st.value >> 16} of workgroup {st.value & 0xffff} timed out "
+        return int(st.value)
+
+    def check_persist_status(self):
+        """Raises if the last persistent launch was abandoned (callers with no saved input to re-run from)."""
+        st = self.persist_status()
+        if st:
+            raise RuntimeError(f"persistent latent kernel: wait kind {st >> 16} of workgroup {st & 0xffff} timed out "
                                "(is another process holding CUs of this GPU?  set PCD_LATENT_PERSISTENT=0 to use the per-layer launches)")
+
+    def inject_persist_fault(self, workgroup: int, step: int = 0) -> None:
+        """Recovery tests: workgroup `workgroup` of the following persistent launches leaves at step `step` (-1: off)."""
+        h, _ = self._persist_handle()
+        _lib.check(_lib.load().pcd_latent_persist_inject_fault(h, int(workgroup), int(step)), "latent_persist_inject_fault")
 
     def forward_persist(self, z, tbias_row, out=None):
         """eps = model(z, t) for ONE t shared by the batch (tbias_row = time_bias(t)[0], 128 values), one launch."""

@@ -243,7 +243,9 @@ class Ranks:
         torch.cuda.set_device(self.device)
         self.dist = None
         self.backend = None
-        if self.world > 1:
+        # PCD_DIST_FORCE_COLLECTIVE=1: a one-rank world still builds its process group, so that the RCCL branch of every
+        # collective below runs on a one-GPU box (tests/test_gpu_dist.py::test_rccl_branch_on_one_gpu); not a scaling run
+        if self.world > 1 or os.environ.get("PCD_DIST_FORCE_COLLECTIVE") == "1":
             import torch.distributed as dist
             self.backend = "gloo" if self.shared else "nccl"
             kw = {} if self.shared else {"device_id": self.device}
@@ -711,10 +713,8 @@ def run_cfg4(args, R: Ranks):
 
 def main():
     args = parse_args()
-    if os.environ.get("PCD_BENCH_SHARE_GPU") == "1":
-        # several ranks on ONE GPU (the one-GPU rehearsal of the multi-rank path): the persistent latent kernel needs every
-        # CU of its device, two of them cannot be resident together -> the per-layer launches
-        os.environ.setdefault("PCD_LATENT_PERSISTENT", "0")
+    # (several ranks on ONE GPU, PCD_BENCH_SHARE_GPU=1: the library itself keeps the persistent latent kernel off when ranks of
+    # a job share a device -- LatentDiffusion._persistent_allowed -- and falls back if a launch cannot complete)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_children(args))           # the parent stays GPU-free
 

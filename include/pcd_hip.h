@@ -321,7 +321,13 @@ int pcd_latent_persist_forward(pcd_latent_persist_t* h, const float* z, int batc
 int pcd_latent_persist_ddim(pcd_latent_persist_t* h, float* z, float* x0, int batch, const float* tb_table, int tb_elems,
                             const float* rate_tables, int rate_width, int n_steps_table, int* counter, int nsteps,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* drains the device, then reads the status word of the last launch: 0 = every wait was met; else (wait kind << 16) | workgroup.
+ * A non-zero status means the launch was ABANDONED (its outputs are undefined): the caller re-runs from its saved input on
+ * the per-layer path (shapegen_amd.diffusion.LatentDiffusion._run does). */
 int pcd_latent_persist_status(const void* workspace, unsigned* status_host);
+/* fault injection for the recovery tests: in the following launches workgroup `workgroup` (role index 0..255) leaves at the
+ * start of step `step`, as a workgroup that never became resident would; workgroup < 0 switches it off. */
+int pcd_latent_persist_inject_fault(pcd_latent_persist_t* h, int workgroup, int step);
 /* host-only self check of the kernel's static work assignment (no device needed): bytes of one buffer set, or -1 */
 int pcd_latent_persist_plan_check(void);
 /* host-only: phase id (2 * layer + finish, -1 = none) of every workgroup's units, [256][8] ints */

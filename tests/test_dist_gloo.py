@@ -59,6 +59,32 @@ def test_two_rank_gloo(tmp_path):
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
 
 
+def _forced_one_rank_worker(rank, world, port, tmp):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import shapegen_amd  # noqa: F401
+    from shapegen_amd import dist as D
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      PCD_DIST_FORCE_COLLECTIVE="1")
+    assert D.init_from_env("gloo") == (0, 1, 0) and dist.is_initialized()
+    t = torch.arange(6.).reshape(2, 3)
+    out = D.all_gather_rows(t)
+    assert out is not t and torch.equal(out, t)                  # went through the backend, not the world == 1 shortcut
+    assert torch.equal(D.all_gather_rows(t, counts=[2]), t)
+    clouds = [torch.ones(3, 3), torch.zeros(0, 3), torch.full((5, 3), 2.0)]
+    got = D.all_gather_clouds(clouds)
+    assert len(got) == 3 and all(torch.equal(a, b) for a, b in zip(got, clouds))
+    dist.destroy_process_group()
+    open(os.path.join(tmp, "forced_ok"), "w").write("ok")
+
+
+def test_forced_collective_in_a_one_rank_world(tmp_path):
+    """PCD_DIST_FORCE_COLLECTIVE=1: the switch that lets a one-GPU box execute the RCCL branch (tests/test_gpu_dist.py)
+    covered on the CPU backend: a world of one rank initialises its group and every gather goes through the backend."""
+    mp.spawn(_forced_one_rank_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / "forced_ok").exists()
+
+
 def test_single_process_passthrough():
     from shapegen_amd import dist as D
     assert D.world() == (0, 1)

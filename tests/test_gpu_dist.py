@@ -62,6 +62,39 @@ def test_bench_launches_its_own_ranks(config):
         assert rec["roofline_vae_decode"]["bound"] == "mfma"
 
 
+def _one_rank_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("PCD_BENCH_SHARE_GPU",)}
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=_port(), PYTHONPATH=ROOT,
+               HSA_ENABLE_IPC_MODE_LEGACY="0", PCD_DIST_FORCE_COLLECTIVE="1", PCD_COLLECTIVE_TIMEOUT_S="120")
+    return env
+
+
+def test_rccl_branch_on_one_gpu():
+    """The production collective branch (backend "nccl" = RCCL, device tensors, `device_id=`) executed on the one GPU of
+    this box: a one-rank world with PCD_DIST_FORCE_COLLECTIVE=1 takes no `world == 1` shortcut, so `all_gather_rows`
+    (with and without counts), `all_gather_clouds` on ragged device clouds, `evaluate_sharded`, `sample_sharded` and
+    `bench.Ranks.max_over_ranks / collective_ranks` all run through RCCL in a child process.  Not a scaling measurement."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_one_gpu_worker.py")], env=_one_rank_env(),
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert res["backend"] == "nccl" and res["ranks_backend"] == "nccl" and res["world"] == 1 and res["host_staged"] is False
+    for k in ("rows_equal", "clouds_equal", "eval_equal", "mean_ok", "sampler_equal"):
+        assert res[k] is True, k
+    assert res["max_over_ranks"] == 1.25 and res["collective_ranks"] == 1
+
+
+def test_bench_cfg5_line_over_rccl_on_one_gpu():
+    """`bench.py --config cfg5` as ONE rank over RCCL (forced): the all-gather of the ragged clouds and of the metric rows
+    run on device tensors; the line says so (`collective_backend` "nccl", `rccl_ranks` 1)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "cfg5", "--no-cpu-baseline"],
+                       env=_one_rank_env(), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2500:]
+    rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["config"]["rccl_ranks"] == 1 and rec["config"]["collective_backend"] == "nccl"
+    assert rec["steps"] == 1000 and rec["config"]["global_batch"] == 32 and len(rec["config"]["mean_metrics"]) == 3
+
+
 def test_bench_cfg4_line():
     """`python bench.py --config cfg4` (BASELINE configs[3] on one GPU): encode 32 grids, 1000 latent steps, decode,
     voxel -> points; the line carries the latent step against the HBM roofline and the VAE legs against the MFMA peak."""

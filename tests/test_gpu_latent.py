@@ -417,6 +417,65 @@ def test_latent_persistent_ddim_steps(ldm):
     assert rel_l2(a5.cpu(), want5.cpu()) < 2e-3
 
 
+def test_latent_persistent_launch_fails_soft(ldm):
+    """A persistent launch that cannot complete is not an error: with a fault injected -- one workgroup
+    leaves at step 3, as a workgroup that never became resident would -- every wait inside gives up within its bound, the
+    status word is set, and `LatentDiffusion._run` re-runs the loop from its saved start state on the per-layer launches with
+    ONE warning and stays on them.  The result is bitwise the per-layer path's; the caller's z_T is untouched."""
+    from shapegen_amd.diffusion import LatentDiffusion
+    if not ldm.model.persist_supported(32):
+        pytest.skip("needs a 256-CU device")
+    g = torch.Generator().manual_seed(21)
+    zT = torch.randn(32, 256, generator=g).cuda()
+    keep = zT.clone()
+    try:
+        ldm.use_persistent = False
+        _, want = ldm.sample(32, num_steps=40, z_T=zT, return_latent=True)
+        for wg, step, batch in ((77, 3, 32), (0, 0, 32), (200, 5, 48)):
+            ldm.use_persistent = True
+            ldm.model.inject_persist_fault(wg, step)
+            with pytest.warns(RuntimeWarning, match="per-layer launches"):
+                _, got = ldm.sample(batch, num_steps=40, z_T=zT[:batch] if batch <= 32 else torch.cat([zT, zT[:batch - 32]]), return_latent=True)
+            assert ldm.model.persist_status() != 0                      # the abandoned launch said so
+            assert ldm.use_persistent is False                          # and the module stays on the per-layer launches
+            assert torch.equal(got[:32], want)
+        ldm.model.inject_persist_fault(-1, -1)
+        ldm.use_persistent = True
+        _, ok = ldm.sample(32, num_steps=40, z_T=zT, return_latent=True)      # the kernel itself is fine afterwards
+        assert ldm.model.persist_status() == 0 and ldm.use_persistent is True
+        assert rel_l2(ok.cpu(), want.cpu()) < 2e-3
+    finally:
+        ldm.model.inject_persist_fault(-1, -1)
+        ldm.use_persistent = LatentDiffusion.use_persistent
+    assert torch.equal(zT, keep)
+
+
+def test_latent_non_finite_rows_stay_in_their_rows(ldm):
+    """z_T with an inf row and a NaN row: GroupNorm is per row (networks.py:984-1036), so every other row must come out
+    bitwise as if the bad rows were not there.  The persistent kernel's exchange cannot carry non-finite state (a value is its
+    own ready flag), so such a call is routed to the per-layer launches up front -- no timeout, no warning."""
+    import warnings
+    from shapegen_amd.diffusion import LatentDiffusion
+    g = torch.Generator().manual_seed(22)
+    zT = torch.randn(32, 256, generator=g).cuda()
+    bad = zT.clone()
+    bad[3, 10] = float("inf")
+    bad[17] = float("nan")
+    good_rows = [i for i in range(32) if i not in (3, 17)]
+    try:
+        ldm.use_persistent = False
+        _, want = ldm.sample(32, num_steps=25, z_T=zT, return_latent=True)
+        ldm.use_persistent = True
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            _, got = ldm.sample(32, num_steps=25, z_T=bad, return_latent=True)
+        assert ldm.use_persistent is True                                # nothing timed out
+    finally:
+        ldm.use_persistent = LatentDiffusion.use_persistent
+    assert torch.equal(got[good_rows], want[good_rows])
+    assert not torch.isfinite(got[3]).all() and not torch.isfinite(got[17]).all()
+
+
 def test_latent_sample2_sample3_and_errors(ldm):
     from oracle import torch_oracle as O
     from shapegen_amd.diffusion import LatentDiffusion
