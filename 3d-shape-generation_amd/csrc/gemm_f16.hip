@@ -10,6 +10,7 @@
 // fed to v_mfma_f32_16x16x32_f16.  Double-buffered, one barrier per 64-deep K tile.
 //
 // Tile: BM x BN x 64, 256 threads = 4 waves as 2(M) x 2(N).
+#include <mutex>
 #include "common.h"
 #include <type_traits>
 
@@ -644,15 +645,24 @@ static int launch(const GemmParams& p0, hipStream_t s, int blocks_per_cu) {
                         (int64_t)255 * p.lda1 * 2 + 128 < 0x7fffffffLL && (int64_t)255 * p.ldw * 2 + 128 < 0x7fffffffLL;
         if (ok && (p.bias == nullptr || p.shape_bias == nullptr)) {
             // a zero row stands in for a missing bias (fixed number of LDS-DMA pieces per tile: the waits are counted)
-            static float* zeros = nullptr;
-            constexpr int kZeroCols = 16384;
-            if (zeros == nullptr && p.c <= kZeroCols) {
-                // one-time allocation: never inside a stream capture (a launch that is being captured takes the generic kernel instead)
-                hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-                if (hipStreamIsCapturing(s, &cap) != hipSuccess) { cap = hipStreamCaptureStatusActive; (void)hipGetLastError(); }
-                if (cap == hipStreamCaptureStatusNone &&
-                    (hipMalloc(&zeros, kZeroCols * sizeof(float)) != hipSuccess || hipMemset(zeros, 0, kZeroCols * sizeof(float)) != hipSuccess))
-                    zeros = nullptr;
+            // one row per DEVICE (a process may drive several), created under a lock
+            constexpr int kZeroCols = 16384, kMaxDev = 64;
+            static float* zeros_of[kMaxDev] = {};
+            static std::mutex zeros_mu;
+            float* zeros = nullptr;
+            int dev = -1;
+            if (p.c <= kZeroCols && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDev) {
+                std::lock_guard<std::mutex> lock(zeros_mu);
+                if (zeros_of[dev] == nullptr) {
+                    // one-time allocation: never inside a stream capture (a launch that is being captured takes the generic kernel instead)
+                    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+                    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { cap = hipStreamCaptureStatusActive; (void)hipGetLastError(); }
+                    float* z = nullptr;
+                    if (cap == hipStreamCaptureStatusNone && hipMalloc(&z, kZeroCols * sizeof(float)) == hipSuccess) {
+                        if (hipMemset(z, 0, kZeroCols * sizeof(float)) == hipSuccess) zeros_of[dev] = z; else (void)hipFree(z);
+                    }
+                }
+                zeros = zeros_of[dev];
             }
             if (zeros != nullptr && p.c <= kZeroCols) {
                 if (p.bias == nullptr) p.bias = zeros;

@@ -51,24 +51,32 @@ def _tail(path: str, limit: int = 1500) -> str:
         return ""
 
 
+def _signal_group(p: subprocess.Popen, sig: int) -> None:
+    """Ranks are session leaders (`start_new_session=True`): signal the rank's whole process group, so that a rank's own
+    children (DataLoader workers) do not outlive it and keep the GPU busy.  Only groups this launcher created are touched."""
+    try:
+        os.killpg(p.pid, sig)            # pgid == pid for a session leader
+    except (OSError, ProcessLookupError):
+        try:
+            p.send_signal(sig)
+        except OSError:
+            pass
+
+
 def _stop(procs: Sequence[subprocess.Popen], grace_s: float = 5.0) -> None:
-    """SIGTERM to the exact PIDs we started, then SIGKILL to whatever is still alive after `grace_s`."""
+    """SIGTERM to the process groups of the exact PIDs we started, then SIGKILL to whatever is still alive after `grace_s`."""
     for p in procs:
         if p.poll() is None:
-            try:
-                p.send_signal(signal.SIGTERM)
-            except OSError:
-                pass
+            _signal_group(p, signal.SIGTERM)
     t_end = time.monotonic() + grace_s
     for p in procs:
         while p.poll() is None and time.monotonic() < t_end:
             time.sleep(0.05)
         if p.poll() is None:
-            try:
-                p.kill()
-            except OSError:
-                pass
+            _signal_group(p, signal.SIGKILL)
             p.wait()
+        else:
+            _signal_group(p, signal.SIGKILL)      # the rank is gone; sweep what it may have left in its group
 
 
 def launch_ranks(argv: Sequence[str], world: int, timeout_s: float = 600.0, log_dir: Optional[str] = None,
@@ -80,29 +88,34 @@ def launch_ranks(argv: Sequence[str], world: int, timeout_s: float = 600.0, log_
     os.makedirs(log_dir, exist_ok=True)
     procs: List[subprocess.Popen] = []
     files = []
-    for rank in range(world):
-        out = open(os.path.join(log_dir, f"rank{rank}.out"), "wb")
-        err = open(os.path.join(log_dir, f"rank{rank}.err"), "wb")
-        files += [out, err]
-        procs.append(subprocess.Popen(list(argv), env=rank_env(rank, world, port, env, max(30, int(timeout_s // 2))),
-                                      stdout=out, stderr=err))
-    t_end = time.monotonic() + timeout_s
     why = ""
-    while True:
-        codes = [p.poll() for p in procs]
-        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
-        if bad:
-            why = f"ranks failed (rank, exit code): {bad}; siblings terminated"
-            break
-        if all(c == 0 for c in codes):
-            break
-        if time.monotonic() > t_end:
-            why = f"timeout after {timeout_s:.0f} s; still running: {[r for r, c in enumerate(codes) if c is None]}"
-            break
-        time.sleep(poll_s)
-    _stop(procs)
-    for f in files:
-        f.close()
+    try:
+        for rank in range(world):
+            out = open(os.path.join(log_dir, f"rank{rank}.out"), "wb")
+            files.append(out)
+            err = open(os.path.join(log_dir, f"rank{rank}.err"), "wb")
+            files.append(err)
+            procs.append(subprocess.Popen(list(argv), env=rank_env(rank, world, port, env, max(30, int(timeout_s // 2))),
+                                          stdout=out, stderr=err, start_new_session=True))
+        t_end = time.monotonic() + timeout_s
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                why = f"ranks failed (rank, exit code): {bad}; siblings terminated"
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > t_end:
+                why = f"timeout after {timeout_s:.0f} s; still running: {[r for r, c in enumerate(codes) if c is None]}"
+                break
+            time.sleep(poll_s)
+    except OSError as e:                   # a rank could not be started (ENOMEM, bad argv): stop the ones that were
+        why = f"could not start rank {len(procs)}: {e}; siblings terminated"
+    finally:
+        _stop(procs)
+        for f in files:
+            f.close()
     out0 = ""
     try:
         out0 = open(os.path.join(log_dir, "rank0.out"), "r", errors="replace").read()

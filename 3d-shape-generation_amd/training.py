@@ -20,6 +20,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Dict, List, Optional, Tuple
 
+import contextlib
+
 import torch
 
 from . import _lib
@@ -717,6 +719,35 @@ def save_checkpoint(model, path: str, epoch: int, extra: Optional[dict] = None) 
     torch.save(payload, path)
 
 
+class _RankRng:
+    """Context manager: inside, torch's CPU / device generators (and `torch.initial_seed()`, which seeds the on-device Philox
+    stream) are this rank's private stream; outside, the process keeps the RNG state all ranks share."""
+
+    def __init__(self, device, rank: int):
+        self.device = torch.device(device)
+        shared = self._get()
+        torch.manual_seed((torch.initial_seed() + 0x9E3779B1 * (rank + 1)) & 0x7FFFFFFFFFFFFFFF)
+        self.mine = self._get()
+        self._set(shared)
+
+    def _get(self):
+        return torch.get_rng_state(), (torch.cuda.get_rng_state(self.device) if self.device.type == "cuda" else None)
+
+    def _set(self, st):
+        torch.set_rng_state(st[0])
+        if st[1] is not None:
+            torch.cuda.set_rng_state(st[1], self.device)
+
+    def __enter__(self):
+        self.shared = self._get()
+        self._set(self.mine)
+
+    def __exit__(self, *exc):
+        self.mine = self._get()
+        self._set(self.shared)
+        return False
+
+
 def fit(model, data_module, max_epochs: int = 500, ckpt_dir: Optional[str] = None, log=print, max_steps: Optional[int] = None,
         save_top_k: int = 10, ckpt_name: str = "point_cloud_diffusion"):
     """What `pl.Trainer(max_epochs=...).fit(model, data_module)` does for the reference's train_point_ddpm.py:78-87 and
@@ -742,10 +773,12 @@ def fit(model, data_module, max_epochs: int = 500, ckpt_dir: Optional[str] = Non
             inv = getattr(sub, "invalidate", None)      # pre-broadcast values on ranks > 0: rebuild them on next use
             if callable(inv):
                 inv()
-        # ranks hold different data batches and must not draw the same (t, noise, dropout) for them: every torch draw and the
-        # on-device Philox stream (seeded by torch.initial_seed()) are moved to a per-rank seed; val_loss is all-reduced
-        # below, so the scheduler and the top-k logic still see one number on every rank
-        torch.manual_seed((torch.initial_seed() + 0x9E3779B1 * rank) & 0x7FFFFFFFFFFFFFFF)
+    # Ranks hold different data batches and must not draw the same (t, noise, dropout) for them, but they MUST enumerate the same
+    # shuffled batch sequence (`group[rank]` below deals consecutive batches of ONE permutation out to the ranks; the loaders'
+    # RandomSampler seeds itself from the global torch RNG).  So the global RNG stays shared, and only the model's own draws --
+    # torch.rand for t, the on-device Philox stream seeded by torch.initial_seed() -- run under a per-rank RNG state that is
+    # swapped in around training_step / validation_step and swapped out again (it does not leak out of fit() either).
+    rank_rng = _RankRng(model.device, rank) if world > 1 else contextlib.nullcontext()
     kept: List[Tuple[float, str]] = []
     steps = 0
     history = []
@@ -763,14 +796,18 @@ def fit(model, data_module, max_epochs: int = 500, ckpt_dir: Optional[str] = Non
                 continue                       # an incomplete last group is dropped: every rank takes the same number of
             i, batch = group[rank]             # steps, so each optimizer all-reduce pairs the same step on all ranks
             group = []
-            loss = model.training_step(batch, i)
+            with rank_rng:
+                loss = model.training_step(batch, i)
             opt.step()
             tl.append(loss)
             steps += 1
             if max_steps is not None and steps >= max_steps:
                 break
         model.eval()
-        vl = [model.validation_step(b, i) for i, b in enumerate(data_module.val_dataloader())]
+        vl = []
+        for i, b in enumerate(data_module.val_dataloader()):
+            with rank_rng:
+                vl.append(model.validation_step(b, i))
         train_loss = float(torch.stack(tl).mean()) if tl else float("nan")
         val_loss = float(torch.stack(vl).mean()) if vl else train_loss
         if world > 1:                          # one val_loss for the scheduler and the top-k logic on every rank
