@@ -162,6 +162,10 @@ _SIGS = {
     "pcd_latent_destroy": (None, [vp]),
     "pcd_latent_workspace_bytes": (sz, [i32]),
     "pcd_latent_forward": (i32, [vp, vp, i32, vp, i32, vp, vp, sz, vp]),
+    "pcd_latent_f32_create": (i32, [C.POINTER(LatentDesc), C.POINTER(vp)]),
+    "pcd_latent_f32_destroy": (None, [vp]),
+    "pcd_latent_f32_workspace_bytes": (sz, [i32]),
+    "pcd_latent_f32_forward": (i32, [vp, vp, i32, vp, i32, vp, vp, sz, vp]),
     "pcd_latent_persist_supported": (i32, [i32]),
     "pcd_latent_persist_create": (i32, [C.POINTER(LatentDesc), C.POINTER(vp)]),
     "pcd_latent_persist_destroy": (None, [vp]),
@@ -193,6 +197,7 @@ _SIGS = {
     "pcd_set_attention_workspace_bytes": (sz, [i32, i32, i32]),
     "pcd_set_attention_f16": (i32, [vp, i32, i32, i32, i32, vp, vp, sz, vp]),
     "pcd_set_attention_config": (i32, [i32]),
+    "pcd_set_attention_last_kernel": (C.c_char_p, []),
     "pcd_add_shape_bias_f16": (i32, [vp, i64, i32, i32, vp, vp, vp]),
     "pcd_add_shape_bias_strided_f16": (i32, [vp, i64, i32, i32, vp, i64, vp, vp]),
     "pcd_tail3": (i32, [vp, i32, vp, i32, i64, vp, vp, vp, vp, vp, vp]),

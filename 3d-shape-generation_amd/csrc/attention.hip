@@ -895,6 +895,10 @@ extern "C" int pcd_set_attention_config(int force_generic) {
     return PCD_OK;
 }
 
+static const char* g_attn_last_kernel = "";   // which kernel the last pcd_set_attention_f16 call launched (bench.py reports it)
+
+extern "C" const char* pcd_set_attention_last_kernel(void) { return g_attn_last_kernel; }
+
 extern "C" int pcd_set_attention_f16(const void* qkv, int batch, int n_points, int c, int heads, void* out,
                                      void* workspace, size_t workspace_bytes, void* stream) {
     (void)workspace; (void)workspace_bytes;
@@ -911,6 +915,7 @@ extern "C" int pcd_set_attention_f16(const void* qkv, int batch, int n_points, i
         dim3 sgrid((unsigned)((n_points / 256) * batch * heads));
         hipLaunchKernelGGL(set_attention_sp_kernel, sgrid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads,
                            scale_log2e, (half_t*)out);
+        g_attn_last_kernel = "set_attention_sp_kernel";
         PCD_CHECK_LAUNCH();
         return PCD_OK;
     }
@@ -920,6 +925,7 @@ extern "C" int pcd_set_attention_f16(const void* qkv, int batch, int n_points, i
         if (d == 16) hipLaunchKernelGGL((set_attention_om_kernel<16>), grid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads, scale_log2e, (half_t*)out);
         else if (d == 32) hipLaunchKernelGGL((set_attention_om_kernel<32>), grid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads, scale_log2e, (half_t*)out);
         else hipLaunchKernelGGL((set_attention_om_kernel<64>), grid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads, scale_log2e, (half_t*)out);
+        g_attn_last_kernel = d == 16 ? "set_attention_om_kernel<16>" : d == 32 ? "set_attention_om_kernel<32>" : "set_attention_om_kernel<64>";
         PCD_CHECK_LAUNCH();
         return PCD_OK;
     }
@@ -932,6 +938,7 @@ extern "C" int pcd_set_attention_f16(const void* qkv, int batch, int n_points, i
     else
         hipLaunchKernelGGL((set_attention_kernel<64, QT>), grid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads,
                            scale_log2e, (half_t*)out);
+    g_attn_last_kernel = d == 16 ? "set_attention_kernel<16>" : d == 32 ? "set_attention_kernel<32>" : "set_attention_kernel<64>";
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

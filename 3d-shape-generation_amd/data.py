@@ -184,23 +184,6 @@ class PointCloudDataset(Dataset):
         return point_cloud[list(range(len(point_cloud))) + extra.tolist()]
 
     @staticmethod
-    def farthest_point_sample(point_cloud, num_points):
-        """data.py:256-287 (unused by the reference's own pipeline: 'makes dataloading very slow')."""
-        if len(point_cloud) == num_points:
-            return point_cloud
-        xyz = point_cloud[:, :3]
-        centroids = np.zeros((num_points,))
-        distance = np.ones((point_cloud.shape[0],)) * 1e10
-        farthest = np.random.randint(0, point_cloud.shape[0])
-        for i in range(num_points):
-            centroids[i] = farthest
-            dist = np.sum((xyz - xyz[farthest, :]) ** 2, axis=-1)
-            mask = dist < distance
-            distance[mask] = dist[mask]
-            farthest = np.argmax(distance, axis=-1)
-        return point_cloud[centroids.astype(np.int32)]
-
-    @staticmethod
     def jitter_points(points, sigma=0.01, clip=0.05):
         """data.py:289-295."""
         return np.clip(sigma * np.random.randn(*points.shape), -clip, clip) + points

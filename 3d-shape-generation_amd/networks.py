@@ -454,11 +454,26 @@ class SimpleLatentUNetPointNet(_HipModule):
         self.latent_dim, self.dim, self.time_dim = latent_dim, dim, time_dim
         self._build_from_spec(specs.latent_unet_spec(latent_dim, dim, time_dim))
         self._handle = None
+        self._handle_f32 = False
         self._persist = None
+        self.precision = os.environ.get("PCD_PARITY", "fp16")     # "fp32": the parity mode of csrc/latent_f32.hip (see UNetPointNetLarge)
+        if self.precision not in UNetPointNetLarge.PRECISIONS:
+            raise ValueError(f"PCD_PARITY must be one of {UNetPointNetLarge.PRECISIONS}, got {self.precision!r}")
+
+    def set_precision(self, precision: str) -> "SimpleLatentUNetPointNet":
+        """"fp16" (default: fp16 operands, the per-layer launches / the persistent kernel) or "fp32" (fp32 weights, activations
+        and products, one launch per layer: the reference's arithmetic type, eps rel-L2 <= 1e-4)."""
+        if precision not in UNetPointNetLarge.PRECISIONS:
+            raise ValueError(f"precision must be one of {UNetPointNetLarge.PRECISIONS}, got {precision!r}")
+        if precision != self.precision:
+            self.invalidate()
+            self.precision = precision
+        return self
 
     def _release(self):
         if getattr(self, "_handle", None):
-            _lib.load().pcd_latent_destroy(self._handle)
+            lib = _lib.load()
+            (lib.pcd_latent_f32_destroy if self._handle_f32 else lib.pcd_latent_destroy)(self._handle)
         if getattr(self, "_persist", None):
             _lib.load().pcd_latent_persist_destroy(self._persist)
         self._handle = None
@@ -475,6 +490,8 @@ class SimpleLatentUNetPointNet(_HipModule):
     def persist_supported(self, batch: int) -> bool:
         """True when `csrc/latent_persist.hip` can run on this device for this batch (batch <= 64, a 256-CU gfx950)."""
         self._need_cuda()
+        if self.precision != "fp16":
+            return False                                   # the persistent kernel is an fp16-operand kernel
         return bool(_lib.load().pcd_latent_persist_supported(int(batch)))
 
     def _persist_handle(self):
@@ -539,16 +556,20 @@ class SimpleLatentUNetPointNet(_HipModule):
         for k, v in ex.items():
             keep[k] = _dev32(v, dev)
         desc = _lib.LatentDesc()
+        f32 = self.precision == "fp32"
         for i, (w, b) in enumerate(lin):
-            keep[f"w{i}"], keep[f"b{i}"] = _dev16(w, dev), _dev32(b, dev)
+            keep[f"w{i}"], keep[f"b{i}"] = (_dev32 if f32 else _dev16)(w, dev), _dev32(b, dev)
             desc.lin[i].w, desc.lin[i].b = keep[f"w{i}"].data_ptr(), keep[f"b{i}"].data_ptr()
             desc.lin[i].c, desc.lin[i].k = w.shape
         for i, (gm, bt) in enumerate(gn):
             keep[f"g{i}"], keep[f"be{i}"] = _dev32(gm, dev), _dev32(bt, dev)
             desc.gn_gamma[i], desc.gn_beta[i] = keep[f"g{i}"].data_ptr(), keep[f"be{i}"].data_ptr()
         handle = C.c_void_p()
-        _lib.check(_lib.load().pcd_latent_create(C.byref(desc), C.byref(handle)), "latent_create")
-        self._handle, self._packed, self._desc = handle, keep, desc
+        if f32:
+            _lib.check(_lib.load().pcd_latent_f32_create(C.byref(desc), C.byref(handle)), "latent_f32_create")
+        else:
+            _lib.check(_lib.load().pcd_latent_create(C.byref(desc), C.byref(handle)), "latent_create")
+        self._handle, self._handle_f32, self._packed, self._desc = handle, f32, keep, desc
         return keep
 
     def time_bias(self, t: torch.Tensor) -> torch.Tensor:
@@ -566,9 +587,14 @@ class SimpleLatentUNetPointNet(_HipModule):
         self._ensure_packed()
         lib = _lib.load()
         b = z.shape[0]
-        ws = self._workspace((b,), lib.pcd_latent_workspace_bytes(b))
         if out is None:
             out = torch.empty_like(z)
+        if self._handle_f32:
+            ws = self._workspace((b,), lib.pcd_latent_f32_workspace_bytes(b))
+            _lib.check(lib.pcd_latent_f32_forward(self._handle, z.data_ptr(), b, tbias.data_ptr(), shape_stride,
+                                                  out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "latent_f32_forward")
+            return out
+        ws = self._workspace((b,), lib.pcd_latent_workspace_bytes(b))
         _lib.check(lib.pcd_latent_forward(self._handle, z.data_ptr(), b, tbias.data_ptr(), shape_stride,
                                           out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "latent_forward")
         return out

@@ -290,6 +290,16 @@ int pcd_latent_forward(pcd_latent_t* h, const float* z, int batch, const float* 
                        int tbias_shape_stride, float* eps, void* workspace, size_t workspace_bytes,
                        void* stream);
 
+/* fp32 parity mode of the latent denoiser (csrc/latent_f32.hip): pcd_latent_forward's network with fp32 weights (EVERY
+ * lin[i].w of the descriptor is fp32 [C][K] here), fp32 activations and products, one launch per layer and GroupNorm;
+ * held to eps rel-L2 <= 1e-4 against the reference's fp32 arithmetic (networks.py:1051-1086). */
+typedef struct pcd_latent_f32 pcd_latent_f32_t;
+int pcd_latent_f32_create(const pcd_latent_desc_t* desc, pcd_latent_f32_t** out);
+void pcd_latent_f32_destroy(pcd_latent_f32_t* h);
+size_t pcd_latent_f32_workspace_bytes(int batch);
+int pcd_latent_f32_forward(pcd_latent_f32_t* h, const float* z, int batch, const float* tbias, int tbias_shape_stride,
+                           float* eps, void* workspace, size_t workspace_bytes, void* stream);
+
 /* The same network, and whole DDIM timesteps of the latent sampler (the loop body of LatentDiffusion.sample / sample3,
  * diffusion.py:637-645, 691-700), as ONE persistent launch for batch <= 64 (csrc/latent_persist.hip; 33 .. 64 rows run as two interleaved streams of <= 32): 256 workgroups, one
  * per CU, keep all 38 MB of fp16 weights in LDS for the whole call and exchange activations through self-validating
@@ -436,6 +446,8 @@ int pcd_set_attention_f16(const void* qkv, int batch, int n_points, int c, int h
 /* testing / tuning hook: force_generic = 1 routes every call through the generic kernel (any N, d = 16/32/64)
  * instead of the software-pipelined d = 64 kernel that N % 256 == 0 selects; 0 restores the default. */
 int pcd_set_attention_config(int force_generic);
+/* name of the kernel the last pcd_set_attention_f16 call of this process launched (measurement reports quote it) */
+const char* pcd_set_attention_last_kernel(void);
 
 /* x[m][c] + e[m / rows_per_shape][c] -> out (fp16 in/out, e fp32): the additive per-level time
  * embeddings of UNetAttentionPointExperimental (networks.py:669-698). */
