@@ -211,3 +211,31 @@ def test_sab_c_entry_rejects_bad_arguments():
     x = torch.zeros(256, 96, dtype=torch.float16, device="cuda")
     assert lib.pcd_sab_forward(C.byref(d), x.data_ptr(), 1, 256, 4, x.data_ptr(), x.data_ptr(), 1 << 20, 0) != 0
     assert b"bad argument" in lib.pcd_last_error()
+
+
+def test_full_size_attention_next_to_the_oracle():
+    """The launches bench.py times (B = 64, N = 2048: `set_attention_sp_kernel` at C = 256 with its XCD-aware block map over
+    64 shapes x 4 heads, the whole attention U-Net at full grid) checked against the ORACLE, not against a smaller launch of
+    themselves: shapes are independent, so rows of the full batch must equal the oracle on those shapes."""
+    from shapegen_amd.networks import SetAttentionBlock, UNetAttentionPointExperimental
+    from oracle import torch_oracle as O
+    gen = torch.Generator().manual_seed(6464)
+    sd = sab_sd(256)
+    blk = SetAttentionBlock(256, 4)
+    blk.load_state_dict(sd, strict=True)
+    blk = blk.to("cuda").eval()
+    x = torch.randn(64, 2048, 256, generator=gen) * 1.5
+    out = blk(x.cuda()).cpu()
+    for rows in ((9, 10), (63, 64)):                       # one shape from the middle, the last one (last XCD group)
+        want = O.set_attention_block(sd, "", x[rows[0]:rows[1]], 4)
+        assert rel_l2(out[rows[0]:rows[1]], want) < 3e-3, rows
+    del blk, out, x
+    usd = una_sd()
+    net = UNetAttentionPointExperimental(2048)
+    net.load_state_dict(usd, strict=True)
+    net = net.to("cuda").eval()
+    xp, t = torch.randn(64, 2048, 3, generator=gen) * 1.2, torch.rand(64, generator=gen)
+    eps = net(xp.cuda(), t.cuda()).cpu()
+    for rows in ((20, 21), (63, 64)):
+        want = O.unet_attention(usd, "", xp[rows[0]:rows[1]], t[rows[0]:rows[1]])
+        assert rel_l2(eps[rows[0]:rows[1]], want) < 5e-3, rows

@@ -315,6 +315,24 @@ def test_pair_metrics_batched_equals_per_pair_calls():
     assert abs(float(ex[0, 1]) - float(M.earth_mover_distance_cpu(x[0], y[0]))) < 1e-6
 
 
+def test_pair_metrics_at_the_evaluation_size_next_to_the_oracle():
+    """`pair_metrics` at the size an evaluation of BASELINE configs[1] runs it (64 pairs of 2048 x 2048 points in one enqueue:
+    Chamfer, Sinkhorn EMD, voxel BCE) against the ORACLE's per-pair `compute_metrics` on four of the pairs (first, two in the
+    middle, last).  Chamfer: the oracle's matmul-form cdist is ~1e-4 (x1e3: 0.1) off the exact value."""
+    from shapegen_amd import metrics as M
+    from oracle import torch_oracle as O
+    g = torch.Generator().manual_seed(2048)
+    a = torch.tanh(torch.randn(64, 2048, 3, generator=g))
+    b = (a + 0.05 * torch.randn(64, 2048, 3, generator=g)).clamp(-1, 1)
+    rows = M.pair_metrics(a.cuda(), b.cuda(), use_approximate_gpu_emd=True).cpu()
+    assert rows.shape == (64, 3) and torch.isfinite(rows).all()
+    for i in (0, 21, 42, 63):
+        want = [float(v) for v in O.compute_metrics(a[i], b[i], True)]
+        assert abs(float(rows[i, 0]) - want[0]) < 0.15 + 1e-4 * want[0], i
+        assert abs(float(rows[i, 1]) - want[1]) <= 2e-3 * max(1.0, want[1]) + 1e-5, i
+        assert float(rows[i, 2]) == want[2], i
+
+
 def test_pair_metrics_c_entry_point_with_an_empty_cloud():
     """the C entry point itself (not only the Python wrapper, which filters such pairs) answers a zero count with a
     NaN row and leaves the other pairs untouched."""
