@@ -246,3 +246,72 @@ def test_linear_schedule_step_tables_bit_exact(golden):
     tab = m.from_state_table(torch.tensor(0.3), 8)
     assert tab.width == 1                                                          # 0-d t: shared by the batch
     assert np.array_equal(torch.stack([tab.n[:, 0], tab.s[:, 0]], dim=1).numpy(), g["sample3_rates"])
+
+
+# ------------------------------------------------------------------ G19-G21: the 1000-step fixtures at N = 2048
+def _t1000_cloud(b, n, seed):
+    out = np.zeros((b, n, 3), np.float32)
+    for i in range(b):
+        u = specs.hash_uniform(f"cloud{i}", 3 * 4096, seed).reshape(-1, 3)
+        blob = np.round((u * 0.5 + 0.5) * np.array([31, 15, 9]) + np.array([0, 8, 11]))
+        pts = np.unique(blob, axis=0)
+        pts = pts - pts.mean(0)
+        pts = pts / np.max(np.linalg.norm(pts, axis=1))
+        sel = (specs.hash_uniform(f"sel{i}", n, seed) * 0.5 + 0.5) * len(pts)
+        out[i] = pts[np.clip(sel.astype(np.int64), 0, len(pts) - 1)]
+    return out
+
+
+def test_hash_normal_is_pinned():
+    """The generator the T = 1000 DDPM fixtures rebuild their 999 per-step noise tensors from: fixed bits (additions and one
+    halving in a fixed order), moments of a unit normal."""
+    z = specs.hash_normal("g20.z7", 12288, 0)
+    assert z.dtype == np.float64 and abs(z.mean()) < 0.03 and abs(z.std() - 1.0) < 0.02 and np.abs(z).max() < 6.0
+    assert np.array_equal(z, specs.hash_normal("g20.z7", 12288, 0))
+    assert not np.array_equal(z, specs.hash_normal("g20.z8", 12288, 0))
+    u = specs.hash_uniform("g20.z7", 24, 0).reshape(2, 12)
+    acc = u[:, 0].copy()
+    for j in range(1, 12):
+        acc += u[:, j]
+    assert np.array_equal(specs.hash_normal("g20.z7", 2, 0), acc * 0.5)
+
+
+def test_t1000_fixtures_last_step_with_the_oracle(golden):
+    """The three 1000-step captures at N = 2048 (G19 DDIM, G20b DDPM at gain 1.0, G21 reconstruction) store the state the
+    reference handed its denoiser at call 999; one oracle forward from there must land on the reference's returned cloud
+    (x_0 of the last step, diffusion.py:246,283,330): the oracle pinned at the full point count at the far end of the horizon.
+    G21's input is rebuilt here exactly as the GPU test rebuilds it (hashed cloud + hashed noise through `add_noise`)."""
+    sd = point_sd()
+    model = lambda x, t: O.unet_pointnet_large(sd, "model.", x, t)
+    g = golden("point_t1000_ddim.npz")
+    assert np.array_equal(g["ckpt_x"][0], g["xT"]) and int(g["ckpt_calls"][-1]) == 999
+    x = torch.from_numpy(g["ckpt_x"][-1])
+    t = torch.ones(2) - 999 * (1.0 / 1000)
+    n, s = O.offset_cosine_schedule(t)
+    assert rel_l2(O.remove_noise(x, model(x, t), n, s), g["out"]) < 2e-6
+    g = golden("point_t1000_recon.npz")
+    x0 = torch.from_numpy(_t1000_cloud(4, 2048, int(g["seed_cloud"])))
+    eps = torch.from_numpy(specs.hash_normal("g21.eps", 4 * 2048 * 3, 0).astype(np.float32).reshape(4, 2048, 3))
+    noisy, nr, sr = O.add_noise(x0, torch.ones(4) * 0.010, eps)
+    assert np.array_equal(noisy.numpy(), g["noisy"])
+    assert np.array_equal(np.array([nr[0].item(), sr[0].item()], np.float32), g["add_rates"])
+    x = torch.from_numpy(g["ckpt_x"][-1])                       # row 0 only
+    tz = torch.zeros(())
+    n, s = O.offset_cosine_schedule(tz)
+    assert rel_l2(O.remove_noise(x, model(x, tz.expand(1)), n, s), g["out"][:1]) < 2e-6
+    cd = float(O.chamfer_distance(x0[0], torch.from_numpy(g["out"][0]), 1))
+    assert abs(cd - g["cd_s1"][0]) < 1e-6
+
+
+def test_t1000_ddpm_fixtures_last_step_with_the_oracle(golden):
+    from helpers import as_torch
+    for name, gain in (("point_t1000_ddpm_stable.npz", 1.0), ("point_t1000_ddpm.npz", 1.3)):
+        g = golden(name)
+        sd = as_torch(specs.synth_state_dict(specs.unet_pointnet_large_spec(prefix="model."), seed=0, gain=gain))
+        x = torch.from_numpy(g["ckpt_x"][-1])
+        t = torch.zeros(2)                                        # i = 0: t = 0 / T, x_t = x_0 (diffusion.py:241-257)
+        n, s = O.offset_cosine_schedule(t)
+        out = O.remove_noise(x, O.unet_pointnet_large(sd, "model.", x, t), n, s)
+        assert rel_l2(out, g["out"]) < 2e-6, name
+    assert float(np.abs(golden("point_t1000_ddpm.npz")["out"]).max()) > 1e8        # the runaway record (gain 1.3)
+    assert float(np.abs(golden("point_t1000_ddpm_stable.npz")["out"]).max()) < 5e3
