@@ -39,9 +39,10 @@ class UnetDesc(C.Structure):
                 ("e1w_xyz", vp), ("e1w_t", vp), ("e1b", vp),
                 ("lin", LinearDesc * PCD_UNET_NLIN),
                 ("wg", vp), ("wg_k", i32), ("wg_c", i32),
-                ("head_w", vp), ("head_b", vp)]
+                ("head_w", vp), ("head_b", vp), ("hilo_mask", C.c_uint)]
 
 
+PCD_UNET_HILO_ALLOWED = 0x3C00013        # lin 0, 1, 4, 22 .. 25 (include/pcd_hip.h)
 PCD_LATENT_NLIN = 12
 
 
@@ -106,6 +107,7 @@ _SIGS = {
     "pcd_abi_version": (i32, []),
     "pcd_device_check": (i32, []),
     "pcd_gemm_f16": (i32, [C.POINTER(GemmDesc), vp, i64, vp]),
+    "pcd_gemm_f16_hilo": (i32, [C.POINTER(GemmDesc), vp, i64, vp]),
     "pcd_gemm_f16_out32": (i32, [C.POINTER(GemmDesc), vp, i64, vp]),
     "pcd_gemm_f16_splitk": (i32, [C.POINTER(GemmDesc), i32, vp, vp]),
     "pcd_sum_slabs_f32": (i32, [vp, i32, i64, i32, vp, i64, vp]),
@@ -127,6 +129,8 @@ _SIGS = {
     "pcd_randn_step": (i32, [vp, i64, u64, u64, u64, vp, vp]),
     "pcd_head3": (i32, [vp, i64, i32, vp, vp, vp, vp]),
     "pcd_pw_chain_enc1": (i32, [vp, i64, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
+    "pcd_pw_chain_enc1_hilo": (i32, [vp, i64, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
+    "pcd_pw_chain_tail_hilo": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "pcd_pw_chain_128": (i32, [vp, i64, vp, vp, vp, vp, vp, vp]),
     "pcd_pw_chain_tail": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "pcd_unet_config": (i32, [i32]),
@@ -150,6 +154,7 @@ _SIGS = {
     "pcd_unet_f32_workspace_bytes": (sz, [i32, i32]),
     "pcd_unet_f32_forward": (i32, [vp, vp, i32, i32, vp, i32, vp, vp, sz, vp]),
     "pcd_unet_f32_tap": (i32, [vp, C.c_char_p, i32, i32, vp, vp, sz, vp]),
+    "pcd_unet_f32_round_activations": (i32, [vp, C.c_uint]),
     "pcd_groupnorm_relu_f16": (i32, [vp, i32, i32, i32, vp, vp, vp, vp]),
     "pcd_skinny_slabs": (i32, [i32, i32]),
     "pcd_skinny_gemm_f16": (i32, [vp, i32, vp, i32, vp, i64, i32, i32, vp, vp]),

@@ -11,6 +11,13 @@
 // (weights as the A operand): a lane then holds 4 consecutive channels of one point per accumulator group, which is an
 // 8-byte piece of the next layer's [point][channel] LDS image (or of the output row).  Waves never synchronise after the
 // weights are in place.  fp32 accumulation, bias + ReLU + fp16 rounding per layer exactly as the GEMM epilogue does.
+//
+// Round 4: hi / lo weights (E1 and D1).  These 64..128-channel layers are the direct route from the input coordinates to the
+// predicted noise, and the fp16 rounding of THEIR weights is what the 1000-step DDPM trajectory of the fp16 path deviates by
+// (tools/attribute_fp16_layers.py, profiles/r04_f: 1.4e-3 of cloud error from layers 0, 1, 22-25 against 2.6e-5 from the fourteen big
+// layers in between).  With LO the weight image carries, next to the fp16 weights, the fp16 of their rounding residuals
+// (W = hi + lo to ~22 bits), and every layer runs its K loop twice: first against hi, then against lo (the order
+// pcd_gemm_f16_hilo uses, so the per-layer launches stay bit-identical).  < 2 % of the step's FLOPs.
 #include "common.h"
 
 namespace pcd {
@@ -24,7 +31,7 @@ struct PwChainParams {
     const float* xyz; const float* w_xyz; const float* tbias; int tb_stride;      // [m][3], [64][3], [n_t][64], row stride
     // E2 / D1 input
     const half_t* in16;              // [m][128]
-    const half_t* w[PW_MAXL]; const float* b[PW_MAXL];                             // fp16 [C][K], fp32 [C]
+    const half_t* w[PW_MAXL]; const float* b[PW_MAXL];                             // fp16 [C][K] (LO: [C][2 K] = hi | lo), fp32 [C]
     const float* head_w; const float* head_b;                                      // D1: fp32 [3][64], [3]
     half_t* out16; float* out32;
 };
@@ -33,9 +40,10 @@ template <int K> struct PwImg { static constexpr int STR = K + 8; };            
 
 // one layer for this wave's 32 points: act_in [32][K + 8] (LDS) x W image [C][K + 8] (LDS) -> act_out [32][C + 8] (LDS) or
 // global rows [pt0 + point][C]
-template <int K, int C, bool TO_GLOBAL, bool RELU = true>
+template <int K, int C, bool TO_GLOBAL, bool RELU = true, bool LO = false>
 __device__ __forceinline__ void pw_layer(const half_t* act_in, const half_t* wimg, const float* __restrict__ bias,
-                                         half_t* act_out, half_t* __restrict__ gout, int64_t pt0, int64_t m, int lane) {
+                                         half_t* act_out, half_t* __restrict__ gout, int64_t pt0, int64_t m, int lane,
+                                         const half_t* wimg_lo = nullptr) {
     constexpr int NT = C / 32;
     const int pnt = lane & 31, hh = lane >> 5;
     f32x16 acc[NT];
@@ -50,6 +58,17 @@ __device__ __forceinline__ void pw_layer(const half_t* act_in, const half_t* wim
         for (int t = 0; t < NT; ++t) {
             const half8 afrag = *(const half8*)(wimg + (32 * t + pnt) * PwImg<K>::STR + 16 * s + 8 * hh);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag, bfrag, acc[t], 0, 0, 0);
+        }
+    }
+    if constexpr (LO) {           // second pass of the K loop against the residual weights (after ALL the hi products, like pcd_gemm_f16_hilo)
+#pragma unroll 2
+        for (int s = 0; s < K / 16; ++s) {
+            const half8 bfrag = *(const half8*)(act_in + pnt * PwImg<K>::STR + 16 * s + 8 * hh);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const half8 afrag = *(const half8*)(wimg_lo + (32 * t + pnt) * PwImg<K>::STR + 16 * s + 8 * hh);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag, bfrag, acc[t], 0, 0, 0);
+            }
         }
     }
     // accumulator register 4 g + e of tile t: channel 32 t + 8 g + 4 hh + e of point pnt
@@ -95,30 +114,38 @@ __device__ __forceinline__ void pw_load_w(const half_t* __restrict__ w, int64_t 
     }
 }
 
-template <int CHAIN>
-__global__ __launch_bounds__(PW_THREADS) void pw_chain_kernel(PwChainParams p) {
+template <int CHAIN, bool LO = false, int WAVES = PW_WAVES>
+__global__ __launch_bounds__(64 * WAVES) void pw_chain_kernel(PwChainParams p) {
     // layer shapes of the chain
     constexpr int K0 = CHAIN == 0 ? 64 : 128, C0 = CHAIN == 0 ? 64 : 128;
     constexpr int K1 = C0, C1 = CHAIN == 0 ? 128 : (CHAIN == 1 ? 128 : 64);
     constexpr int K2 = 64, C2 = 64;                                              // D1 only: output.0
     constexpr int W0 = C0 * PwImg<K0>::STR, W1 = C1 * PwImg<K1>::STR, W2 = CHAIN == 2 ? C2 * PwImg<K2>::STR : 0;
+    constexpr int WALL = W0 + W1 + W2;
     constexpr int ACT = 32 * PwImg<128>::STR;
-    __shared__ __attribute__((aligned(16))) half_t wimg[W0 + W1 + W2];
-    __shared__ __attribute__((aligned(16))) half_t act[PW_WAVES][ACT];      // one buffer per wave, rewritten in place layer by layer
+    constexpr int NTHR = 64 * WAVES, TILE = 32 * WAVES;
+    __shared__ __attribute__((aligned(16))) half_t wimg[WALL * (LO ? 2 : 1)];   // LO: the residual images behind the weight images
+    __shared__ __attribute__((aligned(16))) half_t act[WAVES][ACT];         // one buffer per wave, rewritten in place layer by layer
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pnt = lane & 31, hh = lane >> 5;
-    pw_load_w<K0, C0>(p.w[0], K0, wimg);
-    pw_load_w<K1, C1>(p.w[1], K1, wimg + W0);
-    if (CHAIN == 2) pw_load_w<K2, C2>(p.w[2], K2, wimg + W0 + W1);
+    constexpr int LDM = LO ? 2 : 1;                                          // global rows are [hi K | lo K] when LO
+    pw_load_w<K0, C0, NTHR>(p.w[0], LDM * K0, wimg);
+    pw_load_w<K1, C1, NTHR>(p.w[1], LDM * K1, wimg + W0);
+    if (CHAIN == 2) pw_load_w<K2, C2, NTHR>(p.w[2], LDM * K2, wimg + W0 + W1);
+    if constexpr (LO) {
+        pw_load_w<K0, C0, NTHR>(p.w[0] + K0, 2 * K0, wimg + WALL);
+        pw_load_w<K1, C1, NTHR>(p.w[1] + K1, 2 * K1, wimg + WALL + W0);
+        if (CHAIN == 2) pw_load_w<K2, C2, NTHR>(p.w[2] + K2, 2 * K2, wimg + WALL + W0 + W1);
+    }
     __syncthreads();
     half_t* buf = act[wave];
-    const int64_t ntiles = (p.m + PW_TILE - 1) / PW_TILE;
+    const int64_t ntiles = (p.m + TILE - 1) / TILE;
     // E2 / D1: the next tile's [32 points][128] fp16 rows travel in registers while this tile computes (one wave per
     // SIMD: nothing else hides the load latency).  16 chunks of 16 B per point, 8 per lane.
     half8 pre[8];
     auto fetch = [&](int64_t tile) __attribute__((always_inline)) {
-        const int64_t pt0 = tile * PW_TILE + wave * 32;
+        const int64_t pt0 = tile * TILE + wave * 32;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int c = i * 64 + lane;
@@ -129,7 +156,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_chain_kernel(PwChainParams p) {
     };
     if (CHAIN != 0 && (int64_t)blockIdx.x < ntiles) fetch(blockIdx.x);
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t pt0 = tile * PW_TILE + wave * 32;
+        const int64_t pt0 = tile * TILE + wave * 32;
         // ---- input -> buf
         if (CHAIN == 0) {
             // enc1.conv1: K = 3 half + per-shape time bias + ReLU (the arithmetic of enc1_xyz_kernel); lane = (point, 32 channels)
@@ -161,12 +188,13 @@ __global__ __launch_bounds__(PW_THREADS) void pw_chain_kernel(PwChainParams p) {
             if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
         }
         // ---- layers
-        pw_layer<K0, C0, false>(buf, wimg, p.b[0], buf, nullptr, pt0, p.m, lane);
+        const half_t* wlo = wimg + WALL;
+        pw_layer<K0, C0, false, true, LO>(buf, wimg, p.b[0], buf, nullptr, pt0, p.m, lane, wlo);
         if (CHAIN != 2) {
-            pw_layer<K1, C1, true>(buf, wimg + W0, p.b[1], buf, p.out16, pt0, p.m, lane);
+            pw_layer<K1, C1, true, true, LO>(buf, wimg + W0, p.b[1], buf, p.out16, pt0, p.m, lane, wlo + W0);
         } else {
-            pw_layer<K1, C1, false>(buf, wimg + W0, p.b[1], buf, nullptr, pt0, p.m, lane);
-            pw_layer<K2, C2, false>(buf, wimg + W0 + W1, p.b[2], buf, nullptr, pt0, p.m, lane);
+            pw_layer<K1, C1, false, true, LO>(buf, wimg + W0, p.b[1], buf, nullptr, pt0, p.m, lane, wlo + W0);
+            pw_layer<K2, C2, false, true, LO>(buf, wimg + W0 + W1, p.b[2], buf, nullptr, pt0, p.m, lane, wlo + W0 + W1);
             // output.3: 64 -> 3, fp32 (the arithmetic of head3_kernel): lanes 0..31, one point each
             if (hh == 0 && pt0 + pnt < p.m) {
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f;
@@ -256,6 +284,20 @@ extern "C" int pcd_pw_chain_enc1(const float* x, int64_t m, int rows_per_shape, 
     return PCD_OK;
 }
 
+extern "C" int pcd_pw_chain_enc1_hilo(const float* x, int64_t m, int rows_per_shape, const float* w_xyz, const float* tbias,
+                                      int tbias_shape_stride, const void* w_conv2, const float* b_conv2, const void* w_conv3,
+                                      const float* b_conv3, void* x1, void* stream) {
+    PCD_CHECK_ARG(x && w_xyz && tbias && w_conv2 && b_conv2 && w_conv3 && b_conv3 && x1);
+    PCD_CHECK_ARG(m > 0 && rows_per_shape > 0 && tbias_shape_stride >= 0);
+    PwChainParams p{};
+    p.m = m; p.rows_per_shape = rows_per_shape; p.xyz = x; p.w_xyz = w_xyz; p.tbias = tbias; p.tb_stride = tbias_shape_stride;
+    p.w[0] = (const half_t*)w_conv2; p.b[0] = b_conv2; p.w[1] = (const half_t*)w_conv3; p.b[1] = b_conv3;
+    p.out16 = (half_t*)x1;
+    hipLaunchKernelGGL((pw_chain_kernel<0, true, PW_WAVES>), dim3(pw_grid(m)), dim3(PW_THREADS), 0, (hipStream_t)stream, p);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
 extern "C" int pcd_pw_chain_128(const void* in, int64_t m, const void* w_a, const float* b_a, const void* w_b,
                                 const float* b_b, void* out, void* stream) {
     PCD_CHECK_ARG(in && w_a && b_a && w_b && b_b && out && m > 0);
@@ -277,6 +319,22 @@ extern "C" int pcd_pw_chain_tail(const void* in, int64_t m, const void* w_a, con
     p.w[0] = (const half_t*)w_a; p.b[0] = b_a; p.w[1] = (const half_t*)w_b; p.b[1] = b_b; p.w[2] = (const half_t*)w_c; p.b[2] = b_c;
     p.head_w = head_w; p.head_b = head_b; p.out32 = eps;
     hipLaunchKernelGGL((pw_chain_kernel<2>), dim3(pw_grid(m)), dim3(PW_THREADS), 0, (hipStream_t)stream, p);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+// D1 with hi / lo weights: two weight images (2 x 61 KB) leave room for four waves' activation buffers, not eight
+extern "C" int pcd_pw_chain_tail_hilo(const void* in, int64_t m, const void* w_a, const float* b_a, const void* w_b,
+                                      const float* b_b, const void* w_c, const float* b_c, const float* head_w,
+                                      const float* head_b, float* eps, void* stream) {
+    PCD_CHECK_ARG(in && w_a && b_a && w_b && b_b && w_c && b_c && head_w && head_b && eps && m > 0);
+    PwChainParams p{};
+    p.m = m; p.rows_per_shape = 1; p.in16 = (const half_t*)in;
+    p.w[0] = (const half_t*)w_a; p.b[0] = b_a; p.w[1] = (const half_t*)w_b; p.b[1] = b_b; p.w[2] = (const half_t*)w_c; p.b[2] = b_c;
+    p.head_w = head_w; p.head_b = head_b; p.out32 = eps;
+    constexpr int WV = 4;
+    const int64_t tiles = (m + 32 * WV - 1) / (32 * WV);
+    hipLaunchKernelGGL((pw_chain_kernel<2, true, WV>), dim3((unsigned)(tiles < 256 ? tiles : 256)), dim3(64 * WV), 0, (hipStream_t)stream, p);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

@@ -33,6 +33,8 @@ struct GemmParams {
     // slice s reads A and W at column offset s*k1 and writes the fp32 slab out32 + s*split_out
     int splits; int64_t split_out;
     int xp_depth;             // gemm_xp_kernel: K tiles of the next tile requested before the epilogue's stores (1 or 2)
+    int krep;                 // 2 = hi / lo weights (pcd_gemm_f16_hilo): the sources are walked TWICE, first against columns [0, K) of W (the fp16
+                              // weights), then against [K, 2K) (fp16 of the rounding residuals): ~22-bit weights on the fp16 matrix cores; 0 / 1 = once
 };
 
 constexpr int BK = 64;          // K granularity required by the API (k1, k2 multiples of 64)
@@ -111,15 +113,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f16_kernel(GemmParams p) 
     // of the current one, so its load latency and the store tail overlap.
     const int tiles_mn = p.tiles_m * p.tiles_n;
     const int ntiles = tiles_mn * p.splits;
-    const int nk1 = p.k1 / BKT, nk = (p.k1 + p.k2) / BKT;
+    const int nk1 = p.k1 / BKT, nks = (p.k1 + p.k2) / BKT, nk = p.krep == 2 ? 2 * nks : nks;
 
     f32x4 acc[MI][NI];
 
     auto stage = [&](int m0, int n0, int kt, int buf, int split = 0) {
         char* base = smem + buf * STAGE_BYTES;
         const int64_t koff = (int64_t)split * p.k1;          // split-K: slice `split` of the reduction (k2 == 0 then)
-        if (kt < nk1) stage_rows<BM, NT, BKT>(p.a1 + koff, p.lda1, m0, p.m, kt * BKT, base, wave, lane);
-        else          stage_rows<BM, NT, BKT>(p.a2, p.lda2, m0, p.m, (kt - nk1) * BKT, base, wave, lane);
+        const int ka = kt >= nks ? kt - nks : kt;            // hi / lo weights: the second pass re-reads the sources against W's lo columns
+        if (ka < nk1) stage_rows<BM, NT, BKT>(p.a1 + koff, p.lda1, m0, p.m, ka * BKT, base, wave, lane);
+        else          stage_rows<BM, NT, BKT>(p.a2, p.lda2, m0, p.m, (ka - nk1) * BKT, base, wave, lane);
         stage_rows<BN, NT, BKT>(p.w + koff, p.ldw, n0, p.c, kt * BKT, base + BM * ROWB, wave, lane);
     };
 
@@ -639,7 +642,7 @@ static int launch(const GemmParams& p0, hipStream_t s, int blocks_per_cu) {
     if constexpr (BM == 256 && BN == 256 && (EPI == EPI_F16 || EPI == EPI_COLMAX || EPI == EPI_RESID) && STAGES == 2 && BKT == 64) {
         // whole tiles, one A layout, per-shape bias only if a tile lies in one shape: the variant that refills both LDS stages for
         // the next tile before the epilogue's stores (gemm_xp_kernel)
-        const bool ok = g_xp && p.m % 256 == 0 && p.c % 256 == 0 && p.splits == 1 && (p.k1 + p.k2) >= 128 &&
+        const bool ok = g_xp && p.krep != 2 && p.m % 256 == 0 && p.c % 256 == 0 && p.splits == 1 && (p.k1 + p.k2) >= 128 &&
                         (p.k2 == 0 || p.lda2 == p.lda1) && (p.shape_bias == nullptr || p.rows_per_shape % 256 == 0) &&
                         (EPI != EPI_COLMAX || p.cm_rps % 128 == 0) &&
                         (int64_t)255 * p.lda1 * 2 + 128 < 0x7fffffffLL && (int64_t)255 * p.ldw * 2 + 128 < 0x7fffffffLL;
@@ -741,6 +744,16 @@ extern "C" int pcd_gemm_f16(const pcd_gemm_desc_t* d, void* out, int64_t ldo, vo
     if (rc) return rc;
     PCD_CHECK_ARG(out != nullptr && ldo >= d->c && ldo % 8 == 0 && d->c % 8 == 0);
     p.out16 = (half_t*)out; p.ldo = ldo;
+    return dispatch<EPI_F16>(p, (hipStream_t)stream);
+}
+
+extern "C" int pcd_gemm_f16_hilo(const pcd_gemm_desc_t* d, void* out, int64_t ldo, void* stream) {
+    GemmParams p;
+    int rc = fill(d, p);
+    if (rc) return rc;
+    PCD_CHECK_ARG(out != nullptr && ldo >= d->c && ldo % 8 == 0 && d->c % 8 == 0);
+    PCD_CHECK_ARG(d->ldw >= 2 * (int64_t)(d->k1 + d->k2));
+    p.out16 = (half_t*)out; p.ldo = ldo; p.krep = 2;
     return dispatch<EPI_F16>(p, (hipStream_t)stream);
 }
 

@@ -89,6 +89,10 @@ extern "C" int pcd_unet_create(const pcd_unet_desc_t* desc, pcd_unet_t** out) {
     PCD_CHECK_ARG(desc->freqs && desc->tw0 && desc->tb0 && desc->tw2 && desc->tb2);
     PCD_CHECK_ARG(desc->e1w_xyz && desc->e1w_t && desc->e1b && desc->wg && desc->head_w && desc->head_b);
     PCD_CHECK_ARG(desc->wg_k == 4096 && desc->wg_c == 1024);
+    if (desc->hilo_mask & ~PCD_UNET_HILO_ALLOWED) {
+        set_error("pcd_unet_create: hilo_mask 0x%x names layers outside 0x%x", desc->hilo_mask, PCD_UNET_HILO_ALLOWED);
+        return PCD_ERR_ARG;
+    }
     for (int i = 0; i < PCD_UNET_NLIN; ++i) {
         if (desc->lin[i].w == nullptr || desc->lin[i].b == nullptr || desc->lin[i].k != kLinK[i] ||
             desc->lin[i].c != kLinC[i]) {
@@ -164,11 +168,12 @@ static int run_lin(const pcd_unet_desc_t& d, int idx, int64_t m, const void* a1,
     const pcd_linear_desc_t& L = d.lin[idx];
     g.a1 = a1; g.k1 = L.k - k2; g.lda1 = g.k1;
     g.a2 = a2; g.k2 = k2; g.lda2 = k2;
-    g.w = L.w; g.ldw = L.k;
+    const bool hilo = (d.hilo_mask >> idx) & 1u;          // [c][2 k]: the fp16 weights | the fp16 of their rounding residuals
+    g.w = L.w; g.ldw = hilo ? 2 * L.k : L.k;
     g.bias = shape_bias ? nullptr : L.b;
     g.shape_bias = shape_bias; g.rows_per_shape = rps;
     g.relu = 1; g.m = (int)m; g.c = L.c;
-    return pcd_gemm_f16(&g, out, L.c, s);
+    return hilo ? pcd_gemm_f16_hilo(&g, out, L.c, s) : pcd_gemm_f16(&g, out, L.c, s);
 }
 
 extern "C" int pcd_unet_forward(pcd_unet_t* h, const float* x, int batch, int n_points, const float* tbias,
@@ -196,8 +201,18 @@ extern "C" int pcd_unet_forward(pcd_unet_t* h, const float* x, int batch, int n_
     const bool wide = (g_unet_chains & 2) != 0 && m % 256 == 0;     // enc3 / dec2 as register-resident chains (whole 256-point tiles only)
     if (chains) {
         // enc1 (xyz -> 64 -> 64 -> 128) and enc2.conv1-2 (128 -> 128 -> 128): one launch each, intermediates in LDS
-        RUN(pcd_pw_chain_enc1(x, m, n_points, d.e1w_xyz, tbias, tbias_shape_stride, d.lin[0].w, d.lin[0].b, d.lin[1].w,
-                              d.lin[1].b, x1, s));
+        const unsigned e1 = d.hilo_mask & 3u;              // lin 0, 1 travel together (one launch)
+        if (e1 == 3u)
+            RUN(pcd_pw_chain_enc1_hilo(x, m, n_points, d.e1w_xyz, tbias, tbias_shape_stride, d.lin[0].w, d.lin[0].b, d.lin[1].w,
+                                       d.lin[1].b, x1, s));
+        else if (e1 == 0u)
+            RUN(pcd_pw_chain_enc1(x, m, n_points, d.e1w_xyz, tbias, tbias_shape_stride, d.lin[0].w, d.lin[0].b, d.lin[1].w,
+                                  d.lin[1].b, x1, s));
+        else {
+            RUN(pcd_enc1_xyz(x, m, n_points, d.e1w_xyz, 64, tbias, tbias_shape_stride, s0, s));
+            RUN(run_lin(d, 0, m, s0, nullptr, 0, nullptr, 0, s1, s));
+            RUN(run_lin(d, 1, m, s1, nullptr, 0, nullptr, 0, x1, s));
+        }
         RUN(pcd_pw_chain_128(x1, m, d.lin[2].w, d.lin[2].b, d.lin[3].w, d.lin[3].b, s1, s));
     } else {
         RUN(pcd_enc1_xyz(x, m, n_points, d.e1w_xyz, 64, tbias, tbias_shape_stride, s0, s));
@@ -268,10 +283,15 @@ extern "C" int pcd_unet_forward(pcd_unet_t* h, const float* x, int batch, int n_
     }
     TAP(2, s1, 128);
     RUN(run_lin(d, 22, m, s1, x1, 128, nullptr, 0, s0, s));
-    if (chains && h->dec_tap[3] == nullptr) {
+    const unsigned tl = (d.hilo_mask >> 23) & 7u;         // lin 23, 24, 25 travel together (one launch)
+    if (chains && h->dec_tap[3] == nullptr && (tl == 0u || tl == 7u)) {
         // dec1.conv2 -> conv3 -> output.0 -> output.3 (128 -> 128 -> 64 -> 64 -> 3): one launch
-        RUN(pcd_pw_chain_tail(s0, m, d.lin[23].w, d.lin[23].b, d.lin[24].w, d.lin[24].b, d.lin[25].w, d.lin[25].b, d.head_w,
-                              d.head_b, eps, s));
+        if (tl == 7u)
+            RUN(pcd_pw_chain_tail_hilo(s0, m, d.lin[23].w, d.lin[23].b, d.lin[24].w, d.lin[24].b, d.lin[25].w, d.lin[25].b, d.head_w,
+                                       d.head_b, eps, s));
+        else
+            RUN(pcd_pw_chain_tail(s0, m, d.lin[23].w, d.lin[23].b, d.lin[24].w, d.lin[24].b, d.lin[25].w, d.lin[25].b, d.head_w,
+                                  d.head_b, eps, s));
     } else {
         RUN(run_lin(d, 23, m, s0, nullptr, 0, nullptr, 0, s1, s));
         RUN(run_lin(d, 24, m, s1, nullptr, 0, nullptr, 0, s0, s));

@@ -28,6 +28,7 @@ struct GemmF32 {
     int relu; int m; int c;
     float* out; int64_t ldo;          // store epilogue
     float* pooled;                    // column-max epilogue: [shape][c], zero-initialised (values are post-ReLU, >= 0)
+    int round16;                      // diagnostic: round the stored activation to fp16 and back (where does ACTIVATION rounding matter?)
 };
 
 // out[m][c] = act([A1 | A2][m][k] . W[c][k]^T + bias[c] (or shape_bias[row / rows_per_shape][c]))
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32 p) {
                         float v = acc[i][j][e];
                         v += p.shape_bias ? p.shape_bias[(r / p.rows_per_shape) * p.c + col] : bcol;
                         if (p.relu) v = fmaxf(v, 0.f);
+                        if (p.round16) v = (float)to_half_sat(v);
                         p.out[r * p.ldo + col] = v;
                     }
                 }
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32 p) {
 __global__ __launch_bounds__(256) void enc1_xyz_f32_kernel(const float* __restrict__ x, int64_t m, int rows_per_shape,
                                                             const float* __restrict__ w, int c1,
                                                             const float* __restrict__ tbias, int tb_stride,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, int round16) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= m * c1) return;
     const int64_t pt = idx / c1;
@@ -150,7 +152,8 @@ __global__ __launch_bounds__(256) void enc1_xyz_f32_kernel(const float* __restri
     v = fmaf(w[ch * 3 + 0], x[pt * 3 + 0], v);
     v = fmaf(w[ch * 3 + 1], x[pt * 3 + 1], v);
     v = fmaf(w[ch * 3 + 2], x[pt * 3 + 2], v);
-    out[idx] = fmaxf(v, 0.f);
+    v = fmaxf(v, 0.f);
+    out[idx] = round16 ? (float)to_half_sat(v) : v;
 }
 
 // output.3: eps[m][0..2] = W3 . h[m] + b3, one thread per point
@@ -226,6 +229,7 @@ Ws32 carve32(int64_t batch, int64_t n) {
 
 struct pcd_unet_f32 {
     pcd_unet_desc_t d;
+    unsigned round_mask = 0;          // pcd_unet_f32_round_activations: bit i = round lin[i]'s output to fp16 (bit 26: enc1.conv1's)
 };
 
 extern "C" int pcd_gemm_f32(const float* a1, int64_t lda1, int k1, const float* a2, int64_t lda2, int k2, const float* w,
@@ -255,6 +259,12 @@ extern "C" int pcd_unet_f32_create(const pcd_unet_desc_t* desc, pcd_unet_f32_t**
 
 extern "C" void pcd_unet_f32_destroy(pcd_unet_f32_t* h) { delete h; }
 
+extern "C" int pcd_unet_f32_round_activations(pcd_unet_f32_t* h, unsigned mask) {
+    PCD_CHECK_ARG(h != nullptr);
+    h->round_mask = mask;
+    return PCD_OK;
+}
+
 extern "C" size_t pcd_unet_f32_workspace_bytes(int batch, int n_points) {
     if (batch <= 0 || n_points <= 0) return 0;
     return carve32(batch, n_points).total;
@@ -283,11 +293,11 @@ extern "C" int pcd_unet_f32_forward(pcd_unet_f32_t* h, const float* x, int batch
     auto lin = [&](int idx, const float* a1, const float* a2, int k2, const float* shape_bias, float* out) {
         const pcd_linear_desc_t& L = d.lin[idx];
         GemmF32 g{a1, L.k - k2, L.k - k2, a2, k2, k2, (const float*)L.w, L.k, shape_bias ? nullptr : L.b, shape_bias,
-                  n_points, 1, (int)m, L.c, out, L.c, nullptr};
+                  n_points, 1, (int)m, L.c, out, L.c, nullptr, (int)((h->round_mask >> idx) & 1u)};
         return launch_gemm(g, false, s);
     };
     hipLaunchKernelGGL(enc1_xyz_f32_kernel, dim3((unsigned)ceil_div(m * 64, 256)), dim3(256), 0, s, x, m, n_points,
-                       d.e1w_xyz, 64, tbias, tbias_shape_stride, s0);
+                       d.e1w_xyz, 64, tbias, tbias_shape_stride, s0, (int)((h->round_mask >> 26) & 1u));
     PCD_CHECK_LAUNCH();
     RUN(lin(0, s0, nullptr, 0, nullptr, s1));
     RUN(lin(1, s1, nullptr, 0, nullptr, x1));

@@ -136,6 +136,19 @@ class UNetPointNetLarge(_HipModule):
         self.precision = os.environ.get("PCD_PARITY", "fp16")
         if self.precision not in self.PRECISIONS:
             raise ValueError(f"PCD_PARITY must be one of {self.PRECISIONS}, got {self.precision!r}")
+        # fp16 mode: the narrow layers at the two ends of the U-net (enc1.conv2/3, enc2.conv3, dec1.*, output.0: the direct route from
+        # the coordinates to the predicted noise) carry hi / lo weights -- the fp16 weights and the fp16 of their rounding residuals,
+        # two MFMA passes, < 2 % of the FLOPs -- because the fp16 rounding of THESE weights is what the 1000-step DDPM trajectory
+        # deviated by.  PCD_NARROW_HILO=0 / set_hilo_mask(0): plain fp16 weights everywhere.
+        self.hilo_mask = _lib.PCD_UNET_HILO_ALLOWED if os.environ.get("PCD_NARROW_HILO", "1") != "0" else 0
+
+    def set_hilo_mask(self, mask: int) -> "UNetPointNetLarge":
+        if mask & ~_lib.PCD_UNET_HILO_ALLOWED:
+            raise ValueError(f"hi / lo weights are available for layers {_lib.PCD_UNET_HILO_ALLOWED:#x} only, got {mask:#x}")
+        if mask != self.hilo_mask:
+            self.invalidate()
+            self.hilo_mask = mask
+        return self
 
     def set_precision(self, precision: str) -> "UNetPointNetLarge":
         if precision not in self.PRECISIONS:
@@ -177,8 +190,15 @@ class UNetPointNetLarge(_HipModule):
         for k in ("freqs", "tw0", "tb0", "tw2", "tb2", "e1w_xyz", "e1w_t", "e1b", "head_w", "head_b", "wg"):
             setattr(desc, k, keep[k].data_ptr())
         desc.wg_k, desc.wg_c = 4096, 1024
+        desc.hilo_mask = 0 if f32 else self.hilo_mask
         for i, (w, b) in enumerate(lin):
-            keep[f"w{i}"], keep[f"b{i}"] = devw(w, dev), _dev32(b, dev)
+            if (desc.hilo_mask >> i) & 1:
+                hi = w.astype(np.float16)
+                lo = (w - hi.astype(np.float64)).astype(np.float16)
+                keep[f"w{i}"] = _dev16(np.concatenate([hi, lo], axis=1), dev)        # [C][2 K] = hi | lo
+            else:
+                keep[f"w{i}"] = devw(w, dev)
+            keep[f"b{i}"] = _dev32(b, dev)
             desc.lin[i].w, desc.lin[i].b = keep[f"w{i}"].data_ptr(), keep[f"b{i}"].data_ptr()
             desc.lin[i].c, desc.lin[i].k = w.shape
         handle = C.c_void_p()

@@ -34,6 +34,15 @@ def gemm_f16(a1, w, bias=None, a2=None, shape_bias=None, rows_per_shape=0, relu=
     return out
 
 
+def gemm_f16_hilo(a1, w_hilo, bias=None, a2=None, relu=False) -> torch.Tensor:
+    """out = act([a1 | a2] . (hi + lo)^T + bias): `w_hilo` is [C][2 K] = the fp16 weights | the fp16 of their rounding residuals."""
+    d = _desc(a1, w_hilo, bias, a2, relu=relu)
+    assert w_hilo.shape[1] == 2 * (d.k1 + d.k2)
+    out = torch.empty(d.m, d.c, dtype=torch.float16, device=a1.device)
+    _lib.check(_lib.load().pcd_gemm_f16_hilo(d, out.data_ptr(), d.c, _lib.stream_ptr()), "gemm_f16_hilo")
+    return out
+
+
 def gemm_f16_out32(a1, w, bias=None, a2=None, shape_bias=None, rows_per_shape=0, relu=False) -> torch.Tensor:
     d = _desc(a1, w, bias, a2, shape_bias, rows_per_shape, relu)
     out = torch.empty(d.m, d.c, dtype=torch.float32, device=a1.device)

@@ -59,6 +59,9 @@ typedef struct {
 
 /* epilogue: store fp16 out[m][ldo] */
 int pcd_gemm_f16(const pcd_gemm_desc_t* d, void* out, int64_t ldo, void* stream);
+/* the same with hi / lo weights: w is [c][2 (k1 + k2)] (ldw >= that): columns [0, K) the fp16 weights, [K, 2K) the fp16 of their
+ * rounding residuals; the sources are walked twice (all hi products, then all lo products, fp32 accumulation): ~22-bit weights */
+int pcd_gemm_f16_hilo(const pcd_gemm_desc_t* d, void* out, int64_t ldo, void* stream);
 /* epilogue: store fp32 out[m][ldo] */
 int pcd_gemm_f16_out32(const pcd_gemm_desc_t* d, float* out, int64_t ldo, void* stream);
 /* split-K form for short-and-wide products with a long reduction (the backward-weight products dW = dz^T a of the
@@ -165,7 +168,11 @@ typedef struct {
     pcd_linear_desc_t lin[PCD_UNET_NLIN];     /* execution order, see csrc/unet.hip */
     const void* wg; int wg_k, wg_c;           /* dec4.conv1 global-feature half fp16 [1024][4096] */
     const float* head_w; const float* head_b; /* output.3 fp32 [3][64], [3] */
+    unsigned hilo_mask;                       /* bit i: lin[i].w is [c][2 k] = the fp16 weights | the fp16 of their rounding residuals
+                                                 (hi / lo weights, ~22 bits): allowed for the narrow layers PCD_UNET_HILO_ALLOWED */
 } pcd_unet_desc_t;
+/* layers that may carry hi / lo weights: enc1.conv2, enc1.conv3 (0, 1), enc2.conv3 (4), dec1.conv1 .. output.0 (22 .. 25) */
+#define PCD_UNET_HILO_ALLOWED 0x3C00013u
 
 /* Chains of the narrow pointwise layers of UNetPointNetLarge in one launch each (csrc/chain.hip): a wave carries 32
  * points through the chain with the intermediates in LDS, the chain's weights (fp16 [C][K], BatchNorm folded) resident
@@ -180,6 +187,14 @@ int pcd_pw_chain_128(const void* in, int64_t m, const void* w_a, const float* b_
                      void* out, void* stream);
 int pcd_pw_chain_tail(const void* in, int64_t m, const void* w_a, const float* b_a, const void* w_b, const float* b_b,
                       const void* w_c, const float* b_c, const float* head_w, const float* head_b, float* eps, void* stream);
+/* enc1 and tail chains with hi / lo weights (every w_* is [C][2 K] = hi | lo; see pcd_gemm_f16_hilo): the same arithmetic with the K
+ * loop run against hi, then against lo.  These narrow layers are the direct route from the coordinates to the predicted noise; the
+ * fp16 rounding of their weights is what the fp16 path's 1000-step DDPM trajectory deviates by. */
+int pcd_pw_chain_enc1_hilo(const float* x, int64_t m, int rows_per_shape, const float* w_xyz, const float* tbias,
+                           int tbias_shape_stride, const void* w_conv2, const float* b_conv2, const void* w_conv3,
+                           const float* b_conv3, void* x1, void* stream);
+int pcd_pw_chain_tail_hilo(const void* in, int64_t m, const void* w_a, const float* b_a, const void* w_b, const float* b_b,
+                           const void* w_c, const float* b_c, const float* head_w, const float* head_b, float* eps, void* stream);
 /* One pointwise layer out[m][c] = act(in[m][k] . W^T + bias) with the weights resident in LDS: the 1x1x1 shortcut
  * convolutions of ResidualBlock3D (reference networks.py:485-490) on NDHWC rows.  in fp16 [m][k]; w fp16 [c][ldw] (k used);
  * bias fp32 [c]; relu 0/1; out fp16 [m][c].  Shapes: (k, c) = (32, 64), (64, 128), (128, 256) -- pcd_conv1x1_supported(). */
@@ -238,6 +253,9 @@ void pcd_unet_f32_destroy(pcd_unet_f32_t* h);
 size_t pcd_unet_f32_workspace_bytes(int batch, int n_points);
 int pcd_unet_f32_forward(pcd_unet_f32_t* h, const float* x, int batch, int n_points, const float* tbias,
                          int tbias_shape_stride, float* eps, void* workspace, size_t workspace_bytes, void* stream);
+/* diagnostic: bit i of `mask` makes lin[i]'s output (bit 26: enc1.conv1's) round to fp16 and back before it is stored, everything else
+ * staying fp32 -- locates where ACTIVATION rounding of the fp16 product path matters (tools/attribute_fp16_layers.py); 0 = off */
+int pcd_unet_f32_round_activations(pcd_unet_f32_t* h, unsigned mask);
 int pcd_unet_f32_tap(pcd_unet_f32_t* h, const char* name, int batch, int n_points, const void* workspace, void* dst,
                      size_t dst_bytes, void* stream);
 

@@ -123,6 +123,41 @@ def test_gemm_dual_source_shape_bias_residual(ops):
     assert torch.equal(got, want.half().double())
 
 
+@pytest.mark.parametrize("m,k1,k2,c", [(512, 64, 0, 64), (300, 64, 0, 128), (1000, 128, 128, 128), (256, 128, 0, 256)])
+def test_gemm_hilo_weights(ops, m, k1, k2, c):
+    """pcd_gemm_f16_hilo: W = hi + lo as two fp16 halves ([C][2 K]), the sources walked twice.  (1) Exact on integers with weights that
+    NEED the second half (2049 = 2048 + 1 is not an fp16 number).  (2) On random fp32 weights the result follows the float64 product
+    with the UNROUNDED weights ~500 times closer than the plain fp16-weight GEMM does."""
+    g = torch.Generator().manual_seed(m + c)
+    k = k1 + k2
+    a = torch.randint(0, 3, (m, k), generator=g).float()
+    w = torch.randint(-1, 2, (c, k), generator=g).float() * 2049.0
+    hi = w.half()
+    lo = (w.double() - hi.double()).half()
+    assert not torch.equal(hi.double(), w.double()) and torch.equal(hi.double() + lo.double(), w.double())
+    wh = torch.cat([hi, lo], 1).cuda().contiguous()
+    a1, a2 = a[:, :k1].half().cuda().contiguous(), (a[:, k1:].half().cuda().contiguous() if k2 else None)
+    scale = 1.0 / 64                                              # keep |out| inside fp16: fold a power of two into the inputs
+    got = ops.gemm_f16_hilo((a1 * scale).half(), wh, None, a2=None if a2 is None else (a2 * scale).half(), relu=True).cpu().double()
+    want = (a.double() * scale @ w.double().t()).clamp_min(0)
+    assert float(want.max()) < 65504 and torch.equal(got, want.half().double())
+    # random weights: error against the unrounded product
+    a = torch.randn(m, k, generator=g).half()
+    w = torch.randn(c, k, generator=g).double() / k ** 0.5
+    hi = w.half()
+    lo = (w - hi.double()).half()
+    wh = torch.cat([hi, lo], 1).cuda().contiguous()
+    a1, a2 = a[:, :k1].cuda().contiguous(), (a[:, k1:].cuda().contiguous() if k2 else None)
+    exact = a.double() @ w.t()
+    plain = ops.gemm_f16_out32(a1, hi.cuda().contiguous(), None, a2=a2).cpu().double()
+    hilo32 = a.double() @ (hi.double() + lo.double()).t()
+    got = ops.gemm_f16_hilo(a1, wh, None, a2=a2).cpu().double()
+    e_plain = float((plain - exact).norm() / exact.norm())
+    e_split = float((hilo32 - exact).norm() / exact.norm())
+    assert e_plain > 1e-4 and e_split < 1e-6                      # what the second half buys, before the fp16 store
+    assert float((got - hilo32.half().double()).abs().max()) <= 2 * float(torch.finfo(torch.float16).eps) * float(exact.abs().max())
+
+
 @pytest.mark.parametrize("m,rps", [(512, 128), (512, 64), (480, 96), (300, 100)])
 def test_gemm_colmax(ops, m, rps):
     k, c = 128, 200 if m == 300 else 256

@@ -153,14 +153,10 @@ def test_ddpm_1000_steps_at_2048_points(golden, prec):
     out, rec, calls, xT = _run_ddpm(m, g)
     want = torch.from_numpy(g["out"])
     check_cloud(prec, out.cpu(), want, "DDPM T=1000 final x")
-    # The Chamfer gate on THIS trajectory: the untrained denoiser does not cancel the re-injected noise, the state is a noise
-    # accumulation of rms ~ 310 whose fp16-operand error grows linearly with the steps (2e-4 at call 100, 1.45e-3 at 1000:
-    # profiles/r04_b_t1000_divergence.txt), and `normalize_to_cube` divides the cloud by its single largest coordinate, so a
-    # cloud-wide relative error e moves CD by ~ e * CD.  fp32 mode: north_star's 1e-4.  fp16 path: MEASURED 2.5e-4 -- above 1e-4 --
-    # and held to the cloud tolerance's equivalent, 5e-3 * CD_ref (= 1.8e-3); DESIGN.md section 8 states this deviation.  The
-    # DDIM sampler and the reconstruction flow meet 1e-4 over the same horizon.
-    cd_ref = 0.3514
-    chamfer_gate(out, want.cuda(), xT, bound=1e-4 if prec == "fp32" else 5e-3 * cd_ref)
+    # north_star's Chamfer gate on this trajectory too.  With plain fp16 weights everywhere the fp16 path measured |dCD| = 2.5e-4 here
+    # (cloud rel-L2 1.45e-3): `tools/attribute_fp16_layers.py` traced 1.4e-3 of it to the fp16 rounding of the WEIGHTS of six narrow
+    # layers (enc1.conv2/3, dec1.*, output.0), which now carry hi / lo weights (`UNetPointNetLarge.hilo_mask`).
+    chamfer_gate(out, want.cuda(), xT)
     for i, c in enumerate(calls):
         check_cloud(prec, rec[c], torch.from_numpy(g["ckpt_x"][i]), f"   state before call {c}")
 
