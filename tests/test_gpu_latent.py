@@ -318,8 +318,10 @@ def test_cfg4_launch_shapes_vs_reference(ldm, golden):
         finally:
             ldm.use_persistent = type(ldm).use_persistent
         err = rel_l2(z0.cpu(), g["z0"])
+        worst = max(rel_l2(z0[i].cpu(), g["z0"][i]) for i in range(32))
+        print(f"latent DDIM T=1000 at B=32 vs reference ({'persistent launch' if persistent else 'per-layer launches'}): rel-L2 {err:.3e}, worst row {worst:.3e}")
         assert err < 5e-3, (persistent, err)
-        assert max(rel_l2(z0[i].cpu(), g["z0"][i]) for i in range(32)) < 1e-2
+        assert worst < 1e-2
     counts = np.array([len(p) for p in pcs])
     assert np.all(np.abs(counts - g["counts"]) <= 0.02 * g["counts"] + 8)
     # decode at B = 32 of the REFERENCE's latents (so the comparison is of the decoder alone), four rows kept in the fixture.  With
