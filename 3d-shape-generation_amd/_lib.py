@@ -124,6 +124,7 @@ _SIGS = {
     "pcd_remove_noise": (i32, [vp, vp, vp, vp, i32, i64, i64, vp, vp]),
     "pcd_ddim_update": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i64, vp, vp, vp]),
     "pcd_ddpm_update": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i64, i64, vp, vp, vp]),
+    "pcd_ddpm_update_philox": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i64, vp, vp, u64, u64, u64, vp, vp]),
     "pcd_randn": (i32, [vp, i64, u64, u64, vp]),
     "pcd_step_select": (i32, [vp, i32, vp, i32, vp, vp, i32, vp, vp]),
     "pcd_randn_step": (i32, [vp, i64, u64, u64, u64, vp, vp]),

@@ -34,6 +34,8 @@ struct PwChainParams {
     const half_t* w[PW_MAXL]; const float* b[PW_MAXL];                             // fp16 [C][K] (LO: [C][2 K] = hi | lo), fp32 [C]
     const float* head_w; const float* head_b;                                      // D1: fp32 [3][64], [3]
     half_t* out16; float* out32;
+    float* zero; int64_t zero_n;     // E1 only (internal): floats to clear while the chain runs -- the pooled-maximum buffer the column-max GEMM later
+                                     // in the same forward accumulates into (one launch less per step; multiple of 4, 16-byte aligned)
 };
 
 template <int K> struct PwImg { static constexpr int STR = K + 8; };              // halfs per LDS row (16-byte pad)
@@ -139,6 +141,10 @@ __global__ __launch_bounds__(64 * WAVES) void pw_chain_kernel(PwChainParams p) {
         if (CHAIN == 2) pw_load_w<K2, C2, NTHR>(p.w[2] + K2, 2 * K2, wimg + WALL + W0 + W1);
     }
     __syncthreads();
+    if (CHAIN == 0 && p.zero != nullptr) {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        for (int64_t i = (int64_t)blockIdx.x * NTHR + threadIdx.x; i < p.zero_n / 4; i += (int64_t)gridDim.x * NTHR) ((f32x4*)p.zero)[i] = z4;
+    }
     half_t* buf = act[wave];
     const int64_t ntiles = (p.m + TILE - 1) / TILE;
     // E2 / D1: the next tile's [32 points][128] fp16 rows travel in registers while this tile computes (one wave per
@@ -270,32 +276,37 @@ static inline unsigned pw_grid(int64_t m) {
     return (unsigned)(tiles < 256 ? tiles : 256);        // persistent: the weight image is loaded once per workgroup
 }
 
-extern "C" int pcd_pw_chain_enc1(const float* x, int64_t m, int rows_per_shape, const float* w_xyz, const float* tbias,
-                                 int tbias_shape_stride, const void* w_conv2, const float* b_conv2, const void* w_conv3,
-                                 const float* b_conv3, void* x1, void* stream) {
+namespace pcd {
+// pcd_pw_chain_enc1[_hilo] + an optional buffer to clear in the same launch (csrc/unet.hip: the pooled maxima)
+int pw_chain_enc1_impl(const float* x, int64_t m, int rows_per_shape, const float* w_xyz, const float* tbias, int tbias_shape_stride,
+                       const void* w_conv2, const float* b_conv2, const void* w_conv3, const float* b_conv3, void* x1, bool hilo,
+                       float* zero, int64_t zero_n, void* stream) {
     PCD_CHECK_ARG(x && w_xyz && tbias && w_conv2 && b_conv2 && w_conv3 && b_conv3 && x1);
     PCD_CHECK_ARG(m > 0 && rows_per_shape > 0 && tbias_shape_stride >= 0);
+    PCD_CHECK_ARG(zero == nullptr || (zero_n % 4 == 0 && ((uintptr_t)zero & 15) == 0));
     PwChainParams p{};
     p.m = m; p.rows_per_shape = rows_per_shape; p.xyz = x; p.w_xyz = w_xyz; p.tbias = tbias; p.tb_stride = tbias_shape_stride;
     p.w[0] = (const half_t*)w_conv2; p.b[0] = b_conv2; p.w[1] = (const half_t*)w_conv3; p.b[1] = b_conv3;
-    p.out16 = (half_t*)x1;
-    hipLaunchKernelGGL((pw_chain_kernel<0>), dim3(pw_grid(m)), dim3(PW_THREADS), 0, (hipStream_t)stream, p);
+    p.out16 = (half_t*)x1; p.zero = zero; p.zero_n = zero_n;
+    if (hilo) hipLaunchKernelGGL((pw_chain_kernel<0, true, PW_WAVES>), dim3(pw_grid(m)), dim3(PW_THREADS), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((pw_chain_kernel<0>), dim3(pw_grid(m)), dim3(PW_THREADS), 0, (hipStream_t)stream, p);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
+}
+}  // namespace pcd
+
+extern "C" int pcd_pw_chain_enc1(const float* x, int64_t m, int rows_per_shape, const float* w_xyz, const float* tbias,
+                                 int tbias_shape_stride, const void* w_conv2, const float* b_conv2, const void* w_conv3,
+                                 const float* b_conv3, void* x1, void* stream) {
+    return pcd::pw_chain_enc1_impl(x, m, rows_per_shape, w_xyz, tbias, tbias_shape_stride, w_conv2, b_conv2, w_conv3, b_conv3, x1, false,
+                                   nullptr, 0, stream);
 }
 
 extern "C" int pcd_pw_chain_enc1_hilo(const float* x, int64_t m, int rows_per_shape, const float* w_xyz, const float* tbias,
                                       int tbias_shape_stride, const void* w_conv2, const float* b_conv2, const void* w_conv3,
                                       const float* b_conv3, void* x1, void* stream) {
-    PCD_CHECK_ARG(x && w_xyz && tbias && w_conv2 && b_conv2 && w_conv3 && b_conv3 && x1);
-    PCD_CHECK_ARG(m > 0 && rows_per_shape > 0 && tbias_shape_stride >= 0);
-    PwChainParams p{};
-    p.m = m; p.rows_per_shape = rows_per_shape; p.xyz = x; p.w_xyz = w_xyz; p.tbias = tbias; p.tb_stride = tbias_shape_stride;
-    p.w[0] = (const half_t*)w_conv2; p.b[0] = b_conv2; p.w[1] = (const half_t*)w_conv3; p.b[1] = b_conv3;
-    p.out16 = (half_t*)x1;
-    hipLaunchKernelGGL((pw_chain_kernel<0, true, PW_WAVES>), dim3(pw_grid(m)), dim3(PW_THREADS), 0, (hipStream_t)stream, p);
-    PCD_CHECK_LAUNCH();
-    return PCD_OK;
+    return pcd::pw_chain_enc1_impl(x, m, rows_per_shape, w_xyz, tbias, tbias_shape_stride, w_conv2, b_conv2, w_conv3, b_conv3, x1, true,
+                                   nullptr, 0, stream);
 }
 
 extern "C" int pcd_pw_chain_128(const void* in, int64_t m, const void* w_a, const float* b_a, const void* w_b,

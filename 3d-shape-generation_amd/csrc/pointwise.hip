@@ -167,6 +167,19 @@ __global__ __launch_bounds__(256) void ddim_update_kernel(const float* __restric
     }
 }
 
+// one element of the DDPM update (diffusion.py:246-255), shared by ddpm_update_kernel and the Philox-fused form below
+__device__ __forceinline__ void ddpm_elem(float xv, float ev, float zv, float nb, float sb, float cb, float s2b, bool next, float& x0, float& xn) {
+    const float ne = nb * ev;
+    x0 = (xv - ne) / sb;
+    xn = 0.f;
+    if (next) {
+        const float a = s2b * x0;
+        const float cn = cb * nb;          // (coefficient * noise_rates) * noise, diffusion.py:255
+        const float c = cn * zv;
+        xn = a + c;
+    }
+}
+
 __global__ __launch_bounds__(256) void ddpm_update_kernel(const float* __restrict__ x, const float* __restrict__ eps,
                                                            const float* __restrict__ z, const float* __restrict__ n,
                                                            const float* __restrict__ s, const float* __restrict__ coef,
@@ -513,11 +526,63 @@ extern "C" int pcd_reparameterize(const float* mu, const float* logvar, const fl
     return PCD_OK;
 }
 
+// DDPM update with its normal draw generated in place: thread = 4 consecutive elements = one Philox counter, the counter layout and
+// the Box-Muller arithmetic of randn_step_kernel, the update arithmetic of ddpm_update_kernel (ddpm_elem): bitwise the two launches
+__global__ __launch_bounds__(256) void ddpm_update_philox_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                                                  const float* __restrict__ n, const float* __restrict__ s,
+                                                                  const float* __restrict__ coef, const float* __restrict__ s2,
+                                                                  int stride, int64_t total, int64_t per_shape,
+                                                                  float* __restrict__ x0o, float* __restrict__ xn, uint64_t seed,
+                                                                  uint64_t base, uint64_t pstride, const int* __restrict__ counter) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q * 4 >= total) return;
+    const uint64_t ctr = (uint64_t)q + base + pstride * (uint64_t)counter[1];
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    float v[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float u2 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float r = sqrtf(-2.0f * logf(u1));
+        float sn, cs;
+        sincosf(6.28318530717958647692f * u2, &sn, &cs);
+        v[2 * h] = r * cs;
+        v[2 * h + 1] = r * sn;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int64_t i = q * 4 + e;
+        if (i >= total) break;
+        const int64_t b = (i / per_shape) * stride;
+        float x0, xv;
+        ddpm_elem(x[i], eps[i], v[e], n[b], s[b], coef[b], s2[b], xn != nullptr, x0, xv);
+        if (x0o != nullptr) x0o[i] = x0;
+        if (xn != nullptr) xn[i] = xv;
+    }
+}
+
 extern "C" int pcd_step_select(int* counter, int n_steps, const float* tb_table, int tb_elems, float* tb_cur,
                                const float* rate_tables, int width, float* rates_cur, void* stream) {
     PCD_CHECK_ARG(counter && tb_table && tb_cur && rate_tables && rates_cur && n_steps > 0 && tb_elems > 0 && width > 0);
     hipLaunchKernelGGL(step_select_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, counter, n_steps, tb_table,
                        tb_elems, tb_cur, rate_tables, width, rates_cur);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_ddpm_update_philox(const float* x, const float* eps, const float* n, const float* s, const float* coef,
+                                      const float* s2, int stride, int64_t total, int64_t per_shape, float* x0, float* x_next,
+                                      uint64_t seed, uint64_t base_offset, uint64_t per_step_stride, const int* counter, void* stream) {
+    PCD_CHECK_ARG(x && eps && n && s && coef && s2 && counter && total > 0 && per_shape > 0 && (stride == 0 || stride == 1));
+    PCD_CHECK_ARG(x0 != nullptr || x_next != nullptr);
+    hipLaunchKernelGGL(ddpm_update_philox_kernel, dim3(nblk(ceil_div(total, 4))), dim3(256), 0, (hipStream_t)stream, x, eps, n, s, coef, s2,
+                       stride, total, per_shape, x0, x_next, seed, base_offset, per_step_stride, counter);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

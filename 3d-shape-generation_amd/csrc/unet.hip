@@ -44,6 +44,11 @@ struct pcd_unet {
 
 namespace pcd {
 
+// csrc/chain.hip: the enc1 chain with an optional buffer cleared in the same launch
+int pw_chain_enc1_impl(const float* x, int64_t m, int rows_per_shape, const float* w_xyz, const float* tbias, int tbias_shape_stride,
+                       const void* w_conv2, const float* b_conv2, const void* w_conv3, const float* b_conv3, void* x1, bool hilo,
+                       float* zero, int64_t zero_n, void* stream);
+
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 struct UnetWs {
@@ -198,17 +203,17 @@ extern "C" int pcd_unet_forward(pcd_unet_t* h, const float* x, int batch, int n_
     int rc;
 #define RUN(expr) do { rc = (expr); if (rc) return rc; } while (0)
     const bool chains = (g_unet_chains & 1) != 0;
+    bool pooled_cleared = false;
     const bool wide = (g_unet_chains & 2) != 0 && m % 256 == 0;     // enc3 / dec2 as register-resident chains (whole 256-point tiles only)
     if (chains) {
         // enc1 (xyz -> 64 -> 64 -> 128) and enc2.conv1-2 (128 -> 128 -> 128): one launch each, intermediates in LDS
         const unsigned e1 = d.hilo_mask & 3u;              // lin 0, 1 travel together (one launch)
-        if (e1 == 3u)
-            RUN(pcd_pw_chain_enc1_hilo(x, m, n_points, d.e1w_xyz, tbias, tbias_shape_stride, d.lin[0].w, d.lin[0].b, d.lin[1].w,
-                                       d.lin[1].b, x1, s));
-        else if (e1 == 0u)
-            RUN(pcd_pw_chain_enc1(x, m, n_points, d.e1w_xyz, tbias, tbias_shape_stride, d.lin[0].w, d.lin[0].b, d.lin[1].w,
-                                  d.lin[1].b, x1, s));
-        else {
+        if (e1 == 3u || e1 == 0u) {
+            // the same launch clears the pooled maxima that global_feat.3's column-max epilogue accumulates into further down
+            RUN(pw_chain_enc1_impl(x, m, n_points, d.e1w_xyz, tbias, tbias_shape_stride, d.lin[0].w, d.lin[0].b, d.lin[1].w, d.lin[1].b, x1,
+                                   e1 == 3u, pooled, (int64_t)batch * 4096, s));
+            pooled_cleared = true;
+        } else {
             RUN(pcd_enc1_xyz(x, m, n_points, d.e1w_xyz, 64, tbias, tbias_shape_stride, s0, s));
             RUN(run_lin(d, 0, m, s0, nullptr, 0, nullptr, 0, s1, s));
             RUN(run_lin(d, 1, m, s1, nullptr, 0, nullptr, 0, x1, s));
@@ -234,7 +239,7 @@ extern "C" int pcd_unet_forward(pcd_unet_t* h, const float* x, int batch, int n_
     RUN(run_lin(d, 10, m, s1, nullptr, 0, nullptr, 0, x4, s));
     RUN(run_lin(d, 11, m, x4, nullptr, 0, nullptr, 0, s0, s));
     {   // global_feat.3 + max over the N points of each shape
-        RUN(pcd_fill_zero(pooled, (size_t)batch * 4096 * sizeof(float), s));
+        if (!pooled_cleared) RUN(pcd_fill_zero(pooled, (size_t)batch * 4096 * sizeof(float), s));
         pcd_gemm_desc_t g{};
         g.a1 = s0; g.k1 = 2048; g.lda1 = 2048; g.w = d.lin[12].w; g.ldw = 2048; g.bias = d.lin[12].b;
         g.relu = 1; g.m = (int)m; g.c = 4096;

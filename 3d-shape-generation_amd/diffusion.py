@@ -315,8 +315,12 @@ class Stepper:
             if self.noises is not None:
                 self.z.copy_(self.noises[k].to(x.device, torch.float32).reshape(self.z.shape))
             else:
-                _lib.check(lib.pcd_randn_step(self.z.data_ptr(), self.z.numel(), self.seed, self.philox_base,
-                                              self.philox_stride, self.counter.data_ptr(), st), "randn_step")
+                # on-device noise: the draw and the update are one launch (z is never stored; bitwise pcd_randn_step + pcd_ddpm_update)
+                _lib.check(lib.pcd_ddpm_update_philox(x.data_ptr(), self.eps.data_ptr(), rp, rp + 4 * R, rp + 8 * R, rp + 12 * R,
+                                                      self.tab.stride, x.numel(), self.per_shape, self.x0.data_ptr(), nxt, self.seed,
+                                                      self.philox_base, self.philox_stride, self.counter.data_ptr(), st),
+                           "ddpm_update_philox")
+                return
             zp = self.z.data_ptr()
         _lib.check(lib.pcd_ddpm_update(x.data_ptr(), self.eps.data_ptr(), zp, rp, rp + 4 * R, rp + 8 * R, rp + 12 * R,
                                        self.tab.stride, x.numel(), self.per_shape, self.x0.data_ptr(), nxt, st),

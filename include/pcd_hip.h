@@ -131,6 +131,11 @@ int pcd_ddim_update(const float* x, const float* eps, const float* n, const floa
 int pcd_ddpm_update(const float* x, const float* eps, const float* z, const float* n, const float* s,
                     const float* coef, const float* s2, int stride,
                     int64_t total, int64_t per_shape, float* x0, float* x_next, void* stream);
+/* pcd_randn_step + pcd_ddpm_update in ONE launch: the step's normal draw z is generated in place (same Philox counters:
+ * base_offset + per_step_stride * counter[1] + element / 4, same Box-Muller arithmetic) and never stored; bitwise the two launches. */
+int pcd_ddpm_update_philox(const float* x, const float* eps, const float* n, const float* s, const float* coef, const float* s2,
+                           int stride, int64_t total, int64_t per_shape, float* x0, float* x_next, uint64_t seed,
+                           uint64_t base_offset, uint64_t per_step_stride, const int* counter, void* stream);
 /* standard normal fill (Philox4x32-10 + Box-Muller), for perf runs (diffusion.py:239,254,275) */
 int pcd_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
 

@@ -178,6 +178,36 @@ def test_gemm_random_fp16_accuracy(ops):
     assert rel_l2(got, want) < 2e-6   # fp32 accumulation of exact fp16 products
 
 
+@pytest.mark.parametrize("shape,stride", [((3, 100, 3), 0), ((2, 64, 3), 1), ((5, 256), 1), ((1, 7, 3), 0)])
+def test_ddpm_update_with_in_place_philox_draw(shape, stride):
+    """pcd_ddpm_update_philox = pcd_randn_step + pcd_ddpm_update in one launch (the draw is never stored): bitwise the two launches, for
+    shared and per-shape rates, sizes that are not multiples of 4, with and without the next state, in place."""
+    from shapegen_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g).cuda()
+    eps = torch.randn(*shape, generator=g).cuda()
+    B = shape[0]
+    R = B if stride else 1
+    rates = (torch.rand(4, R, generator=g) * 0.8 + 0.1).cuda()
+    n, s_, co, s2 = (rates[i].contiguous() for i in range(4))
+    counter = torch.tensor([6, 5], dtype=torch.int32, device="cuda")           # counter[1] = the step whose block is drawn
+    seed, base, pstride = 0x1234567890ABCDEF, 1000, (x.numel() + 3) // 4
+    per_shape = x.numel() // B
+    z = torch.empty_like(x)
+    _lib.check(lib.pcd_randn_step(z.data_ptr(), z.numel(), seed, base, pstride, counter.data_ptr(), _lib.stream_ptr()))
+    for with_next in (True, False):
+        x0a, xna = torch.empty_like(x), torch.empty_like(x)
+        _lib.check(lib.pcd_ddpm_update(x.data_ptr(), eps.data_ptr(), z.data_ptr(), n.data_ptr(), s_.data_ptr(), co.data_ptr(), s2.data_ptr(),
+                                       stride, x.numel(), per_shape, x0a.data_ptr(), xna.data_ptr() if with_next else 0, _lib.stream_ptr()))
+        x0b, xin = torch.empty_like(x), x.clone()
+        _lib.check(lib.pcd_ddpm_update_philox(xin.data_ptr(), eps.data_ptr(), n.data_ptr(), s_.data_ptr(), co.data_ptr(), s2.data_ptr(),
+                                              stride, x.numel(), per_shape, x0b.data_ptr(), xin.data_ptr() if with_next else 0, seed, base,
+                                              pstride, counter.data_ptr(), _lib.stream_ptr()))
+        assert torch.equal(x0a, x0b)
+        assert torch.equal(xin, xna if with_next else x)                       # in place when asked, untouched otherwise
+
+
 def test_elementwise_updates_bit_exact(golden):
     """K4 kernels vs the reference's torch expressions: bit exact (fp contraction off)."""
     from shapegen_amd import _lib
