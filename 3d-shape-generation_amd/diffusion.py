@@ -519,11 +519,17 @@ class LatentDiffusion(_DiffusionBase):
     def _persistent_allowed(self, x) -> bool:
         if not self.use_persistent or x.dim() != 2:
             return False
+        # ranks of one job sharing a device (a one-GPU rehearsal of the multi-rank path): two persistent grids cannot be resident together.
+        # Said explicitly (PCD_SHARED_GPU=1, or bench.py's PCD_BENCH_SHARE_GPU=1), or inferred when more local ranks exist than devices
+        # are visible and no per-rank visibility mask is in play (with a mask every rank sees "one device" that is its own).  Whatever
+        # this misses is caught by the fail-soft path below at the price of one abandoned launch (0.2 s) and a warning.
+        if os.environ.get("PCD_SHARED_GPU") == "1" or os.environ.get("PCD_BENCH_SHARE_GPU") == "1":
+            return False
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
-            # ranks of one job sharing a device (a one-GPU rehearsal of the multi-rank path): two persistent grids cannot be resident together
+            masked = any(os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"))
             local_world = int(os.environ.get("LOCAL_WORLD_SIZE", dist.get_world_size()))
-            if local_world > max(torch.cuda.device_count(), 1):
+            if not masked and local_world > max(torch.cuda.device_count(), 1):
                 return False
         return self.model.persist_supported(x.shape[0])
 

@@ -389,8 +389,12 @@ def latent_legs(m, device, B=32, T=SCHEDULE_STEPS):
     g = torch.Generator().manual_seed(24)
     vox = (torch.rand(B, 1, 32, 32, 32, generator=g) > 0.9).float().to(device)
 
-    def timed(fn, reps):
-        fn()
+    def timed(fn, reps, ramp=1):
+        # `ramp` untimed calls first: from idle the chip needs tens of milliseconds of load to reach its running clocks (the same ramp the
+        # attention legs take: the first chunk of a train of launches measures ~10 % slow); the VAE legs are ~1-ms calls timed in a
+        # train of 10, so they get 30 calls (~40 ms) of ramp -- with one warm-up call they were being timed ON the ramp
+        for _ in range(ramp):
+            fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -401,7 +405,7 @@ def latent_legs(m, device, B=32, T=SCHEDULE_STEPS):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps, (time.perf_counter() - t0) / reps * 1e3, out
 
-    enc_ms, _, (mu, logvar) = timed(lambda: m.vae.encode(vox), 10)
+    enc_ms, _, (mu, logvar) = timed(lambda: m.vae.encode(vox), 10, ramp=30)
     zT = m.vae.reparameterize(mu, logvar)
 
     def loop():
@@ -410,7 +414,7 @@ def latent_legs(m, device, B=32, T=SCHEDULE_STEPS):
         return m._run(z, tab, m.model.time_bias(tab.t), m._forward_fn(), "ddim")
 
     _, loop_wall_ms, z0 = timed(loop, 2)
-    dec_ms, _, dec = timed(lambda: m.vae.decode(z0), 10)
+    dec_ms, _, dec = timed(lambda: m.vae.decode(z0), 10, ramp=30)
     _, fin_wall_ms, clouds = timed(lambda: m._finish(z0, 0.4), 3)
 
     def whole():
@@ -643,7 +647,7 @@ def other_configs(model, device):
             "vae_decode_ms": legs["decode_ms"], "vae_decode_frac_of_mfma_peak": dec["frac"],
             "vae_encode_ms": legs["encode_ms"], "vae_encode_frac_of_mfma_peak": enc["frac"],
             "note": "cfg3: two whole DDIM-50 sampler calls at B=64, N=2048 (tables, graph capture included); cfg4: encode 32 grids + "
-                    "1000 latent DDIM steps + decode + voxel->points, wall clock; VAE legs by HIP events over 10 calls"}
+                    "1000 latent DDIM steps + decode + voxel->points, wall clock; VAE legs by HIP events over 10 calls after a 30-call clock ramp"}
 
 
 # ------------------------------------------------------------------------------------------ cfg3
