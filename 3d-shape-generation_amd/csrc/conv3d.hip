@@ -839,6 +839,60 @@ __global__ __launch_bounds__(256) void conv3d_last_halo_kernel(const half_t* __r
     }
 }
 
+// The same layer with an 8 x 8 x 8 output block per workgroup (512 threads = 512 voxels, all 27 taps per thread).  The 4 x 4 x 8 form above
+// fetches every input voxel 2.8 times (6 x 6 x 10 halo per 128 outputs: 188 MB of L2 -> LDS traffic at B = 32) and that, not its arithmetic,
+// is what bounds it (a packed-fp16 dot-product form ran in the same 61 us: profiles/r04_j); here the halo is 10 x 10 x 10 per 512 outputs = 1.95 x.
+template <int TZ>
+__global__ __launch_bounds__(64 * TZ) void conv3d_last_halo8_kernel(const half_t* __restrict__ in, int B, int D, int H, int W,
+                                                                    const float* __restrict__ w, float bias,
+                                                                    float* __restrict__ out, int ntz, int nty, int ntx) {
+    // rows padded to 80 bytes (conflict-free 16-byte reads of x-adjacent voxels).  Unpadded 64-byte rows with an XOR swizzle (64 KB per workgroup: two
+    // per CU) measured the same (52.9 v. 51.8 us): the layer is VALU-bound now (864 v_fma_mix_f32 per voxel = ~48 us at B = 32), profiles/r04_j
+    constexpr int CIN = 32, RB = CIN * 2, P = RB + 16, CPR = RB / 16, T = 8, HH = T + 2, ROWS = (TZ + 2) * HH * HH, NTH = 64 * TZ;
+    constexpr int HIT = (ROWS * CPR + NTH - 1) / NTH;
+    __shared__ __attribute__((aligned(16))) char smem[ROWS * P];
+    const int tid = threadIdx.x;
+    int t = blockIdx.x;
+    const int tx = t % ntx; t /= ntx;
+    const int ty = t % nty; t /= nty;
+    const int tz = t % ntz; const int b = t / ntz;
+    const int z0 = tz * TZ, y0 = ty * T, x0 = tx * T;
+    half8 hv[HIT];
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {                           // every load of the halo in flight before the first LDS store
+        const int c = it * NTH + tid;
+        const int row = c / CPR, ch = c - row * CPR;
+        const int hx = row % HH; const int r2 = row / HH;
+        const int hy = r2 % HH, hz = r2 / HH;
+        const int iz = z0 - 1 + hz, iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const bool ok = row < ROWS && (unsigned)iz < (unsigned)D && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        hv[it] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (ok) hv[it] = *(const half8*)(in + ((((int64_t)b * D + iz) * H + iy) * W + ix) * CIN + ch * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+        const int c = it * NTH + tid;
+        const int row = c / CPR, ch = c - row * CPR;
+        if (row < ROWS) *(half8*)(smem + row * P + ch * 16) = hv[it];
+    }
+    __syncthreads();
+    const int x = tid & 7, y = (tid >> 3) & 7, z = tid >> 6;
+    const int r0 = (z * HH + y) * HH + x;
+    float a = bias;
+#pragma unroll 3
+    for (int tap = 0; tap < 27; ++tap) {
+        const int row = r0 + ((tap / 9) * HH + (tap / 3) % 3) * HH + tap % 3;
+        const float* wk = w + tap * CIN;                          // uniform address: s_load
+#pragma unroll
+        for (int c8 = 0; c8 < CIN / 8; ++c8) {
+            const half8 v = *(const half8*)(smem + row * P + c8 * 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a = fmaf(wk[c8 * 8 + e], (float)v[e], a);
+        }
+    }
+    out[(((int64_t)b * D + z0 + z) * H + y0 + y) * W + x0 + x] = 1.f / (1.f + expf(-a));
+}
+
 // VAE3D's last layer (networks.py:2018-2019): ConvTranspose3d(CIN, 1, k3, s2, p1, output_padding 1) + Sigmoid.
 // o = 2 i - 1 + k per dimension: even o takes (k=1, i=o/2); odd o takes (k=0, i=(o+1)/2) and (k=2, i=(o-1)/2).
 // in fp16 NDHWC [B][D][H][W][CIN]; w fp32 [27][CIN] (tap-major); out fp32 [B][2D][2H][2W].
@@ -986,9 +1040,12 @@ extern "C" int pcd_conv3d_f16(const pcd_conv3d_desc_t* d, void* stream) {
 }
 
 static int g_halo_tall = 1;          // tuning / testing hook (pcd_conv3d_config)
+static int g_last8 = 1;       // pcd_conv3d_config + 8: the 4 x 4 x 8 block form of the last layer instead of the 8 x 8 x 8 one
+
 extern "C" int pcd_conv3d_config(int tall_halo_tiles) {
-    PCD_CHECK_ARG(tall_halo_tiles >= 0 && tall_halo_tiles <= 2);
-    g_halo_tall = tall_halo_tiles;
+    PCD_CHECK_ARG(tall_halo_tiles >= 0 && (tall_halo_tiles & 7) <= 2 && tall_halo_tiles < 16);
+    g_halo_tall = tall_halo_tiles & 7;
+    g_last8 = (tall_halo_tiles & 8) ? 0 : 1;
     return PCD_OK;
 }
 
@@ -1069,7 +1126,10 @@ extern "C" int pcd_conv3d_last_sigmoid(const void* in, int batch, int d, int h, 
     PCD_CHECK_ARG(in && wgt && out && batch > 0 && d > 0 && h > 0 && w > 0);
     PCD_CHECK_ARG(cin == 32);
     const int64_t total = (int64_t)batch * d * h * w;
-    if (d % HTZ == 0 && h % HTY == 0 && w % HTX == 0 && total / 128 <= 0x7fffffff) {
+    if (g_last8 != 0 && d % 8 == 0 && h % 8 == 0 && w % 8 == 0 && total / 512 <= 0x7fffffff) {
+        hipLaunchKernelGGL(conv3d_last_halo8_kernel<8>, dim3((unsigned)(total / 512)), dim3(512), 0, (hipStream_t)stream,
+                           (const half_t*)in, batch, d, h, w, wgt, bias, out, d / 8, h / 8, w / 8);
+    } else if (d % HTZ == 0 && h % HTY == 0 && w % HTX == 0 && total / 128 <= 0x7fffffff) {
         hipLaunchKernelGGL(conv3d_last_halo_kernel, dim3((unsigned)(total / 128)), dim3(256), 0, (hipStream_t)stream,
                            (const half_t*)in, batch, d, h, w, wgt, bias, out, d / HTZ, h / HTY, w / HTX);
     } else {

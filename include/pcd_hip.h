@@ -397,7 +397,9 @@ size_t pcd_conv3d_workspace_bytes(const pcd_conv3d_desc_t* descs, int n);
 int pcd_conv3d_f16_multi(const pcd_conv3d_desc_t* descs, int n, void* workspace, size_t workspace_bytes,
                          void* stream);
 /* testing / tuning hook for pcd_conv3d_k3s1_f16 at C_in = 32, C_out <= 32: 0 = 128-row workgroups, 1 (default) = 256-row workgroups
- * (4 x 8 x 8 voxels, eight waves) where the grid has at least 512 of them, 2 = wherever H % 8 == 0 (tests).  Same bits. */
+ * (4 x 8 x 8 voxels, eight waves) where the grid has at least 512 of them, 2 = wherever H % 8 == 0 (tests).  Same bits.
+ * + 8: pcd_conv3d_last_sigmoid on 4 x 4 x 8 output blocks instead of 8 x 8 x 8 (the same sums in the same order per voxel up to the split of
+ * the taps over two threads: results agree to 1e-6). */
 int pcd_conv3d_config(int tall_halo_tiles);
 /* Conv3d(k3, stride 1, pad 1) (+ folded BN, residual, ReLU) with the input halo of a 4x4x8 output block held in
  * LDS and reused by all 27 taps -- the 32^3 layers of VAE3DLarge (encoder.2, decoder.8-11; networks.py:2227,

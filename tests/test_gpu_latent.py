@@ -184,6 +184,14 @@ def test_conv3d_first_and_last_layers(dims, stride):
         _lib.check(lib.pcd_conv3d_last_sigmoid(h.data_ptr(), b, dims[0], dims[1], dims[2], 32, dwl.data_ptr(), bl,
                                                o2.data_ptr(), _lib.stream_ptr()))
         assert (o2.cpu().double() - want2).abs().max() <= 2e-6
+        _lib.check(lib.pcd_conv3d_config(8 + 1))           # the 4 x 4 x 8 block form of the last layer (8 x 8 x 8 is the default where it divides)
+        try:
+            o3 = torch.empty_like(o2)
+            _lib.check(lib.pcd_conv3d_last_sigmoid(h.data_ptr(), b, dims[0], dims[1], dims[2], 32, dwl.data_ptr(), bl,
+                                                   o3.data_ptr(), _lib.stream_ptr()))
+        finally:
+            _lib.check(lib.pcd_conv3d_config(1))           # the library's default
+        assert (o3.cpu().double() - want2).abs().max() <= 2e-6
 
 
 def test_conv_transpose3d_classes_exact():
