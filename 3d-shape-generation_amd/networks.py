@@ -193,9 +193,7 @@ class UNetPointNetLarge(_HipModule):
         desc.hilo_mask = 0 if f32 else self.hilo_mask
         for i, (w, b) in enumerate(lin):
             if (desc.hilo_mask >> i) & 1:
-                hi = w.astype(np.float16)
-                lo = (w - hi.astype(np.float64)).astype(np.float16)
-                keep[f"w{i}"] = _dev16(np.concatenate([hi, lo], axis=1), dev)        # [C][2 K] = hi | lo
+                keep[f"w{i}"] = _dev16(packing.split_hilo(w), dev)                   # [C][2 K] = hi | lo
             else:
                 keep[f"w{i}"] = devw(w, dev)
             keep[f"b{i}"] = _dev32(b, dev)

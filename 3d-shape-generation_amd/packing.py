@@ -78,6 +78,15 @@ def pack_point_unet(sd: Dict[str, torch.Tensor], prefix: str, time_dim: int, dim
     return lin, ex
 
 
+def split_hilo(w: np.ndarray) -> np.ndarray:
+    """[C][K] float64 weights -> fp16 [C][2 K] = the fp16 weights | the fp16 of their rounding residuals (hi / lo weights: the narrow layers
+    of the point denoiser, `csrc/chain.hip`, `pcd_gemm_f16_hilo`).  hi + lo reproduces w to ~2^-22 relative: the kernels run their K loop twice."""
+    w = np.asarray(w, np.float64)
+    hi = w.astype(np.float16)
+    lo = (w - hi.astype(np.float64)).astype(np.float16)
+    return np.concatenate([hi, lo], axis=1)
+
+
 def timestep_freqs(time_dim: int) -> torch.Tensor:
     """f_j of the sinusoidal embedding, computed with the reference's exact torch ops
     (networks.py:831-833) so the fp32 table is bit-identical."""

@@ -91,6 +91,57 @@ def test_packing_is_exact_algebra():
         packing.pack_point_unet(sd, "", 256, 512)
 
 
+def test_hi_lo_weight_split_and_the_forward_it_implies():
+    """`packing.split_hilo`: [C][2 K] fp16 = hi | lo with hi + lo = w to ~2^-22; and a float64 emulation of the product path's WEIGHT
+    precision on (2, 32): folded weights rounded to fp16 everywhere, against the same with the narrow layers (the library's
+    PCD_UNET_HILO_ALLOWED mask) carried as hi + lo -- the second is closer to the oracle on eps (activations stay float64 here, so
+    this isolates what the hi / lo weights change; the measured 1000-step effect is in profiles/r04_f)."""
+    from shapegen_amd import _lib, packing
+    from oracle import torch_oracle as O
+    from helpers import point_sd, rel_l2
+    g = np.random.default_rng(0)
+    w = g.standard_normal((64, 128)) / 11.3
+    hl = packing.split_hilo(w)
+    assert hl.dtype == np.float16 and hl.shape == (64, 256)
+    back = hl[:, :128].astype(np.float64) + hl[:, 128:].astype(np.float64)
+    assert np.abs(back - w).max() <= 2.0 ** -21 * np.abs(w).max()
+    assert np.abs(hl[:, :128].astype(np.float64) - w).max() > 2.0 ** -14 * np.abs(w).max()      # what plain fp16 rounding loses
+    assert _lib.PCD_UNET_HILO_ALLOWED == sum(1 << i for i in (0, 1, 4, 22, 23, 24, 25))
+    sd = point_sd("")
+    lin, ex = packing.pack_point_unet(sd, "", 256, 256)
+    gen = torch.Generator().manual_seed(1)
+    x, t = torch.randn(2, 32, 3, generator=gen), torch.tensor([0.4, 0.7])
+    want = O.unet_pointnet_large(sd, "", x, t)
+    temb = O.time_mlp(sd, "", O.timestep_embedding(t, 256)).double().numpy()
+    relu = lambda v: np.maximum(v, 0)
+    r16 = lambda a: a.astype(np.float16).astype(np.float64)
+
+    def forward(mask):
+        def wq(i):
+            if (mask >> i) & 1:
+                h = packing.split_hilo(lin[i][0]).astype(np.float64)
+                return h[:, :lin[i][0].shape[1]] + h[:, lin[i][0].shape[1]:]
+            return r16(lin[i][0])
+        f = lambda i, v: relu(v @ wq(i).T + lin[i][1])
+        tb = temb @ ex["e1w_t"].T + ex["e1b"]
+        h = relu(x.double().numpy() @ ex["e1w_xyz"].T + tb[:, None, :])
+        h = f(1, f(0, h)); x1 = h
+        h = f(4, f(3, f(2, h))); x2 = h
+        h = f(7, f(6, f(5, h))); x3 = h
+        h = f(10, f(9, f(8, h))); x4 = h
+        pooled = f(12, f(11, h)).max(axis=1)
+        gb = pooled @ r16(ex["wg"]).T + lin[13][1]
+        h = relu(x4 @ wq(13).T + gb[:, None, :])
+        h = f(15, f(14, h))
+        h = f(18, f(17, f(16, np.concatenate([h, x3], -1))))
+        h = f(21, f(20, f(19, np.concatenate([h, x2], -1))))
+        h = f(24, f(23, f(22, np.concatenate([h, x1], -1))))
+        return f(25, h) @ ex["head_w"].T + ex["head_b"]
+
+    e_plain, e_hilo = rel_l2(forward(0), want), rel_l2(forward(_lib.PCD_UNET_HILO_ALLOWED), want)
+    assert e_hilo < 0.6 * e_plain and e_plain < 3e-3, (e_plain, e_hilo)
+
+
 def test_module_state_dict_and_cpu_failure():
     from shapegen_amd import specs
     from shapegen_amd.diffusion import PointCloudDiffusion
