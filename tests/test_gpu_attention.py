@@ -193,11 +193,17 @@ def test_attention_backbone_under_the_samplers():
     xT = torch.randn(2, 128, 3, generator=g)
     want = O.ddim_sample(model, xT, 12)
     got = m.sample(2, 128, num_steps=12, x_T=xT.cuda())
-    assert rel_l2(got.cpu(), want) < 2e-2
+    r12 = rel_l2(got.cpu(), want)
     zs = torch.randn(5, 2, 128, 3, generator=g)
     want = O.ddpm_sample(model, xT, 6, list(zs))
     got = m.sample2(2, 128, num_steps=6, x_T=xT.cuda(), noises=zs.cuda())
-    assert rel_l2(got.cpu(), want) < 2e-2
+    r6 = rel_l2(got.cpu(), want)
+    # a longer horizon through replayed graphs: 100 DDIM steps (the horizon of BASELINE configs[0]) against the oracle
+    want = O.ddim_sample(model, xT, 100)
+    got = m.sample(2, 128, num_steps=100, x_T=xT.cuda())
+    r100 = rel_l2(got.cpu(), want)
+    print(f"attention backbone vs oracle: DDIM T=12 {r12:.2e}, DDPM T=6 {r6:.2e}, DDIM T=100 {r100:.2e}")
+    assert r12 < 5e-3 and r6 < 5e-3 and r100 < 5e-3            # the point path's sampler bound (measured 8.0e-4 / 6.2e-4 / 5.5e-4)
     with pytest.raises(ValueError):
         PointCloudDiffusion(num_points=128, backbone="transformer")
 
