@@ -548,9 +548,11 @@ class LatentDiffusion(_DiffusionBase):
                 if status == 0:
                     return x0
                 import warnings
-                warnings.warn(f"persistent latent kernel abandoned its launch (wait kind {status >> 16}, workgroup {status & 0xffff}: "
-                              "CUs of this GPU are not all available to this process); re-running on the per-layer launches and "
-                              "staying there (LatentDiffusion.use_persistent = False)", RuntimeWarning, stacklevel=3)
+                warnings.warn(f"persistent latent kernel abandoned its launch (wait kind {status >> 16}, workgroup {status & 0xffff}): either "
+                              "the CUs of this GPU are not all available to this process, or an intermediate value became non-finite (its "
+                              "exchange reads NaN / set sign bits as 'not written yet'); re-running on the per-layer launches, which "
+                              "propagate non-finite values like the reference, and staying there (LatentDiffusion.use_persistent = False)",
+                              RuntimeWarning, stacklevel=3)
                 self.use_persistent = False
                 x.copy_(start)
         return super()._run(x, tab, bias_table, forward, kind, noises, skip_last_update)
