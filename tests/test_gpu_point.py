@@ -3,7 +3,7 @@ against golden vectors from the reference and against the CPU oracle.
 
 Tolerances (fp16 operands, fp32 accumulation):
   eps of one forward:  rel-L2 <= 3e-3
-  sampler outputs:     rel-L2 <= 5e-3 (short horizons), Chamfer delta <= 1e-4 (north_star)
+  sampler outputs:     rel-L2 <= 2e-3 on the cosine schedule (measured 1.5e-4 .. 2.8e-4; 5e-3 on the linear-schedule fixtures), Chamfer delta <= 1e-4 (north_star)
 """
 import numpy as np
 import pytest
@@ -171,7 +171,7 @@ def test_ddim_sample(model, golden, T):
     g = golden("point_samplers.npz")
     out = model.sample(4, 512, num_steps=T, x_T=torch.from_numpy(g[f"sample_T{T}_xT"]).cuda())
     want = torch.from_numpy(g[f"sample_T{T}_out"])
-    assert rel_l2(out.cpu(), want) < 5e-3
+    assert rel_l2(out.cpu(), want) < 2e-3
     # north_star quality gate, SURVEY 8(c): |CD_build - CD_ref| <= 1e-4 (scaling 1) against the same
     # third cloud; CD(gpu cloud, reference cloud) itself is reported, not gated at 1e-4
     other = torch.from_numpy(g[f"sample_T{T}_xT"]).cuda()
@@ -195,7 +195,7 @@ def test_ddim_sample_chamfer_gate_at_2048_points(golden):
     m = m.to("cuda").eval()
     out = m.sample(2, 2048, num_steps=50, x_T=torch.from_numpy(g["xT"]).cuda())
     want = torch.from_numpy(g["out"])
-    assert rel_l2(out.cpu(), want) < 5e-3
+    assert rel_l2(out.cpu(), want) < 2e-3
     other = torch.from_numpy(g["xT"]).cuda()
     cd_build = float(M.chamfer_distance(out, other, 1))
     cd_ref = float(M.chamfer_distance(want.cuda(), other, 1))
@@ -209,7 +209,7 @@ def test_ddpm_sample2(model, golden):
     g = golden("point_samplers.npz")
     out = model.sample2(2, 64, num_steps=20, x_T=torch.from_numpy(g["s2_xT"]).cuda(),
                         noises=torch.from_numpy(g["s2_z"]).cuda())
-    assert rel_l2(out.cpu(), g["s2_out"]) < 5e-3
+    assert rel_l2(out.cpu(), g["s2_out"]) < 2e-3
 
 
 def test_sample3_reconstruction(model, golden):
@@ -220,9 +220,9 @@ def test_sample3_reconstruction(model, golden):
     noisy, noise, n, s = model.add_noise(x0, t, noise=torch.from_numpy(g["s3_noise"]).cuda())
     assert torch.equal(noisy.cpu(), torch.from_numpy(g["s3_noisy"]))          # elementwise: bit exact
     out = model.sample3(2, 64, x=noisy, start_t=t)
-    assert rel_l2(out.cpu(), g["s3_out"]) < 5e-3
+    assert rel_l2(out.cpu(), g["s3_out"]) < 2e-3
     out = model.sample3(2, 64, x=noisy, start_t=torch.ones(2), num_steps=20)
-    assert rel_l2(out.cpu(), g["s3_T20_from1_out"]) < 5e-3
+    assert rel_l2(out.cpu(), g["s3_T20_from1_out"]) < 2e-3
 
 
 def test_step_tables_bit_exact(model, golden):

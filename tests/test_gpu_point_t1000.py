@@ -4,7 +4,8 @@ diffusion.py:226,262,292; test_point_ddpm.py:36,78-92), against goldens captured
 
 Both arithmetic modes of the denoiser run every case:
   fp16 (product path: fp16 operands, fp32 accumulation; graph replay where the sampler uses it)
-      cloud rel-L2 <= 5e-3, |CD_build - CD_ref| <= 1e-4 (scaling 1, north_star's gate)
+      cloud rel-L2 <= 2e-3 (the short-horizon tests' 5e-3, tightened here: measured 9.8e-5 / 3.1e-4 / 2.4e-4 with the hi / lo narrow
+      weights), |CD_build - CD_ref| <= 1e-4 (scaling 1, north_star's gate)
   fp32 (SURVEY 8(c) parity mode, csrc/unet_f32.hip)
       cloud rel-L2 <= 5e-5 and max-abs <= 1e-3 for clouds up to |x| = 100 -- the survey's bound, stated for O(1-100) clouds --
       scaled with the cloud beyond that (max-abs <= 1e-5 max|x_ref|: 1e-3 absolute on a value of 1e3 would be below fp32's own
@@ -28,7 +29,7 @@ from shapegen_amd import specs
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 
-TOL = {"fp16": dict(rel=5e-3, maxabs=None), "fp32": dict(rel=5e-5, maxabs=1e-3)}
+TOL = {"fp16": dict(rel=2e-3, maxabs=None), "fp32": dict(rel=5e-5, maxabs=1e-3)}      # measured: fp16 9.8e-5 ... 3.1e-4, fp32 1.4e-6 ... 2.3e-6
 
 
 @pytest.fixture(scope="module")
