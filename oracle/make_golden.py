@@ -17,6 +17,7 @@ G16 linear.npz (`make_golden.py linear`: the linear schedule's per-shape rate ta
 G18 point_n2048.npz (`make_golden.py n2048`: `PointCloudDiffusion.sample(2, 2048, num_steps=50)` at the BASELINE point count, start noise recorded),
 G17 cfg4.npz (`make_golden.py cfg4`: BASELINE configs[3] at its real launch shape -- 32 grids through `VAE3DLarge.encode`,
 `LatentDiffusion.sample(32, num_steps=1000)` with the start noise recorded, the decoded grids of four rows),
+G22 point_cfg1_ddpm.npz (`make_golden.py g22`: BASELINE configs[0] through `sample2`: 512 points, 100 steps, batch 4),
 G19-G21 point_t1000_{ddim,ddpm,recon}.npz (`make_golden.py g19|g20|g21`: the three point samplers at N = 2048 over the full
 1000-step horizon, see `capture_t1000`).
 """
@@ -237,6 +238,34 @@ def capture_t1000(rd, rm, which):
     print(which, "seconds", time.time() - t0, "|out| max", float(out.abs().max()), "finite", bool(torch.isfinite(out).all()))
     np.savez_compressed(os.path.join(OUT, name), **g)
     print(name, os.path.getsize(os.path.join(OUT, name)))
+
+
+def capture_cfg1_ddpm(rd):
+    """G22: BASELINE configs[0] read literally -- "point-cloud DDPM, 512 points, 100 steps, batch 4" -- through `sample2` (diffusion.py:225-259; the
+    reference's own script calls the DDIM `sample`, which G5 covers at the same shape): per-step noise from `specs.hash_normal("g22.z<k>")`,
+    synthetic weights at DDPM_STABLE_GAIN (see capture_t1000) -> tests/golden/point_cfg1_ddpm.npz."""
+    pspec = specs.unet_pointnet_large_spec(prefix="model.")
+    pcd = rd.PointCloudDiffusion(num_points=512).eval()
+    pcd.load_state_dict(T(specs.synth_state_dict(pspec, seed=0, gain=DDPM_STABLE_GAIN)), strict=True)
+    real = torch.randn_like
+    count = [0]
+
+    def hashed(x, *a, **k):
+        z = specs.hash_normal(f"g22.z{count[0]}", x.numel(), 0).astype(np.float32).reshape(tuple(x.shape))
+        count[0] += 1
+        return torch.from_numpy(z)
+
+    torch.manual_seed(24)
+    torch.randn_like = hashed
+    try:
+        out = pcd.sample2(4, 512, num_steps=100)
+    finally:
+        torch.randn_like = real
+    torch.manual_seed(24)
+    xT = torch.randn(4, 512, 3)
+    assert count[0] == 99
+    print("cfg1 ddpm |out| max", float(out.abs().max()), "rms", float(out.pow(2).mean().sqrt()))
+    np.savez_compressed(os.path.join(OUT, "point_cfg1_ddpm.npz"), xT=xT.numpy(), out=out.numpy(), gain=np.float64(DDPM_STABLE_GAIN))
 
 
 def capture_cfg4(rd, rn, ru):
@@ -518,6 +547,9 @@ def main():
         if which in sys.argv[1:]:
             capture_t1000(rd, rm, which)
             return
+    if "g22" in sys.argv[1:]:
+        capture_cfg1_ddpm(rd)
+        return
     if "n2048" in sys.argv[1:]:
         capture_n2048(rd)
         return

@@ -212,6 +212,38 @@ def test_ddpm_sample2(model, golden):
     assert rel_l2(out.cpu(), g["s2_out"]) < 2e-3
 
 
+class _HashedNoises:
+    def __init__(self, tag, shape):
+        self.tag, self.shape = tag, tuple(shape)
+
+    def __getitem__(self, k):
+        from shapegen_amd import specs
+        return torch.from_numpy(specs.hash_normal(f"{self.tag}{k}", int(np.prod(self.shape)), 0).astype(np.float32).reshape(self.shape))
+
+
+@pytest.mark.parametrize("prec", ["fp16", "fp32"])
+def test_baseline_config0_as_ddpm(golden, prec):
+    """G22: BASELINE configs[0] read literally -- point-cloud DDPM, 512 points, 100 steps, batch 4 -- through `sample2` (the reference's own script
+    runs the DDIM `sample` at this shape: test_ddim_sample[T=100]); the 99 per-step noise tensors are rebuilt from the integer hash; synthetic
+    weights at gain 1.0 (tests/test_gpu_point_t1000.py explains why the DDPM fixtures use that scale).  fp16 product path and fp32 parity mode."""
+    from helpers import as_torch
+    from shapegen_amd import metrics as M, specs
+    from shapegen_amd.diffusion import PointCloudDiffusion
+    g = golden("point_cfg1_ddpm.npz")
+    m = PointCloudDiffusion(num_points=512)
+    m.load_state_dict(as_torch(specs.synth_state_dict(specs.unet_pointnet_large_spec(prefix="model."), seed=0, gain=float(g["gain"]))), strict=True)
+    m = m.to("cuda").eval()
+    m.model.set_precision(prec)
+    xT = torch.from_numpy(g["xT"]).cuda()
+    out = m.sample2(4, 512, num_steps=100, x_T=xT, noises=_HashedNoises("g22.z", (4, 512, 3)))
+    want = torch.from_numpy(g["out"])
+    r = rel_l2(out.cpu(), want)
+    cd_build, cd_ref = float(M.chamfer_distance(out, xT, 1)), float(M.chamfer_distance(want.cuda(), xT, 1))
+    print(f"configs[0] as DDPM [{prec}]: rel-L2 {r:.2e}  |dCD| {abs(cd_build - cd_ref):.2e}")
+    assert r < (2e-3 if prec == "fp16" else 5e-5)
+    assert abs(cd_build - cd_ref) < 1e-4
+
+
 def test_sample3_reconstruction(model, golden):
     """test_point_ddpm.py:78-80: add_noise at t=0.01 then 1000 DDIM steps back."""
     g = golden("point_samplers.npz")

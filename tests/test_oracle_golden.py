@@ -315,3 +315,14 @@ def test_t1000_ddpm_fixtures_last_step_with_the_oracle(golden):
         assert rel_l2(out, g["out"]) < 2e-6, name
     assert float(np.abs(golden("point_t1000_ddpm.npz")["out"]).max()) > 1e8        # the runaway record (gain 1.3)
     assert float(np.abs(golden("point_t1000_ddpm_stable.npz")["out"]).max()) < 5e3
+
+
+def test_baseline_config0_as_ddpm_with_the_oracle(golden):
+    """G22 (configs[0] through `sample2`: 512 points, 100 steps, batch 4, hashed per-step noise, weights at gain 1.0): the oracle's whole loop
+    against the reference's returned cloud."""
+    from helpers import as_torch
+    g = golden("point_cfg1_ddpm.npz")
+    sd = as_torch(specs.synth_state_dict(specs.unet_pointnet_large_spec(prefix="model."), seed=0, gain=float(g["gain"])))
+    zs = [torch.from_numpy(specs.hash_normal(f"g22.z{k}", 4 * 512 * 3, 0).astype(np.float32).reshape(4, 512, 3)) for k in range(99)]
+    out = O.ddpm_sample(lambda x, t: O.unet_pointnet_large(sd, "model.", x, t), torch.from_numpy(g["xT"]), 100, zs)
+    assert rel_l2(out, g["out"]) < 1e-5
