@@ -17,6 +17,7 @@ G16 linear.npz (`make_golden.py linear`: the linear schedule's per-shape rate ta
 G18 point_n2048.npz (`make_golden.py n2048`: `PointCloudDiffusion.sample(2, 2048, num_steps=50)` at the BASELINE point count, start noise recorded),
 G17 cfg4.npz (`make_golden.py cfg4`: BASELINE configs[3] at its real launch shape -- 32 grids through `VAE3DLarge.encode`,
 `LatentDiffusion.sample(32, num_steps=1000)` with the start noise recorded, the decoded grids of four rows),
+G23 latent_ddpm.npz (`make_golden.py g23`: `LatentDiffusion.sample2(8, num_steps=1000)` with hashed per-step noise),
 G22 point_cfg1_ddpm.npz (`make_golden.py g22`: BASELINE configs[0] through `sample2`: 512 points, 100 steps, batch 4),
 G19-G21 point_t1000_{ddim,ddpm,recon}.npz (`make_golden.py g19|g20|g21`: the three point samplers at N = 2048 over the full
 1000-step horizon, see `capture_t1000`).
@@ -266,6 +267,38 @@ def capture_cfg1_ddpm(rd):
     assert count[0] == 99
     print("cfg1 ddpm |out| max", float(out.abs().max()), "rms", float(out.pow(2).mean().sqrt()))
     np.savez_compressed(os.path.join(OUT, "point_cfg1_ddpm.npz"), xT=xT.numpy(), out=out.numpy(), gain=np.float64(DDPM_STABLE_GAIN))
+
+
+def capture_latent_ddpm(rd, rn):
+    """G23: `LatentDiffusion.sample2(8, num_steps=1000)` (the latent DDPM loop, diffusion.py:575-616): z_T recorded, the 999 per-step draws from
+    `specs.hash_normal("g23.z<k>")`, the final latent spied at `vae.decode` -> tests/golden/latent_ddpm.npz.  Synthetic weights as G8 / G17."""
+    vae = rn.VAE3DLarge().eval()
+    ldm = rd.LatentDiffusion(vae).eval()
+    sd_l = specs.synth_state_dict(specs.latent_unet_spec(prefix="model."), seed=0, gain=LATENT_GAIN)
+    sd_v = specs.synth_state_dict(specs.vae3d_large_spec(prefix="vae."), seed=0, gain=VAE_GAIN)
+    ldm.load_state_dict(T({**sd_l, **sd_v}), strict=True)
+    captured = {}
+    vae.decode = lambda zz: captured.__setitem__("z0", zz.detach().clone()) or torch.zeros(zz.shape[0], 1, 32, 32, 32)
+    real = torch.randn_like
+    count = [0]
+
+    def hashed(x, *a, **k):
+        z = specs.hash_normal(f"g23.z{count[0]}", x.numel(), 0).astype(np.float32).reshape(tuple(x.shape))
+        count[0] += 1
+        return torch.from_numpy(z)
+
+    torch.manual_seed(24)
+    torch.randn_like = hashed
+    try:
+        ldm.sample2(8, num_steps=1000)
+    finally:
+        torch.randn_like = real
+    torch.manual_seed(24)
+    zT = torch.randn(8, 256)
+    assert count[0] == 999
+    z0 = captured["z0"]
+    print("latent ddpm |z0| max", float(z0.abs().max()), "rms", float(z0.pow(2).mean().sqrt()), "finite", bool(torch.isfinite(z0).all()))
+    np.savez_compressed(os.path.join(OUT, "latent_ddpm.npz"), zT=zT.numpy(), z0=z0.numpy())
 
 
 def capture_cfg4(rd, rn, ru):
@@ -547,6 +580,9 @@ def main():
         if which in sys.argv[1:]:
             capture_t1000(rd, rm, which)
             return
+    if "g23" in sys.argv[1:]:
+        capture_latent_ddpm(rd, rn)
+        return
     if "g22" in sys.argv[1:]:
         capture_cfg1_ddpm(rd)
         return

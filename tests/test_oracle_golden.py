@@ -326,3 +326,13 @@ def test_baseline_config0_as_ddpm_with_the_oracle(golden):
     zs = [torch.from_numpy(specs.hash_normal(f"g22.z{k}", 4 * 512 * 3, 0).astype(np.float32).reshape(4, 512, 3)) for k in range(99)]
     out = O.ddpm_sample(lambda x, t: O.unet_pointnet_large(sd, "model.", x, t), torch.from_numpy(g["xT"]), 100, zs)
     assert rel_l2(out, g["out"]) < 1e-5
+
+
+def test_latent_ddpm_1000_steps_with_the_oracle(golden):
+    """G23 (`LatentDiffusion.sample2(8, num_steps=1000)`, diffusion.py:575-616, hashed per-step noise): the oracle's latent DDPM loop against
+    the latent the reference handed its decoder."""
+    g = golden("latent_ddpm.npz")
+    sd = latent_sd()
+    zs = [torch.from_numpy(specs.hash_normal(f"g23.z{k}", 8 * 256, 0).astype(np.float32).reshape(8, 256)) for k in range(999)]
+    out = O.ddpm_sample(lambda z, t: O.latent_unet(sd, "model.", z, t), torch.from_numpy(g["zT"]), 1000, zs)
+    assert rel_l2(out, g["z0"]) < 1e-4
