@@ -17,6 +17,7 @@ G16 linear.npz (`make_golden.py linear`: the linear schedule's per-shape rate ta
 G18 point_n2048.npz (`make_golden.py n2048`: `PointCloudDiffusion.sample(2, 2048, num_steps=50)` at the BASELINE point count, start noise recorded),
 G17 cfg4.npz (`make_golden.py cfg4`: BASELINE configs[3] at its real launch shape -- 32 grids through `VAE3DLarge.encode`,
 `LatentDiffusion.sample(32, num_steps=1000)` with the start noise recorded, the decoded grids of four rows),
+G24 attention_n2048.npz (`make_golden.py g24`: `SetAttentionBlock(256, 4)` and `UNetAttentionPointExperimental` at N = 2048),
 G23 latent_ddpm.npz (`make_golden.py g23`: `LatentDiffusion.sample2(8, num_steps=1000)` with hashed per-step noise),
 G22 point_cfg1_ddpm.npz (`make_golden.py g22`: BASELINE configs[0] through `sample2`: 512 points, 100 steps, batch 4),
 G19-G21 point_t1000_{ddim,ddpm,recon}.npz (`make_golden.py g19|g20|g21`: the three point samplers at N = 2048 over the full
@@ -301,6 +302,24 @@ def capture_latent_ddpm(rd, rn):
     np.savez_compressed(os.path.join(OUT, "latent_ddpm.npz"), zT=zT.numpy(), z0=z0.numpy())
 
 
+def capture_attention_n2048(rn):
+    """G24: the attention denoiser at BASELINE's point count, straight from the reference: `SetAttentionBlock(256, 4)` on (1, 2048, 256) and
+    `UNetAttentionPointExperimental` on (2, 2048, 3) (networks.py:51-83, 597-722); inputs from the integer hash (rebuilt by the tests), outputs
+    stored as fp16 (the tests' bounds are 3e-3 / 5e-3 relative) -> tests/golden/attention_n2048.npz."""
+    g = {}
+    blk = rn.SetAttentionBlock(256, 4).eval()
+    blk.load_state_dict(T(specs.synth_state_dict(specs.set_attention_spec(256), seed=256, gain=ATTN_GAIN)), strict=True)
+    xa = torch.from_numpy(specs.hash_uniform("xa2048", 2048 * 256, 0).reshape(1, 2048, 256).astype(np.float32)) * 2
+    g["sab256_out_rows"] = blk(xa).numpy()[0, ::8].astype(np.float16)          # every 8th point (256 rows of 256 channels)
+    una = rn.UNetAttentionPointExperimental(2048).eval()
+    una.load_state_dict(T(specs.synth_state_dict(specs.unet_attention_spec(), seed=0, gain=ATTN_GAIN)), strict=True)
+    xu = torch.from_numpy(specs.hash_uniform("xu2048", 2 * 2048 * 3, 0).reshape(2, 2048, 3).astype(np.float32)) * 1.5
+    tu = torch.tensor([0.65, 0.15])
+    g["una_t"], g["una_eps"] = tu.numpy(), una(xu, tu).numpy()
+    np.savez_compressed(os.path.join(OUT, "attention_n2048.npz"), **g)
+    print("attention_n2048.npz", os.path.getsize(os.path.join(OUT, "attention_n2048.npz")), "|eps| max", float(np.abs(g["una_eps"]).max()))
+
+
 def capture_cfg4(rd, rn, ru):
     """G17: the reference at BASELINE configs[3]'s launch shape (diffusion.py:619-653, networks.py:2299-2339): B = 32,
     T = 1000.  The 32 input grids are `synth_voxels(32, 4)` (the test rebuilds them from the same integer hash; the
@@ -580,6 +599,9 @@ def main():
         if which in sys.argv[1:]:
             capture_t1000(rd, rm, which)
             return
+    if "g24" in sys.argv[1:]:
+        capture_attention_n2048(rn)
+        return
     if "g23" in sys.argv[1:]:
         capture_latent_ddpm(rd, rn)
         return

@@ -245,3 +245,26 @@ def test_full_size_attention_next_to_the_oracle():
     for rows in ((20, 21), (63, 64)):
         want = O.unet_attention(usd, "", xp[rows[0]:rows[1]], t[rows[0]:rows[1]])
         assert rel_l2(eps[rows[0]:rows[1]], want) < 5e-3, rows
+
+
+def test_attention_at_2048_points_against_the_reference(golden):
+    """G24: `SetAttentionBlock(256, 4)` on (1, 2048, 256) and `UNetAttentionPointExperimental` on (2, 2048, 3) captured from the REFERENCE at BASELINE's
+    point count (the other goldens of this file are at N = 128; N = 2048 was oracle-only): inputs rebuilt from the integer hash."""
+    import numpy as np
+    from shapegen_amd import specs
+    from shapegen_amd.networks import SetAttentionBlock, UNetAttentionPointExperimental
+    g = golden("attention_n2048.npz")
+    blk = SetAttentionBlock(256, 4)
+    blk.load_state_dict(sab_sd(256), strict=True)
+    blk = blk.to("cuda").eval()
+    xa = torch.from_numpy(specs.hash_uniform("xa2048", 2048 * 256, 0).reshape(1, 2048, 256).astype(np.float32)) * 2
+    out = blk(xa.cuda()).cpu()
+    assert rel_l2(out[0, ::8], g["sab256_out_rows"].astype(np.float32)) < 3e-3
+    net = UNetAttentionPointExperimental(2048)
+    net.load_state_dict(una_sd(), strict=True)
+    net = net.to("cuda").eval()
+    xu = torch.from_numpy(specs.hash_uniform("xu2048", 2 * 2048 * 3, 0).reshape(2, 2048, 3).astype(np.float32)) * 1.5
+    eps = net(xu.cuda(), torch.from_numpy(g["una_t"]).cuda()).cpu()
+    r = rel_l2(eps, g["una_eps"])
+    print(f"attention U-Net at (2, 2048) vs the reference: rel-L2 {r:.2e}")
+    assert r < 5e-3

@@ -336,3 +336,14 @@ def test_latent_ddpm_1000_steps_with_the_oracle(golden):
     zs = [torch.from_numpy(specs.hash_normal(f"g23.z{k}", 8 * 256, 0).astype(np.float32).reshape(8, 256)) for k in range(999)]
     out = O.ddpm_sample(lambda z, t: O.latent_unet(sd, "model.", z, t), torch.from_numpy(g["zT"]), 1000, zs)
     assert rel_l2(out, g["z0"]) < 1e-4
+
+
+def test_attention_at_2048_points_with_the_oracle(golden):
+    """G24: the oracle's set-attention block and attention U-Net at BASELINE's point count against the reference's outputs."""
+    g = golden("attention_n2048.npz")
+    xa = torch.from_numpy(specs.hash_uniform("xa2048", 2048 * 256, 0).reshape(1, 2048, 256).astype(np.float32)) * 2
+    out = O.set_attention_block(sab_sd(256), "", xa, 4)
+    assert rel_l2(out[0, ::8], g["sab256_out_rows"].astype(np.float32)) < 5e-4            # the fixture is fp16
+    xu = torch.from_numpy(specs.hash_uniform("xu2048", 2 * 2048 * 3, 0).reshape(2, 2048, 3).astype(np.float32)) * 1.5
+    eps = O.unet_attention(una_sd(), "", xu, torch.from_numpy(g["una_t"]))
+    assert rel_l2(eps, g["una_eps"]) < 1e-5
