@@ -215,6 +215,13 @@ _SIGS = {
     "pcd_attn_unet_time_bias": (i32, [vp, vp, i32, vp, vp, vp]),
     "pcd_attn_unet_forward": (i32, [vp, vp, i32, i32, vp, i32, vp, vp, sz, vp]),
     "pcd_attn_unet_tap": (i32, [vp, C.c_char_p, i32, i32, vp, vp, sz, vp]),
+    "pcd_sab_f32_workspace_bytes": (sz, [i64, i32]),
+    "pcd_sab_f32_forward": (i32, [C.POINTER(SabDesc), vp, i32, i32, i32, vp, vp, sz, vp]),
+    "pcd_attn_unet_f32_create": (i32, [C.POINTER(AttnUnetDesc), C.POINTER(vp)]),
+    "pcd_attn_unet_f32_destroy": (None, [vp]),
+    "pcd_attn_unet_f32_workspace_bytes": (sz, [i32, i32]),
+    "pcd_attn_unet_f32_forward": (i32, [vp, vp, i32, i32, vp, i32, vp, vp, sz, vp]),
+    "pcd_attn_unet_f32_tap": (i32, [vp, C.c_char_p, i32, i32, vp, vp, sz, vp]),
     "pcd_normalize_to_cube": (i32, [vp, i32, i32, vp, vp]),
     "pcd_chamfer_sums": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "pcd_voxelize": (i32, [vp, i32, i32, i32, vp, vp]),

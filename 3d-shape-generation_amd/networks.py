@@ -115,6 +115,22 @@ def _dev32(a: np.ndarray, dev) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(a)).to(torch.float32).to(dev).contiguous()
 
 
+PRECISIONS = ("fp16", "fp32")
+
+
+def _check_precision(precision: str) -> None:
+    if precision not in PRECISIONS:
+        raise ValueError(f"precision must be one of {PRECISIONS}, got {precision!r}")
+
+
+def _env_precision() -> str:
+    """PCD_PARITY=fp32 puts every denoiser created afterwards into its fp32 parity mode."""
+    p = os.environ.get("PCD_PARITY", "fp16")
+    if p not in PRECISIONS:
+        raise ValueError(f"PCD_PARITY must be one of {PRECISIONS}, got {p!r}")
+    return p
+
+
 # ------------------------------------------------------------------ UNetPointNetLarge
 class UNetPointNetLarge(_HipModule):
     """Drop-in for reference networks.py:724-838: eps = model(x (B,N,3), t (B,)).
@@ -299,15 +315,16 @@ class UNetPointNetLarge(_HipModule):
 class _PackedSAB:
     """Device weights of one SetAttentionBlock (reference networks.py:51-68) and their C descriptor."""
 
-    def __init__(self, sd, prefix: str, dim: int, dev):
+    def __init__(self, sd, prefix: str, dim: int, dev, f32: bool = False):
         g = lambda k: sd[prefix + k].detach().to("cpu", torch.float64).numpy()
+        devw = _dev32 if f32 else _dev16                                   # fp32 parity mode: fp32 weights (csrc/attn_f32.hip)
         self.dim = dim
-        self.w_in, self.b_in = _dev16(g("attention.in_proj_weight"), dev), _dev32(g("attention.in_proj_bias"), dev)
-        self.w_out, self.b_out = _dev16(g("attention.out_proj.weight"), dev), _dev32(g("attention.out_proj.bias"), dev)
+        self.w_in, self.b_in = devw(g("attention.in_proj_weight"), dev), _dev32(g("attention.in_proj_bias"), dev)
+        self.w_out, self.b_out = devw(g("attention.out_proj.weight"), dev), _dev32(g("attention.out_proj.bias"), dev)
         self.ln1_g, self.ln1_b = _dev32(g("ln1.weight"), dev), _dev32(g("ln1.bias"), dev)
         self.ln2_g, self.ln2_b = _dev32(g("ln2.weight"), dev), _dev32(g("ln2.bias"), dev)
-        self.w_ff1, self.b_ff1 = _dev16(g("ff.0.weight"), dev), _dev32(g("ff.0.bias"), dev)
-        self.w_ff2, self.b_ff2 = _dev16(g("ff.2.weight"), dev), _dev32(g("ff.2.bias"), dev)
+        self.w_ff1, self.b_ff1 = devw(g("ff.0.weight"), dev), _dev32(g("ff.0.bias"), dev)
+        self.w_ff2, self.b_ff2 = devw(g("ff.2.weight"), dev), _dev32(g("ff.2.bias"), dev)
 
     def fill(self, d: "_lib.SabDesc") -> "_lib.SabDesc":
         d.dim = self.dim
@@ -323,12 +340,21 @@ class SetAttentionBlock(_HipModule):
         super().__init__()
         self.dim, self.num_heads = dim, num_heads
         self._build_from_spec(specs.set_attention_spec(dim))
+        self.precision = _env_precision()
+
+    def set_precision(self, precision: str) -> "SetAttentionBlock":
+        """"fp16" (default: fp16 operands, flash-style kernel on the matrix cores) or "fp32" (the reference's arithmetic type, csrc/attn_f32.hip)."""
+        _check_precision(precision)
+        if precision != self.precision:
+            self.invalidate()
+            self.precision = precision
+        return self
 
     def _ensure_packed(self):
         if self._packed is None:
             dev = self._need_cuda()
             _lib.require_gpu()
-            pk = _PackedSAB(self.state_dict(), "", self.dim, dev)
+            pk = _PackedSAB(self.state_dict(), "", self.dim, dev, f32=self.precision == "fp32")
             self._packed = (pk, pk.fill(_lib.SabDesc()))
         return self._packed
 
@@ -339,6 +365,13 @@ class SetAttentionBlock(_HipModule):
             raise ValueError(f"expected {self.dim} channels, got {c}")
         _, desc = self._ensure_packed()
         lib = _lib.load()
+        if self.precision == "fp32":
+            x32 = x.to(torch.float32).contiguous().reshape(b * n, c)
+            y32 = torch.empty_like(x32)
+            ws = self._workspace((b, n), lib.pcd_sab_f32_workspace_bytes(b * n, c))
+            _lib.check(lib.pcd_sab_f32_forward(C.byref(desc), x32.data_ptr(), b, n, self.num_heads, y32.data_ptr(), ws.data_ptr(),
+                                               ws.numel(), _lib.stream_ptr()), "sab_f32_forward")
+            return y32.reshape(b, n, c).to(x.dtype)
         x16 = x.to(torch.float16).contiguous().reshape(b * n, c)
         y16 = torch.empty_like(x16)
         ws = self._workspace((b, n), lib.pcd_sab_workspace_bytes(b * n, c))
@@ -359,11 +392,24 @@ class UNetAttentionPointExperimental(_HipModule):
         self.num_points, self.dim, self.num_heads, self.time_dim = num_points, dim, num_heads, time_dim
         self._build_from_spec(specs.unet_attention_spec(dim, time_dim))
         self._handle = None
+        self._handle32 = None
+        self.precision = _env_precision()
+
+    def set_precision(self, precision: str) -> "UNetAttentionPointExperimental":
+        """"fp16" (default) or "fp32" (fp32 weights / activations / arithmetic, csrc/attn_f32.hip: the reference's arithmetic type, 1e-4)."""
+        _check_precision(precision)
+        if precision != self.precision:
+            self.invalidate()
+            self.precision = precision
+        return self
 
     def _release(self):
         if getattr(self, "_handle", None):
             _lib.load().pcd_attn_unet_destroy(self._handle)
+        if getattr(self, "_handle32", None):
+            _lib.load().pcd_attn_unet_f32_destroy(self._handle32)
         self._handle = None
+        self._handle32 = None
 
     def __del__(self):
         try:
@@ -419,6 +465,22 @@ class UNetAttentionPointExperimental(_HipModule):
         handle = C.c_void_p()
         _lib.check(_lib.load().pcd_attn_unet_create(C.byref(desc), C.byref(handle)), "attn_unet_create")
         self._handle, self._packed = handle, keep
+        if self.precision == "fp32":
+            # the fp32 parity mode: a second descriptor whose layer / attention weights are fp32 (the time path above is fp32 in both modes
+            # and stays with the first handle: pcd_attn_unet_time_bias)
+            d32 = _lib.AttnUnetDesc()
+            C.memmove(C.byref(d32), C.byref(desc), C.sizeof(desc))
+            for j, (name, i) in enumerate(stages):
+                w, b = packing.fold_conv_bn(sd, f"{name}.conv{i}", f"{name}.bn{i}")
+                keep[f"w32_{j}"] = _dev32(w, dev)
+                d32.lin[j].w = keep[f"w32_{j}"].data_ptr()
+            for j, (name, c) in enumerate((("att1", 64), ("att2", 128), ("att3", 256), ("bottleneck", 256), ("att_dec3", 256),
+                                           ("att_dec2", 128), ("att_dec1", 64))):
+                keep[name + "_32"] = _PackedSAB(sd, name + ".", c, dev, f32=True)
+                keep[name + "_32"].fill(d32.sab[j])
+            h32 = C.c_void_p()
+            _lib.check(_lib.load().pcd_attn_unet_f32_create(C.byref(d32), C.byref(h32)), "attn_unet_f32_create")
+            self._handle32 = h32
         return keep
 
     def time_bias(self, t: torch.Tensor) -> torch.Tensor:
@@ -437,9 +499,14 @@ class UNetAttentionPointExperimental(_HipModule):
         self._ensure_packed()
         b, n, _ = x.shape
         lib = _lib.load()
-        ws = self._workspace((b, n), lib.pcd_attn_unet_workspace_bytes(b, n))
         if out is None:
             out = torch.empty_like(x)
+        if self._handle32 is not None:
+            ws = self._workspace((b, n), lib.pcd_attn_unet_f32_workspace_bytes(b, n))
+            _lib.check(lib.pcd_attn_unet_f32_forward(self._handle32, x.data_ptr(), b, n, tbias.data_ptr(), shape_stride,
+                                                     out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "attn_unet_f32_forward")
+            return out
+        ws = self._workspace((b, n), lib.pcd_attn_unet_workspace_bytes(b, n))
         _lib.check(lib.pcd_attn_unet_forward(self._handle, x.data_ptr(), b, n, tbias.data_ptr(), shape_stride,
                                              out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "attn_unet_forward")
         return out
@@ -454,8 +521,13 @@ class UNetAttentionPointExperimental(_HipModule):
         return self.forward_with_bias(x, self.time_bias(t), 1)
 
     def tap(self, name: str, batch: int, n_points: int) -> torch.Tensor:
-        """Skip tensor of the last forward (parity tests): x1 / x2 / x3 as (B, N, 64 / 128 / 256) fp16."""
+        """Skip tensor of the last forward (parity tests): x1 / x2 / x3 as (B, N, 64 / 128 / 256) fp16 (fp32 in the fp32 parity mode)."""
         ws = self._ws[(batch, n_points)]
+        if self._handle32 is not None:
+            dst = torch.empty(batch, n_points, {"x1": 64, "x2": 128, "x3": 256}[name], dtype=torch.float32, device=self.device)
+            _lib.check(_lib.load().pcd_attn_unet_f32_tap(self._handle32, name.encode(), batch, n_points, ws.data_ptr(), dst.data_ptr(),
+                                                         dst.numel() * 4, _lib.stream_ptr()), "attn_unet_f32_tap")
+            return dst
         dst = torch.empty(batch, n_points, {"x1": 64, "x2": 128, "x3": 256}[name], dtype=torch.float16, device=self.device)
         _lib.check(_lib.load().pcd_attn_unet_tap(self._handle, name.encode(), batch, n_points, ws.data_ptr(), dst.data_ptr(),
                                                  dst.numel() * 2, _lib.stream_ptr()), "attn_unet_tap")

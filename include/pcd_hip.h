@@ -531,6 +531,23 @@ int pcd_attn_unet_forward(pcd_attn_unet_t* h, const float* x, int batch, int n_p
 int pcd_attn_unet_tap(pcd_attn_unet_t* h, const char* name, int batch, int n_points, const void* workspace, void* dst,
                       size_t dst_bytes, void* stream);
 
+/* ------------------------------------------------ fp32 parity mode of the set-attention block and the attention U-Net (csrc/attn_f32.hip)
+ * pcd_sab_forward / pcd_attn_unet_forward with fp32 weights (EVERY weight pointer of the descriptors is fp32 here), fp32 activations and
+ * fp32 arithmetic (pcd_gemm_f32, fp32 LayerNorm, a plain fp32 softmax(q k^T / sqrt d) v kernel): the reference's arithmetic type
+ * (networks.py:51-83, 597-722), held to 1e-4.  x / y / eps fp32; tbias = the 704-float rows of pcd_attn_unet_time_bias (fp32 in both modes).
+ * Taps of the last forward: x1 / x2 / x3, fp32. */
+size_t pcd_sab_f32_workspace_bytes(int64_t rows, int dim);
+int pcd_sab_f32_forward(const pcd_sab_desc_t* d, const float* x, int batch, int n_points, int heads, float* y, void* workspace,
+                        size_t workspace_bytes, void* stream);
+typedef struct pcd_attn_unet_f32 pcd_attn_unet_f32_t;
+int pcd_attn_unet_f32_create(const pcd_attn_unet_desc_t* desc, pcd_attn_unet_f32_t** out);
+void pcd_attn_unet_f32_destroy(pcd_attn_unet_f32_t* h);
+size_t pcd_attn_unet_f32_workspace_bytes(int batch, int n_points);
+int pcd_attn_unet_f32_forward(pcd_attn_unet_f32_t* h, const float* x, int batch, int n_points, const float* tbias,
+                              int tbias_shape_stride, float* eps, void* workspace, size_t workspace_bytes, void* stream);
+int pcd_attn_unet_f32_tap(pcd_attn_unet_f32_t* h, const char* name, int batch, int n_points, const void* workspace, void* dst,
+                          size_t dst_bytes, void* stream);
+
 /* ------------------------------------------------------------- metrics (K10-K12)
  * normalize_to_cube (metrics.py:7-21) for B clouds of N points, fp32 in/out. */
 int pcd_normalize_to_cube(const float* pts, int batch, int n, float* out, void* stream);

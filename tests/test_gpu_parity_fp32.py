@@ -191,3 +191,91 @@ def test_latent_1000_steps_fp32_vs_reference(ldm32, golden):
     for T in (5, 100):
         _, z0 = ldm32.sample(2, num_steps=T, z_T=torch.from_numpy(g8[f"ldm_T{T}_zT"]).cuda(), return_latent=True)
         assert rel_l2(z0.cpu(), g8[f"ldm_T{T}_z0"]) < 1e-4, T
+
+
+# ------------------------------------------------------------------ set attention + the attention U-Net in fp32 (csrc/attn_f32.hip)
+@pytest.mark.parametrize("C", [64, 128, 256])
+def test_set_attention_block_fp32(golden, C):
+    """G10 (`SetAttentionBlock(C, 4)` captured from the reference at N = 128) and ragged / full lengths against the oracle, fp32 weights,
+    activations and softmax: rel-L2 <= 1e-4 (the fp16 product kernel is held to 3e-3 on the same inputs)."""
+    from helpers import sab_sd
+    from oracle import torch_oracle as O
+    from shapegen_amd.networks import SetAttentionBlock
+    g = golden("attention.npz")
+    sd = sab_sd(C)
+    blk = SetAttentionBlock(C, 4)
+    blk.load_state_dict(sd, strict=True)
+    blk = blk.to("cuda").eval().set_precision("fp32")
+    r = rel_l2(blk(torch.from_numpy(g[f"sab{C}_x"]).cuda()).cpu(), g[f"sab{C}_out"])
+    print(f"fp32 set-attention block C={C} vs reference (N=128): {r:.2e}")
+    assert r < EPS_TOL_F32
+    gen = torch.Generator().manual_seed(C)
+    for b, n in ((1, 2048), (3, 333), (2, 50)):
+        x = torch.randn(b, n, C, generator=gen) * 1.5
+        r = rel_l2(blk(x.cuda()).cpu(), O.set_attention_block(sd, "", x, 4))
+        print(f"fp32 set-attention block C={C} vs oracle ({b},{n}): {r:.2e}")
+        assert r < EPS_TOL_F32, (b, n)
+
+
+def test_unet_attention_fp32(golden):
+    """`UNetAttentionPointExperimental` in the fp32 mode: G10 (N = 128) and G24 (N = 2048) captured from the reference, eps rel-L2 <= 1e-4;
+    the three skip tensors against the oracle <= 2e-5; fp16 -> fp32 -> fp16 leaves the fp16 result bit-identical."""
+    from helpers import una_sd
+    from oracle import torch_oracle as O
+    from shapegen_amd import specs
+    from shapegen_amd.networks import UNetAttentionPointExperimental
+    g = golden("attention.npz")
+    sd = una_sd()
+    net = UNetAttentionPointExperimental(128)
+    net.load_state_dict(sd, strict=True)
+    net = net.to("cuda").eval()
+    x, t = torch.from_numpy(g["una_x"]).cuda(), torch.from_numpy(g["una_t"]).cuda()
+    a = net(x, t).clone()
+    eps = net.set_precision("fp32")(x, t).cpu()
+    r = rel_l2(eps, g["una_eps"])
+    print(f"fp32 attention U-Net vs reference (N=128): {r:.2e}")
+    assert r < EPS_TOL_F32
+    taps = {}
+    O.unet_attention(sd, "", x.cpu(), t.cpu(), taps=taps)
+    for name in ("x1", "x2", "x3"):
+        tap = net.tap(name, x.shape[0], 128)
+        assert tap.dtype == torch.float32
+        assert rel_l2(tap.cpu(), taps[name]) < 2e-5, name
+    c = net.set_precision("fp16")(x, t).clone()
+    assert torch.equal(a, c) and 1e-6 < rel_l2(a.cpu(), eps) < 5e-3
+    with pytest.raises(ValueError):
+        net.set_precision("bf16")
+    g24 = golden("attention_n2048.npz")
+    net = UNetAttentionPointExperimental(2048)
+    net.load_state_dict(sd, strict=True)
+    net = net.to("cuda").eval().set_precision("fp32")
+    xu = torch.from_numpy(specs.hash_uniform("xu2048", 2 * 2048 * 3, 0).reshape(2, 2048, 3).astype(np.float32)) * 1.5
+    r = rel_l2(net(xu.cuda(), torch.from_numpy(g24["una_t"]).cuda()).cpu(), g24["una_eps"])
+    print(f"fp32 attention U-Net vs reference (2, 2048): {r:.2e}")
+    assert r < EPS_TOL_F32
+
+
+def test_attention_backbone_samplers_fp32():
+    """The attention backbone under DDIM `sample` (T = 12 and T = 100, graph replay) and DDPM `sample2` (injected noise) in the fp32 mode
+    against the oracle: cloud max-abs <= 1e-3 like the point backbone's fp32 bound."""
+    from helpers import una_sd
+    from oracle import torch_oracle as O
+    from shapegen_amd.diffusion import PointCloudDiffusion
+    sd = {"model." + k: v for k, v in una_sd().items()}
+    m = PointCloudDiffusion(num_points=128, backbone="attention")
+    m.load_state_dict(sd, strict=True)
+    m = m.to("cuda").eval()
+    m.model.set_precision("fp32")
+    model = lambda x, t: O.unet_attention(sd, "model.", x, t)
+    g = torch.Generator().manual_seed(4)
+    xT = torch.randn(2, 128, 3, generator=g)
+    zs = torch.randn(5, 2, 128, 3, generator=g)
+    for T in (12, 100):
+        want = O.ddim_sample(model, xT, T)
+        got = m.sample(2, 128, num_steps=T, x_T=xT.cuda()).cpu()
+        mx = float((got - want).abs().max())
+        print(f"fp32 attention backbone DDIM T={T}: max-abs {mx:.2e} rel-L2 {rel_l2(got, want):.2e}")
+        assert mx < 1e-3 * max(1.0, float(want.abs().max()))
+    want = O.ddpm_sample(model, xT, 6, list(zs))
+    got = m.sample2(2, 128, num_steps=6, x_T=xT.cuda(), noises=zs.cuda()).cpu()
+    assert float((got - want).abs().max()) < 1e-3 * max(1.0, float(want.abs().max()))
