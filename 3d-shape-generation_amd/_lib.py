@@ -77,7 +77,7 @@ class Conv3dDesc(C.Structure):
                 ("out", vp), ("cout", i32),
                 ("out_d", i32), ("out_h", i32), ("out_w", i32), ("out_scale", i32),
                 ("out_off_z", i32), ("out_off_y", i32), ("out_off_x", i32),
-                ("zero_page", vp)]
+                ("zero_page", vp), ("in2", vp), ("cin2", i32)]
 
 
 class VaeConv(C.Structure):
@@ -85,7 +85,7 @@ class VaeConv(C.Structure):
 
 
 class VaeRes(C.Structure):
-    _fields_ = [("c1", VaeConv), ("c2", VaeConv), ("ds", VaeConv), ("has_ds", i32)]
+    _fields_ = [("c1", VaeConv), ("c2", VaeConv), ("ds", VaeConv), ("has_ds", i32), ("fused_ds", i32)]
 
 
 class VaeConvT(C.Structure):

@@ -42,6 +42,8 @@ struct ConvParams {
     int splits;                       // split-K (blockIdx.z); > 1 -> fp32 partials into slabs, conv3d_finish_kernel
     float* slabs;                     // [splits][nvar][M][Cout]
     int nvar;
+    const half_t* in2;                // optional second source on the row grid (pcd_conv3d_desc_t.in2): K tiles kt >= kt2 read it
+    int cin2_shift, kt2;              // log2(cin2); first K tile of the second source (INT_MAX without one)
     ConvVariant var[MAX_VARIANTS];
 };
 
@@ -147,14 +149,23 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
     auto stage = [&](int kt, int buf) {
         char* base = smem + buf * STAGE_BYTES;
         const int kidx = kt * CBK + lchunk * 8;
-        const int4 te = taps_s[kidx >> p.cin_shift];
-        const int dc = te.z + (kidx & (p.Cin - 1));
+        if (kt >= p.kt2) {
+            // second source (uniform per K tile): row m of in2, channels kidx - kt2 * CBK .. ; the row grid IS in2's grid (stride 1), so its
+            // voxel index is rbase / Cin and no bound can fail
+            const int c2 = kidx - p.kt2 * CBK;
 #pragma unroll
-        for (int r = 0; r < AR; ++r) {
-            const bool ok = (((rp1[r] + te.x) & (rp2[r] + te.y)) & 0x808080) == 0x808080;
-            const half_t* g = p.in + (rbase[r] + dc);
-            g = ok ? g : zlane;
-            cglds16_asm(g, base + (r * RPI + wave * RPW) * CROWB);
+            for (int r = 0; r < AR; ++r)
+                cglds16_asm(p.in2 + (((rbase[r] >> p.cin_shift) << p.cin2_shift) + c2), base + (r * RPI + wave * RPW) * CROWB);
+        } else {
+            const int4 te = taps_s[kidx >> p.cin_shift];
+            const int dc = te.z + (kidx & (p.Cin - 1));
+#pragma unroll
+            for (int r = 0; r < AR; ++r) {
+                const bool ok = (((rp1[r] + te.x) & (rp2[r] + te.y)) & 0x808080) == 0x808080;
+                const half_t* g = p.in + (rbase[r] + dc);
+                g = ok ? g : zlane;
+                cglds16_asm(g, base + (r * RPI + wave * RPW) * CROWB);
+            }
         }
 #pragma unroll
         for (int r = 0; r < BR; ++r) cglds16_asm(wrow[r] + kidx, base + BM * CROWB + (r * RPI + wave * RPW) * CROWB);
@@ -293,6 +304,7 @@ struct HaloParams {
     int relu;
     int tiles_n, tz, ty, tx;          // tiles per dimension
     int nblocks;
+    const half_t* in2;                // CIN2 > 0: second source [B][D][H][W][CIN2] (the block input of a projection shortcut), K columns 27 * CIN ..
 };
 
 constexpr int HTZ = 4, HTY = 4, HTX = 8, HHY = HTY + 2, HHX = HTX + 2, HROWS = (HTZ + 2) * HHY * HHX;
@@ -304,7 +316,11 @@ constexpr int HTZ = 4, HTY = 4, HTX = 8, HHY = HTY + 2, HHX = HTX + 2, HROWS = (
 // eight waves with the same wave tiles: the weights of a tap (and a smaller share of halo) are filled once per 256 rows.
 // Used for 32 -> 32, where two such workgroups still fit a CU (64 KB of LDS each): 77 -> 69 us.  At C_in = 64 (94-110 KB,
 // one workgroup per CU) it measured equal or slower, also as a persistent kernel that prefetches its next halo.
-template <int CIN, int BN, int G, int NSTAGE, int NW, int TY = 4>
+// CIN2 = 32: one more 32-deep k step behind the 27 taps -- the rows of a SECOND tensor (the residual block's input x, 32 channels) against
+// weight columns 27 * CIN .. + 32: ResidualBlock3D's 1x1x1 projection shortcut summed into conv2's accumulators (pcd_conv3d_desc_t.in2).
+// x's 128 rows (8 KB) and those 32 weight columns (4 KB) are requested with the halo, wait in registers and pass through the weight ring
+// after the last tap (no LDS of their own: two workgroups must still fit a CU).
+template <int CIN, int BN, int G, int NSTAGE, int NW, int TY = 4, int CIN2 = 0>
 __global__ __launch_bounds__(64 * NW) void conv3d_halo_kernel(HaloParams p) {
     constexpr int NT = 64 * NW;
     constexpr int HHY = TY + 2, HROWS = (HTZ + 2) * HHY * HHX, ROWS = HTZ * TY * HTX, YSH = TY == 8 ? 3 : 2;   // shadow the 128-row geometry
@@ -322,6 +338,10 @@ __global__ __launch_bounds__(64 * NW) void conv3d_halo_kernel(HaloParams p) {
     constexpr int U = (NINSTR + NW - 1) / NW;                       // DMA instructions per wave and stage (uniform, so
     constexpr int DUMP = (NINSTR % NW) ? 1024 : 0;             // the vmcnt arithmetic is: spare ones hit a dump KB)
     static_assert(27 % G == 0 && ROWS * OUT_LD <= HALO_BYTES && HALO_BYTES % 16 == 0 && NS >= NSTAGE, "layout");
+    // second source: its rows and weight columns take over the weight ring once the 27 taps are done (two workgroups per CU need <= 80 KB each)
+    constexpr int X2_OFF = HALO_BYTES, W2_OFF = X2_OFF + ROWS * 64;
+    static_assert(CIN2 == 0 || (CIN2 == 32 && ROWS * 4 % NT == 0 && BN * 4 <= NT && (ROWS + BN) * 64 <= NSTAGE * BST),
+                  "second source: 64-byte rows, one k step, inside the weight ring");
     __shared__ __attribute__((aligned(16))) char smem[HALO_BYTES + NSTAGE * BST + DUMP];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -354,6 +374,21 @@ __global__ __launch_bounds__(64 * NW) void conv3d_halo_kernel(HaloParams p) {
         okmask |= ok ? 1u << it : 0u;
         const int cz = min(max(iz, 0), p.D - 1), cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
         hv[it] = *(const half8*)(p.in + ((((int64_t)b * p.D + cz) * p.H + cy) * p.W + cx) * CIN + ch * 8);
+    }
+
+    // rows of the second source and its 32 weight columns: requested with the halo, stored behind it
+    constexpr int X2IT = CIN2 ? ROWS * 4 / NT : 1;
+    half8 x2v[X2IT], w2v;
+    if constexpr (CIN2 > 0) {
+#pragma unroll
+        for (int it = 0; it < X2IT; ++it) {
+            const int c = it * NT + tid, m = c >> 2, ch = c & 3;
+            const int x = m & 7, y = (m >> 3) & (TY - 1), z = m >> (3 + YSH);
+            x2v[it] = *(const half8*)(p.in2 + ((((int64_t)b * p.D + z0 + z) * p.H + y0 + y) * p.W + x0 + x) * CIN2 + ch * 8);
+        }
+        int nn = n0 + (tid >> 2);
+        nn = nn < p.Cout ? nn : p.Cout - 1;
+        w2v = *(const half8*)(p.w + (int64_t)nn * p.kpad + 27 * CIN + (tid & 3) * 8);
     }
 
     auto stageB = [&](int s, int buf) {
@@ -479,6 +514,34 @@ __global__ __launch_bounds__(64 * NW) void conv3d_halo_kernel(HaloParams p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[par][i], bf[par][j], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+    }
+
+    if constexpr (CIN2 > 0) {
+        // the 28th k step: second-source rows x the shortcut's weight columns, through the weight ring (every tap has been read and no
+        // DMA is in flight: the last stage was waited for two taps ago).  64-byte rows, chunk c of row r at c ^ ((-(r >> 2)) & 3) (swz<32>)
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < X2IT; ++it) {
+            const int c = it * NT + tid, m = c >> 2, ch = c & 3;
+            *(half8*)(smem + X2_OFF + m * 64 + ((ch ^ ((-(m >> 2)) & 3)) << 4)) = x2v[it];
+        }
+        if (tid < BN * 4) *(half8*)(smem + W2_OFF + (tid >> 2) * 64 + (((tid & 3) ^ ((-(tid >> 4)) & 3)) << 4)) = w2v;
+        __syncthreads();
+        half8 a2[MI], b2[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = wm * WMR + i * 16 + (lane & 15);
+            a2[i] = *(const half8*)(smem + X2_OFF + m * 64 + ((q ^ ((-(m >> 2)) & 3)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = wn * WNC + j * 16 + (lane & 15);
+            b2[j] = *(const half8*)(smem + W2_OFF + n * 64 + ((q ^ ((-(n >> 2)) & 3)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[i], b2[j], acc[i][j], 0, 0, 0);
     }
 
     // epilogue (same rounding points as conv3d_igemm_kernel): bias -> fp16 in LDS -> 16-B row stores
@@ -960,6 +1023,13 @@ static int conv_check(const pcd_conv3d_desc_t* d) {
     PCD_CHECK_ARG(d->rows_d > 0 && d->rows_h > 0 && d->rows_w > 0 && d->stride > 0);
     PCD_CHECK_ARG(d->out_scale > 0 && d->out_d > 0 && d->out_h > 0 && d->out_w > 0);
     PCD_CHECK_ARG((int64_t)d->batch * d->rows_d * d->rows_h * d->rows_w <= 0x7fffffff);
+    if (d->in2 != nullptr) {
+        // second source: the row grid is its grid, its K columns start on a K-tile boundary behind the taps
+        PCD_CHECK_ARG(d->cin2 >= 32 && (d->cin2 & (d->cin2 - 1)) == 0 && d->resid == nullptr);
+        PCD_CHECK_ARG(d->stride == 1 && d->out_scale == 1 && d->rows_d == d->in_d && d->rows_h == d->in_h && d->rows_w == d->in_w);
+        PCD_CHECK_ARG((d->ntaps * d->cin) % CBK == 0 && d->kpad >= d->ntaps * d->cin + d->cin2);
+        PCD_CHECK_ARG((int64_t)d->batch * d->in_d * d->in_h * d->in_w * d->cin2 <= 0x7fffffff);
+    }
     return PCD_OK;
 }
 
@@ -990,8 +1060,10 @@ extern "C" int pcd_conv3d_f16_multi(const pcd_conv3d_desc_t* descs, int n, void*
                       e->rows_w == d->rows_w && e->stride == d->stride && e->ntaps == d->ntaps && e->kpad == d->kpad &&
                       e->bias == d->bias && e->resid == d->resid && e->relu == d->relu && e->out == d->out &&
                       e->cout == d->cout && e->out_d == d->out_d && e->out_h == d->out_h && e->out_w == d->out_w &&
-                      e->out_scale == d->out_scale);
+                      e->out_scale == d->out_scale && e->in2 == d->in2 && e->cin2 == d->cin2);
     }
+    // the implicit GEMM reads a second source in whole K tiles, with no padding behind it
+    PCD_CHECK_ARG(d->in2 == nullptr || (d->cin2 % CBK == 0 && d->kpad == d->ntaps * d->cin + d->cin2));
     ConvParams p{};
     p.in = (const half_t*)d->in; p.D = d->in_d; p.H = d->in_h; p.W = d->in_w; p.Cin = d->cin;
     p.cin_shift = __builtin_ctz((unsigned)d->cin);
@@ -1002,6 +1074,9 @@ extern "C" int pcd_conv3d_f16_multi(const pcd_conv3d_desc_t* descs, int n, void*
     p.OD = d->out_d; p.OH = d->out_h; p.OW = d->out_w; p.os = d->out_scale;
     p.relu = d->relu;
     p.zero = (const half_t*)d->zero_page;
+    p.in2 = (const half_t*)d->in2;
+    p.cin2_shift = d->in2 ? __builtin_ctz((unsigned)d->cin2) : 0;
+    p.kt2 = d->in2 ? d->ntaps * d->cin / CBK : 0x7fffffff;
     p.nvar = n;
     for (int i = 0; i < n; ++i) {
         p.var[i].taps = descs[i].taps; p.var[i].w = (const half_t*)descs[i].w;
@@ -1054,7 +1129,8 @@ static bool halo_supported(const pcd_conv3d_desc_t* d) {
            d->cout % 8 == 0 && d->kpad >= 27 * d->cin &&
            d->rows_d == d->in_d && d->rows_h == d->in_h && d->rows_w == d->in_w && d->out_d == d->in_d &&
            d->out_h == d->in_h && d->out_w == d->in_w && d->in_d % HTZ == 0 && d->in_h % HTY == 0 &&
-           d->in_w % HTX == 0 && d->out_off_z == 0 && d->out_off_y == 0 && d->out_off_x == 0;
+           d->in_w % HTX == 0 && d->out_off_z == 0 && d->out_off_y == 0 && d->out_off_x == 0 &&
+           (d->in2 == nullptr || (d->cin == 64 && d->cout % 64 == 0 && d->cin2 == 32));
 }
 
 extern "C" int pcd_conv3d_k3s1_supported(const pcd_conv3d_desc_t* d) {
@@ -1070,6 +1146,7 @@ extern "C" int pcd_conv3d_k3s1_f16(const pcd_conv3d_desc_t* d, void* stream) {
     p.in = (const half_t*)d->in; p.B = d->batch; p.D = d->in_d; p.H = d->in_h; p.W = d->in_w;
     p.w = (const half_t*)d->w; p.kpad = d->kpad; p.bias = d->bias; p.resid = (const half_t*)d->resid;
     p.out = (half_t*)d->out; p.Cout = d->cout; p.relu = d->relu;
+    p.in2 = (const half_t*)d->in2;
     const int bn = d->cout <= 32 ? 32 : 64;
     p.tiles_n = (int)ceil_div(d->cout, bn);
     // 32 -> 32: 256-row workgroups (4 x 8 x 8 voxels, eight waves) where they still give every CU two rounds of work
@@ -1086,6 +1163,7 @@ extern "C" int pcd_conv3d_k3s1_f16(const pcd_conv3d_desc_t* d, void* stream) {
     // weight stage = one tap (three taps for 32 -> 32, where a tap is only 4 MFMAs per wave); 4 waves: the
     // 2-wave / 64 x 64 wave-tile form (fewer LDS reads per MFMA, but one wave per SIMD) measured 345 vs 304 us
     if (tall) hipLaunchKernelGGL((conv3d_halo_kernel<32, 32, 3, 4, 8, 8>), grid, blk, 0, s, p);
+    else if (d->in2 != nullptr) hipLaunchKernelGGL((conv3d_halo_kernel<64, 64, 1, 4, 4, 4, 32>), grid, blk, 0, s, p);
     else if (d->cin == 64 && bn == 64) hipLaunchKernelGGL((conv3d_halo_kernel<64, 64, 1, 4, 4>), grid, blk, 0, s, p);
     else if (d->cin == 64) hipLaunchKernelGGL((conv3d_halo_kernel<64, 32, 1, 4, 4>), grid, blk, 0, s, p);
     else if (bn == 64) hipLaunchKernelGGL((conv3d_halo_kernel<32, 64, 1, 4, 4>), grid, blk, 0, s, p);

@@ -43,7 +43,7 @@ struct Runner {
     hipStream_t s;
 
     void fill(pcd_conv3d_desc_t& c, const pcd_vae_conv_t& L, const void* in, int din, int stride, const int* taps, int ntaps,
-              int dout, int relu, const void* resid, void* out) const {
+              int dout, int relu, const void* resid, void* out, const void* in2 = nullptr, int cin2 = 0) const {
         c = pcd_conv3d_desc_t{};
         c.in = in; c.batch = batch; c.in_d = c.in_h = c.in_w = din; c.cin = L.cin;
         c.rows_d = c.rows_h = c.rows_w = dout; c.stride = stride;
@@ -52,6 +52,7 @@ struct Runner {
         c.out = out; c.cout = L.cout;
         c.out_d = c.out_h = c.out_w = dout; c.out_scale = 1;
         c.zero_page = d.zero_page;
+        c.in2 = in2; c.cin2 = in2 ? cin2 : 0;
     }
     int launch(const pcd_conv3d_desc_t* descs, int n) const {
         size_t need = pcd_conv3d_workspace_bytes(descs, n);
@@ -60,17 +61,25 @@ struct Runner {
     }
     // Conv3d(k, stride, pad) [+ residual] [+ ReLU]
     int conv(const pcd_vae_conv_t& L, const void* in, int din, int stride, const int* taps, int dout, int relu,
-             const void* resid, void* out) const {
+             const void* resid, void* out, const void* in2 = nullptr, int cin2 = 0) const {
         pcd_conv3d_desc_t c;
-        fill(c, L, in, din, stride, taps, L.k * L.k * L.k, dout, relu, resid, out);
+        fill(c, L, in, din, stride, taps, L.k * L.k * L.k, dout, relu, resid, out, in2, cin2);
         if (L.k == 3 && stride == 1 && pcd_conv3d_k3s1_supported(&c)) return pcd_conv3d_k3s1_f16(&c, s);   // LDS-resident halo
         return launch(&c, 1);
     }
-    // ResidualBlock3D: relu(bn2(conv2(relu(bn1(conv1 x)))) + (downsample(x) | x))
-    int res(const pcd_vae_res_t& R, const void* x, int dim, void* h, void* r, void* out) const {
+    // ResidualBlock3D: relu(bn2(conv2(relu(bn1(conv1 x)))) + (downsample(x) | x)).  x <- the block's output; h, r: scratch buffers.
+    int res(const pcd_vae_res_t& R, void*& x, int dim, void*& h, void*& r) const {
         int rc = conv(R.c1, x, dim, 1, d.taps3, dim, 1, nullptr, h);
         if (rc) return rc;
         const void* resid = x;
+        void* out = x;                                                // in place: conv2 reads h and the residual row it overwrites
+        if (R.has_ds && R.fused_ds) {
+            // projection shortcut inside conv2's launch: its weights are K columns behind the 27 taps, x the second source.  NOT in
+            // place: rows of x (ds.cin channels) and rows of the output (c2.cout channels) have different strides
+            rc = conv(R.c2, h, dim, 1, d.taps3, dim, 1, nullptr, r, x, R.ds.cin);
+            void* t = x; x = r; r = t;
+            return rc;
+        }
         if (R.has_ds) {
             // 1x1x1 shortcut + BN: a pointwise layer over the NDHWC rows (weights in LDS) where the shape has one
             if (pcd_conv1x1_supported(R.ds.cin, R.ds.cout))
@@ -101,7 +110,13 @@ struct Runner {
 };
 
 static bool conv_ok(const pcd_vae_conv_t& L) { return L.w && L.b && L.cin > 0 && L.cout > 0 && L.kpad > 0 && L.k > 0; }
-static bool res_ok(const pcd_vae_res_t& R) { return conv_ok(R.c1) && conv_ok(R.c2) && (!R.has_ds || conv_ok(R.ds)); }
+static bool res_ok(const pcd_vae_res_t& R) {
+    if (!conv_ok(R.c1) || !conv_ok(R.c2)) return false;
+    if (R.has_ds && R.fused_ds)
+        return R.ds.cin >= 32 && R.ds.cout == R.c2.cout && R.c2.kpad >= 27 * R.c2.cin + R.ds.cin &&
+               (R.ds.cin == 32 || R.c2.kpad == 27 * R.c2.cin + R.ds.cin);
+    return !R.has_ds || conv_ok(R.ds);
+}
 
 }  // namespace pcd
 
@@ -142,26 +157,33 @@ extern "C" size_t pcd_vae_workspace_bytes(int batch) {
         return PCD_ERR_WORKSPACE;                                                             \
     }                                                                                         \
     char* ws = (char*)workspace;                                                              \
-    void *A = ws + w.a, *B = ws + w.b, *Cc = ws + w.c;                                        \
+    void *x = ws + w.a, *hb = ws + w.b, *r = ws + w.c, *t_;  /* x: current activation; hb, r: the other two */ \
     const pcd_vae_desc_t& d = h->d;                                                           \
     hipStream_t s = (hipStream_t)stream;                                                      \
     const Runner R{d, batch, ws + w.scratch, w.scratch_bytes, s};                             \
     int rc
 #define RUN(expr) do { rc = (expr); if (rc) return rc; } while (0)
+#define SWAP(a, b) do { t_ = a; a = b; b = t_; } while (0)
 
 extern "C" int pcd_vae_encode(pcd_vae_t* h, const float* vox, int batch, float* mu_logvar, void* workspace,
                               size_t workspace_bytes, void* stream) {
     PCD_CHECK_ARG(h && vox && mu_logvar && workspace && batch > 0);
     VAE_PROLOGUE();
     // encoder.0/1: Conv3d(1, 32, k3, p1) + ReLU straight from the fp32 occupancy grid
-    RUN(pcd_conv3d_first(vox, batch, 32, 32, 32, 1, d.enc0_w, d.enc0_b, 32, A, s));
-    RUN(R.res(d.enc_res[0], A, 32, B, Cc, A));                                   // encoder.2   32 -> 64 @ 32^3   (A <- out)
-    RUN(R.conv(d.enc_down[0], A, 32, 2, d.taps4s2, 16, 1, nullptr, B));          // encoder.3/4 k4 s2 -> 16^3
-    RUN(R.res(d.enc_res[1], B, 16, A, Cc, B));                                   // encoder.5   64 -> 128
-    RUN(R.conv(d.enc_down[1], B, 16, 2, d.taps4s2, 8, 1, nullptr, A));           // encoder.6/7 -> 8^3
-    RUN(R.res(d.enc_res[2], A, 8, B, Cc, A));                                    // encoder.8   128 -> 256
-    RUN(R.conv(d.enc_down[2], A, 8, 2, d.taps4s2, 4, 1, nullptr, B));            // encoder.9/10 -> 4^3
-    RUN(R.res(d.enc_res[3], B, 4, A, Cc, B));                                    // encoder.11  256 -> 512
+    // a residual block leaves its output in x, whichever buffer that is
+    RUN(pcd_conv3d_first(vox, batch, 32, 32, 32, 1, d.enc0_w, d.enc0_b, 32, x, s));
+    RUN(R.res(d.enc_res[0], x, 32, hb, r));                                       // encoder.2   32 -> 64 @ 32^3
+    RUN(R.conv(d.enc_down[0], x, 32, 2, d.taps4s2, 16, 1, nullptr, hb));          // encoder.3/4 k4 s2 -> 16^3
+    SWAP(x, hb);
+    RUN(R.res(d.enc_res[1], x, 16, hb, r));                                       // encoder.5   64 -> 128
+    RUN(R.conv(d.enc_down[1], x, 16, 2, d.taps4s2, 8, 1, nullptr, hb));           // encoder.6/7 -> 8^3
+    SWAP(x, hb);
+    RUN(R.res(d.enc_res[2], x, 8, hb, r));                                        // encoder.8   128 -> 256
+    RUN(R.conv(d.enc_down[2], x, 8, 2, d.taps4s2, 4, 1, nullptr, hb));            // encoder.9/10 -> 4^3
+    SWAP(x, hb);
+    RUN(R.res(d.enc_res[3], x, 4, hb, r));                                        // encoder.11  256 -> 512
+    void* const B = x; void* const A = hb;                                       // below: B = encoder.11's output, A = scratch
+    (void)r;
     // encoder.12/13: k4 p0 on a 4^3 grid = one row of 32768 inputs per sample -> (B, 512).  With <= 256 samples that is the
     // weight-streaming GEMM of the latent denoiser (33.5 MB of weights against B rows), not a 128-row convolution tile
     const int k_last = d.enc_last.cin * 64;
@@ -198,17 +220,22 @@ extern "C" int pcd_vae_decode(pcd_vae_t* h, const float* z, int batch, float* ou
     pcd_gemm_desc_t g{};                                                         // decoder_input, columns already in NDHWC order
     g.a1 = z16; g.k1 = d.latent_dim; g.lda1 = d.latent_dim; g.w = d.din_w; g.ldw = d.latent_dim; g.bias = d.din_b;
     g.relu = 0; g.m = batch; g.c = 512 * 64;
-    RUN(pcd_gemm_f16(&g, A, 512 * 64, s));                                       // (B, 4,4,4, 512)
-    RUN(R.convT(d.dec_up[0], A, 4, B));                                          // decoder.0/1  512 -> 256 @ 8^3
-    RUN(R.res(d.dec_res[0], B, 8, A, Cc, B));                                    // decoder.2
-    RUN(R.convT(d.dec_up[1], B, 8, A));                                          // decoder.3/4  256 -> 128 @ 16^3
-    RUN(R.res(d.dec_res[1], A, 16, B, Cc, A));                                   // decoder.5
-    RUN(R.convT(d.dec_up[2], A, 16, B));                                         // decoder.6/7  128 -> 64 @ 32^3
-    RUN(R.res(d.dec_res[2], B, 32, A, Cc, B));                                   // decoder.8
-    RUN(R.conv(d.dec_conv9, B, 32, 1, d.taps3, 32, 1, nullptr, A));              // decoder.9/10  64 -> 32
-    RUN(R.res(d.dec_res[3], A, 32, B, Cc, A));                                   // decoder.11
-    RUN(pcd_conv3d_last_sigmoid(A, batch, 32, 32, 32, 32, d.last_w, d.last_b, out, s));   // decoder.12/13
+    RUN(pcd_gemm_f16(&g, x, 512 * 64, s));                                       // (B, 4,4,4, 512)
+    RUN(R.convT(d.dec_up[0], x, 4, hb));                                          // decoder.0/1  512 -> 256 @ 8^3
+    SWAP(x, hb);
+    RUN(R.res(d.dec_res[0], x, 8, hb, r));                                        // decoder.2
+    RUN(R.convT(d.dec_up[1], x, 8, hb));                                          // decoder.3/4  256 -> 128 @ 16^3
+    SWAP(x, hb);
+    RUN(R.res(d.dec_res[1], x, 16, hb, r));                                       // decoder.5
+    RUN(R.convT(d.dec_up[2], x, 16, hb));                                         // decoder.6/7  128 -> 64 @ 32^3
+    SWAP(x, hb);
+    RUN(R.res(d.dec_res[2], x, 32, hb, r));                                       // decoder.8
+    RUN(R.conv(d.dec_conv9, x, 32, 1, d.taps3, 32, 1, nullptr, hb));              // decoder.9/10  64 -> 32
+    SWAP(x, hb);
+    RUN(R.res(d.dec_res[3], x, 32, hb, r));                                       // decoder.11
+    RUN(pcd_conv3d_last_sigmoid(x, batch, 32, 32, 32, 32, d.last_w, d.last_b, out, s));   // decoder.12/13
     return PCD_OK;
 }
+#undef SWAP
 #undef RUN
 #undef VAE_PROLOGUE

@@ -8,6 +8,7 @@ The training surface (`calculate_loss`, `training_step`, `configure_optimizers`)
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Tuple
 
 import numpy as np
@@ -87,11 +88,20 @@ class VAE3DLarge(_HipModule):
         self.latent_dim = latent_dim
         self._build_from_spec(specs.vae3d_large_spec(latent_dim))
         self._handle = None
+        # the residual blocks' 1x1x1 projection shortcuts inside their conv2 launches (csrc/conv3d.hip, second source);
+        # PCD_VAE_FUSE_SHORTCUT=0 / set_fuse_shortcut(False): a pointwise launch + a residual read per block, as before round 4
+        self.fuse_shortcut = os.environ.get("PCD_VAE_FUSE_SHORTCUT", "1") != "0"
         # reference init_weights (networks.py:2281-2283): xavier-normal(gain 0.01) for the latent heads
         with torch.no_grad():
             for name in ("fc_mu", "fc_logvar"):
                 w = self._modules[name].weight
                 w.normal_(0.0, 0.01 * (2.0 / (w.shape[0] + w.shape[1])) ** 0.5)
+
+    def set_fuse_shortcut(self, on: bool) -> "VAE3DLarge":
+        if bool(on) != self.fuse_shortcut:
+            self.invalidate()
+            self.fuse_shortcut = bool(on)
+        return self
 
     @classmethod
     def load_from_checkpoint(cls, path, map_location="cpu", **kwargs):
@@ -168,12 +178,16 @@ class VAE3DLarge(_HipModule):
         pk["taps4p0"] = torch.from_numpy(_taps_regular(4, 0)).to(dev)
         pk["taps1"] = torch.from_numpy(_taps_regular(1, 0)).to(dev)
 
-        def conv(key, bn=None):
+        def fold(key, bn):
             w, b = g(key + ".weight"), g(key + ".bias")
             if bn is not None:
                 scale = g(bn + ".weight") / np.sqrt(g(bn + ".running_var") + packing.BN_EPS)
                 w = w * scale[:, None, None, None, None]
                 b = (b - g(bn + ".running_mean")) * scale + g(bn + ".bias")
+            return w, b
+
+        def conv(key, bn=None):
+            w, b = fold(key, bn)
             wk, b, kpad = _pack_conv(w, b)
             return {"w": _dev16(wk, dev), "b": _dev32(b, dev), "kpad": kpad, "cin": w.shape[1], "cout": w.shape[0],
                     "k": w.shape[2]}
@@ -182,6 +196,17 @@ class VAE3DLarge(_HipModule):
             d = {"c1": conv(key + ".conv1", key + ".bn1"), "c2": conv(key + ".conv2", key + ".bn2")}
             if (key + ".downsample.weight") in sd:
                 d["ds"] = conv(key + ".downsample")
+                if self.fuse_shortcut:
+                    # relu(bn2(conv2 h) + downsample(x)) = relu([gather(h) | x] . [W2 | Wds]^T + b2 + bds): the shortcut's weights as K
+                    # columns behind conv2's 27 taps, x as the launch's second source (pcd_conv3d_desc_t.in2) -- no shortcut tensor
+                    w2, b2 = fold(key + ".conv2", key + ".bn2")
+                    wd, bd = fold(key + ".downsample", None)
+                    wk = np.concatenate([np.transpose(w2, (0, 2, 3, 4, 1)).reshape(w2.shape[0], -1), wd.reshape(wd.shape[0], -1)], axis=1)
+                    kpad = (wk.shape[1] + 63) // 64 * 64
+                    wp = np.zeros((wk.shape[0], kpad))
+                    wp[:, :wk.shape[1]] = wk
+                    d["c2"] = {"w": _dev16(wp, dev), "b": _dev32(b2 + bd, dev), "kpad": kpad, "cin": w2.shape[1], "cout": w2.shape[0], "k": 3}
+                    d["fused"] = True
             return d
 
         def convT(key):
@@ -218,6 +243,7 @@ class VAE3DLarge(_HipModule):
         def rdesc(dst, R):
             cdesc(dst.c1, R["c1"]); cdesc(dst.c2, R["c2"])
             dst.has_ds = 1 if "ds" in R else 0
+            dst.fused_ds = 1 if R.get("fused") else 0
             if "ds" in R:
                 cdesc(dst.ds, R["ds"])
 

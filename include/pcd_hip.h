@@ -385,6 +385,13 @@ typedef struct {
     void* out; int cout;                                   /* fp16 [B][out_d][out_h][out_w][cout], cout % 8 == 0 */
     int out_d, out_h, out_w, out_scale, out_off_z, out_off_y, out_off_x;
     const void* zero_page;                                 /* >= 128 bytes of zeros */
+    /* optional SECOND SOURCE (NULL = none): fp16 [B][rows_d][rows_h][rows_w][cin2] on the row grid; K columns
+     * [ntaps*cin, ntaps*cin + cin2) of w multiply row m of in2 -- a 1x1x1 convolution of another tensor summed into the same
+     * accumulators, which is how ResidualBlock3D's projection shortcut (networks.py:485-490, 500-503) rides in conv2's launch:
+     * relu(bn2(conv2 h) + downsample(x)) = relu([gather(h) | x] . [W2 | Wds]^T + b2 + bds), one fp16 rounding, no shortcut
+     * tensor.  Needs stride 1, out_scale 1, rows == in dims, resid NULL, ntaps*cin % 64 == 0; the implicit GEMM takes cin2 a
+     * power of two >= 64 with kpad == ntaps*cin + cin2, the k3s1 halo kernel cin 64, cout % 64 == 0 with cin2 == 32. */
+    const void* in2; int cin2;
 } pcd_conv3d_desc_t;
 int pcd_conv3d_f16(const pcd_conv3d_desc_t* d, void* stream);
 /* n (1..8) problems in ONE launch that share everything except taps, w and out_off_* -- the 2x2x2
@@ -427,7 +434,10 @@ int pcd_reparameterize(const float* mu, const float* logvar, const float* eps, f
  * points above expect: Conv3d [cout][k^3 * cin] tap-major zero-padded to kpad; each ConvTranspose3d(k4,s2,p1) as 8
  * output-parity classes [cout][8 * cin] with their 2x2x2 tap tables (class index = 4 pz + 2 py + px). */
 typedef struct { const void* w; const float* b; int kpad, cin, cout, k; } pcd_vae_conv_t;
-typedef struct { pcd_vae_conv_t c1, c2, ds; int has_ds; } pcd_vae_res_t;              /* ResidualBlock3D */
+/* ResidualBlock3D.  fused_ds (with has_ds): c2 is [conv2 | downsample] -- kpad >= 27*c2.cin + ds.cin, the shortcut's folded weights in the
+ * K columns behind the 27 taps, c2.b = b2 + b_ds -- and the block runs as two launches (pcd_conv3d_desc_t.in2); ds.cin / ds.cout describe
+ * the shortcut, ds.w / ds.b are not read. */
+typedef struct { pcd_vae_conv_t c1, c2, ds; int has_ds; int fused_ds; } pcd_vae_res_t;
 typedef struct { const void* w[8]; const int* taps[8]; const float* b; int cin, cout; } pcd_vae_convT_t;
 typedef struct {
     int latent_dim;

@@ -132,6 +132,71 @@ def test_conv3d_k3s1_halo_exact(cin, cout, dims, b):
     assert lib.pcd_conv3d_k3s1_supported(d) == 0 and lib.pcd_conv3d_k3s1_f16(d, _lib.stream_ptr()) != 0
 
 
+@pytest.mark.parametrize("cin,cout,cin2,dims,b,split", [(64, 128, 64, (4, 8, 8), 2, False), (128, 256, 128, (4, 4, 4), 1, True),
+                                                         (64, 72, 64, (5, 3, 7), 3, False), (64, 64, 32, (4, 8, 16), 4, False),
+                                                         (64, 128, 32, (8, 4, 8), 3, False)])
+def test_conv3d_second_source_exact(cin, cout, cin2, dims, b, split):
+    """ResidualBlock3D's projection shortcut inside conv2's launch (pcd_conv3d_desc_t.in2; reference networks.py:485-490, 500-503):
+    relu(conv3(h) + conv1(x) + bias) with x as the second source, on exactly representable integers -- the implicit GEMM (cin2 in whole
+    K tiles, split-K too) and the k3s1 halo kernel (cin 64, cin2 32: the extra k step through the weight ring; one and two C_out tiles)."""
+    from shapegen_amd import _lib
+    from shapegen_amd.vae import _pack_conv, _taps_regular
+    lib = _lib.load()
+    h, x = _int((b, cin) + dims, 31), _int((b, cin2) + dims, 32)
+    w, wd, bias = _int((cout, cin, 3, 3, 3), 33, -1, 2), _int((cout, cin2, 1, 1, 1), 34, -1, 2), _int((cout,), 35)
+    want = (F.conv3d(h.double(), w.double(), bias.double(), padding=1) + F.conv3d(x.double(), wd.double())).clamp_min(0).half().double()
+    wk = np.concatenate([_pack_conv(w.double().numpy(), None)[0][:, :27 * cin], wd.double().numpy().reshape(cout, cin2)], axis=1)
+    kpad = (wk.shape[1] + 63) // 64 * 64
+    wp = np.zeros((cout, kpad)); wp[:, :wk.shape[1]] = wk
+    dh = h.permute(0, 2, 3, 4, 1).contiguous().half().cuda()
+    dx = x.permute(0, 2, 3, 4, 1).contiguous().half().cuda()
+    dw, db = torch.from_numpy(wp).half().cuda(), bias.cuda()
+    taps = torch.from_numpy(_taps_regular(3, 1)).cuda()
+    zero = torch.zeros(64, dtype=torch.float16, device="cuda")
+    out = torch.full((b * dims[0] * dims[1] * dims[2], cout), 9.0, dtype=torch.float16, device="cuda")
+    d = _lib.Conv3dDesc()
+    d.inp, d.batch, d.in_d, d.in_h, d.in_w, d.cin = dh.data_ptr(), b, dims[0], dims[1], dims[2], cin
+    d.rows_d, d.rows_h, d.rows_w = dims
+    d.out_d, d.out_h, d.out_w = dims
+    d.stride, d.taps, d.ntaps, d.kpad = 1, taps.data_ptr(), 27, kpad
+    d.w, d.bias, d.relu = dw.data_ptr(), db.data_ptr(), 1
+    d.out, d.cout, d.out_scale, d.zero_page = out.data_ptr(), cout, 1, zero.data_ptr()
+    d.in2, d.cin2 = dx.data_ptr(), cin2
+    halo = cin2 == 32
+    assert lib.pcd_conv3d_k3s1_supported(d) == (1 if halo else 0)
+    if halo:
+        _lib.check(lib.pcd_conv3d_k3s1_f16(d, _lib.stream_ptr()))
+        assert lib.pcd_conv3d_f16(d, _lib.stream_ptr()) != 0            # the implicit GEMM takes whole K tiles only
+    elif split:
+        need = int(lib.pcd_conv3d_workspace_bytes(d, 1))
+        assert need > 0
+        ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+        _lib.check(lib.pcd_conv3d_f16_multi(d, 1, ws.data_ptr(), need, _lib.stream_ptr()))
+    else:
+        _lib.check(lib.pcd_conv3d_f16(d, _lib.stream_ptr()))
+    got = out.float().cpu().reshape((b,) + dims + (cout,)).permute(0, 4, 1, 2, 3).double()
+    assert torch.equal(got, want)
+    d.resid = dh.data_ptr()                                               # a residual on top of a second source is refused
+    assert lib.pcd_conv3d_f16(d, _lib.stream_ptr()) != 0 and lib.pcd_conv3d_k3s1_supported(d) == 0
+
+
+def test_vae_fused_shortcut_matches_the_separate_launches(ldm):
+    """The encoder with the projection shortcuts inside conv2 (default) against the same weights run as pointwise launch + residual read:
+    same function, one fp16 rounding fewer per block -- mu / logvar agree to 2e-3, and both forms stay inside the golden bound (above)."""
+    vox = synth_voxels(8, 5).cuda()
+    assert ldm.vae.fuse_shortcut
+    mu_f, lv_f = ldm.vae.encode(vox)
+    try:
+        mu_s, lv_s = ldm.vae.set_fuse_shortcut(False).encode(vox)
+    finally:
+        ldm.vae.set_fuse_shortcut(True)
+    r = rel_l2(mu_f.cpu(), mu_s.cpu()), rel_l2(lv_f.cpu(), lv_s.cpu())
+    print(f"fused v. separate shortcut launches: mu {r[0]:.2e} logvar {r[1]:.2e}")
+    assert 0 < r[0] < 2e-3 and 0 < r[1] < 2e-3
+    mu2, _ = ldm.vae.encode(vox)
+    assert torch.equal(mu2, mu_f)
+
+
 @pytest.mark.parametrize("k,c,ldw,m,relu", [(32, 64, 64, 1000, 0), (32, 64, 32, 77, 1), (64, 128, 64, 4096 + 31, 0),
                                             (128, 256, 128, 515, 0), (128, 256, 192, 128, 1)])
 def test_conv1x1_pointwise_exact_integers(k, c, ldw, m, relu):
