@@ -586,6 +586,185 @@ __global__ __launch_bounds__(64 * NW) void conv3d_halo_kernel(HaloParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// ConvTranspose3d(k4, s2, p1) + ReLU, C_in = 128 -> C_out = 64 (decoder.6, reference networks.py:2253), with the input halo in LDS.
+// As eight output-parity classes through the implicit GEMM above this layer is a 128 x 64 tile per class (43 FLOP per gathered
+// byte) and every input voxel is fetched 8 x 8 times: 556 TFLOP/s.  Here a workgroup owns 4 x 4 x 8 INPUT voxels, loads their
+// 6 x 6 x 10 halo (offsets -1 .. +1 cover every class: o = 2 i - 1 + k) ONCE -- 92 KB -- and computes all eight classes
+// (8 x 128 output voxels x 64 channels) from it; only the weights stream (1 MB per workgroup, 16-KB stages in a ring of four).
+//   * eight waves: two classes at a time (px = 0 / 1 of one (pz, py) pair), four waves per class as 2 voxel halves x 2 channel
+//     halves, wave tile 64 voxels x 32 channels;
+//   * the product is taken TRANSPOSED, D[channel][voxel] (weights = MFMA A operand, voxels = B), so a lane's accumulators are
+//     four consecutive channels of one voxel: two 16-channel blocks trade halves (v_permlane16_swap) and every lane stores
+//     16 contiguous bytes of an output row -- no LDS staging, so the weight ring keeps streaming through the epilogues;
+//   * halo image: voxel v = (hz * 6 + hy) * 10 + hx at v * 256 B (one 64-bank row per voxel), its 16-byte chunk c at slot
+//     c ^ ((hx & 7) << 1): a ds_read_b128 lane group holds 8 voxels with chunk c and 8 with chunk c ^ 1 (MI355X_MICROARCH.md, LDS),
+//     the 16 voxels of an MFMA block have 8 distinct x twice, so the slots are 16 distinct ones for every tap shift;
+//   * weight stage = one tap x one 64-channel half of K x two classes (2 x 64 rows of 128 B, the swz<64> of the GEMM),
+//     requested three stages ahead, counted vmcnt (the epilogue's four stores per wave are counted too).
+struct ConvTHaloParams {
+    const half_t* in; int B, D, H, W;
+    const half_t* w[8];               // class 4 pz + 2 py + px: [64][8 * 128], tap t = (tz * 2 + ty) * 2 + tx reads input offset p - t per axis
+    const float* bias;
+    half_t* out;                      // [B][2D][2H][2W][64]
+    int tz, ty, tx, nblocks;
+};
+
+__global__ __launch_bounds__(512) void convT3d_halo_kernel(ConvTHaloParams p) {
+    constexpr int CIN = 128, COUT = 64, VB = CIN * 2, NW = 8, NT = 512, NSTAGE = 4;
+    constexpr int HALO_BYTES = HROWS * VB;                   // 360 voxels x 256 B
+    constexpr int BST = 2 * COUT * 128;                      // stage: 2 classes x 64 rows x 64 k
+    constexpr int U = BST / 1024 / NW;                       // DMA instructions per wave and stage (2)
+    constexpr int NSTG = 64;                                 // 4 class pairs x 8 taps x 2 K halves
+    constexpr int HIT = (HROWS * 16 + NT - 1) / NT;
+    constexpr int NSTORE = 4;                                // epilogue stores per wave and class pair
+    static_assert(U * NW * 1024 == BST && HALO_BYTES + NSTAGE * BST <= 160 * 1024, "layout");
+    __shared__ __attribute__((aligned(16))) char smem[HALO_BYTES + NSTAGE * BST];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cw = wave >> 2, wv = (wave >> 1) & 1, wc = wave & 1;   // class in the pair (= px), voxel half, channel half
+    int bid = blockIdx.x;
+    if ((p.nblocks & 7) == 0) bid = (bid & 7) * (p.nblocks >> 3) + (bid >> 3);
+    int t = bid;
+    const int tx = t % p.tx; t /= p.tx;
+    const int ty = t % p.ty; t /= p.ty;
+    const int tz = t % p.tz; const int b = t / p.tz;
+    const int z0 = tz * HTZ, y0 = ty * HTY, x0 = tx * HTX;
+
+    // ---- halo: global -> registers (all loads in flight) -> LDS
+    half8 hv[HIT];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+        const int c = it * NT + tid;
+        const int row = c >> 4, ch = c & 15;
+        const int hx = row % HHX; const int r2 = row / HHX;
+        const int hy = r2 % HHY, hz = r2 / HHY;
+        const int iz = z0 - 1 + hz, iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const bool ok = row < HROWS && (unsigned)iz < (unsigned)p.D && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        okmask |= ok ? 1u << it : 0u;
+        const int cz = min(max(iz, 0), p.D - 1), cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
+        hv[it] = *(const half8*)(p.in + ((((int64_t)b * p.D + cz) * p.H + cy) * p.W + cx) * CIN + ch * 8);
+    }
+
+    const int q = lane >> 4, n16 = lane & 15;
+    float bv[2][4];                                    // bias of this lane's channels (requested before any DMA: older in vmcnt order)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[i][r] = p.bias != nullptr ? p.bias[wc * 32 + i * 16 + q * 4 + r] : 0.f;
+
+    // stage S = (pair, tap, K half): instruction it = wave + 8 u covers rows it * 8 .. + 7 of the 128 (class u, channels (wave * 8 ..) + lane / 8)
+    auto stageW = [&](int S, int buf) {
+        const int pair = S >> 4, tap = (S >> 1) & 7, kh = S & 1;
+        char* base = smem + HALO_BYTES + buf * BST;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int n = wave * 8 + (lane >> 3);
+            const int lch = (lane & 7) ^ ((n >> 1) & 7);
+            cglds16_asm(p.w[2 * pair + u] + n * (8 * CIN) + tap * CIN + kh * 64 + lch * 8, base + (wave + NW * u) * 1024);
+        }
+    };
+    stageW(0, 0);
+    stageW(1, 1);
+    stageW(2, 2);
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+        const int c = it * NT + tid;
+        const int row = c >> 4, ch = c & 15;
+        const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int hx = row % HHX;
+        if (row < HROWS) *(half8*)(smem + row * VB + ((ch ^ ((hx & 7) << 1)) << 4)) = (okmask >> it) & 1 ? hv[it] : zero8;
+    }
+
+    // voxel blocks of this wave: j -> (z = 2 wv + (j >> 1), y = 2 (j & 1) + (n16 >> 3), x = n16 & 7); halo voxel without a tap = + (1, 1, 1)
+    const int vx = n16 & 7;
+    int vrow[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vrow[j] = (((2 * wv + (j >> 1) + 1) * HHY + 2 * (j & 1) + (n16 >> 3) + 1) * HHX + vx + 1) * VB;
+    // weight rows of this wave in a stage: class cw, channels wc * 32 + i * 16 + n16
+    int wrow[2], wsw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int n = wc * 32 + i * 16 + n16;
+        wrow[i] = HALO_BYTES + (cw * COUT + n) * 128;
+        wsw[i] = (n >> 1) & 7;
+    }
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    conv_wait_vmcnt<2 * U>();                          // stage 0 (and, before it, the halo loads) landed; stages 1, 2 in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const int OD = 2 * p.D, OH = 2 * p.H, OW = 2 * p.W;
+#pragma unroll 1
+    for (int pair = 0; pair < 4; ++pair) {
+        const int pz = pair >> 1, py = pair & 1, px = cw;
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            const int S = pair * 16 + st;
+            if (S + 1 < NSTG) {
+                // publish stage S + 1: behind it at most stage S + 2 (and, right after a pair's epilogue, that epilogue's stores) may stay in flight
+                if (st < 2) {
+                    if (pair > 0) conv_wait_vmcnt<U + NSTORE>(); else conv_wait_vmcnt<U>();
+                } else if (st == 14 && pair == 3) {
+                    conv_wait_vmcnt<0>();
+                } else {
+                    conv_wait_vmcnt<U>();
+                }
+                __builtin_amdgcn_s_barrier();
+                if (S + 3 < NSTG) stageW(S + 3, (S + 3) & 3);
+            }
+            const int tap = st >> 1, kh = st & 1;
+            const int dz = pz - (tap >> 2), dy = py - ((tap >> 1) & 1), dx = px - (tap & 1);
+            const int voff = ((dz * HHY + dy) * HHX + dx) * VB;
+            const int sw = ((vx + 1 + dx) & 7) << 1;
+            const char* wb = smem + (S & 3) * BST;
+#pragma unroll
+            for (int ksl = 0; ksl < 2; ++ksl) {
+                half8 af[2], bf[4];
+                const int kc = (kh * 2 + ksl) * 4 + q;                     // 16-byte chunk of the voxel's 128 channels
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[i] = *(const half8*)(wb + wrow[i] + (((ksl * 4 + q) ^ wsw[i]) << 4));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[j] = *(const half8*)(smem + vrow[j] + voff + ((kc ^ sw) << 4));
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        // epilogue of the pair: bias, ReLU, fp16; channel blocks 0 / 1 trade halves, lane group q stores 8 consecutive channels of
+        // block (q & 1) at offset 8 * (q >> 1) of its voxel's output row
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned pk[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+                half2_t lo2, hi2;
+                lo2[0] = to_half_sat(fmaxf(acc[i][j][0] + bv[i][0], 0.f)); lo2[1] = to_half_sat(fmaxf(acc[i][j][1] + bv[i][1], 0.f));
+                hi2[0] = to_half_sat(fmaxf(acc[i][j][2] + bv[i][2], 0.f)); hi2[1] = to_half_sat(fmaxf(acc[i][j][3] + bv[i][3], 0.f));
+                pk[i][0] = __builtin_bit_cast(unsigned, lo2);
+                pk[i][1] = __builtin_bit_cast(unsigned, hi2);
+                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+            const int z = 2 * wv + (j >> 1), y = 2 * (j & 1) + (n16 >> 3);
+            const int64_t orow = (((int64_t)b * OD + 2 * (z0 + z) + pz) * OH + 2 * (y0 + y) + py) * OW + 2 * (x0 + vx) + px;
+            *(u32x4*)(p.out + orow * COUT + wc * 32 + (q & 1) * 16 + (q >> 1) * 8) = o;
+        }
+    }
+}
+
 // split-K finish: sum the slabs in split order (deterministic), then the same epilogue as above.
 // thread = (variant, row, 8-column chunk)
 __global__ __launch_bounds__(256) void conv3d_finish_kernel(ConvParams p) {
@@ -1168,6 +1347,31 @@ extern "C" int pcd_conv3d_k3s1_f16(const pcd_conv3d_desc_t* d, void* stream) {
     else if (d->cin == 64) hipLaunchKernelGGL((conv3d_halo_kernel<64, 32, 1, 4, 4>), grid, blk, 0, s, p);
     else if (bn == 64) hipLaunchKernelGGL((conv3d_halo_kernel<32, 64, 1, 4, 4>), grid, blk, 0, s, p);
     else hipLaunchKernelGGL((conv3d_halo_kernel<32, 32, 3, 4, 4>), grid, blk, 0, s, p);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_convt3d_k4s2_halo_supported(int batch, int d, int h, int w, int cin, int cout) {
+    return batch > 0 && cin == 128 && cout == 64 && d > 0 && h > 0 && w > 0 && d % HTZ == 0 && h % HTY == 0 && w % HTX == 0 &&
+           (int64_t)batch * d * h * w * 8 * cout <= 0x7fffffff ? 1 : 0;
+}
+
+extern "C" int pcd_convt3d_k4s2_halo_f16(const void* in, int batch, int d, int h, int w, int cin, const void* const* w8, const float* bias,
+                                         int cout, void* out, void* stream) {
+    PCD_CHECK_ARG(in && w8 && out);
+    PCD_CHECK_ARG(pcd_convt3d_k4s2_halo_supported(batch, d, h, w, cin, cout));
+    ConvTHaloParams p{};
+    p.in = (const half_t*)in; p.B = batch; p.D = d; p.H = h; p.W = w;
+    for (int k = 0; k < 8; ++k) {
+        PCD_CHECK_ARG(w8[k] != nullptr);
+        p.w[k] = (const half_t*)w8[k];
+    }
+    p.bias = bias; p.out = (half_t*)out;
+    p.tz = d / HTZ; p.ty = h / HTY; p.tx = w / HTX;
+    const int64_t blocks = (int64_t)batch * p.tz * p.ty * p.tx;
+    PCD_CHECK_ARG(blocks <= 0x7fffffff);
+    p.nblocks = (int)blocks;
+    hipLaunchKernelGGL(convT3d_halo_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, p);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

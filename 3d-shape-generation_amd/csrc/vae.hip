@@ -35,6 +35,8 @@ static VaeWs vae_carve(int batch) {
     return w;
 }
 
+static int g_convt_halo = 1;     // pcd_vae_config: 0 = decoder.6 as eight implicit-GEMM class launches (A/B, tests)
+
 struct Runner {
     const pcd_vae_desc_t& d;
     int batch;
@@ -93,6 +95,9 @@ struct Runner {
     }
     // ConvTranspose3d(k4, s2, p1) + ReLU: the 8 output-parity classes (2x2x2 taps each) in one launch
     int convT(const pcd_vae_convT_t& T, const void* in, int din, void* out) const {
+        // decoder.6 (128 -> 64, 16^3 -> 32^3): all eight classes from one LDS-resident input halo
+        if (g_convt_halo && pcd_convt3d_k4s2_halo_supported(batch, din, din, din, T.cin, T.cout))
+            return pcd_convt3d_k4s2_halo_f16(in, batch, din, din, din, T.cin, T.w, T.b, T.cout, out, s);
         pcd_conv3d_desc_t c[8];
         for (int k = 0; k < 8; ++k) {
             c[k] = pcd_conv3d_desc_t{};
@@ -121,6 +126,12 @@ static bool res_ok(const pcd_vae_res_t& R) {
 }  // namespace pcd
 
 using namespace pcd;
+
+extern "C" int pcd_vae_config(int convt_halo) {
+    PCD_CHECK_ARG(convt_halo == 0 || convt_halo == 1);
+    g_convt_halo = convt_halo;
+    return PCD_OK;
+}
 
 extern "C" int pcd_vae_create(const pcd_vae_desc_t* desc, pcd_vae_t** out) {
     PCD_CHECK_ARG(desc != nullptr && out != nullptr);

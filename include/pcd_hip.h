@@ -415,6 +415,16 @@ int pcd_conv3d_config(int tall_halo_tiles);
  * dims multiples of (4, 4, 8), out_scale 1; pcd_conv3d_k3s1_supported() tells (1/0), unsupported -> PCD_ERR_ARG. */
 int pcd_conv3d_k3s1_supported(const pcd_conv3d_desc_t* d);
 int pcd_conv3d_k3s1_f16(const pcd_conv3d_desc_t* d, void* stream);
+/* ConvTranspose3d(k4, s2, p1) + ReLU (decoder.6/7, networks.py:2253-2254) with the 6 x 6 x 10 input halo of a 4 x 4 x 8 block of INPUT
+ * voxels in LDS and all eight output-parity classes computed from it (csrc/conv3d.hip: convT3d_halo_kernel): in fp16 [B][d][h][w][cin],
+ * out fp16 [B][2d][2h][2w][cout].  w8[4 pz + 2 py + px] = that class's fp16 [cout][8 * cin] matrix, K column (tz * 2 + tz... tap t) * cin + c
+ * with t = (tz * 2 + ty) * 2 + tx, tap t_axis of parity p_axis reading input offset p - t (kernel index 1 + 2 t - p ... i.e. o = 2 i - 1 + k:
+ * parity 0 -> k = 1, 3 at offsets 0, -1; parity 1 -> k = 0, 2 at offsets +1, 0) -- the layout pcd_vae_convT_t carries.  Supported:
+ * cin 128, cout 64, dims multiples of (4, 4, 8); pcd_convt3d_k4s2_halo_supported() tells (1 / 0), unsupported -> PCD_ERR_ARG.
+ * Same sums as the eight pcd_conv3d_f16 class launches in another order (fp32 accumulation; exact on integer operands). */
+int pcd_convt3d_k4s2_halo_supported(int batch, int d, int h, int w, int cin, int cout);
+int pcd_convt3d_k4s2_halo_f16(const void* in, int batch, int d, int h, int w, int cin, const void* const* w8, const float* bias,
+                              int cout, void* out, void* stream);
 /* encoder.0: Conv3d(1, cout, k3, stride 1|2, p1) (+ folded BN) + ReLU straight from the fp32 occupancy
  * grid x [B][D][H][W]; w fp32 [cout][27], out fp16 NDHWC (VAE3DLarge networks.py:2226, VAE3D :1999). */
 int pcd_conv3d_first(const float* x, int batch, int d, int h, int w, int stride, const float* wgt,
@@ -456,6 +466,8 @@ typedef struct {
 } pcd_vae_desc_t;
 typedef struct pcd_vae pcd_vae_t;
 int pcd_vae_create(const pcd_vae_desc_t* desc, pcd_vae_t** out);
+/* testing / tuning hook: 1 (default) = decoder.6 through pcd_convt3d_k4s2_halo_f16, 0 = as eight implicit-GEMM class launches */
+int pcd_vae_config(int convt_halo);
 void pcd_vae_destroy(pcd_vae_t* h);
 size_t pcd_vae_workspace_bytes(int batch);
 /* vox fp32 [B][1][32][32][32] in [0,1] -> mu_logvar fp32 [B][2*latent] = [mu | logvar] */

@@ -306,6 +306,73 @@ def test_conv_transpose3d_classes_exact():
     assert lib.pcd_conv3d_f16_multi(arr, 8, ws.data_ptr(), need, _lib.stream_ptr()) != 0
 
 
+@pytest.mark.parametrize("dims,b", [((4, 4, 8), 1), ((8, 4, 16), 3), ((8, 8, 8), 8)])
+def test_conv_transpose3d_halo_exact(dims, b):
+    """decoder.6's kernel (C_in 128 -> C_out 64; input halo in LDS, all eight parity classes per workgroup, transposed product with
+    16-byte direct stores) against F.conv_transpose3d on exactly representable integers: every border, non-cubic grids, block counts that
+    are and are not multiples of 8 (XCD remap), and bit-identical to the eight implicit-GEMM class launches."""
+    import ctypes as C
+    from shapegen_amd import _lib
+    from shapegen_amd.vae import _pack_convT_class
+    lib = _lib.load()
+    cin, cout = 128, 64
+    x, w, bias = _int((b, cin) + dims, 41), _int((cin, cout, 4, 4, 4), 42, -1, 2), _int((cout,), 43)
+    want = F.conv_transpose3d(x.double(), w.double(), bias.double(), stride=2, padding=1).clamp_min(0).half().double()
+    dx = x.permute(0, 2, 3, 4, 1).contiguous().half().cuda()
+    db = bias.cuda()
+    odims = tuple(2 * v for v in dims)
+    nvox = b * odims[0] * odims[1] * odims[2]
+    out = torch.full((nvox, cout), 5.0, dtype=torch.float16, device="cuda")
+    keep, ptrs, descs = [], (C.c_void_p * 8)(), []
+    zero = torch.zeros(64, dtype=torch.float16, device="cuda")
+    out2 = torch.empty_like(out)
+    for pz in (0, 1):
+        for py in (0, 1):
+            for px in (0, 1):
+                wc, taps = _pack_convT_class(w.double().numpy(), pz, py, px)
+                dw, dt = torch.from_numpy(wc).half().cuda(), torch.from_numpy(taps).cuda()
+                keep += [dw, dt]
+                ptrs[4 * pz + 2 * py + px] = dw.data_ptr()
+                d = _lib.Conv3dDesc()
+                d.inp, d.batch, d.in_d, d.in_h, d.in_w, d.cin = dx.data_ptr(), b, dims[0], dims[1], dims[2], cin
+                d.rows_d, d.rows_h, d.rows_w = dims
+                d.stride, d.taps, d.ntaps, d.kpad = 1, dt.data_ptr(), 8, 8 * cin
+                d.w, d.bias, d.relu = dw.data_ptr(), db.data_ptr(), 1
+                d.out, d.cout = out2.data_ptr(), cout
+                d.out_d, d.out_h, d.out_w = odims
+                d.out_scale, d.out_off_z, d.out_off_y, d.out_off_x = 2, pz, py, px
+                d.zero_page = zero.data_ptr()
+                descs.append(d)
+    assert lib.pcd_convt3d_k4s2_halo_supported(b, dims[0], dims[1], dims[2], cin, cout) == 1
+    _lib.check(lib.pcd_convt3d_k4s2_halo_f16(dx.data_ptr(), b, dims[0], dims[1], dims[2], cin, ptrs, db.data_ptr(), cout, out.data_ptr(),
+                                             _lib.stream_ptr()))
+    got = out.float().cpu().reshape((b,) + odims + (cout,)).permute(0, 4, 1, 2, 3).double()
+    assert torch.equal(got, want)
+    arr = (_lib.Conv3dDesc * 8)(*descs)
+    _lib.check(lib.pcd_conv3d_f16_multi(arr, 8, None, 0, _lib.stream_ptr()))
+    assert torch.equal(out, out2)
+    assert lib.pcd_convt3d_k4s2_halo_supported(b, dims[0], dims[1], dims[2] + 4, cin, cout) == 0
+    assert lib.pcd_convt3d_k4s2_halo_supported(b, dims[0], dims[1], dims[2], 64, cout) == 0
+    assert lib.pcd_convt3d_k4s2_halo_f16(dx.data_ptr(), b, dims[0], dims[1], dims[2], 64, ptrs, db.data_ptr(), cout, out.data_ptr(), 0) != 0
+
+
+def test_vae_decode_halo_transposed_convolution_matches_the_class_launches(ldm):
+    """decoder.6 through the LDS-halo kernel (default) against the eight implicit-GEMM class launches inside the whole decode: the same fp16
+    products summed in fp32 in another order, one fp16 rounding either way -- decoded probabilities agree to 2e-3 (measured below)."""
+    from shapegen_amd import _lib
+    lib = _lib.load()
+    z = torch.randn(8, 256, generator=torch.Generator().manual_seed(77)).cuda()
+    a = ldm.vae.decode(z).clone()
+    _lib.check(lib.pcd_vae_config(0))
+    try:
+        c = ldm.vae.decode(z).clone()
+    finally:
+        _lib.check(lib.pcd_vae_config(1))
+    err = (a - c).abs()
+    print(f"decode: halo transposed convolution v. class launches: max {float(err.max()):.2e} mean {float(err.mean()):.2e}")
+    assert float(err.max()) < 2e-3 and torch.equal(ldm.vae.decode(z), a)
+
+
 def test_latent_unet_forward(ldm, golden):
     g = golden("latent.npz")
     eps = ldm.model(torch.from_numpy(g["lat_z"]).cuda(), torch.from_numpy(g["lat_t"]).cuda()).cpu()

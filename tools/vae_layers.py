@@ -33,6 +33,11 @@ def passes(rows):
         else: groups.append([n, (e - s) / 1000, 1])
     return groups
 g = passes(rows)
+if not any("pw_1x1" in x[0] for x in g):
+    # shortcuts fused into conv2 (second K source): no shortcut launches; their FLOPs belong to conv2
+    sc = {lab.split()[0]: fl for lab, fl, _ in ENC if "shortcut" in lab}
+    ENC = [(lab + (" + shortcut" if "conv2" in lab and lab.split()[0] in sc else ""), fl + (sc.get(lab.split()[0], 0) if "conv2" in lab else 0), x)
+           for lab, fl, x in ENC if "shortcut" not in lab]
 # last decode starts at the last 'gemm_f16_kernel<128, 128, 2, 2, 2, 0' (decoder_input); encode starts at conv3d_first
 names = [x[0] for x in g]
 di = max(i for i, n in enumerate(names) if "gemm_f16_kernel" in n and ", 0, 64>" in n)
