@@ -765,6 +765,209 @@ __global__ __launch_bounds__(512) void convT3d_halo_kernel(ConvTHaloParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Conv3d(k4, s2, p1) + ReLU, C_in = 64 -> C_out = 64 (encoder.3, reference networks.py:2229), with LDS-resident input.
+// Through the implicit GEMM this layer is a 128 x 64 tile at 43 FLOP per gathered byte (every input voxel fetched 8 times, every
+// tile re-gathering its 64 taps): 584 TFLOP/s, the slowest large layer of the encoder.  The stride-2 kernel splits by INPUT parity:
+// out(o) = sum_k in(2 o - 1 + k) w(k), and per axis the even inputs are reached by k = 1, 3 at sub-grid index o, o + 1, the odd ones
+// by k = 0, 2 at o - 1, o -- eight classes, each a 2 x 2 x 2 stride-1 convolution of one sub-sampled grid, all summed into the SAME
+// output.  A workgroup owns 4 x 4 x 8 output voxels; per class it holds the 5 x 5 x 9 sub-grid halo (input voxel 2 (o0 + h) - parity,
+// in the 6 x 10 pitch and with the swizzle of conv3d_halo_kernel's C_in = 64 image, so the same conflict-free fragment reads)
+// and runs the class's 8 taps from it; the next class's halo is requested at the class's first tap (into registers) and swapped in
+// behind one barrier; the weights stream through the same ring of four 8-KB stages over all 64 (class, tap) stages; the product
+// is taken transposed with 16-byte direct stores like convT3d_halo_kernel.  70 KB of LDS: two workgroups per CU, the other one
+// computes through this one's halo swaps.
+struct ConvS2HaloParams {
+    const half_t* in; int B, D, H, W;    // input grid (even dims); output grid D/2 x H/2 x W/2
+    const half_t* w; int kpad;            // [64][kpad], k = ((kz * 4 + ky) * 4 + kx) * 64 + c
+    const float* bias;
+    half_t* out;
+    int relu;
+    int tz, ty, tx, nblocks;
+};
+
+__global__ __launch_bounds__(256) void conv3d_k4s2_halo_kernel(ConvS2HaloParams p) {
+    constexpr int CIN = 64, COUT = 64, P = CIN * 2, NW = 4, NT = 256, NSTAGE = 4;
+    constexpr int HALO_BYTES = HROWS * P;                    // the 6 x 6 x 10 pitch of the stride-1 kernels (5 x 5 x 9 voxels used)
+    constexpr int BST = COUT * P;                            // one tap: 64 rows x 128 B
+    constexpr int U = BST / 1024 / NW;                       // DMA instructions per wave and stage (2)
+    constexpr int NSTG = 64;                                 // 8 classes x 8 taps
+    constexpr int SV = 5 * 5 * 9, HIT = (SV * 8 + NT - 1) / NT;   // sub-halo voxels; 16-byte chunks per thread (8)
+    __shared__ __attribute__((aligned(16))) char smem[HALO_BYTES + NSTAGE * BST];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                 // voxel half (64 of the 128), channel half
+    int bid = blockIdx.x;
+    if ((p.nblocks & 7) == 0) bid = (bid & 7) * (p.nblocks >> 3) + (bid >> 3);
+    int t = bid;
+    const int tx = t % p.tx; t /= p.tx;
+    const int ty = t % p.ty; t /= p.ty;
+    const int tz = t % p.tz; const int b = t / p.tz;
+    const int z0 = tz * HTZ, y0 = ty * HTY, x0 = tx * HTX;   // output block origin
+
+    // this thread's chunks of a class's sub-halo: chunk c = it * 256 + tid -> voxel c >> 3 = (hz * 5 + hy) * 9 + hx, 16-byte piece c & 7.
+    // Everything that does not depend on the class is worked out once: the chunk's element offset for class (0, 0, 0) (input voxel 2 (o0 + h)),
+    // its LDS address, and six validity bits (per axis: index 2 (o0 + h) inside the grid for an even class / 2 (o0 + h) - 1 for an odd one);
+    // class (cz, cy, cx) then reads (cz H W + cy W + cx) C_in elements earlier
+    half8 hv[HIT];
+    int hoff[HIT], hlds[HIT];
+    unsigned hflags = 0;                                     // 6 bits per chunk... packed 4 chunks per word would not fit: one word per axis pair below
+    unsigned fz = 0, fy = 0, fx = 0;                         // bit 2 it: even class valid, bit 2 it + 1: odd class valid
+    (void)hflags;
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+        const int c = it * NT + tid;
+        const int v = c >> 3, ch = c & 7;
+        const int hx = v % 9; const int r2 = v / 9;
+        const int hy = r2 % 5, hz = r2 / 5;
+        const int iz = 2 * (z0 + hz), iy = 2 * (y0 + hy), ix = 2 * (x0 + hx);
+        const bool real = v < SV;
+        fz |= ((real && iz < p.D) ? 1u : 0u) << (2 * it) | ((real && iz >= 1 && iz - 1 < p.D) ? 2u : 0u) << (2 * it);
+        fy |= ((iy < p.H) ? 1u : 0u) << (2 * it) | ((iy >= 1 && iy - 1 < p.H) ? 2u : 0u) << (2 * it);
+        fx |= ((ix < p.W) ? 1u : 0u) << (2 * it) | ((ix >= 1 && ix - 1 < p.W) ? 2u : 0u) << (2 * it);
+        hoff[it] = (((b * p.D + iz) * p.H + iy) * p.W + ix) * CIN + ch * 8;
+        const int sw = (((hx >> 1) & 1) << 1) | ((hy & 1) << 2);
+        hlds[it] = real ? ((hz * HHY + hy) * HHX + hx) * P + ((ch ^ sw) << 4) : -1;
+    }
+    unsigned okmask = 0;
+    auto halo_request = [&](int cls) __attribute__((always_inline)) {
+        const int cz = cls >> 2, cy = (cls >> 1) & 1, cx = cls & 1;
+        const int delta = ((cz * p.H + cy) * p.W + cx) * CIN;
+        const unsigned m = (fz >> cz) & (fy >> cy) & (fx >> cx);
+        okmask = 0;
+#pragma unroll
+        for (int it = 0; it < HIT; ++it) {
+            const bool ok = (m >> (2 * it)) & 1;
+            okmask |= ok ? 1u << it : 0u;
+            const half_t* g = p.in + (ok ? hoff[it] - delta : 0);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(hv[it]) : "v"(g) : "memory");      // (the kernel owns every vmcnt wait)
+        }
+    };
+    auto halo_store = [&]() __attribute__((always_inline)) {
+        // the loads above are asm: to the compiler their registers were defined at the request.  Re-define them HERE, behind the wait that retired
+        // the loads, so that nothing computed from them (the zero-fill select below) can be scheduled ahead of their landing
+#pragma unroll
+        for (int it = 0; it < HIT; ++it) asm volatile("" : "+v"(hv[it]));
+#pragma unroll
+        for (int it = 0; it < HIT; ++it) {
+            const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (hlds[it] >= 0) *(half8*)(smem + hlds[it]) = (okmask >> it) & 1 ? hv[it] : zero8;
+        }
+    };
+    // stage S = class * 8 + tap (tz, ty, tx): the k4 tap (2 t + 1 - parity) per axis; rows wave * 16 + 8 u + lane / 8 of the 64
+    auto stageW = [&](int S, int buf) __attribute__((always_inline)) {
+        const int cls = S >> 3, st = S & 7;
+        const int kz = 2 * (st >> 2) + 1 - (cls >> 2), ky = 2 * ((st >> 1) & 1) + 1 - ((cls >> 1) & 1), kx = 2 * (st & 1) + 1 - (cls & 1);
+        const int t4 = (kz * 4 + ky) * 4 + kx;
+        char* base = smem + HALO_BYTES + buf * BST;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int n = (wave * U + u) * 8 + (lane >> 3);
+            const int lch = (lane & 7) ^ ((n >> 1) & 7);
+            cglds16_asm(p.w + (int64_t)n * p.kpad + t4 * CIN + lch * 8, base + (wave * U + u) * 1024);
+        }
+    };
+
+    const int q = lane >> 4, n16 = lane & 15;
+    float bv[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[i][r] = p.bias != nullptr ? p.bias[wn * 32 + i * 16 + q * 4 + r] : 0.f;
+    halo_request(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    halo_store();
+    stageW(0, 0);
+    stageW(1, 1);
+    stageW(2, 2);
+
+    // voxel blocks of this wave: j -> local (z = 2 wm + (j >> 1), y = 2 (j & 1) + (n16 >> 3), x = n16 & 7); halo voxel of tap t = + t
+    const int vx = n16 & 7, vyp = n16 >> 3;
+    int vrow[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vrow[j] = (((2 * wm + (j >> 1)) * HHY + 2 * (j & 1) + vyp) * HHX + vx) * P;
+    int wrow[2], wsw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int n = wn * 32 + i * 16 + n16;
+        wrow[i] = HALO_BYTES + n * P;
+        wsw[i] = (n >> 1) & 7;
+    }
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    conv_wait_vmcnt<2 * U>();                          // stage 0 landed; stages 1, 2 in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+#pragma unroll 1
+    for (int cls = 0; cls < 8; ++cls) {
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            const int S = cls * 8 + st;
+            if (S + 1 < NSTG) {
+                // publish stage S + 1: behind it stage S + 2 may stay in flight -- and, at a class's taps 1 and 2, the next class's eight halo loads,
+                // issued behind stage S + 3 at tap 0
+                if ((st == 1 || st == 2) && cls < 7) conv_wait_vmcnt<U + HIT>();
+                else if (S + 2 < NSTG) conv_wait_vmcnt<U>();
+                else conv_wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                if (S + 3 < NSTG) stageW(S + 3, (S + 3) & 3);
+            }
+            if (st == 0 && cls < 7) halo_request(cls + 1);
+            const int voff = (((st >> 2) * HHY + ((st >> 1) & 1)) * HHX + (st & 1)) * P;
+            const int sw = ((((vx + (st & 1)) >> 1) & 1) << 1) | (((vyp + ((st >> 1) & 1)) & 1) << 2);
+            const char* wb = smem + (S & 3) * BST;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                half8 af[2], bf[4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[i] = *(const half8*)(wb + wrow[i] + (((ks * 4 + q) ^ wsw[i]) << 4));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[j] = *(const half8*)(smem + vrow[j] + voff + (((ks * 4 + q) ^ sw) << 4));
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (cls < 7) {
+            // swap the halo: every wave has read the last tap's fragments; the next class's chunks landed long ago (tap 3's wait retired them)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            halo_store();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (published by the next tap's barrier)
+        }
+    }
+    // epilogue: bias, ReLU, fp16; channel blocks 0 / 1 trade halves, lane group q stores 8 consecutive channels of block (q & 1) at offset 8 (q >> 1)
+    const int OD = p.D >> 1, OH = p.H >> 1, OW = p.W >> 1;
+    const float lo = p.relu ? 0.f : -65504.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned pk[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+            half2_t lo2, hi2;
+            lo2[0] = (half_t)__builtin_amdgcn_fmed3f(acc[i][j][0] + bv[i][0], lo, 65504.f); lo2[1] = (half_t)__builtin_amdgcn_fmed3f(acc[i][j][1] + bv[i][1], lo, 65504.f);
+            hi2[0] = (half_t)__builtin_amdgcn_fmed3f(acc[i][j][2] + bv[i][2], lo, 65504.f); hi2[1] = (half_t)__builtin_amdgcn_fmed3f(acc[i][j][3] + bv[i][3], lo, 65504.f);
+            pk[i][0] = __builtin_bit_cast(unsigned, lo2);
+            pk[i][1] = __builtin_bit_cast(unsigned, hi2);
+        }
+        const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+        const int z = 2 * wm + (j >> 1), y = 2 * (j & 1) + vyp;
+        const int64_t orow = (((int64_t)b * OD + z0 + z) * OH + y0 + y) * OW + x0 + vx;
+        *(u32x4*)(p.out + orow * COUT + wn * 32 + (q & 1) * 16 + (q >> 1) * 8) = o;
+    }
+}
+
 // split-K finish: sum the slabs in split order (deterministic), then the same epilogue as above.
 // thread = (variant, row, 8-column chunk)
 __global__ __launch_bounds__(256) void conv3d_finish_kernel(ConvParams p) {
@@ -1347,6 +1550,27 @@ extern "C" int pcd_conv3d_k3s1_f16(const pcd_conv3d_desc_t* d, void* stream) {
     else if (d->cin == 64) hipLaunchKernelGGL((conv3d_halo_kernel<64, 32, 1, 4, 4>), grid, blk, 0, s, p);
     else if (bn == 64) hipLaunchKernelGGL((conv3d_halo_kernel<32, 64, 1, 4, 4>), grid, blk, 0, s, p);
     else hipLaunchKernelGGL((conv3d_halo_kernel<32, 32, 3, 4, 4>), grid, blk, 0, s, p);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_conv3d_k4s2_halo_supported(int batch, int d, int h, int w, int cin, int cout, int kpad) {
+    return batch > 0 && cin == 64 && cout == 64 && kpad >= 64 * 64 && kpad % 8 == 0 && d > 0 && h > 0 && w > 0 && d % (2 * HTZ) == 0 &&
+           h % (2 * HTY) == 0 && w % (2 * HTX) == 0 && d <= 64 && h <= 64 && w <= 64 && ((int64_t)batch + 1) * d * h * w * cin <= 0x7fffffff ? 1 : 0;      // (+ 1: the kernel forms offsets one plane past the end)
+}
+
+extern "C" int pcd_conv3d_k4s2_halo_f16(const void* in, int batch, int d, int h, int w, int cin, const void* wgt, int kpad, const float* bias,
+                                        int relu, int cout, void* out, void* stream) {
+    PCD_CHECK_ARG(in && wgt && out);
+    PCD_CHECK_ARG(pcd_conv3d_k4s2_halo_supported(batch, d, h, w, cin, cout, kpad));
+    ConvS2HaloParams p{};
+    p.in = (const half_t*)in; p.B = batch; p.D = d; p.H = h; p.W = w;
+    p.w = (const half_t*)wgt; p.kpad = kpad; p.bias = bias; p.out = (half_t*)out; p.relu = relu;
+    p.tz = d / 2 / HTZ; p.ty = h / 2 / HTY; p.tx = w / 2 / HTX;
+    const int64_t blocks = (int64_t)batch * p.tz * p.ty * p.tx;
+    PCD_CHECK_ARG(blocks <= 0x7fffffff);
+    p.nblocks = (int)blocks;
+    hipLaunchKernelGGL(conv3d_k4s2_halo_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

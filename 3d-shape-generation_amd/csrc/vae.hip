@@ -67,6 +67,10 @@ struct Runner {
         pcd_conv3d_desc_t c;
         fill(c, L, in, din, stride, taps, L.k * L.k * L.k, dout, relu, resid, out, in2, cin2);
         if (L.k == 3 && stride == 1 && pcd_conv3d_k3s1_supported(&c)) return pcd_conv3d_k3s1_f16(&c, s);   // LDS-resident halo
+        // encoder.3 (k4 s2, 64 -> 64, 32^3 -> 16^3): the eight input-parity classes from LDS-resident sub-grid halos
+        if (g_convt_halo && L.k == 4 && stride == 2 && resid == nullptr && in2 == nullptr && dout * 2 == din &&
+            pcd_conv3d_k4s2_halo_supported(batch, din, din, din, L.cin, L.cout, L.kpad))
+            return pcd_conv3d_k4s2_halo_f16(in, batch, din, din, din, L.cin, L.w, L.kpad, L.b, relu, L.cout, out, s);
         return launch(&c, 1);
     }
     // ResidualBlock3D: relu(bn2(conv2(relu(bn1(conv1 x)))) + (downsample(x) | x)).  x <- the block's output; h, r: scratch buffers.

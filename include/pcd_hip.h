@@ -415,6 +415,14 @@ int pcd_conv3d_config(int tall_halo_tiles);
  * dims multiples of (4, 4, 8), out_scale 1; pcd_conv3d_k3s1_supported() tells (1/0), unsupported -> PCD_ERR_ARG. */
 int pcd_conv3d_k3s1_supported(const pcd_conv3d_desc_t* d);
 int pcd_conv3d_k3s1_f16(const pcd_conv3d_desc_t* d, void* stream);
+/* Conv3d(k4, s2, p1) (+ folded BN) (+ ReLU) with LDS-resident input (encoder.3/4, networks.py:2229-2230; csrc/conv3d.hip: conv3d_k4s2_halo_kernel):
+ * in fp16 [B][d][h][w][cin], w fp16 [cout][kpad] in the tap-major layout of pcd_conv3d_f16 (k = ((kz * 4 + ky) * 4 + kx) * cin + c), out fp16
+ * [B][d/2][h/2][w/2][cout].  The kernel walks the eight input-parity classes (each a 2 x 2 x 2 stride-1 convolution of one sub-sampled grid) of a
+ * 4 x 4 x 8 output block with that class's sub-grid halo in LDS.  Supported: cin 64, cout 64, d, h, w multiples of (8, 8, 16) and <= 64;
+ * pcd_conv3d_k4s2_halo_supported() tells (1 / 0), unsupported -> PCD_ERR_ARG.  Same sums as pcd_conv3d_f16 in another order (exact on integers). */
+int pcd_conv3d_k4s2_halo_supported(int batch, int d, int h, int w, int cin, int cout, int kpad);
+int pcd_conv3d_k4s2_halo_f16(const void* in, int batch, int d, int h, int w, int cin, const void* wgt, int kpad, const float* bias, int relu,
+                             int cout, void* out, void* stream);
 /* ConvTranspose3d(k4, s2, p1) + ReLU (decoder.6/7, networks.py:2253-2254) with the 6 x 6 x 10 input halo of a 4 x 4 x 8 block of INPUT
  * voxels in LDS and all eight output-parity classes computed from it (csrc/conv3d.hip: convT3d_halo_kernel): in fp16 [B][d][h][w][cin],
  * out fp16 [B][2d][2h][2w][cout].  w8[4 pz + 2 py + px] = that class's fp16 [cout][8 * cin] matrix, K column (tz * 2 + tz... tap t) * cin + c
@@ -466,7 +474,8 @@ typedef struct {
 } pcd_vae_desc_t;
 typedef struct pcd_vae pcd_vae_t;
 int pcd_vae_create(const pcd_vae_desc_t* desc, pcd_vae_t** out);
-/* testing / tuning hook: 1 (default) = decoder.6 through pcd_convt3d_k4s2_halo_f16, 0 = as eight implicit-GEMM class launches */
+/* testing / tuning hook: 1 (default) = decoder.6 through pcd_convt3d_k4s2_halo_f16 and encoder.3 through pcd_conv3d_k4s2_halo_f16, 0 = both through
+ * the implicit GEMM */
 int pcd_vae_config(int convt_halo);
 void pcd_vae_destroy(pcd_vae_t* h);
 size_t pcd_vae_workspace_bytes(int batch);

@@ -356,6 +356,36 @@ def test_conv_transpose3d_halo_exact(dims, b):
     assert lib.pcd_convt3d_k4s2_halo_f16(dx.data_ptr(), b, dims[0], dims[1], dims[2], 64, ptrs, db.data_ptr(), cout, out.data_ptr(), 0) != 0
 
 
+@pytest.mark.parametrize("dims,b", [((8, 8, 16), 1), ((16, 8, 32), 3), ((16, 16, 16), 8)])
+def test_conv3d_k4s2_halo_exact(dims, b):
+    """encoder.3's kernel (Conv3d k4 s2 p1, 64 -> 64: eight input-parity classes of a 4 x 4 x 8 output block from LDS-resident sub-grid halos,
+    halo swapped per class, transposed product with 16-byte stores) against F.conv3d on exactly representable integers -- every border, non-cubic
+    grids, block counts that are and are not multiples of 8 -- and bit-identical to the implicit-GEMM launch, with and without ReLU."""
+    from shapegen_amd import _lib
+    from shapegen_amd.vae import _pack_conv
+    lib = _lib.load()
+    cin = cout = 64
+    x, w, bias = _int((b, cin) + dims, 51), _int((cout, cin, 4, 4, 4), 52, -1, 2), _int((cout,), 53)
+    want = F.conv3d(x.double(), w.double(), bias.double(), stride=2, padding=1)
+    wk, _, kpad = _pack_conv(w.double().numpy(), None)
+    dx = x.permute(0, 2, 3, 4, 1).contiguous().half().cuda()
+    dw, db = torch.from_numpy(wk).half().cuda(), bias.cuda()
+    odims = tuple(v // 2 for v in dims)
+    assert lib.pcd_conv3d_k4s2_halo_supported(b, dims[0], dims[1], dims[2], cin, cout, kpad) == 1
+    for relu in (1, 0):
+        out = torch.full((b * odims[0] * odims[1] * odims[2], cout), 5.0, dtype=torch.float16, device="cuda")
+        _lib.check(lib.pcd_conv3d_k4s2_halo_f16(dx.data_ptr(), b, dims[0], dims[1], dims[2], cin, dw.data_ptr(), kpad, db.data_ptr(), relu, cout,
+                                                out.data_ptr(), _lib.stream_ptr()))
+        got = out.float().cpu().reshape((b,) + odims + (cout,)).permute(0, 4, 1, 2, 3).double()
+        ref = (want.clamp_min(0) if relu else want).half().double()
+        assert torch.equal(got, ref), relu
+    if dims[0] == dims[1] == dims[2]:
+        assert torch.equal(got, _run_conv(x, w, bias, 2, 1).double())
+    assert lib.pcd_conv3d_k4s2_halo_supported(b, dims[0], dims[1], dims[2] + 8, cin, cout, kpad) == 0
+    assert lib.pcd_conv3d_k4s2_halo_supported(b, dims[0], dims[1], dims[2], 128, cout, kpad) == 0
+    assert lib.pcd_conv3d_k4s2_halo_f16(dx.data_ptr(), b, dims[0], dims[1], dims[2], cin, dw.data_ptr(), 64, db.data_ptr(), 1, cout, out.data_ptr(), 0) != 0
+
+
 def test_vae_decode_halo_transposed_convolution_matches_the_class_launches(ldm):
     """decoder.6 through the LDS-halo kernel (default) against the eight implicit-GEMM class launches inside the whole decode: the same fp16
     products summed in fp32 in another order, one fp16 rounding either way -- decoded probabilities agree to 2e-3 (measured below)."""
@@ -371,6 +401,17 @@ def test_vae_decode_halo_transposed_convolution_matches_the_class_launches(ldm):
     err = (a - c).abs()
     print(f"decode: halo transposed convolution v. class launches: max {float(err.max()):.2e} mean {float(err.mean()):.2e}")
     assert float(err.max()) < 2e-3 and torch.equal(ldm.vae.decode(z), a)
+    # encoder.3 through its LDS kernel (default) against the implicit GEMM inside the whole encode
+    vox = synth_voxels(8, 6).cuda()
+    mu_a, lv_a = ldm.vae.encode(vox)
+    _lib.check(lib.pcd_vae_config(0))
+    try:
+        mu_c, lv_c = ldm.vae.encode(vox)
+    finally:
+        _lib.check(lib.pcd_vae_config(1))
+    r = rel_l2(mu_a.cpu(), mu_c.cpu()), rel_l2(lv_a.cpu(), lv_c.cpu())
+    print(f"encode: k4 s2 LDS kernel v. implicit GEMM: mu {r[0]:.2e} logvar {r[1]:.2e}")
+    assert r[0] < 2e-3 and r[1] < 2e-3
 
 
 def test_latent_unet_forward(ldm, golden):

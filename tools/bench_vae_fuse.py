@@ -26,6 +26,7 @@ for rep in range(3):
         vae.set_fuse_shortcut(fuse)
         te = timed(lambda: vae.encode(x))
         print(f"B={B} fused={int(fuse)}: encode {te:7.1f} us = {24.48e9 * B / te / 1e6:5.0f} TFLOP/s = {24.48e9 * B / te / 1e6 / 25:4.1f} % of 2.5 PF", flush=True)
+vae.set_fuse_shortcut(True)
 # decoder.6 through the LDS-halo transposed-convolution kernel (default) against the eight implicit-GEMM class launches
 from shapegen_amd import _lib
 lib = _lib.load()
@@ -33,6 +34,6 @@ z = torch.randn(B, 256, device="cuda")
 for rep in range(3):
     for halo in (1, 0):
         _lib.check(lib.pcd_vae_config(halo))
-        td = timed(lambda: vae.decode(z))
-        print(f"B={B} convT halo={halo}: decode {td:7.1f} us = {40.20e9 * B / td / 1e6:5.0f} TFLOP/s = {40.20e9 * B / td / 1e6 / 25:4.1f} % of 2.5 PF", flush=True)
+        td, te = timed(lambda: vae.decode(z)), timed(lambda: vae.encode(x))
+        print(f"B={B} LDS kernels for decoder.6 / encoder.3 = {halo}: decode {td:7.1f} us = {40.20e9 * B / td / 1e6 / 25:4.1f} % | encode {te:7.1f} us = {24.48e9 * B / te / 1e6 / 25:4.1f} % of 2.5 PF", flush=True)
 _lib.check(lib.pcd_vae_config(1))
