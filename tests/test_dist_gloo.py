@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: world_size-2 gloo processes exercise the sharding and the all-gather layer
+"""N > 1 path on CPU: world_size-2 (and one world_size-8) gloo processes exercise the sharding and the all-gather layer
 (`shapegen_amd.dist`) that runs over RCCL on the GPUs."""
 import os
 import socket
@@ -57,6 +57,54 @@ def test_two_rank_gloo(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def _worker_n(rank, world, port, tmp):
+    """The sharding / gathering layer at the world size the driver's scaling run uses (8): uneven shards, ranks with NOTHING to do (fewer samples
+    than ranks), ragged row and cloud gathers with empty contributions, the per-rank Philox sub-blocks."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import shapegen_amd  # noqa: F401
+    from shapegen_amd import dist as D
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, w, _ = D.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    for total in (512, 256, 13, 5, 0):                       # BASELINE configs[2] / [4]'s batches; uneven; fewer samples than ranks; none
+        spans = [D.shard_range(total, k, world) for k in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    g = torch.Generator().manual_seed(24)
+    for total in (13, 5):
+        x_T = torch.randn(total, 16, 3, generator=g)
+        out = D.sample_sharded(_FakeModel(), total, 16, 5, x_T_global=x_T)
+        assert torch.equal(out, x_T * 2.0 + 5)               # rank-order concat == the single-process result, empty shards included
+    n_rows = rank % 3                                        # 0, 1, 2, 0, ... rows per rank
+    rows = torch.full((n_rows, 4), float(rank))
+    allr = D.all_gather_rows(rows)
+    want = torch.cat([torch.full((k % 3, 4), float(k)) for k in range(world)])
+    assert torch.equal(allr, want)
+    clouds = [torch.full((rank + i, 3), float(10 * rank + i)) for i in range(rank % 2 + 1)]          # 1 or 2 clouds, the first of rank 0 empty
+    allc = D.all_gather_clouds(clouds)
+    flat = [(k + i, float(10 * k + i)) for k in range(world) for i in range(k % 2 + 1)]
+    assert [c.shape[0] for c in allc] == [n for n, _ in flat]
+    assert all(c.numel() == 0 or float(c[0, 0]) == v for c, (_, v) in zip(allc, flat))
+    lo, hi = D.shard_range(13, rank, world)
+    class _M:
+        _shard = None
+    from shapegen_amd.diffusion import _DiffusionBase
+    m = _M()
+    with D.shard_context(m, lo, 13):
+        off, span = _DiffusionBase._philox_span(m, max(hi - lo, 1) * 64 * 3, max(hi - lo, 1))
+    assert (off, span) == (lo * 48, 13 * 48)
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(tmp, f"n_ok{rank}"), "w").write("ok")
+
+
+def test_eight_rank_gloo(tmp_path):
+    mp.spawn(_worker_n, args=(8, _free_port(), str(tmp_path)), nprocs=8, join=True)
+    assert all((tmp_path / f"n_ok{k}").exists() for k in range(8))
 
 
 def _forced_one_rank_worker(rank, world, port, tmp):
