@@ -968,6 +968,168 @@ __global__ __launch_bounds__(256) void conv3d_k4s2_halo_kernel(ConvS2HaloParams 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k3 / s1 / p1, C_in = 64, with the WEIGHTS IN REGISTERS: conv3d_halo_kernel above reads, per 32-deep k step and wave, four voxel
+// fragments and two weight fragments from LDS for eight MFMAs -- with eight waves per CU the LDS pipe is busy 384 cycles per 256 MFMA
+// cycles, which caps the matrix pipe at two thirds (and it streams every tap's weights through an LDS ring behind a barrier per tap).
+// Here a workgroup owns 4 x 8 x 8 output voxels (256 rows; halo 6 x 10 x 10 = 76.8 KB: two workgroups per CU, nothing else in LDS), a
+// wave 128 voxels x 32 channels, and the weight fragments never touch LDS: they are stored once per model in MFMA-fragment order
+// (pcd_conv3d_pack_wfrag: [tile][tap][channel half][k step][16-channel block][lane][8]) so that a wave's fragment is ONE coalesced
+// 1-KB global load straight into the registers the MFMA reads, two taps ahead.  Per k step and wave: eight voxel fragment reads (LDS)
+// + two weight loads (L1/L2: 32 B per cycle and CU, half the L1 rate) for 16 MFMAs -- the LDS pipe is busy 512 cycles per 512 MFMA
+// cycles at two waves per SIMD -- and there is NO barrier after the halo is in place: the 27 taps are straight-line code that the
+// compiler pipelines (counted vmcnt / lgkmcnt of its own).  Transposed product, 16-byte direct stores (+ residual), as convT3d_halo_kernel.
+struct HaloWregParams {
+    const half_t* in; int B, D, H, W;
+    const half_t* wfrag;              // [tiles_n][27][2][2][2][64][8]
+    const float* bias;
+    const half_t* resid;
+    half_t* out; int Cout;
+    int relu;
+    int tiles_n, tz, ty, tx, nblocks;
+};
+
+__global__ __launch_bounds__(256, 2) void conv3d_halo_wreg_kernel(HaloWregParams p) {      // two waves per SIMD: at most 256 registers
+    constexpr int CIN = 64, P = CIN * 2, NT = 256, TY8 = 8, HHY8 = TY8 + 2;
+    constexpr int HV = (HTZ + 2) * HHY8 * HHX;                 // 600 halo voxels
+    constexpr int HIT = (HV * 8 + NT - 1) / NT;                // 16-byte chunks per thread (19)
+    __shared__ __attribute__((aligned(16))) char smem[HV * P];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;                   // voxel half (128 of the 256), channel half (32 of the tile's 64)
+    int bid = blockIdx.x;
+    if ((p.nblocks & 7) == 0) bid = (bid & 7) * (p.nblocks >> 3) + (bid >> 3);
+    const int tn = bid % p.tiles_n; int t = bid / p.tiles_n;
+    const int tx = t % p.tx; t /= p.tx;
+    const int ty = t % p.ty; t /= p.ty;
+    const int tz = t % p.tz; const int b = t / p.tz;
+    const int z0 = tz * HTZ, y0 = ty * TY8, x0 = tx * HTX;
+
+    // ---- halo: global -> registers (all loads in flight) -> LDS, chunk c of voxel (hz, hy, hx) at slot c ^ s(hx, hy) (the C_in = 64 image above)
+    {
+        half8 hv[HIT];
+        unsigned okmask = 0;
+#pragma unroll
+        for (int it = 0; it < HIT; ++it) {
+            const int c = it * NT + tid;
+            const int row = c >> 3, ch = c & 7;
+            const int hx = row % HHX; const int r2 = row / HHX;
+            const int hy = r2 % HHY8, hz = r2 / HHY8;
+            const int iz = z0 - 1 + hz, iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+            const bool ok = row < HV && (unsigned)iz < (unsigned)p.D && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            okmask |= ok ? 1u << it : 0u;
+            const int cz = min(max(iz, 0), p.D - 1), cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
+            hv[it] = *(const half8*)(p.in + ((((int64_t)b * p.D + cz) * p.H + cy) * p.W + cx) * CIN + ch * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < HIT; ++it) {
+            const int c = it * NT + tid;
+            const int row = c >> 3, ch = c & 7;
+            const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            const int hx = row % HHX, hy = (row / HHX) % HHY8;
+            const int sw = (((hx >> 1) & 1) << 1) | ((hy & 1) << 2);
+            if (row < HV) *(half8*)(smem + row * P + ((ch ^ sw) << 4)) = (okmask >> it) & 1 ? hv[it] : zero8;
+        }
+    }
+    const int q = lane >> 4, n16 = lane & 15;
+    // this wave's weight fragments: tap t, k step ks, channel block j at wf + ((t * 2 + wc) * 4 + ks * 2 + j) * 512 halfs (+ lane * 8)
+    const half_t* wf = p.wfrag + (int64_t)tn * 27 * 2 * 4 * 512 + lane * 8;
+    float bv[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[j][r] = p.bias != nullptr ? p.bias[tn * 64 + wc * 32 + j * 16 + q * 4 + r] : 0.f;
+    // voxel blocks of this wave: i -> local (z = 2 wr + (i >> 2), y = 2 (i & 3) + (n16 >> 3), x = n16 & 7)
+    const int vx = n16 & 7, vyp = n16 >> 3;
+    int vrow[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vrow[i] = (((2 * wr + (i >> 2)) * HHY8 + 2 * (i & 3) + vyp) * HHX + vx) * P;
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    half8 wq[3][2][2];                                         // weight fragments of taps t, t + 1, t + 2 (ring of three)
+    auto wload = [&](int slot, int tap) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) wq[slot][ks][j] = *(const half8*)(wf + ((tap * 2 + wc) * 4 + ks * 2 + j) * 512);
+    };
+    wload(0, 0);
+    wload(1, 1);
+    __syncthreads();                                           // the halo is in place; no barrier from here on
+
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+        if (tap + 2 < 27) wload((tap + 2) % 3, tap + 2);
+        __builtin_amdgcn_sched_barrier(0);                     // the loads stay HERE, two taps ahead of their use (left alone the scheduler sinks them to it)
+        const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+        const int voff = ((kz * HHY8 + ky) * HHX + kx) * P;
+        const int sw = ((((vx + kx) >> 1) & 1) << 1) | (((vyp + ky) & 1) << 2);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 vf[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) vf[i] = *(const half8*)(smem + vrow[i] + voff + (((ks * 4 + q) ^ sw) << 4));
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[tap % 3][ks][j], vf[i], acc[j][i], 0, 0, 0);
+        }
+    }
+    // epilogue: bias -> fp16 (the rounding point of the other kernels) (+ residual) (+ ReLU); channel blocks 0 / 1 trade halves, lane group q stores
+    // 8 consecutive channels of block (q & 1) at offset 8 (q >> 1)
+    const float lo = (p.relu && p.resid == nullptr) ? 0.f : -65504.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        unsigned pk[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+            half2_t lo2, hi2;
+            lo2[0] = (half_t)__builtin_amdgcn_fmed3f(acc[j][i][0] + bv[j][0], lo, 65504.f); lo2[1] = (half_t)__builtin_amdgcn_fmed3f(acc[j][i][1] + bv[j][1], lo, 65504.f);
+            hi2[0] = (half_t)__builtin_amdgcn_fmed3f(acc[j][i][2] + bv[j][2], lo, 65504.f); hi2[1] = (half_t)__builtin_amdgcn_fmed3f(acc[j][i][3] + bv[j][3], lo, 65504.f);
+            pk[j][0] = __builtin_bit_cast(unsigned, lo2);
+            pk[j][1] = __builtin_bit_cast(unsigned, hi2);
+        }
+        const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+        const int z = 2 * wr + (i >> 2), y = 2 * (i & 3) + vyp;
+        const int64_t orow = (((int64_t)b * p.D + z0 + z) * p.H + y0 + y) * p.W + x0 + vx;
+        const int col = tn * 64 + wc * 32 + (q & 1) * 16 + (q >> 1) * 8;
+        if (p.resid != nullptr) {
+            half8 ov = __builtin_bit_cast(half8, o);
+            const half8 rs = *(const half8*)(p.resid + orow * p.Cout + col);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = (float)ov[e] + (float)rs[e];
+                if (p.relu) f = fmaxf(f, 0.f);
+                ov[e] = to_half_sat(f);
+            }
+            o = __builtin_bit_cast(u32x4, ov);
+        }
+        *(u32x4*)(p.out + orow * p.Cout + col) = o;
+    }
+}
+
+// one thread per 16-byte fragment piece: out[tile][tap][wc][ks][j][lane][8] = w[tile * 64 + wc * 32 + j * 16 + (lane & 15)][tap * 64 + ks * 32 + (lane >> 4) * 8 ..]
+__global__ __launch_bounds__(256) void conv3d_pack_wfrag_kernel(const half_t* __restrict__ w, int kpad, int cout, half_t* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = (cout / 64) * 27 * 2 * 2 * 2 * 64;
+    if (idx >= total) return;
+    const int lane = idx & 63; int r = idx >> 6;
+    const int j = r & 1; r >>= 1;
+    const int ks = r & 1; r >>= 1;
+    const int wc = r & 1; r >>= 1;
+    const int tap = r % 27; const int tile = r / 27;
+    const int n = tile * 64 + wc * 32 + j * 16 + (lane & 15);
+    *(half8*)(out + (int64_t)idx * 8) = *(const half8*)(w + (int64_t)n * kpad + tap * 64 + ks * 32 + (lane >> 4) * 8);
+}
+
 // split-K finish: sum the slabs in split order (deterministic), then the same epilogue as above.
 // thread = (variant, row, 8-column chunk)
 __global__ __launch_bounds__(256) void conv3d_finish_kernel(ConvParams p) {
@@ -1550,6 +1712,43 @@ extern "C" int pcd_conv3d_k3s1_f16(const pcd_conv3d_desc_t* d, void* stream) {
     else if (d->cin == 64) hipLaunchKernelGGL((conv3d_halo_kernel<64, 32, 1, 4, 4>), grid, blk, 0, s, p);
     else if (bn == 64) hipLaunchKernelGGL((conv3d_halo_kernel<32, 64, 1, 4, 4>), grid, blk, 0, s, p);
     else hipLaunchKernelGGL((conv3d_halo_kernel<32, 32, 3, 4, 4>), grid, blk, 0, s, p);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" size_t pcd_conv3d_wfrag_bytes(int cout) { return cout > 0 && cout % 64 == 0 ? (size_t)27 * 64 * cout * sizeof(half_t) : 0; }
+
+extern "C" int pcd_conv3d_pack_wfrag(const void* w, int kpad, int cout, void* wfrag, void* stream) {
+    PCD_CHECK_ARG(w && wfrag && cout > 0 && cout % 64 == 0 && kpad >= 27 * 64 && kpad % 8 == 0);
+    const int total = (cout / 64) * 27 * 2 * 2 * 2 * 64;
+    hipLaunchKernelGGL(conv3d_pack_wfrag_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)w, kpad, cout,
+                       (half_t*)wfrag);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+static bool wreg_supported(const pcd_conv3d_desc_t* d) {
+    return d->ntaps == 27 && d->stride == 1 && d->out_scale == 1 && d->cin == 64 && d->cout % 64 == 0 && d->in2 == nullptr &&
+           d->rows_d == d->in_d && d->rows_h == d->in_h && d->rows_w == d->in_w && d->out_d == d->in_d && d->out_h == d->in_h && d->out_w == d->in_w &&
+           d->in_d % HTZ == 0 && d->in_h % 8 == 0 && d->in_w % HTX == 0 && d->out_off_z == 0 && d->out_off_y == 0 && d->out_off_x == 0;
+}
+
+extern "C" int pcd_conv3d_k3s1_wreg_supported(const pcd_conv3d_desc_t* d) { return d != nullptr && conv_check(d) == PCD_OK && wreg_supported(d) ? 1 : 0; }
+
+extern "C" int pcd_conv3d_k3s1_wreg_f16(const pcd_conv3d_desc_t* d, const void* wfrag, void* stream) {
+    PCD_CHECK_ARG(d != nullptr && wfrag != nullptr);
+    const int rc = conv_check(d);
+    if (rc != PCD_OK) return rc;
+    PCD_CHECK_ARG(wreg_supported(d));
+    HaloWregParams p{};
+    p.in = (const half_t*)d->in; p.B = d->batch; p.D = d->in_d; p.H = d->in_h; p.W = d->in_w;
+    p.wfrag = (const half_t*)wfrag; p.bias = d->bias; p.resid = (const half_t*)d->resid;
+    p.out = (half_t*)d->out; p.Cout = d->cout; p.relu = d->relu;
+    p.tiles_n = d->cout / 64; p.tz = d->in_d / HTZ; p.ty = d->in_h / 8; p.tx = d->in_w / HTX;
+    const int64_t blocks = (int64_t)d->batch * p.tz * p.ty * p.tx * p.tiles_n;
+    PCD_CHECK_ARG(blocks <= 0x7fffffff);
+    p.nblocks = (int)blocks;
+    hipLaunchKernelGGL(conv3d_halo_wreg_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

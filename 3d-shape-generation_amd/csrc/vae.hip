@@ -10,6 +10,10 @@
 
 struct pcd_vae {
     pcd_vae_desc_t d;
+    // fragment-order copies of the k3 layers with C_in = 64 (pcd_conv3d_pack_wfrag), made at create: encoder.5.conv1, decoder.8.conv1 / conv2
+    void* wf_enc5c1 = nullptr;
+    void* wf_dec8c1 = nullptr;
+    void* wf_dec8c2 = nullptr;
 };
 
 namespace pcd {
@@ -63,9 +67,11 @@ struct Runner {
     }
     // Conv3d(k, stride, pad) [+ residual] [+ ReLU]
     int conv(const pcd_vae_conv_t& L, const void* in, int din, int stride, const int* taps, int dout, int relu,
-             const void* resid, void* out, const void* in2 = nullptr, int cin2 = 0) const {
+             const void* resid, void* out, const void* in2 = nullptr, int cin2 = 0, const void* wfrag = nullptr) const {
         pcd_conv3d_desc_t c;
         fill(c, L, in, din, stride, taps, L.k * L.k * L.k, dout, relu, resid, out, in2, cin2);
+        // k3 layers with C_in = 64: weights in registers (fragment-order copy made at create), 256-row workgroups, no barrier in the tap loop
+        if (wfrag != nullptr && g_convt_halo && pcd_conv3d_k3s1_wreg_supported(&c)) return pcd_conv3d_k3s1_wreg_f16(&c, wfrag, s);
         if (L.k == 3 && stride == 1 && pcd_conv3d_k3s1_supported(&c)) return pcd_conv3d_k3s1_f16(&c, s);   // LDS-resident halo
         // encoder.3 (k4 s2, 64 -> 64, 32^3 -> 16^3): the eight input-parity classes from LDS-resident sub-grid halos
         if (g_convt_halo && L.k == 4 && stride == 2 && resid == nullptr && in2 == nullptr && dout * 2 == din &&
@@ -74,8 +80,8 @@ struct Runner {
         return launch(&c, 1);
     }
     // ResidualBlock3D: relu(bn2(conv2(relu(bn1(conv1 x)))) + (downsample(x) | x)).  x <- the block's output; h, r: scratch buffers.
-    int res(const pcd_vae_res_t& R, void*& x, int dim, void*& h, void*& r) const {
-        int rc = conv(R.c1, x, dim, 1, d.taps3, dim, 1, nullptr, h);
+    int res(const pcd_vae_res_t& R, void*& x, int dim, void*& h, void*& r, const void* wf1 = nullptr, const void* wf2 = nullptr) const {
+        int rc = conv(R.c1, x, dim, 1, d.taps3, dim, 1, nullptr, h, nullptr, 0, wf1);
         if (rc) return rc;
         const void* resid = x;
         void* out = x;                                                // in place: conv2 reads h and the residual row it overwrites
@@ -95,7 +101,7 @@ struct Runner {
             if (rc) return rc;
             resid = r;
         }
-        return conv(R.c2, h, dim, 1, d.taps3, dim, 1, resid, out);
+        return conv(R.c2, h, dim, 1, d.taps3, dim, 1, resid, out, nullptr, 0, wf2);
     }
     // ConvTranspose3d(k4, s2, p1) + ReLU: the 8 output-parity classes (2x2x2 taps each) in one launch
     int convT(const pcd_vae_convT_t& T, const void* in, int din, void* out) const {
@@ -154,11 +160,32 @@ extern "C" int pcd_vae_create(const pcd_vae_desc_t* desc, pcd_vae_t** out) {
     pcd_vae* h = new (std::nothrow) pcd_vae;
     PCD_CHECK_ARG(h != nullptr);
     h->d = *desc;
+    // fragment-order weight copies (one-time device work on the null stream, finished before the handle is returned); a failed allocation only
+    // means those layers keep the LDS-ring kernel
+    struct { const pcd_vae_conv_t* L; void** dst; } packs[3] = {{&h->d.enc_res[1].c1, &h->wf_enc5c1}, {&h->d.dec_res[2].c1, &h->wf_dec8c1},
+                                                                 {&h->d.dec_res[2].c2, &h->wf_dec8c2}};
+    for (auto& pk : packs) {
+        const pcd_vae_conv_t& L = *pk.L;
+        if (L.k != 3 || L.cin != 64 || L.cout % 64 != 0 || L.kpad < 27 * 64) continue;
+        void* buf = nullptr;
+        if (hipMalloc(&buf, pcd_conv3d_wfrag_bytes(L.cout)) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (pcd_conv3d_pack_wfrag(L.w, L.kpad, L.cout, buf, nullptr) != PCD_OK || hipStreamSynchronize(nullptr) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(buf);
+            continue;
+        }
+        *pk.dst = buf;
+    }
     *out = h;
     return PCD_OK;
 }
 
-extern "C" void pcd_vae_destroy(pcd_vae_t* h) { delete h; }
+extern "C" void pcd_vae_destroy(pcd_vae_t* h) {
+    if (h == nullptr) return;
+    for (void* b : {h->wf_enc5c1, h->wf_dec8c1, h->wf_dec8c2})
+        if (b != nullptr) (void)hipFree(b);
+    delete h;
+}
 
 extern "C" size_t pcd_vae_workspace_bytes(int batch) {
     if (batch <= 0) return 0;
@@ -190,7 +217,7 @@ extern "C" int pcd_vae_encode(pcd_vae_t* h, const float* vox, int batch, float* 
     RUN(R.res(d.enc_res[0], x, 32, hb, r));                                       // encoder.2   32 -> 64 @ 32^3
     RUN(R.conv(d.enc_down[0], x, 32, 2, d.taps4s2, 16, 1, nullptr, hb));          // encoder.3/4 k4 s2 -> 16^3
     SWAP(x, hb);
-    RUN(R.res(d.enc_res[1], x, 16, hb, r));                                       // encoder.5   64 -> 128
+    RUN(R.res(d.enc_res[1], x, 16, hb, r, h->wf_enc5c1));                         // encoder.5   64 -> 128
     RUN(R.conv(d.enc_down[1], x, 16, 2, d.taps4s2, 8, 1, nullptr, hb));           // encoder.6/7 -> 8^3
     SWAP(x, hb);
     RUN(R.res(d.enc_res[2], x, 8, hb, r));                                        // encoder.8   128 -> 256
@@ -244,7 +271,7 @@ extern "C" int pcd_vae_decode(pcd_vae_t* h, const float* z, int batch, float* ou
     RUN(R.res(d.dec_res[1], x, 16, hb, r));                                       // decoder.5
     RUN(R.convT(d.dec_up[2], x, 16, hb));                                         // decoder.6/7  128 -> 64 @ 32^3
     SWAP(x, hb);
-    RUN(R.res(d.dec_res[2], x, 32, hb, r));                                       // decoder.8
+    RUN(R.res(d.dec_res[2], x, 32, hb, r, h->wf_dec8c1, h->wf_dec8c2));           // decoder.8
     RUN(R.conv(d.dec_conv9, x, 32, 1, d.taps3, 32, 1, nullptr, hb));              // decoder.9/10  64 -> 32
     SWAP(x, hb);
     RUN(R.res(d.dec_res[3], x, 32, hb, r));                                       // decoder.11

@@ -197,6 +197,50 @@ def test_vae_fused_shortcut_matches_the_separate_launches(ldm):
     assert torch.equal(mu2, mu_f)
 
 
+@pytest.mark.parametrize("cout,dims,b", [(64, (4, 8, 8), 1), (64, (8, 16, 8), 3), (128, (4, 8, 16), 2), (192, (4, 8, 8), 4)])
+def test_conv3d_k3s1_weights_in_registers_exact(cout, dims, b):
+    """The weights-in-registers form of the k3 / C_in = 64 layers (256-row workgroups, fragment-order weights loaded straight into the MFMA operand
+    registers, no barrier in the tap loop, transposed product with direct stores) against F.conv3d on exactly representable integers, with and
+    without the residual + ReLU epilogue, one to three C_out tiles -- and bit-identical to pcd_conv3d_k3s1_f16 on the same descriptor."""
+    from shapegen_amd import _lib
+    from shapegen_amd.vae import _pack_conv, _taps_regular
+    lib = _lib.load()
+    cin = 64
+    x, w, bias = _int((b, cin) + dims, 61), _int((cout, cin, 3, 3, 3), 62, -1, 2), _int((cout,), 63)
+    want = F.conv3d(x.double(), w.double(), bias.double(), padding=1)
+    resid = _int(tuple(want.shape), 64)
+    wk, _, kpad = _pack_conv(w.double().numpy(), None)
+    dx = x.permute(0, 2, 3, 4, 1).contiguous().half().cuda()
+    dw, db = torch.from_numpy(wk).half().cuda(), bias.cuda()
+    dr = resid.permute(0, 2, 3, 4, 1).contiguous().half().cuda()
+    taps = torch.from_numpy(_taps_regular(3, 1)).cuda()
+    zero = torch.zeros(64, dtype=torch.float16, device="cuda")
+    wfrag = torch.empty(int(lib.pcd_conv3d_wfrag_bytes(cout)), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.pcd_conv3d_pack_wfrag(dw.data_ptr(), kpad, cout, wfrag.data_ptr(), _lib.stream_ptr()))
+    for use_resid in (False, True):
+        out = torch.full((b * dims[0] * dims[1] * dims[2], cout), 3.0, dtype=torch.float16, device="cuda")
+        d = _lib.Conv3dDesc()
+        d.inp, d.batch, d.in_d, d.in_h, d.in_w, d.cin = dx.data_ptr(), b, dims[0], dims[1], dims[2], cin
+        d.rows_d, d.rows_h, d.rows_w = dims
+        d.out_d, d.out_h, d.out_w = dims
+        d.stride, d.taps, d.ntaps, d.kpad = 1, taps.data_ptr(), 27, kpad
+        d.w, d.bias, d.relu = dw.data_ptr(), db.data_ptr(), 1
+        d.resid = dr.data_ptr() if use_resid else 0
+        d.out, d.cout, d.out_scale, d.zero_page = out.data_ptr(), cout, 1, zero.data_ptr()
+        assert lib.pcd_conv3d_k3s1_wreg_supported(d) == 1
+        _lib.check(lib.pcd_conv3d_k3s1_wreg_f16(d, wfrag.data_ptr(), _lib.stream_ptr()))
+        got = out.float().cpu().reshape((b,) + dims + (cout,)).permute(0, 4, 1, 2, 3).double()
+        ref = want.half().double()
+        ref = (ref + resid.double()).clamp_min(0).half().double() if use_resid else ref.clamp_min(0)
+        assert torch.equal(got, ref), use_resid
+        out2 = torch.empty_like(out)
+        d.out = out2.data_ptr()
+        _lib.check(lib.pcd_conv3d_k3s1_f16(d, _lib.stream_ptr()))
+        assert torch.equal(out, out2)
+    d.in_h = d.rows_h = d.out_h = dims[1] + 4                  # H not a multiple of 8: refused
+    assert lib.pcd_conv3d_k3s1_wreg_supported(d) == 0 and lib.pcd_conv3d_k3s1_wreg_f16(d, wfrag.data_ptr(), _lib.stream_ptr()) != 0
+
+
 @pytest.mark.parametrize("k,c,ldw,m,relu", [(32, 64, 64, 1000, 0), (32, 64, 32, 77, 1), (64, 128, 64, 4096 + 31, 0),
                                             (128, 256, 128, 515, 0), (128, 256, 192, 128, 1)])
 def test_conv1x1_pointwise_exact_integers(k, c, ldw, m, relu):
