@@ -981,7 +981,9 @@ __global__ __launch_bounds__(256) void conv3d_k4s2_halo_kernel(ConvS2HaloParams 
 // compiler pipelines (counted vmcnt / lgkmcnt of its own).  Transposed product, 16-byte direct stores (+ residual), as convT3d_halo_kernel.
 struct HaloWregParams {
     const half_t* in; int B, D, H, W;
-    const half_t* wfrag;              // [tiles_n][27][2][2][2][64][8]
+    const half_t* in2;                // optional second source (pcd_conv3d_desc_t.in2, 32 channels): one more 32-deep k step behind the 27 taps, its voxel
+                                      // fragments straight from global memory (a lane's 16 bytes = 8 of a row's 32 channels), its weights = "tap 27" of wfrag
+    const half_t* wfrag;              // [tiles_n][28][2][2][2][64][8] (tap 27: k step 0 only, the second source's 32 weight columns)
     const float* bias;
     const half_t* resid;
     half_t* out; int Cout;
@@ -1034,7 +1036,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_halo_wreg_kernel(HaloWregParams
     }
     const int q = lane >> 4, n16 = lane & 15;
     // this wave's weight fragments: tap t, k step ks, channel block j at wf + ((t * 2 + wc) * 4 + ks * 2 + j) * 512 halfs (+ lane * 8)
-    const half_t* wf = p.wfrag + (int64_t)tn * 27 * 2 * 4 * 512 + lane * 8;
+    const half_t* wf = p.wfrag + (int64_t)tn * 28 * 2 * 4 * 512 + lane * 8;
     float bv[2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -1079,6 +1081,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_halo_wreg_kernel(HaloWregParams
                 for (int i = 0; i < 8; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[tap % 3][ks][j], vf[i], acc[j][i], 0, 0, 0);
         }
     }
+    if (p.in2 != nullptr) {
+        // the second source's k step: weights = tap 27, voxel fragments from global memory (row m of in2, channels 8 q .. 8 q + 7)
+        half8 w2[2], x2[8];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) w2[j] = *(const half8*)(wf + ((27 * 2 + wc) * 4 + j) * 512);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int z = 2 * wr + (i >> 2), y = 2 * (i & 3) + vyp;
+            x2[i] = *(const half8*)(p.in2 + ((((int64_t)b * p.D + z0 + z) * p.H + y0 + y) * p.W + x0 + vx) * 32 + q * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[j], x2[i], acc[j][i], 0, 0, 0);
+    }
     // epilogue: bias -> fp16 (the rounding point of the other kernels) (+ residual) (+ ReLU); channel blocks 0 / 1 trade halves, lane group q stores
     // 8 consecutive channels of block (q & 1) at offset 8 (q >> 1)
     const float lo = (p.relu && p.resid == nullptr) ? 0.f : -65504.f;
@@ -1116,18 +1133,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_halo_wreg_kernel(HaloWregParams
     }
 }
 
-// one thread per 16-byte fragment piece: out[tile][tap][wc][ks][j][lane][8] = w[tile * 64 + wc * 32 + j * 16 + (lane & 15)][tap * 64 + ks * 32 + (lane >> 4) * 8 ..]
+// one thread per 16-byte fragment piece: out[tile][tap][wc][ks][j][lane][8] = w[tile * 64 + wc * 32 + j * 16 + (lane & 15)][tap * 64 + ks * 32 + (lane >> 4) * 8 ..];
+// "tap 27" = the 32 weight columns of a second source behind the 27 taps (k step 0; zeros where the matrix has none)
 __global__ __launch_bounds__(256) void conv3d_pack_wfrag_kernel(const half_t* __restrict__ w, int kpad, int cout, half_t* __restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total = (cout / 64) * 27 * 2 * 2 * 2 * 64;
+    const int total = (cout / 64) * 28 * 2 * 2 * 2 * 64;
     if (idx >= total) return;
     const int lane = idx & 63; int r = idx >> 6;
     const int j = r & 1; r >>= 1;
     const int ks = r & 1; r >>= 1;
     const int wc = r & 1; r >>= 1;
-    const int tap = r % 27; const int tile = r / 27;
+    const int tap = r % 28; const int tile = r / 28;
     const int n = tile * 64 + wc * 32 + j * 16 + (lane & 15);
-    *(half8*)(out + (int64_t)idx * 8) = *(const half8*)(w + (int64_t)n * kpad + tap * 64 + ks * 32 + (lane >> 4) * 8);
+    const int k = tap * 64 + ks * 32 + (lane >> 4) * 8;
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    *(half8*)(out + (int64_t)idx * 8) = (k + 8 <= kpad && (tap < 27 || ks == 0)) ? *(const half8*)(w + (int64_t)n * kpad + k) : zero8;
 }
 
 // split-K finish: sum the slabs in split order (deterministic), then the same epilogue as above.
@@ -1716,11 +1736,11 @@ extern "C" int pcd_conv3d_k3s1_f16(const pcd_conv3d_desc_t* d, void* stream) {
     return PCD_OK;
 }
 
-extern "C" size_t pcd_conv3d_wfrag_bytes(int cout) { return cout > 0 && cout % 64 == 0 ? (size_t)27 * 64 * cout * sizeof(half_t) : 0; }
+extern "C" size_t pcd_conv3d_wfrag_bytes(int cout) { return cout > 0 && cout % 64 == 0 ? (size_t)28 * 64 * cout * sizeof(half_t) : 0; }
 
 extern "C" int pcd_conv3d_pack_wfrag(const void* w, int kpad, int cout, void* wfrag, void* stream) {
     PCD_CHECK_ARG(w && wfrag && cout > 0 && cout % 64 == 0 && kpad >= 27 * 64 && kpad % 8 == 0);
-    const int total = (cout / 64) * 27 * 2 * 2 * 2 * 64;
+    const int total = (cout / 64) * 28 * 2 * 2 * 2 * 64;
     hipLaunchKernelGGL(conv3d_pack_wfrag_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)w, kpad, cout,
                        (half_t*)wfrag);
     PCD_CHECK_LAUNCH();
@@ -1728,7 +1748,7 @@ extern "C" int pcd_conv3d_pack_wfrag(const void* w, int kpad, int cout, void* wf
 }
 
 static bool wreg_supported(const pcd_conv3d_desc_t* d) {
-    return d->ntaps == 27 && d->stride == 1 && d->out_scale == 1 && d->cin == 64 && d->cout % 64 == 0 && d->in2 == nullptr &&
+    return d->ntaps == 27 && d->stride == 1 && d->out_scale == 1 && d->cin == 64 && d->cout % 64 == 0 && (d->in2 == nullptr || d->cin2 == 32) &&
            d->rows_d == d->in_d && d->rows_h == d->in_h && d->rows_w == d->in_w && d->out_d == d->in_d && d->out_h == d->in_h && d->out_w == d->in_w &&
            d->in_d % HTZ == 0 && d->in_h % 8 == 0 && d->in_w % HTX == 0 && d->out_off_z == 0 && d->out_off_y == 0 && d->out_off_x == 0;
 }
@@ -1742,6 +1762,7 @@ extern "C" int pcd_conv3d_k3s1_wreg_f16(const pcd_conv3d_desc_t* d, const void* 
     PCD_CHECK_ARG(wreg_supported(d));
     HaloWregParams p{};
     p.in = (const half_t*)d->in; p.B = d->batch; p.D = d->in_d; p.H = d->in_h; p.W = d->in_w;
+    p.in2 = (const half_t*)d->in2;
     p.wfrag = (const half_t*)wfrag; p.bias = d->bias; p.resid = (const half_t*)d->resid;
     p.out = (half_t*)d->out; p.Cout = d->cout; p.relu = d->relu;
     p.tiles_n = d->cout / 64; p.tz = d->in_d / HTZ; p.ty = d->in_h / 8; p.tx = d->in_w / HTX;

@@ -11,6 +11,7 @@
 struct pcd_vae {
     pcd_vae_desc_t d;
     // fragment-order copies of the k3 layers with C_in = 64 (pcd_conv3d_pack_wfrag), made at create: encoder.5.conv1, decoder.8.conv1 / conv2
+    void* wf_enc2c2 = nullptr;          // (with its fused projection shortcut's columns as "tap 27")
     void* wf_enc5c1 = nullptr;
     void* wf_dec8c1 = nullptr;
     void* wf_dec8c2 = nullptr;
@@ -88,7 +89,7 @@ struct Runner {
         if (R.has_ds && R.fused_ds) {
             // projection shortcut inside conv2's launch: its weights are K columns behind the 27 taps, x the second source.  NOT in
             // place: rows of x (ds.cin channels) and rows of the output (c2.cout channels) have different strides
-            rc = conv(R.c2, h, dim, 1, d.taps3, dim, 1, nullptr, r, x, R.ds.cin);
+            rc = conv(R.c2, h, dim, 1, d.taps3, dim, 1, nullptr, r, x, R.ds.cin, wf2);
             void* t = x; x = r; r = t;
             return rc;
         }
@@ -162,8 +163,8 @@ extern "C" int pcd_vae_create(const pcd_vae_desc_t* desc, pcd_vae_t** out) {
     h->d = *desc;
     // fragment-order weight copies (one-time device work on the null stream, finished before the handle is returned); a failed allocation only
     // means those layers keep the LDS-ring kernel
-    struct { const pcd_vae_conv_t* L; void** dst; } packs[3] = {{&h->d.enc_res[1].c1, &h->wf_enc5c1}, {&h->d.dec_res[2].c1, &h->wf_dec8c1},
-                                                                 {&h->d.dec_res[2].c2, &h->wf_dec8c2}};
+    struct { const pcd_vae_conv_t* L; void** dst; } packs[4] = {{&h->d.enc_res[1].c1, &h->wf_enc5c1}, {&h->d.dec_res[2].c1, &h->wf_dec8c1},
+                                                                 {&h->d.dec_res[2].c2, &h->wf_dec8c2}, {&h->d.enc_res[0].c2, &h->wf_enc2c2}};
     for (auto& pk : packs) {
         const pcd_vae_conv_t& L = *pk.L;
         if (L.k != 3 || L.cin != 64 || L.cout % 64 != 0 || L.kpad < 27 * 64) continue;
@@ -182,7 +183,7 @@ extern "C" int pcd_vae_create(const pcd_vae_desc_t* desc, pcd_vae_t** out) {
 
 extern "C" void pcd_vae_destroy(pcd_vae_t* h) {
     if (h == nullptr) return;
-    for (void* b : {h->wf_enc5c1, h->wf_dec8c1, h->wf_dec8c2})
+    for (void* b : {h->wf_enc2c2, h->wf_enc5c1, h->wf_dec8c1, h->wf_dec8c2})
         if (b != nullptr) (void)hipFree(b);
     delete h;
 }
@@ -214,7 +215,7 @@ extern "C" int pcd_vae_encode(pcd_vae_t* h, const float* vox, int batch, float* 
     // encoder.0/1: Conv3d(1, 32, k3, p1) + ReLU straight from the fp32 occupancy grid
     // a residual block leaves its output in x, whichever buffer that is
     RUN(pcd_conv3d_first(vox, batch, 32, 32, 32, 1, d.enc0_w, d.enc0_b, 32, x, s));
-    RUN(R.res(d.enc_res[0], x, 32, hb, r));                                       // encoder.2   32 -> 64 @ 32^3
+    RUN(R.res(d.enc_res[0], x, 32, hb, r, nullptr, h->wf_enc2c2));                // encoder.2   32 -> 64 @ 32^3
     RUN(R.conv(d.enc_down[0], x, 32, 2, d.taps4s2, 16, 1, nullptr, hb));          // encoder.3/4 k4 s2 -> 16^3
     SWAP(x, hb);
     RUN(R.res(d.enc_res[1], x, 16, hb, r, h->wf_enc5c1));                         // encoder.5   64 -> 128

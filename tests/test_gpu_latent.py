@@ -237,6 +237,21 @@ def test_conv3d_k3s1_weights_in_registers_exact(cout, dims, b):
         d.out = out2.data_ptr()
         _lib.check(lib.pcd_conv3d_k3s1_f16(d, _lib.stream_ptr()))
         assert torch.equal(out, out2)
+    # with a projection shortcut as second source (32 channels; its weight columns behind the 27 taps = "tap 27" of the fragment copy)
+    x2, wd = _int((b, 32) + dims, 65), _int((cout, 32, 1, 1, 1), 66, -1, 2)
+    want2 = (want + F.conv3d(x2.double(), wd.double())).clamp_min(0).half().double()
+    wk2 = np.concatenate([wk[:, :27 * cin], wd.double().numpy().reshape(cout, 32)], axis=1)
+    kpad2 = (wk2.shape[1] + 63) // 64 * 64
+    wp2 = np.zeros((cout, kpad2)); wp2[:, :wk2.shape[1]] = wk2
+    dw2 = torch.from_numpy(wp2).half().cuda()
+    dx2 = x2.permute(0, 2, 3, 4, 1).contiguous().half().cuda()
+    _lib.check(lib.pcd_conv3d_pack_wfrag(dw2.data_ptr(), kpad2, cout, wfrag.data_ptr(), _lib.stream_ptr()))
+    d.resid, d.w, d.kpad, d.in2, d.cin2, d.out = 0, dw2.data_ptr(), kpad2, dx2.data_ptr(), 32, out.data_ptr()
+    assert lib.pcd_conv3d_k3s1_wreg_supported(d) == 1
+    _lib.check(lib.pcd_conv3d_k3s1_wreg_f16(d, wfrag.data_ptr(), _lib.stream_ptr()))
+    got = out.float().cpu().reshape((b,) + dims + (cout,)).permute(0, 4, 1, 2, 3).double()
+    assert torch.equal(got, want2)
+    d.in2, d.cin2 = 0, 0
     d.in_h = d.rows_h = d.out_h = dims[1] + 4                  # H not a multiple of 8: refused
     assert lib.pcd_conv3d_k3s1_wreg_supported(d) == 0 and lib.pcd_conv3d_k3s1_wreg_f16(d, wfrag.data_ptr(), _lib.stream_ptr()) != 0
 
