@@ -991,15 +991,19 @@ struct HaloWregParams {
     int tiles_n, tz, ty, tx, nblocks;
 };
 
-__global__ __launch_bounds__(256, 2) void conv3d_halo_wreg_kernel(HaloWregParams p) {      // two waves per SIMD: at most 256 registers
-    constexpr int CIN = 64, P = CIN * 2, NT = 256, TY8 = 8, HHY8 = TY8 + 2;
+// CIN = 64 or 32 (32: one k step per tap, 64-byte voxel rows, 38.4 KB of halo: four workgroups per CU); NWC = wave columns: a tile is 32 NWC channels
+// wide and a workgroup 2 x NWC waves (C_out = 32 layers: NWC = 1, two waves).
+template <int CIN, int NWC>
+__global__ __launch_bounds__(128 * NWC, 2) void conv3d_halo_wreg_kernel(HaloWregParams p) {      // >= two waves per SIMD: at most 256 registers
+    constexpr int P = CIN * 2, CPV = CIN / 8, KS = CIN / 32, NT = 128 * NWC, TY8 = 8, HHY8 = TY8 + 2, TC = 32 * NWC;
     constexpr int HV = (HTZ + 2) * HHY8 * HHX;                 // 600 halo voxels
-    constexpr int HIT = (HV * 8 + NT - 1) / NT;                // 16-byte chunks per thread (19)
+    constexpr int HIT = (HV * CPV + NT - 1) / NT;              // 16-byte chunks per thread
+    static_assert(HIT <= 32, "one validity bit per chunk in a 32-bit mask");
     __shared__ __attribute__((aligned(16))) char smem[HV * P];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;                   // voxel half (128 of the 256), channel half (32 of the tile's 64)
+    const int wr = wave / NWC, wc = wave - wr * NWC;           // voxel half (128 of the 256), 32-channel column of the tile
     int bid = blockIdx.x;
     if ((p.nblocks & 7) == 0) bid = (bid & 7) * (p.nblocks >> 3) + (bid >> 3);
     const int tn = bid % p.tiles_n; int t = bid / p.tiles_n;
@@ -1015,7 +1019,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_halo_wreg_kernel(HaloWregParams
 #pragma unroll
         for (int it = 0; it < HIT; ++it) {
             const int c = it * NT + tid;
-            const int row = c >> 3, ch = c & 7;
+            const int row = c / CPV, ch = c - row * CPV;
             const int hx = row % HHX; const int r2 = row / HHX;
             const int hy = r2 % HHY8, hz = r2 / HHY8;
             const int iz = z0 - 1 + hz, iy = y0 - 1 + hy, ix = x0 - 1 + hx;
@@ -1027,21 +1031,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_halo_wreg_kernel(HaloWregParams
 #pragma unroll
         for (int it = 0; it < HIT; ++it) {
             const int c = it * NT + tid;
-            const int row = c >> 3, ch = c & 7;
+            const int row = c / CPV, ch = c - row * CPV;
             const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
             const int hx = row % HHX, hy = (row / HHX) % HHY8;
-            const int sw = (((hx >> 1) & 1) << 1) | ((hy & 1) << 2);
+            const int sw = CIN == 64 ? (((hx >> 1) & 1) << 1) | ((hy & 1) << 2) : (hy & 1) << 1;
             if (row < HV) *(half8*)(smem + row * P + ((ch ^ sw) << 4)) = (okmask >> it) & 1 ? hv[it] : zero8;
         }
     }
     const int q = lane >> 4, n16 = lane & 15;
-    // this wave's weight fragments: tap t, k step ks, channel block j at wf + ((t * 2 + wc) * 4 + ks * 2 + j) * 512 halfs (+ lane * 8)
-    const half_t* wf = p.wfrag + (int64_t)tn * 28 * 2 * 4 * 512 + lane * 8;
+    // this wave's weight fragments: tap t, k step ks, channel block j at wf + (((t * NWC + wc) * KS + ks) * 2 + j) * 512 halfs (+ lane * 8)
+    const half_t* wf = p.wfrag + (int64_t)tn * 28 * NWC * KS * 2 * 512 + lane * 8;
     float bv[2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bv[j][r] = p.bias != nullptr ? p.bias[tn * 64 + wc * 32 + j * 16 + q * 4 + r] : 0.f;
+        for (int r = 0; r < 4; ++r) bv[j][r] = p.bias != nullptr ? p.bias[tn * TC + wc * 32 + j * 16 + q * 4 + r] : 0.f;
     // voxel blocks of this wave: i -> local (z = 2 wr + (i >> 2), y = 2 (i & 3) + (n16 >> 3), x = n16 & 7)
     const int vx = n16 & 7, vyp = n16 >> 3;
     int vrow[8];
@@ -1052,12 +1056,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_halo_wreg_kernel(HaloWregParams
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    half8 wq[3][2][2];                                         // weight fragments of taps t, t + 1, t + 2 (ring of three)
+    half8 wq[3][KS][2];                                        // weight fragments of taps t, t + 1, t + 2 (ring of three)
     auto wload = [&](int slot, int tap) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) wq[slot][ks][j] = *(const half8*)(wf + ((tap * 2 + wc) * 4 + ks * 2 + j) * 512);
+            for (int j = 0; j < 2; ++j) wq[slot][ks][j] = *(const half8*)(wf + (((tap * NWC + wc) * KS + ks) * 2 + j) * 512);
     };
     wload(0, 0);
     wload(1, 1);
@@ -1069,9 +1073,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_halo_wreg_kernel(HaloWregParams
         __builtin_amdgcn_sched_barrier(0);                     // the loads stay HERE, two taps ahead of their use (left alone the scheduler sinks them to it)
         const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
         const int voff = ((kz * HHY8 + ky) * HHX + kx) * P;
-        const int sw = ((((vx + kx) >> 1) & 1) << 1) | (((vyp + ky) & 1) << 2);
+        const int sw = CIN == 64 ? ((((vx + kx) >> 1) & 1) << 1) | (((vyp + ky) & 1) << 2) : ((vyp + ky) & 1) << 1;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             half8 vf[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) vf[i] = *(const half8*)(smem + vrow[i] + voff + (((ks * 4 + q) ^ sw) << 4));
@@ -1081,11 +1085,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_halo_wreg_kernel(HaloWregParams
                 for (int i = 0; i < 8; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[tap % 3][ks][j], vf[i], acc[j][i], 0, 0, 0);
         }
     }
-    if (p.in2 != nullptr) {
+    if (CIN == 64 && p.in2 != nullptr) {
         // the second source's k step: weights = tap 27, voxel fragments from global memory (row m of in2, channels 8 q .. 8 q + 7)
         half8 w2[2], x2[8];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) w2[j] = *(const half8*)(wf + ((27 * 2 + wc) * 4 + j) * 512);
+        for (int j = 0; j < 2; ++j) w2[j] = *(const half8*)(wf + (((27 * NWC + wc) * KS) * 2 + j) * 512);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int z = 2 * wr + (i >> 2), y = 2 * (i & 3) + vyp;
@@ -1117,7 +1121,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_halo_wreg_kernel(HaloWregParams
         u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
         const int z = 2 * wr + (i >> 2), y = 2 * (i & 3) + vyp;
         const int64_t orow = (((int64_t)b * p.D + z0 + z) * p.H + y0 + y) * p.W + x0 + vx;
-        const int col = tn * 64 + wc * 32 + (q & 1) * 16 + (q >> 1) * 8;
+        const int col = tn * TC + wc * 32 + (q & 1) * 16 + (q >> 1) * 8;
         if (p.resid != nullptr) {
             half8 ov = __builtin_bit_cast(half8, o);
             const half8 rs = *(const half8*)(p.resid + orow * p.Cout + col);
@@ -1133,19 +1137,20 @@ __global__ __launch_bounds__(256, 2) void conv3d_halo_wreg_kernel(HaloWregParams
     }
 }
 
-// one thread per 16-byte fragment piece: out[tile][tap][wc][ks][j][lane][8] = w[tile * 64 + wc * 32 + j * 16 + (lane & 15)][tap * 64 + ks * 32 + (lane >> 4) * 8 ..];
+// one thread per 16-byte fragment piece: out[tile][tap][wc][ks][j][lane][8] = w[tile * 32 nwc + wc * 32 + j * 16 + (lane & 15)][tap * cin + ks * 32 + (lane >> 4) * 8 ..];
 // "tap 27" = the 32 weight columns of a second source behind the 27 taps (k step 0; zeros where the matrix has none)
-__global__ __launch_bounds__(256) void conv3d_pack_wfrag_kernel(const half_t* __restrict__ w, int kpad, int cout, half_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void conv3d_pack_wfrag_kernel(const half_t* __restrict__ w, int kpad, int cin, int cout, int nwc, half_t* __restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total = (cout / 64) * 28 * 2 * 2 * 2 * 64;
+    const int kst = cin / 32, tc = 32 * nwc;
+    const int total = (cout / tc) * 28 * nwc * kst * 2 * 64;
     if (idx >= total) return;
     const int lane = idx & 63; int r = idx >> 6;
     const int j = r & 1; r >>= 1;
-    const int ks = r & 1; r >>= 1;
-    const int wc = r & 1; r >>= 1;
+    const int ks = r % kst; r /= kst;
+    const int wc = r % nwc; r /= nwc;
     const int tap = r % 28; const int tile = r / 28;
-    const int n = tile * 64 + wc * 32 + j * 16 + (lane & 15);
-    const int k = tap * 64 + ks * 32 + (lane >> 4) * 8;
+    const int n = tile * tc + wc * 32 + j * 16 + (lane & 15);
+    const int k = tap * cin + ks * 32 + (lane >> 4) * 8;
     const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     *(half8*)(out + (int64_t)idx * 8) = (k + 8 <= kpad && (tap < 27 || ks == 0)) ? *(const half8*)(w + (int64_t)n * kpad + k) : zero8;
 }
@@ -1736,19 +1741,26 @@ extern "C" int pcd_conv3d_k3s1_f16(const pcd_conv3d_desc_t* d, void* stream) {
     return PCD_OK;
 }
 
-extern "C" size_t pcd_conv3d_wfrag_bytes(int cout) { return cout > 0 && cout % 64 == 0 ? (size_t)28 * 64 * cout * sizeof(half_t) : 0; }
+// wave columns of a tile: C_out = 32 layers run 32-wide tiles on two waves, everything else 64-wide tiles on four
+static int wreg_nwc(int cout) { return cout == 32 ? 1 : 2; }
+// (C_in 64 -> C_out 32 is left to conv3d_halo_kernel: two waves over a 76.8-KB halo would be one wave per SIMD)
+static bool wreg_shape_ok(int cin, int cout) { return (cin == 64 || cin == 32) && cout > 0 && ((cout == 32 && cin == 32) || cout % 64 == 0); }
 
-extern "C" int pcd_conv3d_pack_wfrag(const void* w, int kpad, int cout, void* wfrag, void* stream) {
-    PCD_CHECK_ARG(w && wfrag && cout > 0 && cout % 64 == 0 && kpad >= 27 * 64 && kpad % 8 == 0);
-    const int total = (cout / 64) * 28 * 2 * 2 * 2 * 64;
-    hipLaunchKernelGGL(conv3d_pack_wfrag_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)w, kpad, cout,
-                       (half_t*)wfrag);
+extern "C" size_t pcd_conv3d_wfrag_bytes(int cin, int cout) { return wreg_shape_ok(cin, cout) ? (size_t)28 * cin * cout * sizeof(half_t) : 0; }
+
+extern "C" int pcd_conv3d_pack_wfrag(const void* w, int kpad, int cin, int cout, void* wfrag, void* stream) {
+    PCD_CHECK_ARG(w && wfrag && wreg_shape_ok(cin, cout) && kpad >= 27 * cin && kpad % 8 == 0);
+    const int nwc = wreg_nwc(cout);
+    const int total = (cout / (32 * nwc)) * 28 * nwc * (cin / 32) * 2 * 64;
+    hipLaunchKernelGGL(conv3d_pack_wfrag_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)w, kpad, cin, cout,
+                       nwc, (half_t*)wfrag);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }
 
 static bool wreg_supported(const pcd_conv3d_desc_t* d) {
-    return d->ntaps == 27 && d->stride == 1 && d->out_scale == 1 && d->cin == 64 && d->cout % 64 == 0 && (d->in2 == nullptr || d->cin2 == 32) &&
+    return d->ntaps == 27 && d->stride == 1 && d->out_scale == 1 && wreg_shape_ok(d->cin, d->cout) &&
+           (d->in2 == nullptr || (d->cin == 64 && d->cin2 == 32)) &&
            d->rows_d == d->in_d && d->rows_h == d->in_h && d->rows_w == d->in_w && d->out_d == d->in_d && d->out_h == d->in_h && d->out_w == d->in_w &&
            d->in_d % HTZ == 0 && d->in_h % 8 == 0 && d->in_w % HTX == 0 && d->out_off_z == 0 && d->out_off_y == 0 && d->out_off_x == 0;
 }
@@ -1765,11 +1777,16 @@ extern "C" int pcd_conv3d_k3s1_wreg_f16(const pcd_conv3d_desc_t* d, const void* 
     p.in2 = (const half_t*)d->in2;
     p.wfrag = (const half_t*)wfrag; p.bias = d->bias; p.resid = (const half_t*)d->resid;
     p.out = (half_t*)d->out; p.Cout = d->cout; p.relu = d->relu;
-    p.tiles_n = d->cout / 64; p.tz = d->in_d / HTZ; p.ty = d->in_h / 8; p.tx = d->in_w / HTX;
+    const int nwc = wreg_nwc(d->cout);
+    p.tiles_n = d->cout / (32 * nwc); p.tz = d->in_d / HTZ; p.ty = d->in_h / 8; p.tx = d->in_w / HTX;
     const int64_t blocks = (int64_t)d->batch * p.tz * p.ty * p.tx * p.tiles_n;
     PCD_CHECK_ARG(blocks <= 0x7fffffff);
     p.nblocks = (int)blocks;
-    hipLaunchKernelGGL(conv3d_halo_wreg_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)blocks);
+    if (d->cin == 64) hipLaunchKernelGGL((conv3d_halo_wreg_kernel<64, 2>), grid, dim3(256), 0, s, p);
+    else if (nwc == 2) hipLaunchKernelGGL((conv3d_halo_wreg_kernel<32, 2>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv3d_halo_wreg_kernel<32, 1>), grid, dim3(128), 0, s, p);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

@@ -11,7 +11,10 @@
 struct pcd_vae {
     pcd_vae_desc_t d;
     // fragment-order copies of the k3 layers with C_in = 64 (pcd_conv3d_pack_wfrag), made at create: encoder.5.conv1, decoder.8.conv1 / conv2
+    void* wf_enc2c1 = nullptr;
     void* wf_enc2c2 = nullptr;          // (with its fused projection shortcut's columns as "tap 27")
+    void* wf_dec11c1 = nullptr;
+    void* wf_dec11c2 = nullptr;
     void* wf_enc5c1 = nullptr;
     void* wf_dec8c1 = nullptr;
     void* wf_dec8c2 = nullptr;
@@ -163,14 +166,17 @@ extern "C" int pcd_vae_create(const pcd_vae_desc_t* desc, pcd_vae_t** out) {
     h->d = *desc;
     // fragment-order weight copies (one-time device work on the null stream, finished before the handle is returned); a failed allocation only
     // means those layers keep the LDS-ring kernel
-    struct { const pcd_vae_conv_t* L; void** dst; } packs[4] = {{&h->d.enc_res[1].c1, &h->wf_enc5c1}, {&h->d.dec_res[2].c1, &h->wf_dec8c1},
-                                                                 {&h->d.dec_res[2].c2, &h->wf_dec8c2}, {&h->d.enc_res[0].c2, &h->wf_enc2c2}};
+    struct { const pcd_vae_conv_t* L; void** dst; } packs[] = {{&h->d.enc_res[1].c1, &h->wf_enc5c1}, {&h->d.dec_res[2].c1, &h->wf_dec8c1},
+                                                                {&h->d.dec_res[2].c2, &h->wf_dec8c2}, {&h->d.enc_res[0].c2, &h->wf_enc2c2},
+                                                                {&h->d.enc_res[0].c1, &h->wf_enc2c1}, {&h->d.dec_res[3].c1, &h->wf_dec11c1},
+                                                                {&h->d.dec_res[3].c2, &h->wf_dec11c2}};
     for (auto& pk : packs) {
         const pcd_vae_conv_t& L = *pk.L;
-        if (L.k != 3 || L.cin != 64 || L.cout % 64 != 0 || L.kpad < 27 * 64) continue;
+        const size_t bytes = L.k == 3 && L.kpad >= 27 * L.cin ? pcd_conv3d_wfrag_bytes(L.cin, L.cout) : 0;
+        if (bytes == 0) continue;
         void* buf = nullptr;
-        if (hipMalloc(&buf, pcd_conv3d_wfrag_bytes(L.cout)) != hipSuccess) { (void)hipGetLastError(); continue; }
-        if (pcd_conv3d_pack_wfrag(L.w, L.kpad, L.cout, buf, nullptr) != PCD_OK || hipStreamSynchronize(nullptr) != hipSuccess) {
+        if (hipMalloc(&buf, bytes) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (pcd_conv3d_pack_wfrag(L.w, L.kpad, L.cin, L.cout, buf, nullptr) != PCD_OK || hipStreamSynchronize(nullptr) != hipSuccess) {
             (void)hipGetLastError();
             (void)hipFree(buf);
             continue;
@@ -183,7 +189,7 @@ extern "C" int pcd_vae_create(const pcd_vae_desc_t* desc, pcd_vae_t** out) {
 
 extern "C" void pcd_vae_destroy(pcd_vae_t* h) {
     if (h == nullptr) return;
-    for (void* b : {h->wf_enc2c2, h->wf_enc5c1, h->wf_dec8c1, h->wf_dec8c2})
+    for (void* b : {h->wf_enc2c1, h->wf_enc2c2, h->wf_enc5c1, h->wf_dec8c1, h->wf_dec8c2, h->wf_dec11c1, h->wf_dec11c2})
         if (b != nullptr) (void)hipFree(b);
     delete h;
 }
@@ -215,7 +221,7 @@ extern "C" int pcd_vae_encode(pcd_vae_t* h, const float* vox, int batch, float* 
     // encoder.0/1: Conv3d(1, 32, k3, p1) + ReLU straight from the fp32 occupancy grid
     // a residual block leaves its output in x, whichever buffer that is
     RUN(pcd_conv3d_first(vox, batch, 32, 32, 32, 1, d.enc0_w, d.enc0_b, 32, x, s));
-    RUN(R.res(d.enc_res[0], x, 32, hb, r, nullptr, h->wf_enc2c2));                // encoder.2   32 -> 64 @ 32^3
+    RUN(R.res(d.enc_res[0], x, 32, hb, r, h->wf_enc2c1, h->wf_enc2c2));           // encoder.2   32 -> 64 @ 32^3
     RUN(R.conv(d.enc_down[0], x, 32, 2, d.taps4s2, 16, 1, nullptr, hb));          // encoder.3/4 k4 s2 -> 16^3
     SWAP(x, hb);
     RUN(R.res(d.enc_res[1], x, 16, hb, r, h->wf_enc5c1));                         // encoder.5   64 -> 128
@@ -275,7 +281,7 @@ extern "C" int pcd_vae_decode(pcd_vae_t* h, const float* z, int batch, float* ou
     RUN(R.res(d.dec_res[2], x, 32, hb, r, h->wf_dec8c1, h->wf_dec8c2));           // decoder.8
     RUN(R.conv(d.dec_conv9, x, 32, 1, d.taps3, 32, 1, nullptr, hb));              // decoder.9/10  64 -> 32
     SWAP(x, hb);
-    RUN(R.res(d.dec_res[3], x, 32, hb, r));                                       // decoder.11
+    RUN(R.res(d.dec_res[3], x, 32, hb, r, h->wf_dec11c1, h->wf_dec11c2));         // decoder.11
     RUN(pcd_conv3d_last_sigmoid(x, batch, 32, 32, 32, 32, d.last_w, d.last_b, out, s));   // decoder.12/13
     return PCD_OK;
 }

@@ -197,15 +197,15 @@ def test_vae_fused_shortcut_matches_the_separate_launches(ldm):
     assert torch.equal(mu2, mu_f)
 
 
-@pytest.mark.parametrize("cout,dims,b", [(64, (4, 8, 8), 1), (64, (8, 16, 8), 3), (128, (4, 8, 16), 2), (192, (4, 8, 8), 4)])
-def test_conv3d_k3s1_weights_in_registers_exact(cout, dims, b):
+@pytest.mark.parametrize("cin,cout,dims,b", [(64, 64, (4, 8, 8), 1), (64, 64, (8, 16, 8), 3), (64, 128, (4, 8, 16), 2), (64, 192, (4, 8, 8), 4),
+                                             (32, 32, (4, 8, 8), 3), (32, 32, (8, 8, 16), 2), (32, 64, (4, 16, 8), 3)])
+def test_conv3d_k3s1_weights_in_registers_exact(cin, cout, dims, b):
     """The weights-in-registers form of the k3 / C_in = 64 layers (256-row workgroups, fragment-order weights loaded straight into the MFMA operand
     registers, no barrier in the tap loop, transposed product with direct stores) against F.conv3d on exactly representable integers, with and
     without the residual + ReLU epilogue, one to three C_out tiles -- and bit-identical to pcd_conv3d_k3s1_f16 on the same descriptor."""
     from shapegen_amd import _lib
     from shapegen_amd.vae import _pack_conv, _taps_regular
     lib = _lib.load()
-    cin = 64
     x, w, bias = _int((b, cin) + dims, 61), _int((cout, cin, 3, 3, 3), 62, -1, 2), _int((cout,), 63)
     want = F.conv3d(x.double(), w.double(), bias.double(), padding=1)
     resid = _int(tuple(want.shape), 64)
@@ -215,8 +215,8 @@ def test_conv3d_k3s1_weights_in_registers_exact(cout, dims, b):
     dr = resid.permute(0, 2, 3, 4, 1).contiguous().half().cuda()
     taps = torch.from_numpy(_taps_regular(3, 1)).cuda()
     zero = torch.zeros(64, dtype=torch.float16, device="cuda")
-    wfrag = torch.empty(int(lib.pcd_conv3d_wfrag_bytes(cout)), dtype=torch.uint8, device="cuda")
-    _lib.check(lib.pcd_conv3d_pack_wfrag(dw.data_ptr(), kpad, cout, wfrag.data_ptr(), _lib.stream_ptr()))
+    wfrag = torch.empty(int(lib.pcd_conv3d_wfrag_bytes(cin, cout)), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.pcd_conv3d_pack_wfrag(dw.data_ptr(), kpad, cin, cout, wfrag.data_ptr(), _lib.stream_ptr()))
     for use_resid in (False, True):
         out = torch.full((b * dims[0] * dims[1] * dims[2], cout), 3.0, dtype=torch.float16, device="cuda")
         d = _lib.Conv3dDesc()
@@ -237,6 +237,8 @@ def test_conv3d_k3s1_weights_in_registers_exact(cout, dims, b):
         d.out = out2.data_ptr()
         _lib.check(lib.pcd_conv3d_k3s1_f16(d, _lib.stream_ptr()))
         assert torch.equal(out, out2)
+    if cin != 64:
+        return
     # with a projection shortcut as second source (32 channels; its weight columns behind the 27 taps = "tap 27" of the fragment copy)
     x2, wd = _int((b, 32) + dims, 65), _int((cout, 32, 1, 1, 1), 66, -1, 2)
     want2 = (want + F.conv3d(x2.double(), wd.double())).clamp_min(0).half().double()
@@ -245,7 +247,7 @@ def test_conv3d_k3s1_weights_in_registers_exact(cout, dims, b):
     wp2 = np.zeros((cout, kpad2)); wp2[:, :wk2.shape[1]] = wk2
     dw2 = torch.from_numpy(wp2).half().cuda()
     dx2 = x2.permute(0, 2, 3, 4, 1).contiguous().half().cuda()
-    _lib.check(lib.pcd_conv3d_pack_wfrag(dw2.data_ptr(), kpad2, cout, wfrag.data_ptr(), _lib.stream_ptr()))
+    _lib.check(lib.pcd_conv3d_pack_wfrag(dw2.data_ptr(), kpad2, cin, cout, wfrag.data_ptr(), _lib.stream_ptr()))
     d.resid, d.w, d.kpad, d.in2, d.cin2, d.out = 0, dw2.data_ptr(), kpad2, dx2.data_ptr(), 32, out.data_ptr()
     assert lib.pcd_conv3d_k3s1_wreg_supported(d) == 1
     _lib.check(lib.pcd_conv3d_k3s1_wreg_f16(d, wfrag.data_ptr(), _lib.stream_ptr()))
