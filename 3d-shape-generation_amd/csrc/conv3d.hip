@@ -993,9 +993,10 @@ struct HaloWregParams {
 
 // CIN = 64 or 32 (32: one k step per tap, 64-byte voxel rows, 38.4 KB of halo: four workgroups per CU); NWC = wave columns: a tile is 32 NWC channels
 // wide and a workgroup 2 x NWC waves (C_out = 32 layers: NWC = 1, two waves).
-template <int CIN, int NWC>
-__global__ __launch_bounds__(128 * NWC, 2) void conv3d_halo_wreg_kernel(HaloWregParams p) {      // >= two waves per SIMD: at most 256 registers
-    constexpr int P = CIN * 2, CPV = CIN / 8, KS = CIN / 32, NT = 128 * NWC, TY8 = 8, HHY8 = TY8 + 2, TC = 32 * NWC;
+template <int CIN, int NWC, int NWR = 2>
+__global__ __launch_bounds__(64 * NWR * NWC, 2) void conv3d_halo_wreg_kernel(HaloWregParams p) {      // >= two waves per SIMD: at most 256 registers
+    constexpr int P = CIN * 2, CPV = CIN / 8, KS = CIN / 32, NT = 64 * NWR * NWC, TY8 = 8, HHY8 = TY8 + 2, TC = 32 * NWC;
+    constexpr int NB = 16 / NWR;                               // 16-voxel blocks per wave: NWR = 2 wave rows of 128 voxels, or 4 of 64 (C_in 64 -> C_out 32: four waves)
     constexpr int HV = (HTZ + 2) * HHY8 * HHX;                 // 600 halo voxels
     constexpr int HIT = (HV * CPV + NT - 1) / NT;              // 16-byte chunks per thread
     static_assert(HIT <= 32, "one validity bit per chunk in a 32-bit mask");
@@ -1003,7 +1004,7 @@ __global__ __launch_bounds__(128 * NWC, 2) void conv3d_halo_wreg_kernel(HaloWreg
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave / NWC, wc = wave - wr * NWC;           // voxel half (128 of the 256), 32-channel column of the tile
+    const int wr = wave / NWC, wc = wave - wr * NWC;           // voxel rows wr * 16 NB .. of the 256, 32-channel column of the tile
     int bid = blockIdx.x;
     if ((p.nblocks & 7) == 0) bid = (bid & 7) * (p.nblocks >> 3) + (bid >> 3);
     const int tn = bid % p.tiles_n; int t = bid / p.tiles_n;
@@ -1046,16 +1047,16 @@ __global__ __launch_bounds__(128 * NWC, 2) void conv3d_halo_wreg_kernel(HaloWreg
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) bv[j][r] = p.bias != nullptr ? p.bias[tn * TC + wc * 32 + j * 16 + q * 4 + r] : 0.f;
-    // voxel blocks of this wave: i -> local (z = 2 wr + (i >> 2), y = 2 (i & 3) + (n16 >> 3), x = n16 & 7)
+    // voxel blocks of this wave: block g = wr * NB + i -> local (z = g >> 2, y = 2 (g & 3) + (n16 >> 3), x = n16 & 7)
     const int vx = n16 & 7, vyp = n16 >> 3;
-    int vrow[8];
+    int vrow[NB];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) vrow[i] = (((2 * wr + (i >> 2)) * HHY8 + 2 * (i & 3) + vyp) * HHX + vx) * P;
-    f32x4 acc[2][8];
+    for (int i = 0; i < NB; ++i) vrow[i] = ((((wr * NB + i) >> 2) * HHY8 + 2 * ((wr * NB + i) & 3) + vyp) * HHX + vx) * P;
+    f32x4 acc[2][NB];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < NB; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     half8 wq[3][KS][2];                                        // weight fragments of taps t, t + 1, t + 2 (ring of three)
     auto wload = [&](int slot, int tap) __attribute__((always_inline)) {
 #pragma unroll
@@ -1076,35 +1077,35 @@ __global__ __launch_bounds__(128 * NWC, 2) void conv3d_halo_wreg_kernel(HaloWreg
         const int sw = CIN == 64 ? ((((vx + kx) >> 1) & 1) << 1) | (((vyp + ky) & 1) << 2) : ((vyp + ky) & 1) << 1;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            half8 vf[8];
+            half8 vf[NB];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) vf[i] = *(const half8*)(smem + vrow[i] + voff + (((ks * 4 + q) ^ sw) << 4));
+            for (int i = 0; i < NB; ++i) vf[i] = *(const half8*)(smem + vrow[i] + voff + (((ks * 4 + q) ^ sw) << 4));
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[tap % 3][ks][j], vf[i], acc[j][i], 0, 0, 0);
+                for (int i = 0; i < NB; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[tap % 3][ks][j], vf[i], acc[j][i], 0, 0, 0);
         }
     }
     if (CIN == 64 && p.in2 != nullptr) {
         // the second source's k step: weights = tap 27, voxel fragments from global memory (row m of in2, channels 8 q .. 8 q + 7)
-        half8 w2[2], x2[8];
+        half8 w2[2], x2[NB];
 #pragma unroll
         for (int j = 0; j < 2; ++j) w2[j] = *(const half8*)(wf + (((27 * NWC + wc) * KS) * 2 + j) * 512);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int z = 2 * wr + (i >> 2), y = 2 * (i & 3) + vyp;
+        for (int i = 0; i < NB; ++i) {
+            const int z = (wr * NB + i) >> 2, y = 2 * ((wr * NB + i) & 3) + vyp;
             x2[i] = *(const half8*)(p.in2 + ((((int64_t)b * p.D + z0 + z) * p.H + y0 + y) * p.W + x0 + vx) * 32 + q * 8);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[j], x2[i], acc[j][i], 0, 0, 0);
+            for (int i = 0; i < NB; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[j], x2[i], acc[j][i], 0, 0, 0);
     }
     // epilogue: bias -> fp16 (the rounding point of the other kernels) (+ residual) (+ ReLU); channel blocks 0 / 1 trade halves, lane group q stores
     // 8 consecutive channels of block (q & 1) at offset 8 (q >> 1)
     const float lo = (p.relu && p.resid == nullptr) ? 0.f : -65504.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NB; ++i) {
         unsigned pk[2][2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -1119,7 +1120,7 @@ __global__ __launch_bounds__(128 * NWC, 2) void conv3d_halo_wreg_kernel(HaloWreg
         const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
-        const int z = 2 * wr + (i >> 2), y = 2 * (i & 3) + vyp;
+        const int z = (wr * NB + i) >> 2, y = 2 * ((wr * NB + i) & 3) + vyp;
         const int64_t orow = (((int64_t)b * p.D + z0 + z) * p.H + y0 + y) * p.W + x0 + vx;
         const int col = tn * TC + wc * 32 + (q & 1) * 16 + (q >> 1) * 8;
         if (p.resid != nullptr) {
@@ -1743,8 +1744,7 @@ extern "C" int pcd_conv3d_k3s1_f16(const pcd_conv3d_desc_t* d, void* stream) {
 
 // wave columns of a tile: C_out = 32 layers run 32-wide tiles on two waves, everything else 64-wide tiles on four
 static int wreg_nwc(int cout) { return cout == 32 ? 1 : 2; }
-// (C_in 64 -> C_out 32 is left to conv3d_halo_kernel: two waves over a 76.8-KB halo would be one wave per SIMD)
-static bool wreg_shape_ok(int cin, int cout) { return (cin == 64 || cin == 32) && cout > 0 && ((cout == 32 && cin == 32) || cout % 64 == 0); }
+static bool wreg_shape_ok(int cin, int cout) { return (cin == 64 || cin == 32) && cout > 0 && (cout == 32 || cout % 64 == 0); }
 
 extern "C" size_t pcd_conv3d_wfrag_bytes(int cin, int cout) { return wreg_shape_ok(cin, cout) ? (size_t)28 * cin * cout * sizeof(half_t) : 0; }
 
@@ -1784,7 +1784,8 @@ extern "C" int pcd_conv3d_k3s1_wreg_f16(const pcd_conv3d_desc_t* d, const void* 
     p.nblocks = (int)blocks;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)blocks);
-    if (d->cin == 64) hipLaunchKernelGGL((conv3d_halo_wreg_kernel<64, 2>), grid, dim3(256), 0, s, p);
+    if (d->cin == 64 && nwc == 2) hipLaunchKernelGGL((conv3d_halo_wreg_kernel<64, 2>), grid, dim3(256), 0, s, p);
+    else if (d->cin == 64) hipLaunchKernelGGL((conv3d_halo_wreg_kernel<64, 1, 4>), grid, dim3(256), 0, s, p);     // C_out 32: four waves of 64 voxels
     else if (nwc == 2) hipLaunchKernelGGL((conv3d_halo_wreg_kernel<32, 2>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((conv3d_halo_wreg_kernel<32, 1>), grid, dim3(128), 0, s, p);
     PCD_CHECK_LAUNCH();

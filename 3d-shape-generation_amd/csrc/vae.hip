@@ -13,6 +13,7 @@ struct pcd_vae {
     // fragment-order copies of the k3 layers with C_in = 64 (pcd_conv3d_pack_wfrag), made at create: encoder.5.conv1, decoder.8.conv1 / conv2
     void* wf_enc2c1 = nullptr;
     void* wf_enc2c2 = nullptr;          // (with its fused projection shortcut's columns as "tap 27")
+    void* wf_dec9 = nullptr;
     void* wf_dec11c1 = nullptr;
     void* wf_dec11c2 = nullptr;
     void* wf_enc5c1 = nullptr;
@@ -169,7 +170,7 @@ extern "C" int pcd_vae_create(const pcd_vae_desc_t* desc, pcd_vae_t** out) {
     struct { const pcd_vae_conv_t* L; void** dst; } packs[] = {{&h->d.enc_res[1].c1, &h->wf_enc5c1}, {&h->d.dec_res[2].c1, &h->wf_dec8c1},
                                                                 {&h->d.dec_res[2].c2, &h->wf_dec8c2}, {&h->d.enc_res[0].c2, &h->wf_enc2c2},
                                                                 {&h->d.enc_res[0].c1, &h->wf_enc2c1}, {&h->d.dec_res[3].c1, &h->wf_dec11c1},
-                                                                {&h->d.dec_res[3].c2, &h->wf_dec11c2}};
+                                                                {&h->d.dec_res[3].c2, &h->wf_dec11c2}, {&h->d.dec_conv9, &h->wf_dec9}};
     for (auto& pk : packs) {
         const pcd_vae_conv_t& L = *pk.L;
         const size_t bytes = L.k == 3 && L.kpad >= 27 * L.cin ? pcd_conv3d_wfrag_bytes(L.cin, L.cout) : 0;
@@ -189,7 +190,7 @@ extern "C" int pcd_vae_create(const pcd_vae_desc_t* desc, pcd_vae_t** out) {
 
 extern "C" void pcd_vae_destroy(pcd_vae_t* h) {
     if (h == nullptr) return;
-    for (void* b : {h->wf_enc2c1, h->wf_enc2c2, h->wf_enc5c1, h->wf_dec8c1, h->wf_dec8c2, h->wf_dec11c1, h->wf_dec11c2})
+    for (void* b : {h->wf_enc2c1, h->wf_enc2c2, h->wf_enc5c1, h->wf_dec8c1, h->wf_dec8c2, h->wf_dec9, h->wf_dec11c1, h->wf_dec11c2})
         if (b != nullptr) (void)hipFree(b);
     delete h;
 }
@@ -279,7 +280,7 @@ extern "C" int pcd_vae_decode(pcd_vae_t* h, const float* z, int batch, float* ou
     RUN(R.convT(d.dec_up[2], x, 16, hb));                                         // decoder.6/7  128 -> 64 @ 32^3
     SWAP(x, hb);
     RUN(R.res(d.dec_res[2], x, 32, hb, r, h->wf_dec8c1, h->wf_dec8c2));           // decoder.8
-    RUN(R.conv(d.dec_conv9, x, 32, 1, d.taps3, 32, 1, nullptr, hb));              // decoder.9/10  64 -> 32
+    RUN(R.conv(d.dec_conv9, x, 32, 1, d.taps3, 32, 1, nullptr, hb, nullptr, 0, h->wf_dec9));   // decoder.9/10  64 -> 32
     SWAP(x, hb);
     RUN(R.res(d.dec_res[3], x, 32, hb, r, h->wf_dec11c1, h->wf_dec11c2));         // decoder.11
     RUN(pcd_conv3d_last_sigmoid(x, batch, 32, 32, 32, 32, d.last_w, d.last_b, out, s));   // decoder.12/13

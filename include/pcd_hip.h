@@ -419,7 +419,7 @@ int pcd_conv3d_k3s1_f16(const pcd_conv3d_desc_t* d, void* stream);
  * pcd_conv3d_k3s1_f16 (bias, residual, ReLU; d->w / d->kpad / d->taps are not read), the weights given in MFMA-fragment order -- wfrag, made once per
  * layer by pcd_conv3d_pack_wfrag from the [cout][kpad] matrix (pcd_conv3d_wfrag_bytes(cin, cout) bytes).  A workgroup owns 4 x 8 x 8 output voxels with their
  * halo in LDS; weight fragments are coalesced 1-KB global loads straight into MFMA operand registers; no barrier in the tap loop.  Supported: cin 64 or 32,
- * cout a multiple of 64 (cin 32: also cout 32), dims multiples of (4, 8, 8), at cin 64 a second source of 32 channels (its weight columns are "tap 27" of wfrag, its rows come straight
+ * cout 32 or a multiple of 64, dims multiples of (4, 8, 8), at cin 64 a second source of 32 channels (its weight columns are "tap 27" of wfrag, its rows come straight
  * from global memory); pcd_conv3d_k3s1_wreg_supported() tells.  Same sums in the same k order as
  * pcd_conv3d_k3s1_f16 per accumulator (bitwise the same outputs). */
 size_t pcd_conv3d_wfrag_bytes(int cin, int cout);

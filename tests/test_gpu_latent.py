@@ -198,7 +198,7 @@ def test_vae_fused_shortcut_matches_the_separate_launches(ldm):
 
 
 @pytest.mark.parametrize("cin,cout,dims,b", [(64, 64, (4, 8, 8), 1), (64, 64, (8, 16, 8), 3), (64, 128, (4, 8, 16), 2), (64, 192, (4, 8, 8), 4),
-                                             (32, 32, (4, 8, 8), 3), (32, 32, (8, 8, 16), 2), (32, 64, (4, 16, 8), 3)])
+                                             (32, 32, (4, 8, 8), 3), (32, 32, (8, 8, 16), 2), (32, 64, (4, 16, 8), 3), (64, 32, (4, 8, 8), 5)])
 def test_conv3d_k3s1_weights_in_registers_exact(cin, cout, dims, b):
     """The weights-in-registers form of the k3 / C_in = 64 layers (256-row workgroups, fragment-order weights loaded straight into the MFMA operand
     registers, no barrier in the tap loop, transposed product with direct stores) against F.conv3d on exactly representable integers, with and
