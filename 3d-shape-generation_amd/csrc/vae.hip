@@ -175,6 +175,10 @@ extern "C" int pcd_vae_create(const pcd_vae_desc_t* desc, pcd_vae_t** out) {
         const pcd_vae_conv_t& L = *pk.L;
         const size_t bytes = L.k == 3 && L.kpad >= 27 * L.cin ? pcd_conv3d_wfrag_bytes(L.cin, L.cout) : 0;
         if (bytes == 0) continue;
+        // (the copy is allocated on the CURRENT device: only if that is where the weights live -- one process per GPU sets it so)
+        hipPointerAttribute_t at;
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || hipPointerGetAttributes(&at, L.w) != hipSuccess || at.device != cur) { (void)hipGetLastError(); continue; }
         void* buf = nullptr;
         if (hipMalloc(&buf, bytes) != hipSuccess) { (void)hipGetLastError(); continue; }
         if (pcd_conv3d_pack_wfrag(L.w, L.kpad, L.cin, L.cout, buf, nullptr) != PCD_OK || hipStreamSynchronize(nullptr) != hipSuccess) {
