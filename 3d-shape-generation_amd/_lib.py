@@ -190,7 +190,7 @@ _SIGS = {
     "pcd_conv3d_workspace_bytes": (sz, [C.POINTER(Conv3dDesc), i32]),
     "pcd_conv3d_f16_multi": (i32, [C.POINTER(Conv3dDesc), i32, vp, sz, vp]),
     "pcd_conv3d_wfrag_bytes": (sz, [i32, i32]),
-    "pcd_conv3d_pack_wfrag": (i32, [vp, i32, i32, i32, vp, vp]),
+    "pcd_conv3d_pack_wfrag": (i32, [vp, i32, i32, i32, i32, vp, vp]),
     "pcd_conv3d_k3s1_wreg_supported": (i32, [C.POINTER(Conv3dDesc)]),
     "pcd_conv3d_k3s1_wreg_f16": (i32, [C.POINTER(Conv3dDesc), vp, vp]),
     "pcd_conv3d_k4s2_halo_supported": (i32, [i32, i32, i32, i32, i32, i32, i32]),

@@ -981,9 +981,10 @@ __global__ __launch_bounds__(256) void conv3d_k4s2_halo_kernel(ConvS2HaloParams 
 // compiler pipelines (counted vmcnt / lgkmcnt of its own).  Transposed product, 16-byte direct stores (+ residual), as convT3d_halo_kernel.
 struct HaloWregParams {
     const half_t* in; int B, D, H, W;
-    const half_t* in2;                // optional second source (pcd_conv3d_desc_t.in2, 32 channels): one more 32-deep k step behind the 27 taps, its voxel
-                                      // fragments straight from global memory (a lane's 16 bytes = 8 of a row's 32 channels), its weights = "tap 27" of wfrag
-    const half_t* wfrag;              // [tiles_n][28][2][2][2][64][8] (tap 27: k step 0 only, the second source's 32 weight columns)
+    const half_t* in2; int cin2;      // optional second source (pcd_conv3d_desc_t.in2, 32 or 64 channels): one or two more 32-deep k steps behind the taps, its
+                                      // voxel fragments straight from global memory (a lane's 16 bytes = 8 of a row's channels), its weights = the stage
+                                      // behind the last tap's
+    const half_t* wfrag;              // [tiles_n][27 SPT + 1 stages][NWC][KSS][2][64][8]: a stage = up to 64 channels of one tap (SPT per tap), + the second source's
     const float* bias;
     const half_t* resid;
     half_t* out; int Cout;
@@ -992,10 +993,12 @@ struct HaloWregParams {
 };
 
 // CIN = 64 or 32 (32: one k step per tap, 64-byte voxel rows, 38.4 KB of halo: four workgroups per CU); NWC = wave columns: a tile is 32 NWC channels
-// wide and a workgroup 2 x NWC waves (C_out = 32 layers: NWC = 1, two waves).
+// wide and a workgroup NWR x NWC waves (C_out = 32 layers: NWC = 1).  CIN = 128: 256-byte voxel rows (the swizzle of convT3d_halo_kernel), a 153.6-KB halo
+// = ONE workgroup per CU, so it runs eight waves (tiles of 128 channels, NWC = 4); a tap is then two weight stages of 64 channels.
 template <int CIN, int NWC, int NWR = 2>
 __global__ __launch_bounds__(64 * NWR * NWC, 2) void conv3d_halo_wreg_kernel(HaloWregParams p) {      // >= two waves per SIMD: at most 256 registers
-    constexpr int P = CIN * 2, CPV = CIN / 8, KS = CIN / 32, NT = 64 * NWR * NWC, TY8 = 8, HHY8 = TY8 + 2, TC = 32 * NWC;
+    constexpr int P = CIN * 2, CPV = CIN / 8, NT = 64 * NWR * NWC, TY8 = 8, HHY8 = TY8 + 2, TC = 32 * NWC;
+    constexpr int SPT = CIN > 64 ? CIN / 64 : 1, KSS = (CIN > 64 ? 64 : CIN) / 32, NSTG = 27 * SPT;      // weight stages per tap, k steps per stage, stages
     constexpr int NB = 16 / NWR;                               // 16-voxel blocks per wave: NWR = 2 wave rows of 128 voxels, or 4 of 64 (C_in 64 -> C_out 32: four waves)
     constexpr int HV = (HTZ + 2) * HHY8 * HHX;                 // 600 halo voxels
     constexpr int HIT = (HV * CPV + NT - 1) / NT;              // 16-byte chunks per thread
@@ -1035,13 +1038,13 @@ __global__ __launch_bounds__(64 * NWR * NWC, 2) void conv3d_halo_wreg_kernel(Hal
             const int row = c / CPV, ch = c - row * CPV;
             const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
             const int hx = row % HHX, hy = (row / HHX) % HHY8;
-            const int sw = CIN == 64 ? (((hx >> 1) & 1) << 1) | ((hy & 1) << 2) : (hy & 1) << 1;
+            const int sw = CIN == 128 ? (hx & 7) << 1 : (CIN == 64 ? (((hx >> 1) & 1) << 1) | ((hy & 1) << 2) : (hy & 1) << 1);
             if (row < HV) *(half8*)(smem + row * P + ((ch ^ sw) << 4)) = (okmask >> it) & 1 ? hv[it] : zero8;
         }
     }
     const int q = lane >> 4, n16 = lane & 15;
-    // this wave's weight fragments: tap t, k step ks, channel block j at wf + (((t * NWC + wc) * KS + ks) * 2 + j) * 512 halfs (+ lane * 8)
-    const half_t* wf = p.wfrag + (int64_t)tn * 28 * NWC * KS * 2 * 512 + lane * 8;
+    // this wave's weight fragments: stage g, k step ks, channel block j at wf + (((g * NWC + wc) * KSS + ks) * 2 + j) * 512 halfs (+ lane * 8)
+    const half_t* wf = p.wfrag + (int64_t)tn * (NSTG + 1) * NWC * KSS * 2 * 512 + lane * 8;
     float bv[2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -1057,49 +1060,57 @@ __global__ __launch_bounds__(64 * NWR * NWC, 2) void conv3d_halo_wreg_kernel(Hal
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int i = 0; i < NB; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    half8 wq[3][KS][2];                                        // weight fragments of taps t, t + 1, t + 2 (ring of three)
-    auto wload = [&](int slot, int tap) __attribute__((always_inline)) {
+    half8 wq[3][KSS][2];                                       // weight fragments of stages g, g + 1, g + 2 (ring of three)
+    auto wload = [&](int slot, int g) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
+        for (int ks = 0; ks < KSS; ++ks)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) wq[slot][ks][j] = *(const half8*)(wf + (((tap * NWC + wc) * KS + ks) * 2 + j) * 512);
+            for (int j = 0; j < 2; ++j) wq[slot][ks][j] = *(const half8*)(wf + (((g * NWC + wc) * KSS + ks) * 2 + j) * 512);
     };
     wload(0, 0);
     wload(1, 1);
     __syncthreads();                                           // the halo is in place; no barrier from here on
 
 #pragma unroll
-    for (int tap = 0; tap < 27; ++tap) {
-        if (tap + 2 < 27) wload((tap + 2) % 3, tap + 2);
-        __builtin_amdgcn_sched_barrier(0);                     // the loads stay HERE, two taps ahead of their use (left alone the scheduler sinks them to it)
+    for (int g = 0; g < NSTG; ++g) {
+        if (g + 2 < NSTG) wload((g + 2) % 3, g + 2);
+        __builtin_amdgcn_sched_barrier(0);                     // the loads stay HERE, two stages ahead of their use (left alone the scheduler sinks them to it)
+        const int tap = g / SPT, kh = g % SPT;                 // kh: which 64 channels of the tap
         const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
         const int voff = ((kz * HHY8 + ky) * HHX + kx) * P;
-        const int sw = CIN == 64 ? ((((vx + kx) >> 1) & 1) << 1) | (((vyp + ky) & 1) << 2) : ((vyp + ky) & 1) << 1;
+        const int sw = CIN == 128 ? ((vx + kx) & 7) << 1
+                                  : (CIN == 64 ? ((((vx + kx) >> 1) & 1) << 1) | (((vyp + ky) & 1) << 2) : ((vyp + ky) & 1) << 1);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+        for (int ks = 0; ks < KSS; ++ks) {
             half8 vf[NB];
 #pragma unroll
-            for (int i = 0; i < NB; ++i) vf[i] = *(const half8*)(smem + vrow[i] + voff + (((ks * 4 + q) ^ sw) << 4));
+            for (int i = 0; i < NB; ++i) vf[i] = *(const half8*)(smem + vrow[i] + voff + ((((kh * KSS + ks) * 4 + q) ^ sw) << 4));
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int i = 0; i < NB; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[tap % 3][ks][j], vf[i], acc[j][i], 0, 0, 0);
+                for (int i = 0; i < NB; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[g % 3][ks][j], vf[i], acc[j][i], 0, 0, 0);
         }
     }
-    if (CIN == 64 && p.in2 != nullptr) {
-        // the second source's k step: weights = tap 27, voxel fragments from global memory (row m of in2, channels 8 q .. 8 q + 7)
-        half8 w2[2], x2[NB];
+    if (CIN >= 64 && p.in2 != nullptr) {
+        // the second source's k steps (cin2 / 32 of them): weights = the stage behind the last tap's, voxel fragments from global memory (row m of in2,
+        // channels 32 ks + 8 q .. + 7)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) w2[j] = *(const half8*)(wf + (((27 * NWC + wc) * KS) * 2 + j) * 512);
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks * 32 < p.cin2) {
+                half8 w2[2], x2[NB];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int z = (wr * NB + i) >> 2, y = 2 * ((wr * NB + i) & 3) + vyp;
-            x2[i] = *(const half8*)(p.in2 + ((((int64_t)b * p.D + z0 + z) * p.H + y0 + y) * p.W + x0 + vx) * 32 + q * 8);
+                for (int j = 0; j < 2; ++j) w2[j] = *(const half8*)(wf + (((NSTG * NWC + wc) * KSS + ks) * 2 + j) * 512);
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int z = (wr * NB + i) >> 2, y = 2 * ((wr * NB + i) & 3) + vyp;
+                    x2[i] = *(const half8*)(p.in2 + ((((int64_t)b * p.D + z0 + z) * p.H + y0 + y) * p.W + x0 + vx) * p.cin2 + ks * 32 + q * 8);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[j], x2[i], acc[j][i], 0, 0, 0);
+            }
         }
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < NB; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[j], x2[i], acc[j][i], 0, 0, 0);
     }
     // epilogue: bias -> fp16 (the rounding point of the other kernels) (+ residual) (+ ReLU); channel blocks 0 / 1 trade halves, lane group q stores
     // 8 consecutive channels of block (q & 1) at offset 8 (q >> 1)
@@ -1138,22 +1149,25 @@ __global__ __launch_bounds__(64 * NWR * NWC, 2) void conv3d_halo_wreg_kernel(Hal
     }
 }
 
-// one thread per 16-byte fragment piece: out[tile][tap][wc][ks][j][lane][8] = w[tile * 32 nwc + wc * 32 + j * 16 + (lane & 15)][tap * cin + ks * 32 + (lane >> 4) * 8 ..];
-// "tap 27" = the 32 weight columns of a second source behind the 27 taps (k step 0; zeros where the matrix has none)
-__global__ __launch_bounds__(256) void conv3d_pack_wfrag_kernel(const half_t* __restrict__ w, int kpad, int cin, int cout, int nwc, half_t* __restrict__ out) {
+// one thread per 16-byte fragment piece: out[tile][stage][wc][ks][j][lane][8] = w[tile * tc + wc * 32 + j * 16 + (lane & 15)][k ..], k = tap * cin + kh * 64 + ks * 32 +
+// (lane >> 4) * 8 for stage = tap * spt + kh (spt = stages per tap: cin / 64, or 1); the LAST stage = the cin2 weight columns of a second source behind the 27 taps
+__global__ __launch_bounds__(256) void conv3d_pack_wfrag_kernel(const half_t* __restrict__ w, int kpad, int cin, int cout, int cin2, int nwc, half_t* __restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int kst = cin / 32, tc = 32 * nwc;
-    const int total = (cout / tc) * 28 * nwc * kst * 2 * 64;
+    const int spt = cin > 64 ? cin / 64 : 1, kss = (cin > 64 ? 64 : cin) / 32, nstg = 27 * spt + 1, tc = 32 * nwc;
+    const int total = (cout / tc) * nstg * nwc * kss * 2 * 64;
     if (idx >= total) return;
     const int lane = idx & 63; int r = idx >> 6;
     const int j = r & 1; r >>= 1;
-    const int ks = r % kst; r /= kst;
+    const int ks = r % kss; r /= kss;
     const int wc = r % nwc; r /= nwc;
-    const int tap = r % 28; const int tile = r / 28;
+    const int g = r % nstg; const int tile = r / nstg;
     const int n = tile * tc + wc * 32 + j * 16 + (lane & 15);
-    const int k = tap * cin + ks * 32 + (lane >> 4) * 8;
+    const int kk = ks * 32 + (lane >> 4) * 8;
+    const bool extra = g == nstg - 1;
+    const int k = extra ? 27 * cin + kk : (g / spt) * cin + (g % spt) * 64 + kk;
+    const bool real = !extra || kk + 8 <= cin2;
     const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    *(half8*)(out + (int64_t)idx * 8) = (k + 8 <= kpad && (tap < 27 || ks == 0)) ? *(const half8*)(w + (int64_t)n * kpad + k) : zero8;
+    *(half8*)(out + (int64_t)idx * 8) = (real && k + 8 <= kpad) ? *(const half8*)(w + (int64_t)n * kpad + k) : zero8;
 }
 
 // split-K finish: sum the slabs in split order (deterministic), then the same epilogue as above.
@@ -1742,25 +1756,31 @@ extern "C" int pcd_conv3d_k3s1_f16(const pcd_conv3d_desc_t* d, void* stream) {
     return PCD_OK;
 }
 
-// wave columns of a tile: C_out = 32 layers run 32-wide tiles on two waves, everything else 64-wide tiles on four
-static int wreg_nwc(int cout) { return cout == 32 ? 1 : 2; }
-static bool wreg_shape_ok(int cin, int cout) { return (cin == 64 || cin == 32) && cout > 0 && (cout == 32 || cout % 64 == 0); }
+// wave columns of a tile: C_out = 32 layers run 32-wide tiles, C_in = 128 layers 128-wide tiles on eight waves, everything else 64-wide tiles on four
+static int wreg_nwc(int cin, int cout) { return cin == 128 ? 4 : (cout == 32 ? 1 : 2); }
+static bool wreg_shape_ok(int cin, int cout) {
+    return cout > 0 && (((cin == 64 || cin == 32) && (cout == 32 || cout % 64 == 0)) || (cin == 128 && cout % 128 == 0));
+}
+static int wreg_stages(int cin) { return 27 * (cin > 64 ? cin / 64 : 1) + 1; }
 
-extern "C" size_t pcd_conv3d_wfrag_bytes(int cin, int cout) { return wreg_shape_ok(cin, cout) ? (size_t)28 * cin * cout * sizeof(half_t) : 0; }
+extern "C" size_t pcd_conv3d_wfrag_bytes(int cin, int cout) {
+    return wreg_shape_ok(cin, cout) ? (size_t)wreg_stages(cin) * (cin > 64 ? 64 : cin) * cout * sizeof(half_t) : 0;
+}
 
-extern "C" int pcd_conv3d_pack_wfrag(const void* w, int kpad, int cin, int cout, void* wfrag, void* stream) {
-    PCD_CHECK_ARG(w && wfrag && wreg_shape_ok(cin, cout) && kpad >= 27 * cin && kpad % 8 == 0);
-    const int nwc = wreg_nwc(cout);
-    const int total = (cout / (32 * nwc)) * 28 * nwc * (cin / 32) * 2 * 64;
+extern "C" int pcd_conv3d_pack_wfrag(const void* w, int kpad, int cin, int cout, int cin2, void* wfrag, void* stream) {
+    PCD_CHECK_ARG(w && wfrag && wreg_shape_ok(cin, cout) && (cin2 == 0 || (cin >= 64 && (cin2 == 32 || cin2 == 64))));
+    PCD_CHECK_ARG(kpad >= 27 * cin + cin2 && kpad % 8 == 0);
+    const int nwc = wreg_nwc(cin, cout);
+    const int total = (cout / (32 * nwc)) * wreg_stages(cin) * nwc * ((cin > 64 ? 64 : cin) / 32) * 2 * 64;
     hipLaunchKernelGGL(conv3d_pack_wfrag_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)w, kpad, cin, cout,
-                       nwc, (half_t*)wfrag);
+                       cin2, nwc, (half_t*)wfrag);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }
 
 static bool wreg_supported(const pcd_conv3d_desc_t* d) {
     return d->ntaps == 27 && d->stride == 1 && d->out_scale == 1 && wreg_shape_ok(d->cin, d->cout) &&
-           (d->in2 == nullptr || (d->cin == 64 && d->cin2 == 32)) &&
+           (d->in2 == nullptr || (d->cin >= 64 && (d->cin2 == 32 || d->cin2 == 64))) &&
            d->rows_d == d->in_d && d->rows_h == d->in_h && d->rows_w == d->in_w && d->out_d == d->in_d && d->out_h == d->in_h && d->out_w == d->in_w &&
            d->in_d % HTZ == 0 && d->in_h % 8 == 0 && d->in_w % HTX == 0 && d->out_off_z == 0 && d->out_off_y == 0 && d->out_off_x == 0;
 }
@@ -1774,17 +1794,18 @@ extern "C" int pcd_conv3d_k3s1_wreg_f16(const pcd_conv3d_desc_t* d, const void* 
     PCD_CHECK_ARG(wreg_supported(d));
     HaloWregParams p{};
     p.in = (const half_t*)d->in; p.B = d->batch; p.D = d->in_d; p.H = d->in_h; p.W = d->in_w;
-    p.in2 = (const half_t*)d->in2;
+    p.in2 = (const half_t*)d->in2; p.cin2 = d->in2 ? d->cin2 : 0;
     p.wfrag = (const half_t*)wfrag; p.bias = d->bias; p.resid = (const half_t*)d->resid;
     p.out = (half_t*)d->out; p.Cout = d->cout; p.relu = d->relu;
-    const int nwc = wreg_nwc(d->cout);
+    const int nwc = wreg_nwc(d->cin, d->cout);
     p.tiles_n = d->cout / (32 * nwc); p.tz = d->in_d / HTZ; p.ty = d->in_h / 8; p.tx = d->in_w / HTX;
     const int64_t blocks = (int64_t)d->batch * p.tz * p.ty * p.tx * p.tiles_n;
     PCD_CHECK_ARG(blocks <= 0x7fffffff);
     p.nblocks = (int)blocks;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)blocks);
-    if (d->cin == 64 && nwc == 2) hipLaunchKernelGGL((conv3d_halo_wreg_kernel<64, 2>), grid, dim3(256), 0, s, p);
+    if (d->cin == 128) hipLaunchKernelGGL((conv3d_halo_wreg_kernel<128, 4>), grid, dim3(512), 0, s, p);              // eight waves, one workgroup per CU
+    else if (d->cin == 64 && nwc == 2) hipLaunchKernelGGL((conv3d_halo_wreg_kernel<64, 2>), grid, dim3(256), 0, s, p);
     else if (d->cin == 64) hipLaunchKernelGGL((conv3d_halo_wreg_kernel<64, 1, 4>), grid, dim3(256), 0, s, p);     // C_out 32: four waves of 64 voxels
     else if (nwc == 2) hipLaunchKernelGGL((conv3d_halo_wreg_kernel<32, 2>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((conv3d_halo_wreg_kernel<32, 1>), grid, dim3(128), 0, s, p);

@@ -17,6 +17,9 @@ struct pcd_vae {
     void* wf_dec11c1 = nullptr;
     void* wf_dec11c2 = nullptr;
     void* wf_enc5c1 = nullptr;
+    void* wf_enc5c2 = nullptr;          // (128 -> 128 with its 64-channel shortcut)
+    void* wf_dec5c1 = nullptr;
+    void* wf_dec5c2 = nullptr;
     void* wf_dec8c1 = nullptr;
     void* wf_dec8c2 = nullptr;
 };
@@ -170,18 +173,22 @@ extern "C" int pcd_vae_create(const pcd_vae_desc_t* desc, pcd_vae_t** out) {
     struct { const pcd_vae_conv_t* L; void** dst; } packs[] = {{&h->d.enc_res[1].c1, &h->wf_enc5c1}, {&h->d.dec_res[2].c1, &h->wf_dec8c1},
                                                                 {&h->d.dec_res[2].c2, &h->wf_dec8c2}, {&h->d.enc_res[0].c2, &h->wf_enc2c2},
                                                                 {&h->d.enc_res[0].c1, &h->wf_enc2c1}, {&h->d.dec_res[3].c1, &h->wf_dec11c1},
-                                                                {&h->d.dec_res[3].c2, &h->wf_dec11c2}, {&h->d.dec_conv9, &h->wf_dec9}};
+                                                                {&h->d.dec_res[3].c2, &h->wf_dec11c2}, {&h->d.dec_conv9, &h->wf_dec9},
+                                                                {&h->d.enc_res[1].c2, &h->wf_enc5c2}, {&h->d.dec_res[1].c1, &h->wf_dec5c1},
+                                                                {&h->d.dec_res[1].c2, &h->wf_dec5c2}};
     for (auto& pk : packs) {
         const pcd_vae_conv_t& L = *pk.L;
         const size_t bytes = L.k == 3 && L.kpad >= 27 * L.cin ? pcd_conv3d_wfrag_bytes(L.cin, L.cout) : 0;
         if (bytes == 0) continue;
+        // a fused projection shortcut's columns sit behind the 27 taps: up to kpad - 27 cin of them (the packer pads K to a multiple of 64 with zeros)
+        const int extra = L.kpad - 27 * L.cin, cin2 = L.cin >= 64 ? (extra >= 64 ? 64 : (extra >= 32 ? 32 : 0)) : 0;
         // (the copy is allocated on the CURRENT device: only if that is where the weights live -- one process per GPU sets it so)
         hipPointerAttribute_t at;
         int cur = -1;
         if (hipGetDevice(&cur) != hipSuccess || hipPointerGetAttributes(&at, L.w) != hipSuccess || at.device != cur) { (void)hipGetLastError(); continue; }
         void* buf = nullptr;
         if (hipMalloc(&buf, bytes) != hipSuccess) { (void)hipGetLastError(); continue; }
-        if (pcd_conv3d_pack_wfrag(L.w, L.kpad, L.cin, L.cout, buf, nullptr) != PCD_OK || hipStreamSynchronize(nullptr) != hipSuccess) {
+        if (pcd_conv3d_pack_wfrag(L.w, L.kpad, L.cin, L.cout, cin2, buf, nullptr) != PCD_OK || hipStreamSynchronize(nullptr) != hipSuccess) {
             (void)hipGetLastError();
             (void)hipFree(buf);
             continue;
@@ -194,7 +201,7 @@ extern "C" int pcd_vae_create(const pcd_vae_desc_t* desc, pcd_vae_t** out) {
 
 extern "C" void pcd_vae_destroy(pcd_vae_t* h) {
     if (h == nullptr) return;
-    for (void* b : {h->wf_enc2c1, h->wf_enc2c2, h->wf_enc5c1, h->wf_dec8c1, h->wf_dec8c2, h->wf_dec9, h->wf_dec11c1, h->wf_dec11c2})
+    for (void* b : {h->wf_enc2c1, h->wf_enc2c2, h->wf_enc5c1, h->wf_enc5c2, h->wf_dec5c1, h->wf_dec5c2, h->wf_dec8c1, h->wf_dec8c2, h->wf_dec9, h->wf_dec11c1, h->wf_dec11c2})
         if (b != nullptr) (void)hipFree(b);
     delete h;
 }
@@ -229,7 +236,7 @@ extern "C" int pcd_vae_encode(pcd_vae_t* h, const float* vox, int batch, float* 
     RUN(R.res(d.enc_res[0], x, 32, hb, r, h->wf_enc2c1, h->wf_enc2c2));           // encoder.2   32 -> 64 @ 32^3
     RUN(R.conv(d.enc_down[0], x, 32, 2, d.taps4s2, 16, 1, nullptr, hb));          // encoder.3/4 k4 s2 -> 16^3
     SWAP(x, hb);
-    RUN(R.res(d.enc_res[1], x, 16, hb, r, h->wf_enc5c1));                         // encoder.5   64 -> 128
+    RUN(R.res(d.enc_res[1], x, 16, hb, r, h->wf_enc5c1, h->wf_enc5c2));           // encoder.5   64 -> 128
     RUN(R.conv(d.enc_down[1], x, 16, 2, d.taps4s2, 8, 1, nullptr, hb));           // encoder.6/7 -> 8^3
     SWAP(x, hb);
     RUN(R.res(d.enc_res[2], x, 8, hb, r));                                        // encoder.8   128 -> 256
@@ -280,7 +287,7 @@ extern "C" int pcd_vae_decode(pcd_vae_t* h, const float* z, int batch, float* ou
     RUN(R.res(d.dec_res[0], x, 8, hb, r));                                        // decoder.2
     RUN(R.convT(d.dec_up[1], x, 8, hb));                                          // decoder.3/4  256 -> 128 @ 16^3
     SWAP(x, hb);
-    RUN(R.res(d.dec_res[1], x, 16, hb, r));                                       // decoder.5
+    RUN(R.res(d.dec_res[1], x, 16, hb, r, h->wf_dec5c1, h->wf_dec5c2));           // decoder.5
     RUN(R.convT(d.dec_up[2], x, 16, hb));                                         // decoder.6/7  128 -> 64 @ 32^3
     SWAP(x, hb);
     RUN(R.res(d.dec_res[2], x, 32, hb, r, h->wf_dec8c1, h->wf_dec8c2));           // decoder.8

@@ -415,15 +415,16 @@ int pcd_conv3d_config(int tall_halo_tiles);
  * dims multiples of (4, 4, 8), out_scale 1; pcd_conv3d_k3s1_supported() tells (1/0), unsupported -> PCD_ERR_ARG. */
 int pcd_conv3d_k3s1_supported(const pcd_conv3d_desc_t* d);
 int pcd_conv3d_k3s1_f16(const pcd_conv3d_desc_t* d, void* stream);
-/* Conv3d(k3, stride 1, pad 1), C_in = 64 or 32, with the weights in registers (csrc/conv3d.hip: conv3d_halo_wreg_kernel): the same function and descriptor as
+/* Conv3d(k3, stride 1, pad 1), C_in = 128, 64 or 32, with the weights in registers (csrc/conv3d.hip: conv3d_halo_wreg_kernel): the same function and descriptor as
  * pcd_conv3d_k3s1_f16 (bias, residual, ReLU; d->w / d->kpad / d->taps are not read), the weights given in MFMA-fragment order -- wfrag, made once per
  * layer by pcd_conv3d_pack_wfrag from the [cout][kpad] matrix (pcd_conv3d_wfrag_bytes(cin, cout) bytes).  A workgroup owns 4 x 8 x 8 output voxels with their
- * halo in LDS; weight fragments are coalesced 1-KB global loads straight into MFMA operand registers; no barrier in the tap loop.  Supported: cin 64 or 32,
- * cout 32 or a multiple of 64, dims multiples of (4, 8, 8), at cin 64 a second source of 32 channels (its weight columns are "tap 27" of wfrag, its rows come straight
+ * halo in LDS; weight fragments are coalesced 1-KB global loads straight into MFMA operand registers; no barrier in the tap loop.  Supported: cin 128 (eight
+ * waves over a 153.6-KB halo, cout % 128 == 0), 64 or 32 (cout 32 or a multiple of 64), dims multiples of (4, 8, 8), at cin >= 64 a second source of cin2 = 32 or
+ * 64 channels (pack with the same cin2) (its weight columns are "tap 27" of wfrag, its rows come straight
  * from global memory); pcd_conv3d_k3s1_wreg_supported() tells.  Same sums in the same k order as
  * pcd_conv3d_k3s1_f16 per accumulator (bitwise the same outputs). */
 size_t pcd_conv3d_wfrag_bytes(int cin, int cout);
-int pcd_conv3d_pack_wfrag(const void* w, int kpad, int cin, int cout, void* wfrag, void* stream);
+int pcd_conv3d_pack_wfrag(const void* w, int kpad, int cin, int cout, int cin2, void* wfrag, void* stream);
 int pcd_conv3d_k3s1_wreg_supported(const pcd_conv3d_desc_t* d);
 int pcd_conv3d_k3s1_wreg_f16(const pcd_conv3d_desc_t* d, const void* wfrag, void* stream);
 /* Conv3d(k4, s2, p1) (+ folded BN) (+ ReLU) with LDS-resident input (encoder.3/4, networks.py:2229-2230; csrc/conv3d.hip: conv3d_k4s2_halo_kernel):

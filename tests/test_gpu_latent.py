@@ -198,7 +198,8 @@ def test_vae_fused_shortcut_matches_the_separate_launches(ldm):
 
 
 @pytest.mark.parametrize("cin,cout,dims,b", [(64, 64, (4, 8, 8), 1), (64, 64, (8, 16, 8), 3), (64, 128, (4, 8, 16), 2), (64, 192, (4, 8, 8), 4),
-                                             (32, 32, (4, 8, 8), 3), (32, 32, (8, 8, 16), 2), (32, 64, (4, 16, 8), 3), (64, 32, (4, 8, 8), 5)])
+                                             (32, 32, (4, 8, 8), 3), (32, 32, (8, 8, 16), 2), (32, 64, (4, 16, 8), 3), (64, 32, (4, 8, 8), 5),
+                                             (128, 128, (4, 8, 8), 2), (128, 256, (8, 8, 16), 1)])
 def test_conv3d_k3s1_weights_in_registers_exact(cin, cout, dims, b):
     """The weights-in-registers form of the k3 / C_in = 64 layers (256-row workgroups, fragment-order weights loaded straight into the MFMA operand
     registers, no barrier in the tap loop, transposed product with direct stores) against F.conv3d on exactly representable integers, with and
@@ -216,7 +217,7 @@ def test_conv3d_k3s1_weights_in_registers_exact(cin, cout, dims, b):
     taps = torch.from_numpy(_taps_regular(3, 1)).cuda()
     zero = torch.zeros(64, dtype=torch.float16, device="cuda")
     wfrag = torch.empty(int(lib.pcd_conv3d_wfrag_bytes(cin, cout)), dtype=torch.uint8, device="cuda")
-    _lib.check(lib.pcd_conv3d_pack_wfrag(dw.data_ptr(), kpad, cin, cout, wfrag.data_ptr(), _lib.stream_ptr()))
+    _lib.check(lib.pcd_conv3d_pack_wfrag(dw.data_ptr(), kpad, cin, cout, 0, wfrag.data_ptr(), _lib.stream_ptr()))
     for use_resid in (False, True):
         out = torch.full((b * dims[0] * dims[1] * dims[2], cout), 3.0, dtype=torch.float16, device="cuda")
         d = _lib.Conv3dDesc()
@@ -235,20 +236,21 @@ def test_conv3d_k3s1_weights_in_registers_exact(cin, cout, dims, b):
         assert torch.equal(got, ref), use_resid
         out2 = torch.empty_like(out)
         d.out = out2.data_ptr()
-        _lib.check(lib.pcd_conv3d_k3s1_f16(d, _lib.stream_ptr()))
+        _lib.check((lib.pcd_conv3d_k3s1_f16 if cin <= 64 else lib.pcd_conv3d_f16)(d, _lib.stream_ptr()))      # (C_in 128: the implicit GEMM, same k order)
         assert torch.equal(out, out2)
-    if cin != 64:
+    if cin < 64:
         return
-    # with a projection shortcut as second source (32 channels; its weight columns behind the 27 taps = "tap 27" of the fragment copy)
-    x2, wd = _int((b, 32) + dims, 65), _int((cout, 32, 1, 1, 1), 66, -1, 2)
+    # with a projection shortcut as second source (32 channels, 64 at C_in 128; its weight columns sit behind the 27 taps = the last stage of the fragment copy)
+    c2 = 32 if cin == 64 else 64
+    x2, wd = _int((b, c2) + dims, 65), _int((cout, c2, 1, 1, 1), 66, -1, 2)
     want2 = (want + F.conv3d(x2.double(), wd.double())).clamp_min(0).half().double()
-    wk2 = np.concatenate([wk[:, :27 * cin], wd.double().numpy().reshape(cout, 32)], axis=1)
+    wk2 = np.concatenate([wk[:, :27 * cin], wd.double().numpy().reshape(cout, c2)], axis=1)
     kpad2 = (wk2.shape[1] + 63) // 64 * 64
     wp2 = np.zeros((cout, kpad2)); wp2[:, :wk2.shape[1]] = wk2
     dw2 = torch.from_numpy(wp2).half().cuda()
     dx2 = x2.permute(0, 2, 3, 4, 1).contiguous().half().cuda()
-    _lib.check(lib.pcd_conv3d_pack_wfrag(dw2.data_ptr(), kpad2, cin, cout, wfrag.data_ptr(), _lib.stream_ptr()))
-    d.resid, d.w, d.kpad, d.in2, d.cin2, d.out = 0, dw2.data_ptr(), kpad2, dx2.data_ptr(), 32, out.data_ptr()
+    _lib.check(lib.pcd_conv3d_pack_wfrag(dw2.data_ptr(), kpad2, cin, cout, c2, wfrag.data_ptr(), _lib.stream_ptr()))
+    d.resid, d.w, d.kpad, d.in2, d.cin2, d.out = 0, dw2.data_ptr(), kpad2, dx2.data_ptr(), c2, out.data_ptr()
     assert lib.pcd_conv3d_k3s1_wreg_supported(d) == 1
     _lib.check(lib.pcd_conv3d_k3s1_wreg_f16(d, wfrag.data_ptr(), _lib.stream_ptr()))
     got = out.float().cpu().reshape((b,) + dims + (cout,)).permute(0, 4, 1, 2, 3).double()
@@ -448,8 +450,8 @@ def test_conv3d_k4s2_halo_exact(dims, b):
 
 
 def test_vae_decode_halo_transposed_convolution_matches_the_class_launches(ldm):
-    """decoder.6 through the LDS-halo kernel (default) against the eight implicit-GEMM class launches inside the whole decode: the same fp16
-    products summed in fp32 in another order, one fp16 rounding either way -- decoded probabilities agree to 2e-3 (measured below)."""
+    """The round-4 convolution kernels (default) against the implicit-GEMM / LDS-ring forms they replace (pcd_vae_config(0)) inside the whole decode
+    and the whole encode: the same fp16 products summed in fp32, in another order where the old form splits K."""
     from shapegen_amd import _lib
     lib = _lib.load()
     z = torch.randn(8, 256, generator=torch.Generator().manual_seed(77)).cuda()
@@ -461,7 +463,9 @@ def test_vae_decode_halo_transposed_convolution_matches_the_class_launches(ldm):
         _lib.check(lib.pcd_vae_config(1))
     err = (a - c).abs()
     print(f"decode: halo transposed convolution v. class launches: max {float(err.max()):.2e} mean {float(err.mean()):.2e}")
-    assert float(err.max()) < 2e-3 and torch.equal(ldm.vae.decode(z), a)
+    # (decoder.6's two forms are bitwise equal; the C_in = 128 layers' implicit GEMM splits K at this batch, another fp32 summation order than the
+    # weights-in-registers kernel's: the bound is the golden decode test's)
+    assert float(err.max()) < 5e-3 and float(err.mean()) < 5e-4 and torch.equal(ldm.vae.decode(z), a)
     # encoder.3 through its LDS kernel (default) against the implicit GEMM inside the whole encode
     vox = synth_voxels(8, 6).cuda()
     mu_a, lv_a = ldm.vae.encode(vox)
