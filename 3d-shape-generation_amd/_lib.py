@@ -113,6 +113,9 @@ _SIGS = {
     "pcd_sum_slabs_f32": (i32, [vp, i32, i64, i32, vp, i64, vp]),
     "pcd_gemm_f16_residual": (i32, [C.POINTER(GemmDesc), vp, i64, vp, i64, vp]),
     "pcd_gemm_f16_colmax": (i32, [C.POINTER(GemmDesc), vp, i32, vp]),
+    "pcd_gemm_pack_wfrag": (i32, [vp, i64, i32, i32, vp, vp]),
+    "pcd_gemm_f16_colmax_wfrag": (i32, [C.POINTER(GemmDesc), vp, vp, i32, vp]),
+    "pcd_gemm_wfrag_enabled": (i32, []),
     "pcd_gemm_set_config": (i32, [i32]),
     "pcd_fill_zero": (i32, [vp, sz, vp]),
     "pcd_f32_to_f16": (i32, [vp, vp, i64, vp]),

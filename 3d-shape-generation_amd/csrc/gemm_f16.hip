@@ -607,6 +607,191 @@ __global__ __launch_bounds__(512) void gemm_xp_kernel(GemmParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// gemm_xw_kernel: gemm_xp_kernel's tile, waves and tile walk with the WEIGHT fragments straight from global memory.
+// In the kernels above a K tile costs the LDS port 8 waves x 24 KB of fragment reads + 64 KB of LDS-DMA fills = 256 KB = 2048 cycles at
+// 128 B per cycle -- exactly the 2048 cycles the K tile's 2 x 64 MFMAs per SIMD take: the LDS port is as busy as the matrix pipe, and any
+// hiccup of either stalls both (the four-wave assembly kernel of the yardstick moves 192 KB per K tile: profiles/r04_l).  Here only the
+// activation panel goes through LDS (32-KB stages: 8 x 16 KB of reads + 32 KB of fills = 160 KB per K tile, 61 % of the port); a wave's
+// eight weight fragments of a K tile are ONE contiguous 8 KB of a fragment-order copy of W (pcd_gemm_pack_wfrag: [256-column tile][K tile]
+// [wave column][k step][16-column block][lane][8]) and come by eight coalesced 1-KB global loads into the registers the MFMAs read --
+// 64 KB per K tile and CU through L1 = 32 B per cycle, half its rate; the two waves that share a wave column ask for the same lines at
+// the same time.  A k step's four registers-of-four are reloaded with the NEXT K tile's fragments as soon as its MFMAs are issued (asm
+// loads, counted vmcnt: top of a K tile vmcnt(4) = the activation pieces and the first k step's weights have landed; in front of the
+// second k step vmcnt(8)).  Column-max epilogue only (the store epilogue's registers leave no room for weights in flight across it).
+__device__ __forceinline__ half8 gload16_v(const half_t* g) {
+    half8 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(g) : "memory");
+    return v;
+}
+
+__global__ __launch_bounds__(512) void gemm_xw_kernel(GemmParams p, const half_t* __restrict__ wfrag) {
+    constexpr int NST = 4;                                 // the epilogue's atomics per wave (they count in vmcnt)
+    constexpr int BM = 256, BN = 256, BKT = 64, ROWB = 128, WGN = 4;
+    constexpr int WM = 128, WN = 64, MI = 8, NI = 4;
+    constexpr int STAGE_BYTES = BM * ROWB;                 // activation panel only
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) float bias_lds[2][2][BN];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave - wm * WGN;
+    const int tiles_mn = p.tiles_m * p.tiles_n;
+    const int nk1 = p.k1 / BKT, nk = (p.k1 + p.k2) / BKT;
+
+    unsigned voa[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = r * 64 + wave * 8 + (lane >> 3);
+        voa[r] = (unsigned)(row * (int)p.lda1 * 2 + swz<BKT>(row, lane & 7) * 16);
+    }
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    auto stage = [&](int m0, int kt, int buf) __attribute__((always_inline)) {
+        const half_t* ab = kt < nk1 ? p.a1 + (int64_t)m0 * p.lda1 + kt * BKT : p.a2 + (int64_t)m0 * p.lda2 + (kt - nk1) * BKT;
+        const unsigned la = lds0 + buf * STAGE_BYTES + wave * 8 * ROWB;
+        // (the base is wave-uniform; say so: the divergence analysis loses it through the tile walk below and would hand the asm a VGPR pair)
+        const uint64_t av = (uint64_t)ab;
+        const half_t* abu = (const half_t*)(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(av >> 32)) << 32) |
+                                            (unsigned)__builtin_amdgcn_readfirstlane((int)av));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) glds16_s(voa[r], abu, la + r * 64 * ROWB);
+    };
+    const unsigned lds_b = (unsigned)(size_t)&bias_lds[0][0][0];
+    auto stage_bias = [&](int m0, int n0, int par) __attribute__((always_inline)) {
+        const unsigned dst = lds_b + par * (2 * BN * 4) + wn * WN * 4;
+        glds4_s((unsigned)(lane * 4), p.bias + n0 + wn * WN, dst);
+        glds4_s((unsigned)(lane * 4), p.shape_bias + (int64_t)(m0 / p.rows_per_shape) * p.c + n0 + wn * WN, dst + BN * 4);
+    };
+    auto tile_coords = [&](int tile, int& tm, int& tn) {
+        if (p.patch_pn > 0) {
+            const int pn = p.patch_pn, pm = 32 / pn, xn = p.patch_xn, xm = 8 / xn;
+            const int round = tile >> 8, b = tile & 255;
+            const int xcd = b & 7, slot = b >> 3;
+            const int sbn = p.tiles_n / (xn * pn);
+            const int sb_m = round / sbn, sb_n = round - sb_m * sbn;
+            tm = (sb_m * xm + xcd / xn) * pm + slot / pn;
+            tn = (sb_n * xn + xcd % xn) * pn + slot % pn;
+        } else {
+            tm = tile / p.tiles_n;
+            tn = tile - tm * p.tiles_n;
+        }
+    };
+    // this wave's weight fragments of K tile kt of column tile tn: 8 KB at wfrag + ((tn * nk + kt) * 4 + wn) * 4096 halfs: [ks][j][lane][8]
+    auto wbase = [&](int tn_, int kt) __attribute__((always_inline)) {
+        return wfrag + ((int64_t)(tn_ * nk + kt) * 4 + wn) * 4096 + lane * 8;
+    };
+
+    const int ra = wm * WM + (lane & 15), q = lane >> 4;
+    int offa[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) offa[ks] = ra * ROWB + (swz<BKT>(ra, ks * 4 + q) << 4);
+    f32x4 acc[MI][NI];
+    half8 wq[2][NI];                                       // the current K tile's weight fragments, per k step
+
+    int tile = blockIdx.x;
+    if (tile >= tiles_mn) return;
+    int tm, tn;
+    tile_coords(tile, tm, tn);
+    int m0 = tm * BM, n0 = tn * BN;
+    // prologue: K tile 0's activation pieces (4), bias rows (2), weight fragments of both k steps (8)
+    stage(m0, 0, 0);
+    stage_bias(m0, n0, 0);
+    {
+        const half_t* wb = wbase(tn, 0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) wq[ks][j] = gload16_v(wb + (ks * 4 + j) * 512);
+    }
+    int it = 0;
+    int par = 0;
+    bool behind_atomics = false;
+    for (;;) {
+        const int next = tile + (int)gridDim.x;
+        const bool has_next = next < tiles_mn;
+        int m1 = m0, n1 = n0, tn1 = tn;                    // without a next tile the look-ahead re-requests this tile's first K tile (harmless)
+        if (has_next) { int tm1; tile_coords(next, tm1, tn1); m1 = tm1 * BM; n1 = tn1 * BN; }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nk; ++kt) {
+            // issue order per K tile: [A pieces of K tile + 1: 4] [weights of K tile + 1, k step 0: 4, behind k step 0's MFMAs] [... k step 1: 4, behind
+            // k step 1's MFMAs].  Here the youngest four loads are this K tile's k-step-1 weights (+ a tile's NST atomics and 2 bias pieces when the
+            // previous output tile's epilogue came in between)
+            if (kt == 0 && behind_atomics) wait_vmcnt<4 + NST>(); else wait_vmcnt<4>();
+            __builtin_amdgcn_s_barrier();
+            const bool last = kt + 1 == nk;
+            const int mN = last ? m1 : m0, tnN = last ? tn1 : tn, ktN = last ? 0 : kt + 1;
+            stage(mN, ktN, (it + 1) & 1);
+            if (last) stage_bias(m1, n1, par ^ 1);
+            const half_t* wb = wbase(tnN, ktN);
+            const char* base = smem + (it & 1) * STAGE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                half8 af[MI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[i] = *(const half8*)(base + offa[ks] + i * 16 * ROWB);
+                if (ks == 1) { if (last) wait_vmcnt<10>(); else wait_vmcnt<8>(); }      // k step 1's weights: behind them the A pieces (4) [+ bias 2] and k step 0's reload (4)
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], wq[ks][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                // this k step's registers take the next K tile's fragments (the MFMAs that read them have been issued)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) wq[ks][j] = gload16_v(wb + (ks * 4 + j) * 512);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            ++it;
+        }
+        {
+            unsigned* cm = reinterpret_cast<unsigned*>(p.colmax);
+            const int shape = (m0 + wm * WM) / p.cm_rps, colq = lane & 15;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int cl = wn * WN + j * 16 + colq;
+                const float b = bias_lds[par][0][cl] + bias_lds[par][1][cl];
+                float mx = 0.f;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[i][j][r] + b);
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                if (q == 0) atomicMax(cm + (int64_t)shape * p.c + n0 + cl, __float_as_uint(mx));
+            }
+        }
+        if (!has_next) break;
+        behind_atomics = true;
+        par ^= 1;
+        tile = next; m0 = m1; n0 = n1; tn = tn1;
+    }
+    wait_vmcnt<0>();                                       // the look-ahead's loads: nothing may land after the wave has gone
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(wq[ks][j]));
+}
+
+// fragment-order copy of W [c][ldw] for gemm_xw_kernel: one thread per 16-byte piece
+__global__ __launch_bounds__(256) void gemm_pack_wfrag_kernel(const half_t* __restrict__ w, int64_t ldw, int k, int c, half_t* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nk = k / 64;
+    const int64_t total = (int64_t)(c / 256) * nk * 4 * 2 * 4 * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63); int64_t r = idx >> 6;
+    const int j = (int)(r & 3); r >>= 2;
+    const int ks = (int)(r & 1); r >>= 1;
+    const int wn = (int)(r & 3); r >>= 2;
+    const int kt = (int)(r % nk); const int tn = (int)(r / nk);
+    const int col = tn * 256 + wn * 64 + j * 16 + (lane & 15);
+    *(half8*)(out + idx * 8) = *(const half8*)(w + (int64_t)col * ldw + kt * 64 + ks * 32 + (lane >> 4) * 8);
+}
+
+static int g_xw = 1;            // tuning hook (pcd_gemm_set_config(8) / (9)): callers that hold a fragment-order weight copy use gemm_xw_kernel: off / on
 static int g_xp = 1;            // tuning hook (pcd_gemm_set_config(5) / (6) / (7)): the cross-tile prefetching store kernel off / 2 K tiles ahead / 1
 
 static int num_cus() {
@@ -618,6 +803,26 @@ static int num_cus() {
         if (n <= 0) n = 256;
     }
     return n;
+}
+
+// a row of zeros standing in for a missing bias / per-shape bias (the counted-vmcnt kernels stage a fixed number of bias pieces per tile): one row per DEVICE
+// (a process may drive several), created under a lock; never inside a stream capture (nullptr then, and the caller takes another kernel)
+static float* zero_row(int cols, hipStream_t s) {
+    constexpr int kZeroCols = 16384, kMaxDev = 64;
+    static float* zeros_of[kMaxDev] = {};
+    static std::mutex zeros_mu;
+    int dev = -1;
+    if (cols > kZeroCols || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+    std::lock_guard<std::mutex> lock(zeros_mu);
+    if (zeros_of[dev] == nullptr) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess) { cap = hipStreamCaptureStatusActive; (void)hipGetLastError(); }
+        float* z = nullptr;
+        if (cap == hipStreamCaptureStatusNone && hipMalloc(&z, kZeroCols * sizeof(float)) == hipSuccess) {
+            if (hipMemset(z, 0, kZeroCols * sizeof(float)) == hipSuccess) zeros_of[dev] = z; else (void)hipFree(z);
+        }
+    }
+    return zeros_of[dev];
 }
 
 template <int BM, int BN, int WGM, int WGN, int STAGES, int EPI, int BKT = 64>
@@ -648,26 +853,8 @@ static int launch(const GemmParams& p0, hipStream_t s, int blocks_per_cu) {
                         (int64_t)255 * p.lda1 * 2 + 128 < 0x7fffffffLL && (int64_t)255 * p.ldw * 2 + 128 < 0x7fffffffLL;
         if (ok && (p.bias == nullptr || p.shape_bias == nullptr)) {
             // a zero row stands in for a missing bias (fixed number of LDS-DMA pieces per tile: the waits are counted)
-            // one row per DEVICE (a process may drive several), created under a lock
-            constexpr int kZeroCols = 16384, kMaxDev = 64;
-            static float* zeros_of[kMaxDev] = {};
-            static std::mutex zeros_mu;
-            float* zeros = nullptr;
-            int dev = -1;
-            if (p.c <= kZeroCols && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDev) {
-                std::lock_guard<std::mutex> lock(zeros_mu);
-                if (zeros_of[dev] == nullptr) {
-                    // one-time allocation: never inside a stream capture (a launch that is being captured takes the generic kernel instead)
-                    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-                    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { cap = hipStreamCaptureStatusActive; (void)hipGetLastError(); }
-                    float* z = nullptr;
-                    if (cap == hipStreamCaptureStatusNone && hipMalloc(&z, kZeroCols * sizeof(float)) == hipSuccess) {
-                        if (hipMemset(z, 0, kZeroCols * sizeof(float)) == hipSuccess) zeros_of[dev] = z; else (void)hipFree(z);
-                    }
-                }
-                zeros = zeros_of[dev];
-            }
-            if (zeros != nullptr && p.c <= kZeroCols) {
+            float* zeros = zero_row(p.c, s);
+            if (zeros != nullptr) {
                 if (p.bias == nullptr) p.bias = zeros;
                 if (p.shape_bias == nullptr) { p.shape_bias = zeros; p.rows_per_shape = p.m; }       // shape 0 for every tile
             }
@@ -819,8 +1006,43 @@ extern "C" int pcd_gemm_f16_colmax(const pcd_gemm_desc_t* d, float* colmax, int 
     return dispatch<EPI_COLMAX>(p, (hipStream_t)stream);
 }
 
+
+extern "C" int pcd_gemm_pack_wfrag(const void* w, int64_t ldw, int k, int c, void* wfrag, void* stream) {
+    PCD_CHECK_ARG(w && wfrag && k > 0 && k % 64 == 0 && c > 0 && c % 256 == 0 && ldw >= k && ldw % 8 == 0);
+    const int64_t total = (int64_t)(c / 256) * (k / 64) * 4 * 2 * 4 * 64;
+    hipLaunchKernelGGL(gemm_pack_wfrag_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)w, ldw, k, c,
+                       (half_t*)wfrag);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_gemm_f16_colmax_wfrag(const pcd_gemm_desc_t* d, const void* wfrag, float* colmax, int rows_per_shape, void* stream) {
+    GemmParams p;
+    int rc = fill(d, p);
+    if (rc) return rc;
+    PCD_CHECK_ARG(wfrag != nullptr && colmax != nullptr && rows_per_shape > 0 && d->relu == 1);
+    PCD_CHECK_ARG(p.m % 256 == 0 && p.c % 256 == 0 && (p.k1 + p.k2) >= 128 && (p.k2 == 0 || p.lda2 == p.lda1) && rows_per_shape % 128 == 0 &&
+                  p.bias != nullptr && (p.shape_bias == nullptr || p.rows_per_shape % 256 == 0));
+    p.colmax = colmax; p.cm_rps = rows_per_shape;
+    p.tiles_m = p.m / 256; p.tiles_n = p.c / 256;
+    const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n;
+    PCD_CHECK_ARG(tiles >= 256 && tiles % 256 == 0 && p.shape_bias == nullptr);
+    float* zeros = zero_row(p.c, (hipStream_t)stream);
+    if (zeros == nullptr) { set_error("pcd_gemm_f16_colmax_wfrag: no zero row (stream capture before the first eager call, or c > 16384)"); return PCD_ERR_ARG; }
+    p.shape_bias = zeros; p.rows_per_shape = p.m;
+    p.patch_pn = p.patch_xn = 0;
+    const int pn = p.tiles_n >= 8 ? 8 : p.tiles_n, xn = p.tiles_n >= 16 ? 2 : 1;
+    if ((pn & (pn - 1)) == 0 && p.tiles_n % (xn * pn) == 0 && p.tiles_m % ((8 / xn) * (32 / pn)) == 0) { p.patch_pn = pn; p.patch_xn = xn; }
+    hipLaunchKernelGGL(gemm_xw_kernel, dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" int pcd_gemm_wfrag_enabled(void) { return g_xw; }
+
 extern "C" int pcd_gemm_set_config(int cfg) {
-    PCD_CHECK_ARG(cfg >= -1 && cfg <= 7);
+    PCD_CHECK_ARG(cfg >= -1 && cfg <= 9);
+    if (cfg >= 8) { g_xw = cfg - 8; return PCD_OK; }                                // A/B switch of gemm_xw_kernel (pcd_gemm_wfrag_enabled)
     if (cfg >= 5) { g_xp = cfg == 5 ? 0 : (cfg == 6 ? 2 : 1); return PCD_OK; }      // A/B switch of gemm_xp_kernel; the tile choice is left as it is
     g_force_cfg = cfg;
     return PCD_OK;

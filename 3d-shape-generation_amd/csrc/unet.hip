@@ -38,6 +38,8 @@ struct pcd_unet {
     int ev_created = 0;
     // packed stage images + biases of the two 256-channel chains (csrc/widechain.hip): enc3 and dec2
     void* wide[2] = {nullptr, nullptr};
+    // fragment-order copy of global_feat.3's weights for gemm_xw_kernel (csrc/gemm_f16.hip), made at create; null: the LDS-staged kernel runs
+    void* gf3_frag = nullptr;
     // parity-test capture of the decoder blocks' outputs (pcd_unet_capture): dec4 [M][512], dec3 [M][256], dec2 [M][128], dec1 [M][64]
     void* dec_tap[4] = {nullptr, nullptr, nullptr, nullptr};
 };
@@ -124,12 +126,29 @@ extern "C" int pcd_unet_create(const pcd_unet_desc_t* desc, pcd_unet_t** out) {
             return rc;
         }
     }
+    // global_feat.3 (2048 -> 4096): a fragment-order copy of its weights (16.8 MB) for the kernel that reads them straight from global memory;
+    // a failed allocation only means the LDS-staged kernel keeps running
+    hipPointerAttribute_t at;
+    int cur = -1;
+    const bool here = hipGetDevice(&cur) == hipSuccess && hipPointerGetAttributes(&at, desc->lin[12].w) == hipSuccess && at.device == cur;
+    if (!here) (void)hipGetLastError();
+    if (here && hipMalloc(&h->gf3_frag, (size_t)4096 * 2048 * 2) == hipSuccess) {
+        if (pcd_gemm_pack_wfrag(desc->lin[12].w, 2048, 2048, 4096, h->gf3_frag, nullptr) != PCD_OK || hipStreamSynchronize(nullptr) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(h->gf3_frag);
+            h->gf3_frag = nullptr;
+        }
+    } else {
+        (void)hipGetLastError();
+        h->gf3_frag = nullptr;
+    }
     *out = h;
     return PCD_OK;
 }
 
 extern "C" void pcd_unet_destroy(pcd_unet_t* h) {
     if (h == nullptr) return;
+    if (h->gf3_frag) (void)hipFree(h->gf3_frag);
     for (int k = 0; k < 2; ++k) if (h->wide[k]) (void)hipFree(h->wide[k]);
     for (int i = 0; i < h->ev_created; ++i) { (void)hipEventDestroy(h->ev0[i]); (void)hipEventDestroy(h->ev1[i]); }
     delete h;
@@ -252,7 +271,12 @@ extern "C" int pcd_unet_forward(pcd_unet_t* h, const float* x, int batch, int n_
             }
             PCD_CHECK_HIP(hipEventRecord(h->ev0[h->prof_n], s));
         }
-        RUN(pcd_gemm_f16_colmax(&g, pooled, n_points, s));
+        // whole 256 x 256 tiles, a multiple of 256 of them, shapes of whole 128-row wave tiles: the weights-from-global kernel; else the LDS-staged one
+        const int64_t tiles = (m / 256) * 16;
+        if (h->gf3_frag != nullptr && pcd_gemm_wfrag_enabled() && m % 256 == 0 && tiles >= 256 && tiles % 256 == 0 && n_points % 128 == 0)
+            RUN(pcd_gemm_f16_colmax_wfrag(&g, h->gf3_frag, pooled, n_points, s));
+        else
+            RUN(pcd_gemm_f16_colmax(&g, pooled, n_points, s));
         if (prof) { PCD_CHECK_HIP(hipEventRecord(h->ev1[h->prof_n], s)); ++h->prof_n; }
     }
     {   // hoisted global half of dec4.conv1: per-shape bias [B][1024] = pooled . Wg^T + folded bias

@@ -472,7 +472,7 @@ def latent_rooflines(legs):
 def gf3_roofline(gf3_ms, launches, how=None):
     achieved = GF3_FLOP_PER_LAUNCH / (gf3_ms * 1e-3) / 1e12
     traffic, traffic_head, stale = measured_traffic()
-    r = {"bound": "mfma", "kernel": "gemm_xp_kernel<COLMAX> = the 256x256 tile, 2x4 waves, persistent, cross-tile prefetch (global_feat.3 2048->4096 + max over N)",
+    r = {"bound": "mfma", "kernel": "gemm_xw_kernel = the 256x256 tile, 2x4 waves, persistent; activation panel through LDS, fragment-order weights straight from global memory (global_feat.3 2048->4096 + max over N)",
          "achieved": achieved, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
          "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": traffic, "traffic_measured_at": traffic_head,
          "traffic_stale": stale, "avg_launch_ms": gf3_ms, "launches_timed": launches, "flop_per_launch": GF3_FLOP_PER_LAUNCH}

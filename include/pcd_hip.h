@@ -79,10 +79,18 @@ int pcd_gemm_f16_residual(const pcd_gemm_desc_t* d, const void* resid, int64_t l
  * (pcd_fill_zero) before the call; requires d->relu == 1. */
 int pcd_gemm_f16_colmax(const pcd_gemm_desc_t* d, float* colmax, int rows_per_shape, void* stream);
 
+/* the column-max GEMM with the weights in MFMA-fragment order, read straight from global memory into the MFMA operand registers (csrc/gemm_f16.hip:
+ * gemm_xw_kernel; only the activation panel goes through LDS): wfrag = pcd_gemm_pack_wfrag's copy of w ([c][ldw], k = k1 + k2 columns used, c % 256 == 0,
+ * same byte count as the k x c weights).  Whole 256 x 256 tiles, at least 256 of them and a multiple of 256; bias required; no per-shape bias. */
+int pcd_gemm_pack_wfrag(const void* w, int64_t ldw, int k, int c, void* wfrag, void* stream);
+int pcd_gemm_f16_colmax_wfrag(const pcd_gemm_desc_t* d, const void* wfrag, float* colmax, int rows_per_shape, void* stream);
+/* 1 unless pcd_gemm_set_config(8) switched the fragment-order path off (9: on): callers that hold a copy ask before they use it */
+int pcd_gemm_wfrag_enabled(void);
 /* tuning/benchmark hook: force a tile configuration for every following GEMM launch of this
  * process (-1 = shape heuristic; 0: 128x64, 1: 128x128, 2: 256x128 3-stage, 3: 256x256, 4: 128x128 3-stage).
  * 5 / 7 / 6 leave the tile choice alone and switch the 256x256 store / column-max kernel that requests the next tile's first
- * K tile(s) before the epilogue's stores (whole tiles only): off / one K tile ahead (default) / two (store epilogue only). */
+ * K tile(s) before the epilogue's stores (whole tiles only): off / one K tile ahead (default) / two (store epilogue only).
+ * 8 / 9: pcd_gemm_wfrag_enabled() off / on (default on). */
 int pcd_gemm_set_config(int cfg);
 
 int pcd_fill_zero(void* p, size_t bytes, void* stream);

@@ -107,6 +107,51 @@ def test_gemm_cross_tile_prefetch_kernel_exact(ops, depth_cfg):
         lib.pcd_gemm_set_config(7)
 
 
+def test_gemm_colmax_with_fragment_order_weights_exact(ops):
+    """gemm_xw_kernel (global_feat.3's kernel: activation panel through LDS, the weights a fragment-order copy read straight from global memory into
+    the MFMA operand registers, counted vmcnt over LDS-DMA pieces, asm loads and the epilogue's atomics): exact on small integers and bitwise equal
+    to the LDS-staged kernel -- two-K-tile problems, long K, one / two / four output tiles per workgroup, two K sources; every launch repeated
+    (a staging race would show as a column that differs); and the U-Net forward is bit-identical with the path on and off."""
+    from shapegen_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for m, k1, k2, c in [(65536, 128, 0, 256), (65536, 256, 0, 512), (32768, 128, 128, 1024), (16384, 2048, 0, 4096), (131072, 192, 0, 512)]:
+        a1 = torch.randint(-3, 4, (m, k1), generator=g, device="cuda").half()
+        a2 = torch.randint(-3, 4, (m, k2), generator=g, device="cuda").half() if k2 else None
+        w = torch.randint(-2, 3, (c, k1 + k2), generator=g, device="cuda").half()
+        bias = torch.randint(-3, 4, (c,), generator=g, device="cuda").float()
+        want = ((torch.cat([a1, a2], 1) if k2 else a1).float() @ w.float().t() + bias).clamp_min(0).reshape(-1, 2048, c).max(1)[0]
+        wfrag = torch.empty_like(w)
+        _lib.check(lib.pcd_gemm_pack_wfrag(w.data_ptr(), k1 + k2, k1 + k2, c, wfrag.data_ptr(), _lib.stream_ptr()))
+        d = ops._desc(a1, w, bias, a2, relu=True)
+        for rep in range(3):
+            out = torch.zeros(m // 2048, c, dtype=torch.float32, device="cuda")
+            _lib.check(lib.pcd_gemm_f16_colmax_wfrag(d, wfrag.data_ptr(), out.data_ptr(), 2048, _lib.stream_ptr()), "gemm_f16_colmax_wfrag")
+            assert torch.equal(out, want), (m, k1, k2, c, rep)
+        assert torch.equal(out, ops.gemm_f16_colmax(a1, w, bias, 2048) if not k2 else out)
+    # shapes the kernel does not take are refused, not mis-launched: fewer than 256 tiles
+    a = torch.zeros(8192, 128, dtype=torch.float16, device="cuda")
+    w = torch.zeros(256, 128, dtype=torch.float16, device="cuda")
+    d = ops._desc(a, w, torch.zeros(256, device="cuda"), relu=True)
+    out = torch.zeros(4, 256, device="cuda")
+    assert lib.pcd_gemm_f16_colmax_wfrag(d, w.data_ptr(), out.data_ptr(), 2048, _lib.stream_ptr()) != 0
+    # the U-Net forward with the path on (default) and off
+    from shapegen_amd.diffusion import PointCloudDiffusion
+    from helpers import point_sd
+    model = PointCloudDiffusion(num_points=2048)
+    model.load_state_dict(point_sd(), strict=True)
+    model = model.to("cuda").eval()
+    x, t = torch.randn(16, 2048, 3, generator=torch.Generator().manual_seed(3)).cuda(), torch.rand(16, generator=torch.Generator().manual_seed(4)).cuda()
+    assert lib.pcd_gemm_wfrag_enabled() == 1
+    on = model.model(x, t).clone()
+    lib.pcd_gemm_set_config(8)
+    try:
+        off = model.model(x, t).clone()
+    finally:
+        lib.pcd_gemm_set_config(9)
+    assert torch.equal(on, off)
+
+
 def test_gemm_dual_source_shape_bias_residual(ops):
     m, k1, k2, c, rps = 384, 128, 64, 136, 96
     a1, a2, w = _int_mat(m, k1, 4), _int_mat(m, k2, 5), _int_mat(c, k1 + k2, 6)

@@ -16,12 +16,12 @@ python3 - <<PY
 import csv, glob, hashlib, json, os
 def mean(root, counter):
     f = glob.glob(f"{root}/**/*_counter_collection.csv", recursive=True)[0]
-    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if ("gemm_xp_kernel" in r["Kernel_Name"] or "gemm_f16_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == counter]
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if ("gemm_xw_kernel" in r["Kernel_Name"] or "gemm_xp_kernel" in r["Kernel_Name"] or "gemm_f16_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == counter]
     v = v[len(v) // 3:]            # drop warm-up launches
     return sum(v) / len(v)
 fetch_kb, write_kb = mean("$OUT/fetch", "FETCH_SIZE"), mean("$OUT/write", "WRITE_SIZE")
 hit, miss = mean("$OUT/write", "TCC_HIT_sum"), mean("$OUT/write", "TCC_MISS_sum")
-rec = {"kernel": "gemm_xp_kernel<COLMAX> (256x256 tile, 2x4 waves, persistent + XCD patch mapping, next tile's first K tile requested before the epilogue; tools/one_gemm.py)",
+rec = {"kernel": "gemm_xw_kernel (256x256 tile, 2x4 waves, persistent + XCD patch mapping; activation panel through LDS, fragment-order weights straight from global memory; tools/one_gemm.py)",
        "recipe": "tools/pmc_gf3.sh", "git_head": os.environ.get("GIT_HEAD", "unknown"),
        "kernel_source_sha16": hashlib.sha256(open("$ROOT/3d-shape-generation_amd/csrc/gemm_f16.hip", "rb").read()).hexdigest()[:16],
        "fetch_size_kb": fetch_kb, "write_size_kb": write_kb, "l2_hit_rate": hit / (hit + miss),
