@@ -644,8 +644,10 @@ __global__ __launch_bounds__(256, 2) void set_attention_sp_kernel(const half_t* 
 #pragma unroll
         for (int u = 0; u < NSLOT; ++u) {
             // tile t+1 has landed (all but the youngest stage's 4 LDS-DMA) and every wave is done with tile t-1
-            if (!LAST || u < 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (lgkmcnt(0): this wave's own fragment reads have RETURNED before the barrier behind which another wave's LDS-DMA refills a slot --
+            // the compiler's barrier fence says so at three of the four barriers of a group, not at the loop-carried one: tools/check_barrier_reads.py)
+            if (!LAST || u < 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __syncthreads();
             const int cur = u * STAGE, nxt = ((u + 1) % NSLOT) * STAGE;   // last tile: nxt holds stale bytes, S(i+1) unused
             const int st = t0 + u + AHEAD + 1, sslot = (u + AHEAD + 1) % NSLOT;   // tile to stage; its slot == slot of tile t-1

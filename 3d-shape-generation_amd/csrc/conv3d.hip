@@ -66,6 +66,15 @@ __device__ __forceinline__ void conv_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Before a barrier behind which ANOTHER wave's LDS-DMA refills the ring stage this wave has just read: the wave's own ds_reads must have
+// RETURNED, not just been issued.  The compiler sinks a stage's last MFMAs (and the lgkmcnt wait in front of them) below the raw s_barrier,
+// so a wave would pass it with fragment reads of that stage still queued in the LDS pipe; nothing orders them against the DMA's write, and with
+// two workgroups per CU queueing reads and L1-resident weights coming back fast the write did win now and then (conv3d_k4s2_halo_kernel, batch 16:
+// one encode in seven differed from the others by 1e-3..5e-3; tools/diag_vae_batch.py).  tools/check_barrier_reads.py scans the built code for it.
+__device__ __forceinline__ void conv_reads_landed() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 // K tile BKT (64 or 32 halfs: 128- or 64-byte LDS rows) in a ring of NST stages.  A stage is requested NST - 1 K tiles before
 // the barrier that publishes it and NST - 2 younger stages stay in flight behind that barrier's counted vmcnt: with two
 // stages the gather of K tile kt+1 has one K tile of MFMAs (~500 cycles per wave) to come back from L2, and the waves
@@ -197,6 +206,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
         if (NST >= 4 && younger == 2) conv_wait_vmcnt<2 * LPT>();
         else if (NST >= 3 && younger == 1) conv_wait_vmcnt<LPT>();
         else conv_wait_vmcnt<0>();
+        conv_reads_landed();
         __builtin_amdgcn_s_barrier();      // every wave's share of K tile kt is in LDS; the buffer of K tile kt-1 is free
         if (kt + NST - 1 < kt1) {
             int nb = buf + NST - 1;
@@ -486,6 +496,7 @@ __global__ __launch_bounds__(64 * NW) void conv3d_halo_kernel(HaloParams p) {
     for (int s = 0; s < NS; ++s) {
         if (s + 1 < NS) {
             if (NSTAGE == 4 && s + 2 < NS) conv_wait_vmcnt<U>(); else conv_wait_vmcnt<0>();
+            conv_reads_landed();
             __builtin_amdgcn_s_barrier();   // raw: __syncthreads() adds its own waits
             if (s + NSTAGE - 1 < NS) stageB(s + NSTAGE - 1, (s + NSTAGE - 1) % NSTAGE);
         }
@@ -717,6 +728,7 @@ __global__ __launch_bounds__(512) void convT3d_halo_kernel(ConvTHaloParams p) {
                 } else {
                     conv_wait_vmcnt<U>();
                 }
+                conv_reads_landed();
                 __builtin_amdgcn_s_barrier();
                 if (S + 3 < NSTG) stageW(S + 3, (S + 3) & 3);
             }
@@ -915,6 +927,7 @@ __global__ __launch_bounds__(256) void conv3d_k4s2_halo_kernel(ConvS2HaloParams 
                 if ((st == 1 || st == 2) && cls < 7) conv_wait_vmcnt<U + HIT>();
                 else if (S + 2 < NSTG) conv_wait_vmcnt<U>();
                 else conv_wait_vmcnt<0>();
+                conv_reads_landed();
                 __builtin_amdgcn_s_barrier();
                 if (S + 3 < NSTG) stageW(S + 3, (S + 3) & 3);
             }

@@ -47,7 +47,10 @@ static VaeWs vae_carve(int batch) {
     return w;
 }
 
-static int g_convt_halo = 1;     // pcd_vae_config: 0 = decoder.6 as eight implicit-GEMM class launches (A/B, tests)
+// pcd_vae_config: bit mask of the round-4 kernels in use (A/B, tests, bisecting): 2 = decoder.6 from one LDS halo, 4 = encoder.3 from sub-grid halos,
+// 8 = k3 layers with weights in registers; 0 = none (implicit-GEMM / LDS-ring forms), 1 = all
+static int g_convt_halo = 14;
+enum { kCfgConvT = 2, kCfgK4S2 = 4, kCfgWreg = 8 };
 
 struct Runner {
     const pcd_vae_desc_t& d;
@@ -79,10 +82,10 @@ struct Runner {
         pcd_conv3d_desc_t c;
         fill(c, L, in, din, stride, taps, L.k * L.k * L.k, dout, relu, resid, out, in2, cin2);
         // k3 layers with C_in = 64: weights in registers (fragment-order copy made at create), 256-row workgroups, no barrier in the tap loop
-        if (wfrag != nullptr && g_convt_halo && pcd_conv3d_k3s1_wreg_supported(&c)) return pcd_conv3d_k3s1_wreg_f16(&c, wfrag, s);
+        if (wfrag != nullptr && (g_convt_halo & kCfgWreg) && pcd_conv3d_k3s1_wreg_supported(&c)) return pcd_conv3d_k3s1_wreg_f16(&c, wfrag, s);
         if (L.k == 3 && stride == 1 && pcd_conv3d_k3s1_supported(&c)) return pcd_conv3d_k3s1_f16(&c, s);   // LDS-resident halo
         // encoder.3 (k4 s2, 64 -> 64, 32^3 -> 16^3): the eight input-parity classes from LDS-resident sub-grid halos
-        if (g_convt_halo && L.k == 4 && stride == 2 && resid == nullptr && in2 == nullptr && dout * 2 == din &&
+        if ((g_convt_halo & kCfgK4S2) && L.k == 4 && stride == 2 && resid == nullptr && in2 == nullptr && dout * 2 == din &&
             pcd_conv3d_k4s2_halo_supported(batch, din, din, din, L.cin, L.cout, L.kpad))
             return pcd_conv3d_k4s2_halo_f16(in, batch, din, din, din, L.cin, L.w, L.kpad, L.b, relu, L.cout, out, s);
         return launch(&c, 1);
@@ -114,7 +117,7 @@ struct Runner {
     // ConvTranspose3d(k4, s2, p1) + ReLU: the 8 output-parity classes (2x2x2 taps each) in one launch
     int convT(const pcd_vae_convT_t& T, const void* in, int din, void* out) const {
         // decoder.6 (128 -> 64, 16^3 -> 32^3): all eight classes from one LDS-resident input halo
-        if (g_convt_halo && pcd_convt3d_k4s2_halo_supported(batch, din, din, din, T.cin, T.cout))
+        if ((g_convt_halo & kCfgConvT) && pcd_convt3d_k4s2_halo_supported(batch, din, din, din, T.cin, T.cout))
             return pcd_convt3d_k4s2_halo_f16(in, batch, din, din, din, T.cin, T.w, T.b, T.cout, out, s);
         pcd_conv3d_desc_t c[8];
         for (int k = 0; k < 8; ++k) {
@@ -146,8 +149,8 @@ static bool res_ok(const pcd_vae_res_t& R) {
 using namespace pcd;
 
 extern "C" int pcd_vae_config(int convt_halo) {
-    PCD_CHECK_ARG(convt_halo == 0 || convt_halo == 1);
-    g_convt_halo = convt_halo;
+    PCD_CHECK_ARG(convt_halo >= 0 && convt_halo <= 15);
+    g_convt_halo = convt_halo == 1 ? 14 : (convt_halo & 14);
     return PCD_OK;
 }
 

@@ -494,8 +494,8 @@ typedef struct {
 } pcd_vae_desc_t;
 typedef struct pcd_vae pcd_vae_t;
 int pcd_vae_create(const pcd_vae_desc_t* desc, pcd_vae_t** out);
-/* testing / tuning hook: 1 (default) = decoder.6 through pcd_convt3d_k4s2_halo_f16 and encoder.3 through pcd_conv3d_k4s2_halo_f16, 0 = both through
- * the implicit GEMM */
+/* testing / tuning hook, a bit mask of the round-4 kernels in use: 2 = decoder.6 through pcd_convt3d_k4s2_halo_f16, 4 = encoder.3 through
+ * pcd_conv3d_k4s2_halo_f16, 8 = the k3 layers through pcd_conv3d_k3s1_wreg_f16; 1 (default) = all of them, 0 = none (implicit GEMM / LDS-ring forms) */
 int pcd_vae_config(int convt_halo);
 void pcd_vae_destroy(pcd_vae_t* h);
 size_t pcd_vae_workspace_bytes(int batch);
