@@ -54,7 +54,7 @@ class LatentDesc(C.Structure):
 class SabDesc(C.Structure):
     _fields_ = [("dim", i32), ("w_in", vp), ("b_in", vp), ("w_out", vp), ("b_out", vp),
                 ("ln1_g", vp), ("ln1_b", vp), ("ln2_g", vp), ("ln2_b", vp),
-                ("w_ff1", vp), ("b_ff1", vp), ("w_ff2", vp), ("b_ff2", vp)]
+                ("w_ff1", vp), ("b_ff1", vp), ("w_ff2", vp), ("b_ff2", vp), ("tail_packed", vp)]
 
 
 PCD_ATTN_UNET_NLIN, PCD_ATTN_UNET_NSAB, PCD_ATTN_UNET_NEMB, PCD_ATTN_UNET_TB = 14, 7, 6, 704
@@ -221,6 +221,12 @@ _SIGS = {
     "pcd_tail3": (i32, [vp, i32, vp, i32, i64, vp, vp, vp, vp, vp, vp]),
     "pcd_sab_workspace_bytes": (sz, [i64, i32]),
     "pcd_sab_forward": (i32, [C.POINTER(SabDesc), vp, i32, i32, i32, vp, vp, sz, vp]),
+    "pcd_sab_tail_packed_bytes": (sz, [i32]),
+    "pcd_sab_tail_supported": (i32, [i32, i64]),
+    "pcd_sab_tail_pack": (i32, [C.POINTER(SabDesc), vp, vp]),
+    "pcd_sab_tail_f16": (i32, [i32, vp, vp, vp, i64, vp, vp]),
+    "pcd_sab_tail_config": (i32, [i32]),
+    "pcd_sab_tail_enabled": (i32, []),
     "pcd_attn_unet_create": (i32, [C.POINTER(AttnUnetDesc), C.POINTER(vp)]),
     "pcd_attn_unet_destroy": (None, [vp]),
     "pcd_attn_unet_workspace_bytes": (sz, [i32, i32]),

@@ -325,11 +325,22 @@ class _PackedSAB:
         self.ln2_g, self.ln2_b = _dev32(g("ln2.weight"), dev), _dev32(g("ln2.bias"), dev)
         self.w_ff1, self.b_ff1 = devw(g("ff.0.weight"), dev), _dev32(g("ff.0.bias"), dev)
         self.w_ff2, self.b_ff2 = devw(g("ff.2.weight"), dev), _dev32(g("ff.2.bias"), dev)
+        self.tail = None
+        self.f32 = f32
 
     def fill(self, d: "_lib.SabDesc") -> "_lib.SabDesc":
         d.dim = self.dim
         for k in ("w_in", "b_in", "w_out", "b_out", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "w_ff1", "b_ff1", "w_ff2", "b_ff2"):
             setattr(d, k, getattr(self, k).data_ptr())
+        d.tail_packed = None
+        # C <= 128, fp16: the block's tail (out_proj + residual + LN2 + FFN + residual) as one launch needs its weights in fragment-order stage images
+        lib = _lib.load()
+        nbytes = 0 if self.f32 else lib.pcd_sab_tail_packed_bytes(self.dim)
+        if nbytes:
+            if self.tail is None:
+                self.tail = torch.empty(nbytes, dtype=torch.uint8, device=self.w_out.device)
+                _lib.check(lib.pcd_sab_tail_pack(C.byref(d), self.tail.data_ptr(), _lib.stream_ptr()), "sab_tail_pack")
+            d.tail_packed = self.tail.data_ptr()
         return d
 
 

@@ -547,9 +547,23 @@ typedef struct {
     const float* ln1_g; const float* ln1_b; const float* ln2_g; const float* ln2_b;
     const void* w_ff1; const float* b_ff1;           /* ff.0 [4C][C] */
     const void* w_ff2; const float* b_ff2;           /* ff.2 [C][4C] */
+    const void* tail_packed;                         /* optional (dim 64 / 128): pcd_sab_tail_pack's image of w_out .. b_ff2; pcd_sab_forward then runs
+                                                      * out_proj + residual + LN2 + FFN + residual as ONE launch when rows % 256 == 0.  NULL: four launches.
+                                                      * Ignored by the fp32 parity entry points */
 } pcd_sab_desc_t;
 /* bytes of scratch one block needs for `rows` = B*N points */
 size_t pcd_sab_workspace_bytes(int64_t rows, int dim);
+/* the block's tail behind the attention kernel as one launch (csrc/sab_tail.hip; reference networks.py:78-83, the second half of SetAttentionBlock.forward):
+ *   y = x1 + W2 relu(W1 LN2(x1) + b1) + b2,  x1 = x + W_out a + b_out      a = the heads' outputs [rows][dim], x = the block's input, all fp16
+ * pcd_sab_tail_pack writes the fragment-order stage images of w_out / w_ff1 / w_ff2 and the fp32 biases / LayerNorm affine of `d` into `packed`
+ * (pcd_sab_tail_packed_bytes(dim) bytes of device memory; 0 = dim not supported); pcd_sab_tail_supported: dim 64 or 128 and rows % 256 == 0.
+ * pcd_sab_tail_config(0) makes pcd_sab_forward / pcd_attn_unet_forward keep the four launches (A/B, tests); pcd_sab_tail_enabled reads it back. */
+size_t pcd_sab_tail_packed_bytes(int dim);
+int pcd_sab_tail_supported(int dim, int64_t rows);
+int pcd_sab_tail_pack(const pcd_sab_desc_t* d, void* packed, void* stream);
+int pcd_sab_tail_f16(int dim, const void* packed, const void* a, const void* x, int64_t rows, void* y, void* stream);
+int pcd_sab_tail_config(int fused);
+int pcd_sab_tail_enabled(void);
 /* y = x + MHA(LN1 x); y = y + W2 relu(W1 LN2 y)   x, y fp16 [B*N][C], y must not alias x */
 int pcd_sab_forward(const pcd_sab_desc_t* d, const void* x, int batch, int n_points, int heads, void* y,
                     void* workspace, size_t workspace_bytes, void* stream);

@@ -268,3 +268,74 @@ def test_attention_at_2048_points_against_the_reference(golden):
     r = rel_l2(eps, g["una_eps"])
     print(f"attention U-Net at (2, 2048) vs the reference: rel-L2 {r:.2e}")
     assert r < 5e-3
+
+
+def _tail_fp64(a, x, sd):
+    """x1 = x + out_proj(a); y = x1 + ff.2(relu(ff.0(LN2(x1)))) in float64 from the fp16-rounded operands (reference networks.py:78-83)."""
+    f = lambda k: sd[k].double()
+    h = lambda k: sd[k].half().double()
+    x1 = x + a @ h("attention.out_proj.weight").T + f("attention.out_proj.bias")
+    ln = torch.nn.functional.layer_norm(x1, (x1.shape[1],), f("ln2.weight"), f("ln2.bias"), 1e-5)
+    hid = torch.relu(ln.half().double() @ h("ff.0.weight").T + f("ff.0.bias"))
+    return x1 + hid.half().double() @ h("ff.2.weight").T + f("ff.2.bias")
+
+
+@pytest.mark.parametrize("C,rows", [(64, 256), (128, 256), (64, 256 * 7), (128, 256 * 300)])
+def test_sab_tail_one_launch_against_fp64(C, rows):
+    """pcd_sab_tail_f16 (out_proj + residual + LN2 + FFN + residual in one launch, activations in registers) against the same arithmetic in
+    float64: one tile of points, several tiles per workgroup (300 tiles on 256 workgroups: the ring runs across tile boundaries)."""
+    import ctypes as C_
+    from shapegen_amd import _lib
+    from shapegen_amd.networks import _PackedSAB
+    lib = _lib.load()
+    sd = sab_sd(C)
+    g = torch.Generator().manual_seed(C + rows)
+    a = (torch.randn(rows, C, generator=g) * 0.7).half()
+    x = (torch.randn(rows, C, generator=g) * 1.5).half()
+    pk = _PackedSAB(sd, "", C, torch.device("cuda"))
+    desc = pk.fill(_lib.SabDesc())
+    assert desc.tail_packed and lib.pcd_sab_tail_supported(C, rows) == 1 and lib.pcd_sab_tail_supported(C, rows + 64) == 0
+    ad, xd = a.cuda(), x.cuda()
+    y = torch.full((rows, C), float("nan"), dtype=torch.float16, device="cuda")
+    _lib.check(lib.pcd_sab_tail_f16(C, desc.tail_packed, ad.data_ptr(), xd.data_ptr(), rows, y.data_ptr(), _lib.stream_ptr()))
+    pick = slice(0, rows) if rows <= 4096 else torch.cat([torch.arange(0, 512), torch.arange(rows // 2 - 256, rows // 2 + 256), torch.arange(rows - 512, rows)])
+    want = _tail_fp64(a.double()[pick], x.double()[pick], sd)
+    got = y.cpu().double()
+    assert torch.isfinite(got).all()
+    assert rel_l2(got[pick], want) < 1e-3
+    # bitwise repeatable (no atomics, fixed summation order; a ring race would show here)
+    y2 = torch.empty_like(y)
+    for _ in range(5):
+        _lib.check(lib.pcd_sab_tail_f16(C, desc.tail_packed, ad.data_ptr(), xd.data_ptr(), rows, y2.data_ptr(), _lib.stream_ptr()))
+        assert torch.equal(y, y2)
+    # argument checks of the C entry
+    assert lib.pcd_sab_tail_f16(C, desc.tail_packed, ad.data_ptr(), xd.data_ptr(), rows + 1, y.data_ptr(), _lib.stream_ptr()) != 0
+    assert lib.pcd_sab_tail_f16(256, desc.tail_packed, ad.data_ptr(), xd.data_ptr(), rows, y.data_ptr(), _lib.stream_ptr()) != 0
+    assert lib.pcd_sab_tail_f16(C, desc.tail_packed, ad.data_ptr(), xd.data_ptr(), rows, xd.data_ptr(), _lib.stream_ptr()) != 0
+    assert lib.pcd_sab_tail_packed_bytes(256) == 0
+
+
+@pytest.mark.parametrize("C", [64, 128])
+def test_set_attention_block_tail_fused_against_the_four_launches(C):
+    """The block with its tail as one launch (default where rows % 256 == 0) against the four launches it replaces (pcd_sab_tail_config(0)) and the oracle."""
+    from shapegen_amd import _lib
+    from shapegen_amd.networks import SetAttentionBlock
+    from oracle import torch_oracle as O
+    lib = _lib.load()
+    sd = sab_sd(C)
+    blk = SetAttentionBlock(C, 4)
+    blk.load_state_dict(sd, strict=True)
+    blk = blk.to("cuda").eval()
+    x = torch.randn(2, 1024, C, generator=torch.Generator().manual_seed(3 * C)) * 1.5
+    assert lib.pcd_sab_tail_enabled() == 1
+    fused = blk(x.cuda()).cpu()
+    _lib.check(lib.pcd_sab_tail_config(0))
+    try:
+        four = blk(x.cuda()).cpu()
+    finally:
+        _lib.check(lib.pcd_sab_tail_config(1))
+    want = O.set_attention_block(sd, "", x, 4)
+    assert not torch.equal(fused, four)                       # (x1 and LN2(x1) stay fp32 in the one-launch form: the two are not the same bits)
+    assert rel_l2(fused, four) < 1.5e-3
+    assert rel_l2(fused, want) < 3e-3 and rel_l2(four, want) < 3e-3
+    assert rel_l2(fused, want) <= rel_l2(four, want) * 1.05  # and the one-launch form is not the less accurate one
