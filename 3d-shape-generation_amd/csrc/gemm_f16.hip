@@ -33,7 +33,6 @@ struct GemmParams {
     // slice s reads A and W at column offset s*k1 and writes the fp32 slab out32 + s*split_out
     int splits; int64_t split_out;
     int xp_depth;             // gemm_xp_kernel: K tiles of the next tile requested before the epilogue's stores (1 or 2)
-    int nt_store;             // gemm_xp_kernel: the store epilogue's 16-byte stores carry the non-temporal hint
     int krep;                 // 2 = hi / lo weights (pcd_gemm_f16_hilo): the sources are walked TWICE, first against columns [0, K) of W (the fp16
                               // weights), then against [K, 2K) (fp16 of the rounding residuals): ~22-bit weights on the fp16 matrix cores; 0 / 1 = once
 };
@@ -595,8 +594,7 @@ __global__ __launch_bounds__(512) void gemm_xp_kernel(GemmParams p) {
                         for (int e = 0; e < 8; ++e) ov[e] = to_half_sat((float)ov[e] + (float)rs[e]);
                         o = __builtin_bit_cast(u32x4, ov);
                     }
-                    if (p.nt_store) __builtin_nontemporal_store(o, (u32x4*)(orow + col));
-                    else *(u32x4*)(orow + col) = o;
+                    *(u32x4*)(orow + col) = o;
                 }
             }
         }
@@ -795,7 +793,6 @@ __global__ __launch_bounds__(256) void gemm_pack_wfrag_kernel(const half_t* __re
 
 static int g_xw = 1;            // tuning hook (pcd_gemm_set_config(8) / (9)): callers that hold a fragment-order weight copy use gemm_xw_kernel: off / on
 static int g_xp = 1;            // tuning hook (pcd_gemm_set_config(5) / (6) / (7)): the cross-tile prefetching store kernel off / 2 K tiles ahead / 1
-static int g_nt = 0;            // tuning hook (pcd_gemm_set_config(10) / (11)): non-temporal hint on the store epilogue of gemm_xp_kernel off / on
 
 static int num_cus() {
     static int n = 0;
@@ -864,7 +861,6 @@ static int launch(const GemmParams& p0, hipStream_t s, int blocks_per_cu) {
         }
         if (ok && p.bias != nullptr && p.shape_bias != nullptr) {
             p.xp_depth = EPI == EPI_F16 ? g_xp : 1;
-            p.nt_store = g_nt;
             hipLaunchKernelGGL(gemm_xp_kernel<EPI>, dim3(grid), dim3(512), 0, s, p);
             PCD_CHECK_LAUNCH();
             return PCD_OK;
@@ -1045,8 +1041,7 @@ extern "C" int pcd_gemm_f16_colmax_wfrag(const pcd_gemm_desc_t* d, const void* w
 extern "C" int pcd_gemm_wfrag_enabled(void) { return g_xw; }
 
 extern "C" int pcd_gemm_set_config(int cfg) {
-    PCD_CHECK_ARG(cfg >= -1 && cfg <= 11);
-    if (cfg >= 10) { g_nt = cfg - 10; return PCD_OK; }                              // A/B switch: non-temporal stores in gemm_xp_kernel's epilogue
+    PCD_CHECK_ARG(cfg >= -1 && cfg <= 9);
     if (cfg >= 8) { g_xw = cfg - 8; return PCD_OK; }                                // A/B switch of gemm_xw_kernel (pcd_gemm_wfrag_enabled)
     if (cfg >= 5) { g_xp = cfg == 5 ? 0 : (cfg == 6 ? 2 : 1); return PCD_OK; }      // A/B switch of gemm_xp_kernel; the tile choice is left as it is
     g_force_cfg = cfg;

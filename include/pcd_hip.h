@@ -90,7 +90,7 @@ int pcd_gemm_wfrag_enabled(void);
  * process (-1 = shape heuristic; 0: 128x64, 1: 128x128, 2: 256x128 3-stage, 3: 256x256, 4: 128x128 3-stage).
  * 5 / 7 / 6 leave the tile choice alone and switch the 256x256 store / column-max kernel that requests the next tile's first
  * K tile(s) before the epilogue's stores (whole tiles only): off / one K tile ahead (default) / two (store epilogue only).
- * 8 / 9: pcd_gemm_wfrag_enabled() off / on (default on).  10 / 11: non-temporal hint on the 256x256 store epilogue's stores off (default) / on. */
+ * 8 / 9: pcd_gemm_wfrag_enabled() off / on (default on). */
 int pcd_gemm_set_config(int cfg);
 
 int pcd_fill_zero(void* p, size_t bytes, void* stream);
