@@ -44,14 +44,24 @@ static int sab_run(const pcd_sab_desc_t& d, const void* x, int batch, int n, int
     void *t1 = ws + w.t1, *t2 = ws + w.t2, *qkv = ws + w.qkv, *ffh = ws + w.ffh;
     int rc;
 #define RUN(expr) do { rc = (expr); if (rc) return rc; } while (0)
-    RUN(pcd_layernorm_f16(x, m, C, d.ln1_g, d.ln1_b, t1, s));                        // LN1 (q = k = v source)
-    RUN(gemm(t1, C, nullptr, 0, d.w_in, d.b_in, 0, m, 3 * C, nullptr, qkv, s));      // in_proj C -> 3C
+    // C = 256 with packed images: LayerNorm + Linear as one launch of the wide-chain kernel (widechain.hip), B fragments normalised as they are loaded
+    const bool lnlin = pcd_sab_tail_enabled() && pcd_pw_wide_ln_linear_supported(C, m);
+    if (lnlin && d.ln_in_packed != nullptr) {
+        RUN(pcd_pw_wide_ln_linear(d.ln_in_packed, 3, 0, x, m, qkv, s));                  // LN1 + in_proj C -> 3C
+    } else {
+        RUN(pcd_layernorm_f16(x, m, C, d.ln1_g, d.ln1_b, t1, s));                        // LN1 (q = k = v source)
+        RUN(gemm(t1, C, nullptr, 0, d.w_in, d.b_in, 0, m, 3 * C, nullptr, qkv, s));      // in_proj C -> 3C
+    }
     RUN(pcd_set_attention_f16(qkv, batch, n, C, heads, t2, nullptr, 0, s));          // softmax(QK^T/sqrt d) V
     if (d.tail_packed != nullptr && pcd_sab_tail_enabled() && pcd_sab_tail_supported(C, m))
         return pcd_sab_tail_f16(C, d.tail_packed, t2, x, m, y, s);                   // C <= 128: the rest of the block as one launch (sab_tail.hip)
     RUN(gemm(t2, C, nullptr, 0, d.w_out, d.b_out, 0, m, C, x, t1, s));               // x + out_proj(.)
-    RUN(pcd_layernorm_f16(t1, m, C, d.ln2_g, d.ln2_b, t2, s));
-    RUN(gemm(t2, C, nullptr, 0, d.w_ff1, d.b_ff1, 1, m, 4 * C, nullptr, ffh, s));    // Linear(C,4C) + ReLU
+    if (lnlin && d.ln_ff1_packed != nullptr) {
+        RUN(pcd_pw_wide_ln_linear(d.ln_ff1_packed, 4, 1, t1, m, ffh, s));                // LN2 + Linear(C,4C) + ReLU
+    } else {
+        RUN(pcd_layernorm_f16(t1, m, C, d.ln2_g, d.ln2_b, t2, s));
+        RUN(gemm(t2, C, nullptr, 0, d.w_ff1, d.b_ff1, 1, m, 4 * C, nullptr, ffh, s));    // Linear(C,4C) + ReLU
+    }
     RUN(gemm(ffh, 4 * C, nullptr, 0, d.w_ff2, d.b_ff2, 0, m, C, t1, y, s));          // + Linear(4C,C)
 #undef RUN
     return PCD_OK;

@@ -30,13 +30,15 @@ struct WcSeg {
     int cvalid;       // finish 2: channels of this pass that exist (256, or 128 for a padded last layer)
     int bias_off;     // offset into the bias array
     int keep_b;       // 1: the B fragments are needed by the next segment too (second output pass of a 512-channel layer)
-    int pad;
+    int linear;       // 1: no ReLU in this pass's epilogue (a plain Linear: attention in_proj); 0: bias + ReLU
 };
 
 struct WcParams {
     const half_t* in1; const half_t* in2;     // [M][256]
     const char* wpacked;                       // stage images, segment after segment, 4 per segment
     const float* bias;                         // fp32, indexed by bias_off + channel
+    const float* ln;                           // optional LayerNorm over the 256 input channels of in1 (gamma [256] | beta [256], eps 1e-5) applied to the B
+                                               // fragments as they are loaded: LN + Linear(256, 256 P) [+ ReLU] in one launch (pcd_pw_wide_ln_linear)
     half_t* out; int ldo;                      // [M][ldo]
     int64_t m;
     int nseg;
@@ -49,7 +51,7 @@ __device__ __forceinline__ void wc_dma(const char* g, unsigned lds_addr) {
 
 // two accumulator groups (same channel tile, g = 2 gp and 2 gp + 1) -> the 8 consecutive channels a lane needs as the next B fragment /
 // as one 16-byte output piece: lane half 0 ends with channels 16 s .. + 7, lane half 1 with 16 s + 8 .. + 15 (s = 2 t + gp)
-__device__ __forceinline__ half8 wc_regroup(const f32x16& acc, int gp, const float* bias_t, int hh) {
+__device__ __forceinline__ half8 wc_regroup(const f32x16& acc, int gp, const float* bias_t, int hh, float lo = 0.f) {
     // group g holds channels 8 g + 4 hh + e of the 32-channel tile
     unsigned p[2], q[2];
 #pragma unroll
@@ -58,8 +60,8 @@ __device__ __forceinline__ half8 wc_regroup(const f32x16& acc, int gp, const flo
         const float a0 = acc[4 * g0 + 2 * h] + bias_t[8 * g0 + 4 * hh + 2 * h], a1 = acc[4 * g0 + 2 * h + 1] + bias_t[8 * g0 + 4 * hh + 2 * h + 1];
         const float b0 = acc[4 * g1 + 2 * h] + bias_t[8 * g1 + 4 * hh + 2 * h], b1 = acc[4 * g1 + 2 * h + 1] + bias_t[8 * g1 + 4 * hh + 2 * h + 1];
         half2_ pa, pb;
-        pa.x = (half_t)__builtin_amdgcn_fmed3f(a0, 0.f, 65504.f); pa.y = (half_t)__builtin_amdgcn_fmed3f(a1, 0.f, 65504.f);
-        pb.x = (half_t)__builtin_amdgcn_fmed3f(b0, 0.f, 65504.f); pb.y = (half_t)__builtin_amdgcn_fmed3f(b1, 0.f, 65504.f);
+        pa.x = (half_t)__builtin_amdgcn_fmed3f(a0, lo, 65504.f); pa.y = (half_t)__builtin_amdgcn_fmed3f(a1, lo, 65504.f);
+        pb.x = (half_t)__builtin_amdgcn_fmed3f(b0, lo, 65504.f); pb.y = (half_t)__builtin_amdgcn_fmed3f(b1, lo, 65504.f);
         p[h] = __builtin_bit_cast(unsigned, pa);
         q[h] = __builtin_bit_cast(unsigned, pb);
     }
@@ -75,6 +77,9 @@ __device__ __forceinline__ half8 wc_regroup(const f32x16& acc, int gp, const flo
     return __builtin_bit_cast(half8, (u4){f[0], f[1], f[2], f[3]});
 }
 
+// LN = false: the chains of UNetPointNetLarge; LN = true: LayerNorm + Linear (pcd_pw_wide_ln_linear) -- its own instantiation so that the chains keep their
+// register allocation (246 registers, no spill)
+template <bool LN>
 __global__ __launch_bounds__(WC_THREADS, 2) void pw_wide_chain_kernel(WcParams p) {
     extern __shared__ __attribute__((aligned(16))) char wc_smem[];          // [WC_RING][WC_STAGE] | bias copy
     const int lane = threadIdx.x & 63;
@@ -83,6 +88,9 @@ __global__ __launch_bounds__(WC_THREADS, 2) void pw_wide_chain_kernel(WcParams p
     float* bias_lds = (float*)(wc_smem + WC_RING * WC_STAGE);
     const int nbias = p.nseg * 256;
     for (int i = threadIdx.x; i < nbias; i += WC_THREADS) bias_lds[i] = p.bias[i];
+    float* ln_lds = bias_lds + WC_MAXSEG * 256;                // (present when p.ln: the host sizes the allocation)
+    if constexpr (LN)
+        for (int i = threadIdx.x; i < 512; i += WC_THREADS) ln_lds[i] = p.ln[i];
     const unsigned lds0 = (unsigned)(size_t)wc_smem;
     const int64_t ntiles = p.m / WC_TILE;
     const int my_tiles = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
@@ -99,6 +107,7 @@ __global__ __launch_bounds__(WC_THREADS, 2) void pw_wide_chain_kernel(WcParams p
     };
     issue(0);
     issue(1);
+    if constexpr (LN) __syncthreads();                         // ln_lds is read before the first stage barrier
     int n = 0;                                                 // next stage to consume
     for (int ti = 0; ti < my_tiles; ++ti) {
         const int64_t tile = blockIdx.x + (int64_t)ti * gridDim.x;
@@ -113,6 +122,38 @@ __global__ __launch_bounds__(WC_THREADS, 2) void pw_wide_chain_kernel(WcParams p
                 const half_t* row = (S.src == 1 ? p.in1 : p.in2) + pt * 256 + 8 * hh;
 #pragma unroll
                 for (int s = 0; s < 16; ++s) bf[s] = *(const half8*)(row + 16 * s);
+                if constexpr (LN) {
+                    // LayerNorm of the point's 256 channels (this lane holds 128 of them, lane ^ 32 the others): fp32 statistics, result in fp16
+                    // like pcd_layernorm_f16's.  (The first barrier below orders these reads of ln_lds behind its fill; at the first tile of a
+                    // workgroup the fill is ordered by the __syncthreads() in front of the tile loop.)
+                    // (statistics straight from the packed fp16 pairs by v_dot2_f32_f16, fp32 accumulation: sum and sum of squares in one pass -- a second
+                    // pass over converted values keeps 128 more registers alive and spills)
+                    float sum = 0.f, sq = 0.f;
+                    half2_ one2; one2.x = one2.y = (half_t)1.f;
+#pragma unroll
+                    for (int s = 0; s < 16; ++s)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            half2_ v; v.x = bf[s][2 * e]; v.y = bf[s][2 * e + 1];
+                            sum = __builtin_amdgcn_fdot2(v, one2, sum, false);
+                            sq = __builtin_amdgcn_fdot2(v, v, sq, false);
+                        }
+                    sum += __shfl_xor(sum, 32);
+                    sq += __shfl_xor(sq, 32);
+                    const float mean = sum * (1.f / 256.f);
+                    const float ssq = fmaxf(sq - 256.f * mean * mean, 0.f);
+                    const float rstd = rsqrtf(ssq * (1.f / 256.f) + 1e-5f);
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) {
+                        const f32x4 g0 = *(const f32x4*)&ln_lds[16 * s + 8 * hh], g1 = *(const f32x4*)&ln_lds[16 * s + 8 * hh + 4];
+                        const f32x4 b0 = *(const f32x4*)&ln_lds[256 + 16 * s + 8 * hh], b1 = *(const f32x4*)&ln_lds[256 + 16 * s + 8 * hh + 4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            bf[s][e] = (half_t)__builtin_amdgcn_fmed3f(((float)bf[s][e] - mean) * rstd * g0[e] + b0[e], -65504.f, 65504.f);
+                            bf[s][4 + e] = (half_t)__builtin_amdgcn_fmed3f(((float)bf[s][4 + e] - mean) * rstd * g1[e] + b1[e], -65504.f, 65504.f);
+                        }
+                    }
+                }
             }
             if (!S.cont) {
 #pragma unroll
@@ -124,8 +165,8 @@ __global__ __launch_bounds__(WC_THREADS, 2) void pw_wide_chain_kernel(WcParams p
             for (int kt = 0; kt < 4; ++kt) {
                 // stage n has landed (all but this wave's 4 youngest LDS-DMA pieces), every wave is done with stage n - 1: its
                 // slot takes stage n + 2
-                if (n + 1 < total_stages) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (n + 1 < total_stages) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");     // (lgkmcnt: tools/check_barrier_reads.py)
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __syncthreads();
                 issue(n + 2);
                 const char* img = wc_smem + (n % WC_RING) * WC_STAGE + lane * 16;
@@ -141,24 +182,36 @@ __global__ __launch_bounds__(WC_THREADS, 2) void pw_wide_chain_kernel(WcParams p
             }
             if (S.finish == 0) continue;
             const float* bseg = bias_lds + S.bias_off;
+            const float lo = LN && S.linear ? -65504.f : 0.f;
             if (S.finish == 1) {
                 // -> the next layer's B fragments: k-step s = 2 t + gp of the new input
 #pragma unroll
                 for (int t = 0; t < 8; ++t)
 #pragma unroll
-                    for (int gp = 0; gp < 2; ++gp) bf[2 * t + gp] = wc_regroup(acc[t], gp, bseg + 32 * t, hh);
+                    for (int gp = 0; gp < 2; ++gp) bf[2 * t + gp] = wc_regroup(acc[t], gp, bseg + 32 * t, hh, lo);
             } else {
                 half_t* orow = p.out + pt * p.ldo + S.coff + 8 * hh;
 #pragma unroll
                 for (int t = 0; t < 8; ++t)
 #pragma unroll
                     for (int gp = 0; gp < 2; ++gp) {
-                        const half8 v = wc_regroup(acc[t], gp, bseg + 32 * t, hh);
+                        const half8 v = wc_regroup(acc[t], gp, bseg + 32 * t, hh, lo);
                         if (32 * t + 16 * gp < S.cvalid) *(half8*)(orow + 32 * t + 16 * gp) = v;
                     }
             }
         }
     }
+}
+
+// the largest dynamic LDS either launch form asks for (ring + bias rows of WC_MAXSEG passes + LayerNorm affine): set once, for both
+constexpr size_t WC_LDS_MAX = (size_t)WC_RING * WC_STAGE + (size_t)(WC_MAXSEG * 256 + 512) * sizeof(float);
+static hipError_t wc_allow_lds() {
+    static bool attr_set = false;
+    if (attr_set) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute((const void*)pw_wide_chain_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WC_LDS_MAX);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pw_wide_chain_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WC_LDS_MAX);
+    if (e == hipSuccess) attr_set = true;
+    return e;
 }
 
 // W [C][ldw] fp16 (columns k0 .. k0 + 63 of channels c0 .. c0 + 255, rows >= c_limit read as zero) -> one stage image
@@ -235,15 +288,55 @@ extern "C" int pcd_pw_wide_chain(int chain, const void* in1, const void* in2, in
         p.seg[2] = WcSeg{0, 0, 1, 0, 256, 512, 0, 0};
         p.seg[3] = WcSeg{0, 0, 2, 0, 128, 768, 0, 0};
     }
-    static bool attr_set = false;
     const size_t lds = (size_t)WC_RING * WC_STAGE + 4 * 256 * sizeof(float);
-    if (!attr_set) {
-        PCD_CHECK_HIP(hipFuncSetAttribute((const void*)pw_wide_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    PCD_CHECK_HIP(wc_allow_lds());
     const int64_t tiles = m / WC_TILE;
     const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
-    hipLaunchKernelGGL(pw_wide_chain_kernel, dim3(grid), dim3(WC_THREADS), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(pw_wide_chain_kernel<false>, dim3(grid), dim3(WC_THREADS), lds, (hipStream_t)stream, p);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+// ---- LayerNorm(256) + Linear(256, 256 P) [+ ReLU] as one launch of the same kernel (P <= 4 output passes over B fragments that are normalised as they are
+// loaded): the in_proj and the first FFN layer of the C = 256 attention blocks (reference networks.py:61-66, 81-82) without the LayerNorm launch and its
+// 67 + 67 MB.  packed = P x 4 stage images | bias [P][256] fp32 | gamma [256] | beta [256].
+extern "C" size_t pcd_pw_wide_ln_linear_packed_bytes(int passes) {
+    return (passes >= 1 && passes <= 4) ? (size_t)passes * 4 * WC_STAGE + (size_t)(passes * 256 + 512) * sizeof(float) : 0;
+}
+
+extern "C" int pcd_pw_wide_ln_linear_pack(const void* w, const float* b, int passes, const float* ln_g, const float* ln_b, void* packed, void* stream) {
+    PCD_CHECK_ARG(w && b && ln_g && ln_b && packed && passes >= 1 && passes <= 4);
+    hipStream_t s = (hipStream_t)stream;
+    char* img = (char*)packed;
+    for (int i = 0; i < passes; ++i)
+        for (int kt = 0; kt < 4; ++kt)
+            hipLaunchKernelGGL(wc_pack_kernel, dim3(8), dim3(256), 0, s, (const half_t*)w, (int64_t)256, 256 * i, 256 * passes, 64 * kt,
+                               img + (size_t)(4 * i + kt) * WC_STAGE);
+    PCD_CHECK_LAUNCH();
+    float* f = (float*)(img + (size_t)passes * 4 * WC_STAGE);
+    PCD_CHECK_HIP(hipMemcpyAsync(f, b, (size_t)passes * 256 * 4, hipMemcpyDeviceToDevice, s));
+    PCD_CHECK_HIP(hipMemcpyAsync(f + passes * 256, ln_g, 256 * 4, hipMemcpyDeviceToDevice, s));
+    PCD_CHECK_HIP(hipMemcpyAsync(f + passes * 256 + 256, ln_b, 256 * 4, hipMemcpyDeviceToDevice, s));
+    return PCD_OK;
+}
+
+extern "C" int pcd_pw_wide_ln_linear_supported(int dim, int64_t rows) { return dim == 256 && rows > 0 && rows % WC_TILE == 0 ? 1 : 0; }
+
+extern "C" int pcd_pw_wide_ln_linear(const void* packed, int passes, int relu, const void* x, int64_t m, void* out, void* stream) {
+    PCD_CHECK_ARG(packed && x && out && x != out && passes >= 1 && passes <= 4 && m > 0 && m % WC_TILE == 0);
+    WcParams p{};
+    p.in1 = (const half_t*)x; p.in2 = nullptr; p.m = m;
+    p.wpacked = (const char*)packed;
+    p.bias = (const float*)((const char*)packed + (size_t)passes * 4 * WC_STAGE);
+    p.ln = p.bias + passes * 256;
+    p.out = (half_t*)out; p.ldo = 256 * passes;
+    p.nseg = passes;
+    for (int i = 0; i < passes; ++i) p.seg[i] = WcSeg{i == 0 ? 1 : 0, 0, 2, 256 * i, 256, 256 * i, i + 1 < passes ? 1 : 0, relu ? 0 : 1};
+    const size_t lds = WC_LDS_MAX;
+    PCD_CHECK_HIP(wc_allow_lds());
+    const int64_t tiles = m / WC_TILE;
+    const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+    hipLaunchKernelGGL(pw_wide_chain_kernel<true>, dim3(grid), dim3(WC_THREADS), lds, (hipStream_t)stream, p);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

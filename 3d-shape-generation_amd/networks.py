@@ -326,6 +326,7 @@ class _PackedSAB:
         self.w_ff1, self.b_ff1 = devw(g("ff.0.weight"), dev), _dev32(g("ff.0.bias"), dev)
         self.w_ff2, self.b_ff2 = devw(g("ff.2.weight"), dev), _dev32(g("ff.2.bias"), dev)
         self.tail = None
+        self.lnlin = None
         self.f32 = f32
 
     def fill(self, d: "_lib.SabDesc") -> "_lib.SabDesc":
@@ -333,6 +334,7 @@ class _PackedSAB:
         for k in ("w_in", "b_in", "w_out", "b_out", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "w_ff1", "b_ff1", "w_ff2", "b_ff2"):
             setattr(d, k, getattr(self, k).data_ptr())
         d.tail_packed = None
+        d.ln_in_packed = d.ln_ff1_packed = None
         # C <= 128, fp16: the block's tail (out_proj + residual + LN2 + FFN + residual) as one launch needs its weights in fragment-order stage images
         lib = _lib.load()
         nbytes = 0 if self.f32 else lib.pcd_sab_tail_packed_bytes(self.dim)
@@ -341,6 +343,17 @@ class _PackedSAB:
                 self.tail = torch.empty(nbytes, dtype=torch.uint8, device=self.w_out.device)
                 _lib.check(lib.pcd_sab_tail_pack(C.byref(d), self.tail.data_ptr(), _lib.stream_ptr()), "sab_tail_pack")
             d.tail_packed = self.tail.data_ptr()
+        # C = 256, fp16: LN1 + in_proj and LN2 + ff.0 as one launch each (wide-chain kernel with a LayerNorm prologue)
+        if self.dim == 256 and not self.f32:
+            if self.lnlin is None:
+                bufs = []
+                for w, b, passes, g_, b_ in ((self.w_in, self.b_in, 3, self.ln1_g, self.ln1_b), (self.w_ff1, self.b_ff1, 4, self.ln2_g, self.ln2_b)):
+                    buf = torch.empty(lib.pcd_pw_wide_ln_linear_packed_bytes(passes), dtype=torch.uint8, device=self.w_out.device)
+                    _lib.check(lib.pcd_pw_wide_ln_linear_pack(w.data_ptr(), b.data_ptr(), passes, g_.data_ptr(), b_.data_ptr(), buf.data_ptr(),
+                                                              _lib.stream_ptr()), "pw_wide_ln_linear_pack")
+                    bufs.append(buf)
+                self.lnlin = bufs
+            d.ln_in_packed, d.ln_ff1_packed = self.lnlin[0].data_ptr(), self.lnlin[1].data_ptr()
         return d
 
 

@@ -225,6 +225,14 @@ int pcd_unet_config(int use_chains);
 size_t pcd_pw_wide_packed_bytes(int chain);
 int pcd_pw_wide_pack(int chain, const void* const* w, const float* const* b, void* packed, void* stream);
 int pcd_pw_wide_chain(int chain, const void* in1, const void* in2, int64_t m, const void* packed, void* out, void* stream);
+/* LayerNorm(256) + Linear(256, 256 passes) [+ ReLU] as one launch of the wide-chain kernel (csrc/widechain.hip): the B fragments are normalised as they
+ * are loaded (two-pass fp32 statistics, eps 1e-5, fp16 result as pcd_layernorm_f16's), so the LayerNorm launch and its tensor disappear: attention in_proj
+ * (passes 3, relu 0) and ff.0 (passes 4, relu 1) of the C = 256 SetAttentionBlocks (networks.py:61-66, 81-82).  w fp16 [256 passes][256], b fp32;
+ * packed: pcd_pw_wide_ln_linear_packed_bytes(passes) bytes of device memory; rows % 256 == 0; out fp16 [rows][256 passes], out != x. */
+size_t pcd_pw_wide_ln_linear_packed_bytes(int passes);
+int pcd_pw_wide_ln_linear_pack(const void* w, const float* b, int passes, const float* ln_g, const float* ln_b, void* packed, void* stream);
+int pcd_pw_wide_ln_linear_supported(int dim, int64_t rows);
+int pcd_pw_wide_ln_linear(const void* packed, int passes, int relu, const void* x, int64_t rows, void* out, void* stream);
 
 typedef struct pcd_unet pcd_unet_t;
 int pcd_unet_create(const pcd_unet_desc_t* desc, pcd_unet_t** out);
@@ -547,6 +555,8 @@ typedef struct {
     const float* ln1_g; const float* ln1_b; const float* ln2_g; const float* ln2_b;
     const void* w_ff1; const float* b_ff1;           /* ff.0 [4C][C] */
     const void* w_ff2; const float* b_ff2;           /* ff.2 [C][4C] */
+    const void* ln_in_packed; const void* ln_ff1_packed;   /* optional (dim 256): pcd_pw_wide_ln_linear_pack images of (ln1, in_proj: 3 passes) and
+                                                      * (ln2, ff.0: 4 passes): pcd_sab_forward then runs LN + Linear as one launch each when rows % 256 == 0 */
     const void* tail_packed;                         /* optional (dim 64 / 128): pcd_sab_tail_pack's image of w_out .. b_ff2; pcd_sab_forward then runs
                                                       * out_proj + residual + LN2 + FFN + residual as ONE launch when rows % 256 == 0.  NULL: four launches.
                                                       * Ignored by the fp32 parity entry points */

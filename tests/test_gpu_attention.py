@@ -339,3 +339,60 @@ def test_set_attention_block_tail_fused_against_the_four_launches(C):
     assert rel_l2(fused, four) < 1.5e-3
     assert rel_l2(fused, want) < 3e-3 and rel_l2(four, want) < 3e-3
     assert rel_l2(fused, want) <= rel_l2(four, want) * 1.05  # and the one-launch form is not the less accurate one
+
+
+@pytest.mark.parametrize("passes,relu,rows", [(3, 0, 256), (4, 1, 256), (3, 0, 256 * 300), (1, 1, 512)])
+def test_wide_chain_layernorm_linear_against_fp64(passes, relu, rows):
+    """pcd_pw_wide_ln_linear: LayerNorm(256) + Linear(256, 256 passes) [+ ReLU] in one launch (B fragments normalised as they are loaded) against float64
+    from the fp16-rounded operands; the LayerNorm result is rounded to fp16 in both, as pcd_layernorm_f16 does."""
+    from shapegen_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11 * passes + rows)
+    x = (torch.randn(rows, 256, generator=g) * 1.7 + 0.4).half()
+    w = (torch.randn(256 * passes, 256, generator=g) / 16).half()
+    b = torch.randn(256 * passes, generator=g) * 0.1
+    ga, be = 1 + 0.2 * torch.randn(256, generator=g), 0.1 * torch.randn(256, generator=g)
+    dev = lambda t: t.cuda().contiguous()
+    xd, wd, bd, gd, bed = dev(x), dev(w), dev(b), dev(ga), dev(be)
+    packed = torch.empty(lib.pcd_pw_wide_ln_linear_packed_bytes(passes), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.pcd_pw_wide_ln_linear_pack(wd.data_ptr(), bd.data_ptr(), passes, gd.data_ptr(), bed.data_ptr(), packed.data_ptr(), _lib.stream_ptr()))
+    out = torch.full((rows, 256 * passes), float("nan"), dtype=torch.float16, device="cuda")
+    assert lib.pcd_pw_wide_ln_linear_supported(256, rows) == 1 and lib.pcd_pw_wide_ln_linear_supported(128, rows) == 0
+    _lib.check(lib.pcd_pw_wide_ln_linear(packed.data_ptr(), passes, relu, xd.data_ptr(), rows, out.data_ptr(), _lib.stream_ptr()))
+    pick = torch.arange(rows) if rows <= 4096 else torch.cat([torch.arange(0, 512), torch.arange(rows // 2 - 256, rows // 2 + 256), torch.arange(rows - 512, rows)])
+    ln = torch.nn.functional.layer_norm(x.double()[pick], (256,), ga.double(), be.double(), 1e-5).half().double()
+    want = ln @ w.double().T + b.double()
+    want = torch.relu(want) if relu else want
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    assert rel_l2(got[pick], want) < 1e-3
+    if not relu:
+        assert float(got.min()) < 0                             # a plain Linear keeps its negative outputs
+    out2 = torch.empty_like(out)
+    for _ in range(3):
+        _lib.check(lib.pcd_pw_wide_ln_linear(packed.data_ptr(), passes, relu, xd.data_ptr(), rows, out2.data_ptr(), _lib.stream_ptr()))
+        assert torch.equal(out, out2)
+    assert lib.pcd_pw_wide_ln_linear(packed.data_ptr(), passes, relu, xd.data_ptr(), rows + 8, out.data_ptr(), _lib.stream_ptr()) != 0
+    assert lib.pcd_pw_wide_ln_linear(packed.data_ptr(), 5, relu, xd.data_ptr(), rows, out.data_ptr(), _lib.stream_ptr()) != 0
+
+
+def test_set_attention_block_256_layernorm_in_the_linear_launches():
+    """C = 256: LN1 + in_proj and LN2 + ff.0 as one launch each (default where rows % 256 == 0) against the separate launches and the oracle."""
+    from shapegen_amd import _lib
+    from shapegen_amd.networks import SetAttentionBlock
+    from oracle import torch_oracle as O
+    lib = _lib.load()
+    sd = sab_sd(256)
+    blk = SetAttentionBlock(256, 4)
+    blk.load_state_dict(sd, strict=True)
+    blk = blk.to("cuda").eval()
+    x = torch.randn(2, 1024, 256, generator=torch.Generator().manual_seed(77)) * 1.5
+    fused = blk(x.cuda()).cpu()
+    _lib.check(lib.pcd_sab_tail_config(0))
+    try:
+        sep = blk(x.cuda()).cpu()
+    finally:
+        _lib.check(lib.pcd_sab_tail_config(1))
+    want = O.set_attention_block(sd, "", x, 4)
+    assert rel_l2(fused, sep) < 1e-3
+    assert rel_l2(fused, want) < 3e-3 and rel_l2(sep, want) < 3e-3

@@ -20,14 +20,14 @@ def ev(fn, n=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 g = torch.Generator().manual_seed(5)
-for C in (64, 128):
+for C in (64, 128, 256):
     blk = SetAttentionBlock(C, 4); blk.load_state_dict(sab_sd(C), strict=True); blk = blk.to("cuda").eval()
     x = torch.randn(64, 2048, C, generator=g).cuda().half()
     t = {}
     for fused in (1, 0, 1, 0):
         _lib.check(lib.pcd_sab_tail_config(fused))
         t.setdefault(fused, []).append(ev(lambda: blk(x)))
-    print(f"SetAttentionBlock C={C}, B=64, N=2048: tail as one launch {min(t[1]):7.1f} us | four launches {min(t[0]):7.1f} us per block", flush=True)
+    print(f"SetAttentionBlock C={C}, B=64, N=2048: fused launches {min(t[1]):7.1f} us | separate launches {min(t[0]):7.1f} us per block", flush=True)
 _lib.check(lib.pcd_sab_tail_config(1))
 att = PointCloudDiffusion(num_points=2048, backbone="attention").to("cuda").eval()
 x = torch.randn(64, 2048, 3, generator=g).cuda(); tt = torch.rand(64, generator=g).cuda()
