@@ -46,14 +46,17 @@ static int sab_run(const pcd_sab_desc_t& d, const void* x, int batch, int n, int
 #define RUN(expr) do { rc = (expr); if (rc) return rc; } while (0)
     // C = 256 with packed images: LayerNorm + Linear as one launch of the wide-chain kernel (widechain.hip), B fragments normalised as they are loaded
     const bool lnlin = pcd_sab_tail_enabled() && pcd_pw_wide_ln_linear_supported(C, m);
+    const bool fused128 = d.tail_packed != nullptr && pcd_sab_tail_enabled() && pcd_sab_tail_supported(C, m);
     if (lnlin && d.ln_in_packed != nullptr) {
         RUN(pcd_pw_wide_ln_linear(d.ln_in_packed, 3, 0, x, m, qkv, s));                  // LN1 + in_proj C -> 3C
+    } else if (fused128) {
+        RUN(pcd_sab_head_f16(C, d.tail_packed, x, m, qkv, s));                           // C <= 128: the same as one register-resident launch (sab_tail.hip)
     } else {
         RUN(pcd_layernorm_f16(x, m, C, d.ln1_g, d.ln1_b, t1, s));                        // LN1 (q = k = v source)
         RUN(gemm(t1, C, nullptr, 0, d.w_in, d.b_in, 0, m, 3 * C, nullptr, qkv, s));      // in_proj C -> 3C
     }
     RUN(pcd_set_attention_f16(qkv, batch, n, C, heads, t2, nullptr, 0, s));          // softmax(QK^T/sqrt d) V
-    if (d.tail_packed != nullptr && pcd_sab_tail_enabled() && pcd_sab_tail_supported(C, m))
+    if (fused128)
         return pcd_sab_tail_f16(C, d.tail_packed, t2, x, m, y, s);                   // C <= 128: the rest of the block as one launch (sab_tail.hip)
     RUN(gemm(t2, C, nullptr, 0, d.w_out, d.b_out, 0, m, C, x, t1, s));               // x + out_proj(.)
     if (lnlin && d.ln_ff1_packed != nullptr) {

@@ -15,7 +15,8 @@
 //   * only the weights move: packed once per block (pcd_sab_tail_pack) into stage images in fragment order -- [W_out] and, per chunk,
 //     [W1 chunk | W2 chunk] -- they arrive by LDS-DMA in a three-stage ring shared by the workgroup's eight waves (256 points), one barrier
 //     per stage, 262 FLOP per byte of LDS fill.
-// Rows must be a multiple of 256 (otherwise the caller keeps the four launches).  Arithmetic: fp16 operands, fp32 accumulation; x1 and the
+// sab_head_kernel below does the block's first half in the same form (LN1 + in_proj).  Rows must be a multiple of 256 (otherwise the caller keeps the
+// separate launches).  Arithmetic: fp16 operands, fp32 accumulation; x1 and the
 // LayerNorm in fp32 (the four-launch form rounds x1 and LN2(x1) to fp16 in between: this form is the closer one to the reference's fp32).
 #include "common.h"
 
@@ -34,6 +35,13 @@ struct StCfg {
     static constexpr int W2OFF = 2 * KS * 1024;        // the W2 part of a chunk image
     // fp32 parameters behind the images: b_out [C] | ln2 gamma [C] | ln2 beta [C] | b_ff2 [C] | b_ff1 [4C]
     static constexpr int BO = 0, GA = C, BE = 2 * C, B2 = 3 * C, B1 = 4 * C, NPAR = 8 * C;
+    // the head (LN1 + in_proj, sab_head_kernel) behind the tail's image: three stage images of W_in (one C-wide output pass each), then b_in [3C] | ln1 gamma [C] |
+    // ln1 beta [C]
+    static constexpr int HSTAGE = NT * KS * 1024;      // one pass of W_in: C x C fp16
+    static constexpr int HPPW = HSTAGE / 1024 / ST_WAVES;
+    static constexpr int HB = 0, HGA = 3 * C, HBE = 4 * C, HNPAR = 5 * C;
+    static constexpr size_t TAIL_BYTES = (size_t)NSTG * STAGE + NPAR * sizeof(float);
+    static constexpr size_t HEAD_BYTES = (size_t)3 * HSTAGE + HNPAR * sizeof(float);
     static_assert(C == 64 || C == 128, "the tail kernel is built for C = 64 and C = 128");
     static_assert((2 * KS + 4 * NT) * 1024 == STAGE && NT * KS * 1024 <= STAGE, "stage image layout");
 };
@@ -248,6 +256,124 @@ __global__ __launch_bounds__(ST_THREADS, 2) void sab_tail_kernel(SabTailParams p
     }
 }
 
+// The head of the block for C <= 128: qkv = in_proj(LN1(x)) (reference networks.py:81) in one launch of the same form -- the B fragments of x are normalised
+// as they are loaded (statistics by v_dot2_f32_f16 over the lane's C / 2 channels + lane ^ 32, fp32; result fp16 like pcd_layernorm_f16's), then three
+// C-wide output passes over them, one stage image of W_in each, bias, no activation, 16-byte stores into the [rows][3C] qkv tensor.
+struct SabHeadParams {
+    const half_t* x;          // [M][C] the block's input
+    const char* packed;       // the head part of the block's image: 3 stage images, then HNPAR floats
+    half_t* qkv;              // [M][3C]
+    int64_t m;
+};
+
+template <int C>
+__global__ __launch_bounds__(ST_THREADS, 2) void sab_head_kernel(SabHeadParams p) {
+    using K = StCfg<C>;
+    constexpr int NT = K::NT, KS = K::KS;
+    extern __shared__ __attribute__((aligned(16))) char st_smem[];          // [ST_RING][HSTAGE] | parameters
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pnt = lane & 31, hh = lane >> 5;
+    float* par = (float*)(st_smem + ST_RING * K::HSTAGE);
+    {
+        const float* src = (const float*)(p.packed + (size_t)3 * K::HSTAGE);
+        for (int i = threadIdx.x; i < K::HNPAR; i += ST_THREADS) par[i] = src[i];
+    }
+    const unsigned lds0 = (unsigned)(size_t)st_smem;
+    const int64_t ntiles = p.m / ST_TILE;
+    const int my_tiles = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
+    const int total_stages = my_tiles * 3;
+    auto issue = [&](int n) __attribute__((always_inline)) {
+        if (n < total_stages) {
+            const char* src = p.packed + (size_t)(n % 3) * K::HSTAGE + (size_t)(K::HPPW * wave) * 1024 + lane * 16;
+            const unsigned dst = lds0 + (n % ST_RING) * K::HSTAGE + (K::HPPW * wave) * 1024;
+#pragma unroll
+            for (int i = 0; i < K::HPPW; ++i) st_dma(src + i * 1024, dst + i * 1024);
+        }
+    };
+    issue(0);
+    issue(1);
+    __syncthreads();                                           // the LayerNorm affine is read before the first stage barrier
+    int n = 0;
+    auto acquire = [&]() __attribute__((always_inline)) -> const char* {
+        if (n + 1 < total_stages) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(K::HPPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        issue(n + 2);
+        return st_smem + (n % ST_RING) * K::HSTAGE + lane * 16;
+    };
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        const int64_t tile = blockIdx.x + (int64_t)ti * gridDim.x;
+        const int64_t pt = tile * ST_TILE + wave * 32 + pnt;
+        half8 bf[KS];
+        {
+            const half_t* row = p.x + pt * C + 8 * hh;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) bf[s] = *(const half8*)(row + 16 * s);
+        }
+        {
+            float sum = 0.f, sq = 0.f;
+            half2_ one2; one2.x = one2.y = (half_t)1.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    half2_ v; v.x = bf[s][2 * e]; v.y = bf[s][2 * e + 1];
+                    sum = __builtin_amdgcn_fdot2(v, one2, sum, false);
+                    sq = __builtin_amdgcn_fdot2(v, v, sq, false);
+                }
+            sum += __shfl_xor(sum, 32);
+            sq += __shfl_xor(sq, 32);
+            const float mean = sum * (1.f / C);
+            const float rstd = rsqrtf(fmaxf(sq - C * mean * mean, 0.f) * (1.f / C) + 1e-5f);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const f32x4 g0 = *(const f32x4*)&par[K::HGA + 16 * s + 8 * hh], g1 = *(const f32x4*)&par[K::HGA + 16 * s + 8 * hh + 4];
+                const f32x4 b0 = *(const f32x4*)&par[K::HBE + 16 * s + 8 * hh], b1 = *(const f32x4*)&par[K::HBE + 16 * s + 8 * hh + 4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bf[s][e] = (half_t)__builtin_amdgcn_fmed3f(((float)bf[s][e] - mean) * rstd * g0[e] + b0[e], -65504.f, 65504.f);
+                    bf[s][4 + e] = (half_t)__builtin_amdgcn_fmed3f(((float)bf[s][4 + e] - mean) * rstd * g1[e] + b1[e], -65504.f, 65504.f);
+                }
+            }
+        }
+        half_t* orow = p.qkv + pt * (3 * C) + 8 * hh;
+#pragma unroll 1
+        for (int pass = 0; pass < 3; ++pass) {
+            const char* img = acquire();
+            f32x16 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+#pragma unroll
+            for (int q = 0; q < KS; ++q) {
+                half8 af[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) af[t] = *(const half8*)(img + (t * KS + q) * 1024);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t], bf[q], acc[t], 0, 0, 0);
+            }
+            ++n;
+            const float* bb = par + K::HB + pass * C + 4 * hh;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    float v[2][4];
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        const int g = 2 * gp + w;
+                        const f32x4 b4 = *(const f32x4*)&bb[32 * t + 8 * g];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[w][e] = __builtin_amdgcn_fmed3f(acc[t][4 * g + e] + b4[e], -65504.f, 65504.f);
+                    }
+                    *(half8*)(orow + pass * C + 32 * t + 16 * gp) = st_pack_swap(v[0], v[1]);
+                }
+        }
+    }
+}
+
 // W [.][ldw] fp16 -> fragment-order pieces: piece (t * nq + q) * 64 + lane = the 8 halfs W[c0 + 32 t + (lane & 31)][k0 + 16 q + 8 (lane >> 5) .. + 7]
 __global__ __launch_bounds__(256) void st_pack_kernel(const half_t* __restrict__ w, int64_t ldw, int c0, int k0, int ntile, int nq, char* __restrict__ img) {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -280,6 +406,32 @@ static int tail_pack(const pcd_sab_desc_t& d, char* packed, hipStream_t s) {
     PCD_CHECK_HIP(hipMemcpyAsync(par + K::BE, d.ln2_b, C * 4, hipMemcpyDeviceToDevice, s));
     PCD_CHECK_HIP(hipMemcpyAsync(par + K::B2, d.b_ff2, C * 4, hipMemcpyDeviceToDevice, s));
     PCD_CHECK_HIP(hipMemcpyAsync(par + K::B1, d.b_ff1, 4 * C * 4, hipMemcpyDeviceToDevice, s));
+    // the head's part: W_in as three passes, b_in, LN1 affine
+    char* head = packed + K::TAIL_BYTES;
+    for (int i = 0; i < 3; ++i) pack(d.w_in, C, i * C, 0, K::NT, K::KS, head + (size_t)i * K::HSTAGE);
+    PCD_CHECK_LAUNCH();
+    float* hpar = (float*)(head + (size_t)3 * K::HSTAGE);
+    PCD_CHECK_HIP(hipMemcpyAsync(hpar + K::HB, d.b_in, 3 * C * 4, hipMemcpyDeviceToDevice, s));
+    PCD_CHECK_HIP(hipMemcpyAsync(hpar + K::HGA, d.ln1_g, C * 4, hipMemcpyDeviceToDevice, s));
+    PCD_CHECK_HIP(hipMemcpyAsync(hpar + K::HBE, d.ln1_b, C * 4, hipMemcpyDeviceToDevice, s));
+    return PCD_OK;
+}
+
+template <int C>
+static int head_launch(const void* packed, const void* x, int64_t m, void* qkv, hipStream_t s) {
+    using K = StCfg<C>;
+    SabHeadParams p{};
+    p.x = (const half_t*)x; p.packed = (const char*)packed + K::TAIL_BYTES; p.qkv = (half_t*)qkv; p.m = m;
+    static bool attr_set = false;
+    const size_t lds = (size_t)ST_RING * K::HSTAGE + K::HNPAR * sizeof(float);
+    if (!attr_set) {
+        PCD_CHECK_HIP(hipFuncSetAttribute((const void*)sab_head_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int64_t tiles = m / ST_TILE;
+    const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+    hipLaunchKernelGGL(sab_head_kernel<C>, dim3(grid), dim3(ST_THREADS), lds, s, p);
+    PCD_CHECK_LAUNCH();
     return PCD_OK;
 }
 
@@ -306,8 +458,8 @@ static int tail_launch(const void* packed, const void* a, const void* x, int64_t
 using namespace pcd;
 
 extern "C" size_t pcd_sab_tail_packed_bytes(int dim) {
-    if (dim == 128) return (size_t)StCfg<128>::NSTG * StCfg<128>::STAGE + StCfg<128>::NPAR * sizeof(float);
-    if (dim == 64) return (size_t)StCfg<64>::NSTG * StCfg<64>::STAGE + StCfg<64>::NPAR * sizeof(float);
+    if (dim == 128) return StCfg<128>::TAIL_BYTES + StCfg<128>::HEAD_BYTES;
+    if (dim == 64) return StCfg<64>::TAIL_BYTES + StCfg<64>::HEAD_BYTES;
     return 0;
 }
 
@@ -326,6 +478,7 @@ extern "C" int pcd_sab_tail_enabled(void) { return g_sab_tail; }
 extern "C" int pcd_sab_tail_pack(const pcd_sab_desc_t* d, void* packed, void* stream) {
     PCD_CHECK_ARG(d && packed && (d->dim == 64 || d->dim == 128));
     PCD_CHECK_ARG(d->w_out && d->b_out && d->ln2_g && d->ln2_b && d->w_ff1 && d->b_ff1 && d->w_ff2 && d->b_ff2);
+    PCD_CHECK_ARG(d->w_in && d->b_in && d->ln1_g && d->ln1_b);
     return d->dim == 128 ? tail_pack<128>(*d, (char*)packed, (hipStream_t)stream) : tail_pack<64>(*d, (char*)packed, (hipStream_t)stream);
 }
 
@@ -333,4 +486,10 @@ extern "C" int pcd_sab_tail_f16(int dim, const void* packed, const void* a, cons
     PCD_CHECK_ARG(packed && a && x && y && y != a && y != x);
     PCD_CHECK_ARG(pcd_sab_tail_supported(dim, rows));
     return dim == 128 ? tail_launch<128>(packed, a, x, rows, y, (hipStream_t)stream) : tail_launch<64>(packed, a, x, rows, y, (hipStream_t)stream);
+}
+
+extern "C" int pcd_sab_head_f16(int dim, const void* packed, const void* x, int64_t rows, void* qkv, void* stream) {
+    PCD_CHECK_ARG(packed && x && qkv && qkv != x);
+    PCD_CHECK_ARG(pcd_sab_tail_supported(dim, rows));
+    return dim == 128 ? head_launch<128>(packed, x, rows, qkv, (hipStream_t)stream) : head_launch<64>(packed, x, rows, qkv, (hipStream_t)stream);
 }

@@ -565,13 +565,15 @@ typedef struct {
 size_t pcd_sab_workspace_bytes(int64_t rows, int dim);
 /* the block's tail behind the attention kernel as one launch (csrc/sab_tail.hip; reference networks.py:78-83, the second half of SetAttentionBlock.forward):
  *   y = x1 + W2 relu(W1 LN2(x1) + b1) + b2,  x1 = x + W_out a + b_out      a = the heads' outputs [rows][dim], x = the block's input, all fp16
- * pcd_sab_tail_pack writes the fragment-order stage images of w_out / w_ff1 / w_ff2 and the fp32 biases / LayerNorm affine of `d` into `packed`
+ * pcd_sab_tail_pack writes the fragment-order stage images of w_out / w_ff1 / w_ff2 (and w_in, for pcd_sab_head_f16) and the fp32 biases / LayerNorm affine of `d` into `packed`
  * (pcd_sab_tail_packed_bytes(dim) bytes of device memory; 0 = dim not supported); pcd_sab_tail_supported: dim 64 or 128 and rows % 256 == 0.
  * pcd_sab_tail_config(0) makes pcd_sab_forward / pcd_attn_unet_forward keep the four launches (A/B, tests); pcd_sab_tail_enabled reads it back. */
 size_t pcd_sab_tail_packed_bytes(int dim);
 int pcd_sab_tail_supported(int dim, int64_t rows);
 int pcd_sab_tail_pack(const pcd_sab_desc_t* d, void* packed, void* stream);
 int pcd_sab_tail_f16(int dim, const void* packed, const void* a, const void* x, int64_t rows, void* y, void* stream);
+/* the block's head in the same form, from the same image: qkv [rows][3 dim] = in_proj(LN1(x)) (networks.py:81), one launch instead of LayerNorm + GEMM */
+int pcd_sab_head_f16(int dim, const void* packed, const void* x, int64_t rows, void* qkv, void* stream);
 int pcd_sab_tail_config(int fused);
 int pcd_sab_tail_enabled(void);
 /* y = x + MHA(LN1 x); y = y + W2 relu(W1 LN2 y)   x, y fp16 [B*N][C], y must not alias x */

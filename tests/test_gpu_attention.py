@@ -396,3 +396,32 @@ def test_set_attention_block_256_layernorm_in_the_linear_launches():
     want = O.set_attention_block(sd, "", x, 4)
     assert rel_l2(fused, sep) < 1e-3
     assert rel_l2(fused, want) < 3e-3 and rel_l2(sep, want) < 3e-3
+
+
+@pytest.mark.parametrize("C,rows", [(64, 256), (128, 256), (64, 256 * 300), (128, 256 * 7)])
+def test_sab_head_one_launch_against_fp64(C, rows):
+    """pcd_sab_head_f16: qkv = in_proj(LN1(x)) in one launch (B fragments normalised as they are loaded, three C-wide output passes) against float64 from the
+    fp16-rounded operands, the LayerNorm result rounded to fp16 in both."""
+    from shapegen_amd import _lib
+    from shapegen_amd.networks import _PackedSAB
+    lib = _lib.load()
+    sd = sab_sd(C)
+    g = torch.Generator().manual_seed(5 * C + rows)
+    x = (torch.randn(rows, C, generator=g) * 1.5 + 0.3).half()
+    pk = _PackedSAB(sd, "", C, torch.device("cuda"))
+    desc = pk.fill(_lib.SabDesc())
+    xd = x.cuda()
+    qkv = torch.full((rows, 3 * C), float("nan"), dtype=torch.float16, device="cuda")
+    _lib.check(lib.pcd_sab_head_f16(C, desc.tail_packed, xd.data_ptr(), rows, qkv.data_ptr(), _lib.stream_ptr()))
+    pick = torch.arange(rows) if rows <= 4096 else torch.cat([torch.arange(0, 512), torch.arange(rows // 2 - 256, rows // 2 + 256), torch.arange(rows - 512, rows)])
+    ln = torch.nn.functional.layer_norm(x.double()[pick], (C,), sd["ln1.weight"].double(), sd["ln1.bias"].double(), 1e-5).half().double()
+    want = ln @ sd["attention.in_proj_weight"].half().double().T + sd["attention.in_proj_bias"].double()
+    got = qkv.cpu().double()
+    assert torch.isfinite(got).all()
+    assert rel_l2(got[pick], want) < 1e-3
+    q2 = torch.empty_like(qkv)
+    for _ in range(3):
+        _lib.check(lib.pcd_sab_head_f16(C, desc.tail_packed, xd.data_ptr(), rows, q2.data_ptr(), _lib.stream_ptr()))
+        assert torch.equal(qkv, q2)
+    assert lib.pcd_sab_head_f16(C, desc.tail_packed, xd.data_ptr(), rows + 1, qkv.data_ptr(), _lib.stream_ptr()) != 0
+    assert lib.pcd_sab_head_f16(C, desc.tail_packed, xd.data_ptr(), rows, xd.data_ptr(), _lib.stream_ptr()) != 0
