@@ -31,6 +31,28 @@ def test_merge_and_wait_model():
     assert t.check_kernel(body("vmcnt(0)")[1:]) == []
 
 
+def test_load_destination_model():
+    """The second check: a load's destination registers may not be touched before a wait that covers the load (in-order vmcnt)."""
+    t = _tool()
+    ld = lambda d, a: (None, "global_load_dwordx4", f"v[{d}:{d + 3}], v[{a}:{a + 1}], off")
+    use = (None, "v_mfma_f32_16x16x32_f16", "a[0:3], v[8:11], v[20:23], a[0:3]")
+    end = (None, "s_endpgm", "")
+    # two loads, wait for all but the youngest, use the OLDER one's registers: fine; use the younger one's: reported
+    assert t.check_vmem_kernel([ld(8, 0), ld(20, 2), (None, "s_waitcnt", "vmcnt(1)"), (None, "v_add_f32_e32", "v1, v8, v9"), end]) == []
+    hits = t.check_vmem_kernel([ld(8, 0), ld(20, 2), (None, "s_waitcnt", "vmcnt(1)"), use, end])
+    assert len(hits) == 1 and ("v", 20) in hits[0][1]
+    # a store in between counts in vmcnt like a load; an LDS-DMA has no destination registers
+    seq = [ld(8, 0), (None, "global_store_dwordx4", "v[0:1], v[30:33], off"), (None, "global_load_lds_dwordx4", "v[2:3], off"),
+           (None, "s_waitcnt", "vmcnt(2)"), (None, "v_add_f32_e32", "v1, v8, v9"), end]
+    assert t.check_vmem_kernel(seq) == []
+    seq[3] = (None, "s_waitcnt", "vmcnt(3)")
+    assert len(t.check_vmem_kernel(seq)) == 1
+    # a copy of an in-flight register (what a spill or a coalescing move of an asm-loaded value would be) is reported
+    assert len(t.check_vmem_kernel([ld(8, 0), (None, "v_mov_b32_e32", "v40, v9"), (None, "s_waitcnt", "vmcnt(0)"), end])) == 1
+    # the second arm of a lane-divergent load into the same register is not
+    assert t.check_vmem_kernel([ld(8, 0), (None, "global_load_dword", "v8, v[4:5], off"), (None, "s_waitcnt", "vmcnt(0)"), end]) == []
+
+
 def test_built_library_has_no_read_outstanding_at_a_ring_barrier(capsys):
     t = _tool()
     lib = os.path.join(ROOT, "3d-shape-generation_amd", "libpcd_hip.so")
@@ -48,4 +70,4 @@ def test_built_library_has_no_read_outstanding_at_a_ring_barrier(capsys):
         sys.argv = argv
     out = capsys.readouterr().out
     assert rc == 0, out
-    assert "0 barrier(s)" in out
+    assert "0 barrier(s)" in out and " 0 use(s)" in out
