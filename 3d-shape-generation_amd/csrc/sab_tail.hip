@@ -429,7 +429,8 @@ static int head_launch(const void* packed, const void* x, int64_t m, void* qkv, 
         attr_set = true;
     }
     const int64_t tiles = m / ST_TILE;
-    const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+    const int64_t cap = C == 64 ? 768 : 256;                   // C = 64: 74 registers, 26 KB of LDS: three workgroups per CU (HBM-bound: 67 MB per launch at cfg2)
+    const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
     hipLaunchKernelGGL(sab_head_kernel<C>, dim3(grid), dim3(ST_THREADS), lds, s, p);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
@@ -447,7 +448,9 @@ static int tail_launch(const void* packed, const void* a, const void* x, int64_t
         attr_set = true;
     }
     const int64_t tiles = m / ST_TILE;
-    const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+    // C = 64: 128 registers and 50 KB of LDS let two workgroups share a CU, and the kernel is closer to its HBM bound than to the matrix pipe's
+    const int64_t cap = C == 64 ? 512 : 256;
+    const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
     hipLaunchKernelGGL(sab_tail_kernel<C>, dim3(grid), dim3(ST_THREADS), lds, s, p);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
