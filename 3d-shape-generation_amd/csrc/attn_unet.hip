@@ -232,16 +232,23 @@ extern "C" int pcd_attn_unet_forward(pcd_attn_unet_t* h, const float* x, int bat
     LIN(1, p1, nullptr, 0, p0);
     RUN(sab_run(d.sab[0], p0, batch, N, H, p1, sws, s));                                  // att1
     RUN(pcd_add_shape_bias_strided_f16(p1, m, 64, rps, tb_e2, estr, x1, s));              // x1 + emb2
-    LIN(2, x1, nullptr, 0, p0); LIN(3, p0, nullptr, 0, p1); LIN(4, p1, nullptr, 0, p0);   // enc2
-    RUN(sab_run(d.sab[1], p0, batch, N, H, p1, sws, s));                                  // att2
+    // enc2: 64 -> 128 -> 128 -> 128; the two 128 -> 128 layers as one launch with the intermediate in LDS (pcd_pw_chain_128, chain.hip: bit-identical
+    // to the two GEMM launches), like enc2.conv1-2 of the point U-Net
+    const bool chain = pcd_sab_tail_enabled() != 0;
+    LIN(2, x1, nullptr, 0, p0);
+    if (chain) { RUN(pcd_pw_chain_128(p0, m, d.lin[3].w, d.lin[3].b, d.lin[4].w, d.lin[4].b, p2, s)); }
+    else { LIN(3, p0, nullptr, 0, p1); LIN(4, p1, nullptr, 0, p2); }
+    RUN(sab_run(d.sab[1], p2, batch, N, H, p1, sws, s));                                  // att2
     RUN(pcd_add_shape_bias_strided_f16(p1, m, 128, rps, tb_e3, estr, x2, s));             // x2 + emb3
     LIN(5, x2, nullptr, 0, p0); LIN(6, p0, nullptr, 0, p1); LIN(7, p1, nullptr, 0, p0);   // enc3
     RUN(sab_run(d.sab[2], p0, batch, N, H, x3, sws, s));                                  // att3 -> x3
     RUN(sab_run(d.sab[3], x3, batch, N, H, p0, sws, s));                                  // bottleneck
     RUN(pcd_add_shape_bias_strided_f16(p0, m, 256, rps, tb_d3, estr, p1, s));
     RUN(sab_run(d.sab[4], p1, batch, N, H, p0, sws, s));                                  // att_dec3
-    LIN(8, p0, x3, 256, p1); LIN(9, p1, nullptr, 0, p2); LIN(10, p2, nullptr, 0, p1);     // dec3 on cat[xb | x3]
-    RUN(pcd_add_shape_bias_strided_f16(p1, m, 128, rps, tb_d2, estr, p0, s));
+    LIN(8, p0, x3, 256, p1);                                                              // dec3 on cat[xb | x3]: 512 -> 128 -> 128 -> 128
+    if (chain) { RUN(pcd_pw_chain_128(p1, m, d.lin[9].w, d.lin[9].b, d.lin[10].w, d.lin[10].b, p2, s)); }
+    else { LIN(9, p1, nullptr, 0, p0); LIN(10, p0, nullptr, 0, p2); }
+    RUN(pcd_add_shape_bias_strided_f16(p2, m, 128, rps, tb_d2, estr, p0, s));
     RUN(sab_run(d.sab[5], p0, batch, N, H, p1, sws, s));                                  // att_dec2
     LIN(11, p1, x2, 128, p0); LIN(12, p0, nullptr, 0, p2); LIN(13, p2, nullptr, 0, p0);   // dec2 on cat[. | x2]
     RUN(pcd_add_shape_bias_strided_f16(p0, m, 64, rps, tb_d1, estr, p1, s));
