@@ -231,6 +231,8 @@ _SIGS = {
     "pcd_sab_tail_pack": (i32, [C.POINTER(SabDesc), vp, vp]),
     "pcd_sab_tail_f16": (i32, [i32, vp, vp, vp, i64, vp, vp]),
     "pcd_sab_head_f16": (i32, [i32, vp, vp, i64, vp, vp]),
+    "pcd_sab_tail_bias_f16": (i32, [i32, vp, vp, vp, i64, i32, vp, vp, i64, vp, vp]),
+    "pcd_sab_head_bias_f16": (i32, [i32, vp, vp, i64, i32, vp, i64, vp, vp]),
     "pcd_sab_tail_config": (i32, [i32]),
     "pcd_sab_tail_enabled": (i32, []),
     "pcd_attn_unet_create": (i32, [C.POINTER(AttnUnetDesc), C.POINTER(vp)]),

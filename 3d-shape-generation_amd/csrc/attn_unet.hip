@@ -37,7 +37,14 @@ static int gemm(const void* a1, int k1, const void* a2, int k2, const void* w, c
     return resid ? pcd_gemm_f16_residual(&g, resid, c, out, c, s) : pcd_gemm_f16(&g, out, c, s);
 }
 
-static int sab_run(const pcd_sab_desc_t& d, const void* x, int batch, int n, int heads, void* y, char* ws, hipStream_t s) {
+// pre_e / post_e (optional, only where sab_fuses(): the C <= 128 head / tail launches): the block runs on fp16(x + pre_e[shape]) and y leaves as
+// fp16(block + post_e[shape]) -- the additive time embeddings around the attention U-Net's blocks without their own launches
+static bool sab_fuses(const pcd_sab_desc_t& d, int64_t m) {
+    return d.tail_packed != nullptr && pcd_sab_tail_enabled() && pcd_sab_tail_supported(d.dim, m);
+}
+
+static int sab_run(const pcd_sab_desc_t& d, const void* x, int batch, int n, int heads, void* y, char* ws, hipStream_t s,
+                   const float* pre_e = nullptr, const float* post_e = nullptr, int64_t estride = 0, int rps = 1) {
     const int64_t m = (int64_t)batch * n;
     const int C = d.dim;
     const SabWs w = sab_carve(m, C);
@@ -46,18 +53,19 @@ static int sab_run(const pcd_sab_desc_t& d, const void* x, int batch, int n, int
 #define RUN(expr) do { rc = (expr); if (rc) return rc; } while (0)
     // C = 256 with packed images: LayerNorm + Linear as one launch of the wide-chain kernel (widechain.hip), B fragments normalised as they are loaded
     const bool lnlin = pcd_sab_tail_enabled() && pcd_pw_wide_ln_linear_supported(C, m);
-    const bool fused128 = d.tail_packed != nullptr && pcd_sab_tail_enabled() && pcd_sab_tail_supported(C, m);
+    const bool fused128 = sab_fuses(d, m);
+    if (!fused128 && (pre_e != nullptr || post_e != nullptr)) { set_error("sab_run: embeddings need the fused head / tail launches"); return PCD_ERR_ARG; }
     if (lnlin && d.ln_in_packed != nullptr) {
         RUN(pcd_pw_wide_ln_linear(d.ln_in_packed, 3, 0, x, m, qkv, s));                  // LN1 + in_proj C -> 3C
     } else if (fused128) {
-        RUN(pcd_sab_head_f16(C, d.tail_packed, x, m, qkv, s));                           // C <= 128: the same as one register-resident launch (sab_tail.hip)
+        RUN(pcd_sab_head_bias_f16(C, d.tail_packed, x, m, rps, pre_e, estride, qkv, s)); // C <= 128: the same as one register-resident launch (sab_tail.hip)
     } else {
         RUN(pcd_layernorm_f16(x, m, C, d.ln1_g, d.ln1_b, t1, s));                        // LN1 (q = k = v source)
         RUN(gemm(t1, C, nullptr, 0, d.w_in, d.b_in, 0, m, 3 * C, nullptr, qkv, s));      // in_proj C -> 3C
     }
     RUN(pcd_set_attention_f16(qkv, batch, n, C, heads, t2, nullptr, 0, s));          // softmax(QK^T/sqrt d) V
     if (fused128)
-        return pcd_sab_tail_f16(C, d.tail_packed, t2, x, m, y, s);                   // C <= 128: the rest of the block as one launch (sab_tail.hip)
+        return pcd_sab_tail_bias_f16(C, d.tail_packed, t2, x, m, rps, pre_e, post_e, estride, y, s);                   // C <= 128: the rest of the block as one launch (sab_tail.hip)
     RUN(gemm(t2, C, nullptr, 0, d.w_out, d.b_out, 0, m, C, x, t1, s));               // x + out_proj(.)
     if (lnlin && d.ln_ff1_packed != nullptr) {
         RUN(pcd_pw_wide_ln_linear(d.ln_ff1_packed, 4, 1, t1, m, ffh, s));                // LN2 + Linear(C,4C) + ReLU
@@ -230,16 +238,24 @@ extern "C" int pcd_attn_unet_forward(pcd_attn_unet_t* h, const float* x, int bat
     RUN(pcd_enc1_xyz(x, m, rps, d.e1w, 64, tb_e1, tbias_shape_stride * (PCD_ATTN_UNET_TB / 64), p0, s));
     LIN(0, p0, nullptr, 0, p1);
     LIN(1, p1, nullptr, 0, p0);
-    RUN(sab_run(d.sab[0], p0, batch, N, H, p1, sws, s));                                  // att1
-    RUN(pcd_add_shape_bias_strided_f16(p1, m, 64, rps, tb_e2, estr, x1, s));              // x1 + emb2
+    if (sab_fuses(d.sab[0], m)) {
+        RUN(sab_run(d.sab[0], p0, batch, N, H, x1, sws, s, nullptr, tb_e2, estr, rps));   // att1, + emb2 on the way out
+    } else {
+        RUN(sab_run(d.sab[0], p0, batch, N, H, p1, sws, s));                              // att1
+        RUN(pcd_add_shape_bias_strided_f16(p1, m, 64, rps, tb_e2, estr, x1, s));          // x1 + emb2
+    }
     // enc2: 64 -> 128 -> 128 -> 128; the two 128 -> 128 layers as one launch with the intermediate in LDS (pcd_pw_chain_128, chain.hip: bit-identical
     // to the two GEMM launches), like enc2.conv1-2 of the point U-Net
     const bool chain = pcd_sab_tail_enabled() != 0;
     LIN(2, x1, nullptr, 0, p0);
     if (chain) { RUN(pcd_pw_chain_128(p0, m, d.lin[3].w, d.lin[3].b, d.lin[4].w, d.lin[4].b, p2, s)); }
     else { LIN(3, p0, nullptr, 0, p1); LIN(4, p1, nullptr, 0, p2); }
-    RUN(sab_run(d.sab[1], p2, batch, N, H, p1, sws, s));                                  // att2
-    RUN(pcd_add_shape_bias_strided_f16(p1, m, 128, rps, tb_e3, estr, x2, s));             // x2 + emb3
+    if (sab_fuses(d.sab[1], m)) {
+        RUN(sab_run(d.sab[1], p2, batch, N, H, x2, sws, s, nullptr, tb_e3, estr, rps));   // att2, + emb3 on the way out
+    } else {
+        RUN(sab_run(d.sab[1], p2, batch, N, H, p1, sws, s));                              // att2
+        RUN(pcd_add_shape_bias_strided_f16(p1, m, 128, rps, tb_e3, estr, x2, s));         // x2 + emb3
+    }
     LIN(5, x2, nullptr, 0, p0); LIN(6, p0, nullptr, 0, p1); LIN(7, p1, nullptr, 0, p0);   // enc3
     RUN(sab_run(d.sab[2], p0, batch, N, H, x3, sws, s));                                  // att3 -> x3
     RUN(sab_run(d.sab[3], x3, batch, N, H, p0, sws, s));                                  // bottleneck
@@ -248,12 +264,22 @@ extern "C" int pcd_attn_unet_forward(pcd_attn_unet_t* h, const float* x, int bat
     LIN(8, p0, x3, 256, p1);                                                              // dec3 on cat[xb | x3]: 512 -> 128 -> 128 -> 128
     if (chain) { RUN(pcd_pw_chain_128(p1, m, d.lin[9].w, d.lin[9].b, d.lin[10].w, d.lin[10].b, p2, s)); }
     else { LIN(9, p1, nullptr, 0, p0); LIN(10, p0, nullptr, 0, p2); }
-    RUN(pcd_add_shape_bias_strided_f16(p2, m, 128, rps, tb_d2, estr, p0, s));
-    RUN(sab_run(d.sab[5], p0, batch, N, H, p1, sws, s));                                  // att_dec2
+    if (sab_fuses(d.sab[5], m)) {
+        RUN(sab_run(d.sab[5], p2, batch, N, H, p1, sws, s, tb_d2, nullptr, estr, rps));   // att_dec2 on (dec3 + emb_dec2), the sum formed as x is read
+    } else {
+        RUN(pcd_add_shape_bias_strided_f16(p2, m, 128, rps, tb_d2, estr, p0, s));
+        RUN(sab_run(d.sab[5], p0, batch, N, H, p1, sws, s));                              // att_dec2
+    }
     LIN(11, p1, x2, 128, p0); LIN(12, p0, nullptr, 0, p2); LIN(13, p2, nullptr, 0, p0);   // dec2 on cat[. | x2]
-    RUN(pcd_add_shape_bias_strided_f16(p0, m, 64, rps, tb_d1, estr, p1, s));
-    RUN(sab_run(d.sab[6], p1, batch, N, H, p0, sws, s));                                  // att_dec1
-    RUN(pcd_tail3(p0, 64, x1, 64, m, d.t_w1, d.t_b1, d.t_w234, d.t_b234, eps, s));       // dec1 on cat[. | x1] + output
+    const void* last = p0;
+    if (sab_fuses(d.sab[6], m)) {
+        RUN(sab_run(d.sab[6], p0, batch, N, H, p2, sws, s, tb_d1, nullptr, estr, rps));   // att_dec1 on (dec2 + emb_dec1)
+        last = p2;
+    } else {
+        RUN(pcd_add_shape_bias_strided_f16(p0, m, 64, rps, tb_d1, estr, p1, s));
+        RUN(sab_run(d.sab[6], p1, batch, N, H, p0, sws, s));                              // att_dec1
+    }
+    RUN(pcd_tail3(last, 64, x1, 64, m, d.t_w1, d.t_b1, d.t_w234, d.t_b234, eps, s));     // dec1 on cat[. | x1] + output
 #undef LIN
 #undef RUN
     return PCD_OK;

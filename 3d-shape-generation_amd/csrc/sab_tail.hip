@@ -52,6 +52,9 @@ struct SabTailParams {
     const char* packed;       // NSTG stage images, then NPAR floats
     half_t* y;                // [M][C]
     int64_t m;
+    // the attention U-Net's additive per-level time embeddings (networks.py:669-698) inside the launch: x is read as fp16(x + pre_e[shape]) (the block
+    // runs on x + emb), y leaves as fp16(y + post_e[shape]) (the skip tensor is block(x) + emb); each exactly as pcd_add_shape_bias_strided_f16 rounds it
+    const float* pre_e; const float* post_e; int64_t estride; int rps;
 };
 
 __device__ __forceinline__ void st_dma(const char* g, unsigned lds_addr) {
@@ -130,6 +133,17 @@ __global__ __launch_bounds__(ST_THREADS, 2) void sab_tail_kernel(SabTailParams p
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) xr[t][g] = *(const half4*)(row + 32 * t + 8 * g);
+        }
+        if (p.pre_e != nullptr) {
+            const float* er = p.pre_e + (pt / p.rps) * p.estride + 4 * hh;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 ev = *(const f32x4*)(er + 32 * t + 8 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xr[t][g][e] = to_half_sat((float)xr[t][g][e] + ev[e]);
+                }
         }
         f32x16 acc[NT];
 #pragma unroll
@@ -251,6 +265,15 @@ __global__ __launch_bounds__(ST_THREADS, 2) void sab_tail_kernel(SabTailParams p
                 for (int w = 0; w < 2; ++w)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[w][e] = __builtin_amdgcn_fmed3f(acc[t][4 * (2 * gp + w) + e], -65504.f, 65504.f);
+                if (p.post_e != nullptr) {
+                    const float* er = p.post_e + (pt / p.rps) * p.estride + 32 * t + 4 * hh;
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        const f32x4 ev = *(const f32x4*)(er + 8 * (2 * gp + w));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[w][e] = __builtin_amdgcn_fmed3f((float)(half_t)v[w][e] + ev[e], -65504.f, 65504.f);
+                    }
+                }
                 *(half8*)(orow + 32 * t + 16 * gp) = st_pack_swap(v[0], v[1]);
             }
     }
@@ -264,6 +287,7 @@ struct SabHeadParams {
     const char* packed;       // the head part of the block's image: 3 stage images, then HNPAR floats
     half_t* qkv;              // [M][3C]
     int64_t m;
+    const float* pre_e; int64_t estride; int rps;      // x is read as fp16(x + pre_e[shape]) (see SabTailParams)
 };
 
 template <int C>
@@ -310,6 +334,18 @@ __global__ __launch_bounds__(ST_THREADS, 2) void sab_head_kernel(SabHeadParams p
             const half_t* row = p.x + pt * C + 8 * hh;
 #pragma unroll
             for (int s = 0; s < KS; ++s) bf[s] = *(const half8*)(row + 16 * s);
+        }
+        if (p.pre_e != nullptr) {
+            const float* er = p.pre_e + (pt / p.rps) * p.estride + 8 * hh;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const f32x4 e0 = *(const f32x4*)(er + 16 * s), e1 = *(const f32x4*)(er + 16 * s + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bf[s][e] = to_half_sat((float)bf[s][e] + e0[e]);
+                    bf[s][4 + e] = to_half_sat((float)bf[s][4 + e] + e1[e]);
+                }
+            }
         }
         {
             float sum = 0.f, sq = 0.f;
@@ -418,10 +454,11 @@ static int tail_pack(const pcd_sab_desc_t& d, char* packed, hipStream_t s) {
 }
 
 template <int C>
-static int head_launch(const void* packed, const void* x, int64_t m, void* qkv, hipStream_t s) {
+static int head_launch(const void* packed, const void* x, int64_t m, void* qkv, const float* pre_e, int64_t estride, int rps, hipStream_t s) {
     using K = StCfg<C>;
     SabHeadParams p{};
     p.x = (const half_t*)x; p.packed = (const char*)packed + K::TAIL_BYTES; p.qkv = (half_t*)qkv; p.m = m;
+    p.pre_e = pre_e; p.estride = estride; p.rps = rps > 0 ? rps : 1;
     static bool attr_set = false;
     const size_t lds = (size_t)ST_RING * K::HSTAGE + K::HNPAR * sizeof(float);
     if (!attr_set) {
@@ -437,10 +474,12 @@ static int head_launch(const void* packed, const void* x, int64_t m, void* qkv, 
 }
 
 template <int C>
-static int tail_launch(const void* packed, const void* a, const void* x, int64_t m, void* y, hipStream_t s) {
+static int tail_launch(const void* packed, const void* a, const void* x, int64_t m, void* y, const float* pre_e, const float* post_e, int64_t estride, int rps,
+                       hipStream_t s) {
     using K = StCfg<C>;
     SabTailParams p{};
     p.a = (const half_t*)a; p.x = (const half_t*)x; p.packed = (const char*)packed; p.y = (half_t*)y; p.m = m;
+    p.pre_e = pre_e; p.post_e = post_e; p.estride = estride; p.rps = rps > 0 ? rps : 1;
     static bool attr_set = false;
     const size_t lds = (size_t)ST_RING * K::STAGE + K::NPAR * sizeof(float);
     if (!attr_set) {
@@ -485,14 +524,31 @@ extern "C" int pcd_sab_tail_pack(const pcd_sab_desc_t* d, void* packed, void* st
     return d->dim == 128 ? tail_pack<128>(*d, (char*)packed, (hipStream_t)stream) : tail_pack<64>(*d, (char*)packed, (hipStream_t)stream);
 }
 
-extern "C" int pcd_sab_tail_f16(int dim, const void* packed, const void* a, const void* x, int64_t rows, void* y, void* stream) {
+extern "C" int pcd_sab_tail_bias_f16(int dim, const void* packed, const void* a, const void* x, int64_t rows, int rows_per_shape, const float* pre_e,
+                                     const float* post_e, int64_t e_stride, void* y, void* stream) {
     PCD_CHECK_ARG(packed && a && x && y && y != a && y != x);
     PCD_CHECK_ARG(pcd_sab_tail_supported(dim, rows));
-    return dim == 128 ? tail_launch<128>(packed, a, x, rows, y, (hipStream_t)stream) : tail_launch<64>(packed, a, x, rows, y, (hipStream_t)stream);
+    PCD_CHECK_ARG((pre_e == nullptr && post_e == nullptr) || (rows_per_shape > 0 && e_stride >= 0 && e_stride % 4 == 0));
+    PCD_CHECK_ARG((((uintptr_t)pre_e | (uintptr_t)post_e) & 15) == 0);
+    hipStream_t s = (hipStream_t)stream;
+    return dim == 128 ? tail_launch<128>(packed, a, x, rows, y, pre_e, post_e, e_stride, rows_per_shape, s)
+                      : tail_launch<64>(packed, a, x, rows, y, pre_e, post_e, e_stride, rows_per_shape, s);
+}
+
+extern "C" int pcd_sab_tail_f16(int dim, const void* packed, const void* a, const void* x, int64_t rows, void* y, void* stream) {
+    return pcd_sab_tail_bias_f16(dim, packed, a, x, rows, 0, nullptr, nullptr, 0, y, stream);
+}
+
+extern "C" int pcd_sab_head_bias_f16(int dim, const void* packed, const void* x, int64_t rows, int rows_per_shape, const float* pre_e, int64_t e_stride,
+                                     void* qkv, void* stream) {
+    PCD_CHECK_ARG(packed && x && qkv && qkv != x);
+    PCD_CHECK_ARG(pcd_sab_tail_supported(dim, rows));
+    PCD_CHECK_ARG(pre_e == nullptr || (rows_per_shape > 0 && e_stride >= 0 && e_stride % 4 == 0 && ((uintptr_t)pre_e & 15) == 0));
+    hipStream_t s = (hipStream_t)stream;
+    return dim == 128 ? head_launch<128>(packed, x, rows, qkv, pre_e, e_stride, rows_per_shape, s)
+                      : head_launch<64>(packed, x, rows, qkv, pre_e, e_stride, rows_per_shape, s);
 }
 
 extern "C" int pcd_sab_head_f16(int dim, const void* packed, const void* x, int64_t rows, void* qkv, void* stream) {
-    PCD_CHECK_ARG(packed && x && qkv && qkv != x);
-    PCD_CHECK_ARG(pcd_sab_tail_supported(dim, rows));
-    return dim == 128 ? head_launch<128>(packed, x, rows, qkv, (hipStream_t)stream) : head_launch<64>(packed, x, rows, qkv, (hipStream_t)stream);
+    return pcd_sab_head_bias_f16(dim, packed, x, rows, 0, nullptr, 0, qkv, stream);
 }

@@ -574,6 +574,13 @@ int pcd_sab_tail_pack(const pcd_sab_desc_t* d, void* packed, void* stream);
 int pcd_sab_tail_f16(int dim, const void* packed, const void* a, const void* x, int64_t rows, void* y, void* stream);
 /* the block's head in the same form, from the same image: qkv [rows][3 dim] = in_proj(LN1(x)) (networks.py:81), one launch instead of LayerNorm + GEMM */
 int pcd_sab_head_f16(int dim, const void* packed, const void* x, int64_t rows, void* qkv, void* stream);
+/* both with the attention U-Net's additive per-level time embeddings (networks.py:669-698) folded in: x is read as fp16(x + pre_e[row / rows_per_shape]) and
+ * y leaves as fp16(y + post_e[row / rows_per_shape]), each rounded exactly as pcd_add_shape_bias_strided_f16 rounds it; pre_e / post_e fp32, rows e_stride
+ * floats apart (0: one row for every shape; a multiple of 4), 16-byte aligned, either may be NULL */
+int pcd_sab_tail_bias_f16(int dim, const void* packed, const void* a, const void* x, int64_t rows, int rows_per_shape, const float* pre_e,
+                          const float* post_e, int64_t e_stride, void* y, void* stream);
+int pcd_sab_head_bias_f16(int dim, const void* packed, const void* x, int64_t rows, int rows_per_shape, const float* pre_e, int64_t e_stride,
+                          void* qkv, void* stream);
 int pcd_sab_tail_config(int fused);
 int pcd_sab_tail_enabled(void);
 /* y = x + MHA(LN1 x); y = y + W2 relu(W1 LN2 y)   x, y fp16 [B*N][C], y must not alias x */

@@ -425,3 +425,46 @@ def test_sab_head_one_launch_against_fp64(C, rows):
         assert torch.equal(qkv, q2)
     assert lib.pcd_sab_head_f16(C, desc.tail_packed, xd.data_ptr(), rows + 1, qkv.data_ptr(), _lib.stream_ptr()) != 0
     assert lib.pcd_sab_head_f16(C, desc.tail_packed, xd.data_ptr(), rows, xd.data_ptr(), _lib.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize("C,shared", [(64, False), (128, False), (128, True)])
+def test_sab_head_tail_with_folded_time_embeddings_bitwise(C, shared):
+    """The per-level time embeddings inside the head / tail launches (x read as fp16(x + pre_e[shape]), y leaving as fp16(y + post_e[shape])) give the
+    BITS of the explicit pcd_add_shape_bias_strided_f16 launches around the plain head / tail: rows of e 704 floats apart (the attention U-Net's time-bias
+    rows) or one shared row."""
+    from shapegen_amd import _lib
+    from shapegen_amd.networks import _PackedSAB
+    lib = _lib.load()
+    rows, rps = 256 * 6, 512
+    sd = sab_sd(C)
+    g = torch.Generator().manual_seed(9 * C + shared)
+    a = (torch.randn(rows, C, generator=g) * 0.7).half().cuda()
+    x = (torch.randn(rows, C, generator=g) * 1.5).half().cuda()
+    nshape, stride = rows // rps, 0 if shared else 704
+    e = (torch.randn(max(nshape * stride, 704) + 704, generator=g) * 0.5).cuda()
+    pre, post = e[64:], e[128:]                                  # 256-byte aligned views into one buffer, like the U-Net's tbias offsets
+    pk = _PackedSAB(sd, "", C, torch.device("cuda"))
+    desc = pk.fill(_lib.SabDesc())
+    st = _lib.stream_ptr()
+    rps_arg = rows if shared else rps
+    # explicit: xe = x + pre; y = tail(a, xe); ye = y + post; qkv = head(xe)
+    xe, y, ye = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    qkv, qkv_f = torch.empty(rows, 3 * C, dtype=torch.float16, device="cuda"), torch.empty(rows, 3 * C, dtype=torch.float16, device="cuda")
+    _lib.check(lib.pcd_add_shape_bias_strided_f16(x.data_ptr(), rows, C, rps_arg, pre.data_ptr(), stride, xe.data_ptr(), st))
+    _lib.check(lib.pcd_sab_tail_f16(C, desc.tail_packed, a.data_ptr(), xe.data_ptr(), rows, y.data_ptr(), st))
+    _lib.check(lib.pcd_add_shape_bias_strided_f16(y.data_ptr(), rows, C, rps_arg, post.data_ptr(), stride, ye.data_ptr(), st))
+    _lib.check(lib.pcd_sab_head_f16(C, desc.tail_packed, xe.data_ptr(), rows, qkv.data_ptr(), st))
+    # folded
+    yf = torch.empty_like(x)
+    _lib.check(lib.pcd_sab_tail_bias_f16(C, desc.tail_packed, a.data_ptr(), x.data_ptr(), rows, rps_arg, pre.data_ptr(), post.data_ptr(), stride, yf.data_ptr(), st))
+    _lib.check(lib.pcd_sab_head_bias_f16(C, desc.tail_packed, x.data_ptr(), rows, rps_arg, pre.data_ptr(), stride, qkv_f.data_ptr(), st))
+    assert not torch.equal(xe, x) and not torch.equal(ye, y)
+    assert torch.equal(yf, ye)
+    assert torch.equal(qkv_f, qkv)
+    # one of the two only
+    y1 = torch.empty_like(x)
+    _lib.check(lib.pcd_sab_tail_bias_f16(C, desc.tail_packed, a.data_ptr(), x.data_ptr(), rows, rps_arg, pre.data_ptr(), None, stride, y1.data_ptr(), st))
+    assert torch.equal(y1, y)
+    # misaligned / bad stride is refused
+    assert lib.pcd_sab_tail_bias_f16(C, desc.tail_packed, a.data_ptr(), x.data_ptr(), rows, rps_arg, e[1:].data_ptr(), None, stride, y1.data_ptr(), st) != 0
+    assert lib.pcd_sab_head_bias_f16(C, desc.tail_packed, x.data_ptr(), rows, rps_arg, pre.data_ptr(), 702, qkv_f.data_ptr(), st) != 0
