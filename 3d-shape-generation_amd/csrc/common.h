@@ -52,4 +52,17 @@ __device__ __forceinline__ void lds_dma16(const void* g, const void* lds_wave_ba
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m0v) : "memory", "m0");
 }
 
+
+// Dynamic LDS above 64 KB has to be allowed per kernel AND per device: once per (device, kernel), whichever device is current at the launch.
+struct PcdLdsOnce { unsigned long long done = 0; };          // one bit per device ordinal below 64 (above: set every time)
+static inline hipError_t pcd_allow_lds(PcdLdsOnce& once, const void* kernel, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && ((once.done >> dev) & 1ull)) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && dev >= 0 && dev < 64) once.done |= 1ull << dev;
+    return e;
+}
+
 }  // namespace pcd

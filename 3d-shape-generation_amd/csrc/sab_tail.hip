@@ -459,12 +459,9 @@ static int head_launch(const void* packed, const void* x, int64_t m, void* qkv, 
     SabHeadParams p{};
     p.x = (const half_t*)x; p.packed = (const char*)packed + K::TAIL_BYTES; p.qkv = (half_t*)qkv; p.m = m;
     p.pre_e = pre_e; p.estride = estride; p.rps = rps > 0 ? rps : 1;
-    static bool attr_set = false;
+    static PcdLdsOnce once;
     const size_t lds = (size_t)ST_RING * K::HSTAGE + K::HNPAR * sizeof(float);
-    if (!attr_set) {
-        PCD_CHECK_HIP(hipFuncSetAttribute((const void*)sab_head_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    PCD_CHECK_HIP(pcd_allow_lds(once, (const void*)sab_head_kernel<C>, (int)lds));
     const int64_t tiles = m / ST_TILE;
     const int64_t cap = C == 64 ? 768 : 256;                   // C = 64: 74 registers, 26 KB of LDS: three workgroups per CU (HBM-bound: 67 MB per launch at cfg2)
     const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
@@ -480,12 +477,9 @@ static int tail_launch(const void* packed, const void* a, const void* x, int64_t
     SabTailParams p{};
     p.a = (const half_t*)a; p.x = (const half_t*)x; p.packed = (const char*)packed; p.y = (half_t*)y; p.m = m;
     p.pre_e = pre_e; p.post_e = post_e; p.estride = estride; p.rps = rps > 0 ? rps : 1;
-    static bool attr_set = false;
+    static PcdLdsOnce once;
     const size_t lds = (size_t)ST_RING * K::STAGE + K::NPAR * sizeof(float);
-    if (!attr_set) {
-        PCD_CHECK_HIP(hipFuncSetAttribute((const void*)sab_tail_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    PCD_CHECK_HIP(pcd_allow_lds(once, (const void*)sab_tail_kernel<C>, (int)lds));
     const int64_t tiles = m / ST_TILE;
     // C = 64: 128 registers and 50 KB of LDS let two workgroups share a CU, and the kernel is closer to its HBM bound than to the matrix pipe's
     const int64_t cap = C == 64 ? 512 : 256;

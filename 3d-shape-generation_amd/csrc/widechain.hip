@@ -206,11 +206,9 @@ __global__ __launch_bounds__(WC_THREADS, 2) void pw_wide_chain_kernel(WcParams p
 // the largest dynamic LDS either launch form asks for (ring + bias rows of WC_MAXSEG passes + LayerNorm affine): set once, for both
 constexpr size_t WC_LDS_MAX = (size_t)WC_RING * WC_STAGE + (size_t)(WC_MAXSEG * 256 + 512) * sizeof(float);
 static hipError_t wc_allow_lds() {
-    static bool attr_set = false;
-    if (attr_set) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute((const void*)pw_wide_chain_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WC_LDS_MAX);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pw_wide_chain_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WC_LDS_MAX);
-    if (e == hipSuccess) attr_set = true;
+    static PcdLdsOnce once_chain, once_ln;
+    hipError_t e = pcd_allow_lds(once_chain, (const void*)pw_wide_chain_kernel<false>, (int)WC_LDS_MAX);
+    if (e == hipSuccess) e = pcd_allow_lds(once_ln, (const void*)pw_wide_chain_kernel<true>, (int)WC_LDS_MAX);
     return e;
 }
 
