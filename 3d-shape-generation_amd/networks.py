@@ -335,6 +335,7 @@ class _PackedSAB:
             setattr(d, k, getattr(self, k).data_ptr())
         d.tail_packed = None
         d.ln_in_packed = d.ln_ff1_packed = None
+        packed_now = False
         # C <= 128, fp16: the block's tail (out_proj + residual + LN2 + FFN + residual) as one launch needs its weights in fragment-order stage images
         lib = _lib.load()
         nbytes = 0 if self.f32 else lib.pcd_sab_tail_packed_bytes(self.dim)
@@ -342,6 +343,7 @@ class _PackedSAB:
             if self.tail is None:
                 self.tail = torch.empty(nbytes, dtype=torch.uint8, device=self.w_out.device)
                 _lib.check(lib.pcd_sab_tail_pack(C.byref(d), self.tail.data_ptr(), _lib.stream_ptr()), "sab_tail_pack")
+                packed_now = True
             d.tail_packed = self.tail.data_ptr()
         # C = 256, fp16: LN1 + in_proj and LN2 + ff.0 as one launch each (wide-chain kernel with a LayerNorm prologue)
         if self.dim == 256 and not self.f32:
@@ -353,7 +355,12 @@ class _PackedSAB:
                                                               _lib.stream_ptr()), "pw_wide_ln_linear_pack")
                     bufs.append(buf)
                 self.lnlin = bufs
+                packed_now = True
             d.ln_in_packed, d.ln_ff1_packed = self.lnlin[0].data_ptr(), self.lnlin[1].data_ptr()
+        if packed_now:
+            # the images were written by pack kernels on the CURRENT stream; a forward enqueued on another stream (a side stream, a capture) must find them
+            # complete: one synchronisation per model packing
+            torch.cuda.current_stream().synchronize()
         return d
 
 
