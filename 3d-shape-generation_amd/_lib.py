@@ -13,6 +13,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpcd_hip.so")
+ABI_VERSION = 2          # include/pcd_hip.h PCD_ABI_VERSION these prototypes and ctypes structures are written against
 CSRC = os.path.join(_HERE, "csrc")
 
 vp = C.c_void_p
@@ -117,6 +118,8 @@ _SIGS = {
     "pcd_gemm_pack_wfrag": (i32, [vp, i64, i32, i32, vp, vp]),
     "pcd_gemm_f16_colmax_wfrag": (i32, [C.POINTER(GemmDesc), vp, vp, i32, vp]),
     "pcd_gemm_wfrag_enabled": (i32, []),
+    "pcd_gemm_f16_wfrag": (i32, [C.POINTER(GemmDesc), vp, vp, i64, vp]),
+    "pcd_gemm_store_wfrag_enabled": (i32, []),
     "pcd_gemm_set_config": (i32, [i32]),
     "pcd_fill_zero": (i32, [vp, sz, vp]),
     "pcd_f32_to_f16": (i32, [vp, vp, i64, vp]),
@@ -184,7 +187,7 @@ _SIGS = {
     "pcd_latent_persist_trace": (i32, [vp, vp, i32]),
     "pcd_latent_persist_forward": (i32, [vp, vp, i32, vp, vp, vp, sz, vp]),
     "pcd_latent_persist_ddim": (i32, [vp, vp, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, sz, vp]),
-    "pcd_latent_persist_status": (i32, [vp, C.POINTER(C.c_uint)]),
+    "pcd_latent_persist_status": (i32, [vp, C.POINTER(C.c_uint), vp]),
     "pcd_latent_persist_inject_fault": (i32, [vp, i32, i32]),
     "pcd_latent_persist_plan_check": (i32, []),
     "pcd_latent_persist_plan_dump": (i32, [vp]),
@@ -315,6 +318,10 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)   # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
+    got = lib.pcd_abi_version()
+    if got != ABI_VERSION:       # a stale libpcd_hip.so next to newer bindings (or the reverse): argument lists / struct layouts differ
+        raise RuntimeError(f"{LIB_PATH} reports ABI version {got}, these bindings are written against {ABI_VERSION} "
+                           "(include/pcd_hip.h PCD_ABI_VERSION): rebuild with `python __graft_entry__.py build`")
     _lib = lib
     return lib
 

@@ -16,7 +16,7 @@ void set_error(const char* fmt, ...) {
 
 extern "C" const char* pcd_last_error(void) { return pcd::g_err; }
 
-extern "C" int pcd_abi_version(void) { return 1; }
+extern "C" int pcd_abi_version(void) { return PCD_ABI_VERSION; }
 
 extern "C" int pcd_device_check(void) {
     int n = 0;

@@ -776,6 +776,266 @@ __global__ __launch_bounds__(512) void gemm_xw_kernel(GemmParams p, const half_t
         for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(wq[ks][j]));
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// gemm_xs_kernel: the STORE GEMM on gemm_xw_kernel's structure, with most of the output tile leaving through LDS during the next tile's K loop.
+// Why (profiles/r04_l, r05_a): a round of 256 x 256 output tiles ends in a 32 MB store burst (16 x 1 KB per wave) during which no workgroup
+// computes -- gemm_xp_kernel hides two K tiles of the next tile under it and still pays ~4 us per tile at K = 1024 (514 us against 399 us for
+// the same K loop without stores); dripping the converted tile from REGISTERS needs 64 registers nobody has.  With the weights out of LDS
+// (fragment-order copy, straight into the MFMA operand registers as in gemm_xw_kernel) the activation ring is 64 KB and 88 KB of LDS are
+// free: the epilogue stores ND = 5 (6) of a wave's sixteen 1-KB chunks at once and parks NDRIP = 11 (10) in the wave's own LDS slots; the
+// next tile's K tiles read R = 1 (2) chunks back per K tile (ds_read_b128, 4 transient registers) and store them from there -- one 1-KB store
+// per wave every 1.5 us instead of sixteen at once.  The waves keep their vmcnt waits counted: the drip stores sit at a fixed place of the
+// K tile's issue order ([activation pieces x 4 (+ bias x 2)] [weights of k step 0 x 4] [drip x R] [weights of k step 1 x 4]) and each wait names
+// the operations younger than the ones it needs.  A store must have completed one K tile after its issue (vmcnt retires in order).
+// Output addresses: SGPR base (tile, chunk) + one tile-invariant 32-bit lane offset (global_store_dwordx4 v, v[4], s[2]): no per-row pointers.
+// Same fp16 products summed in fp32 in the same order as gemm_xp_kernel<EPI_F16>: bitwise the same output.
+// Requires whole tiles (m, c % 256 == 0), one A layout, bias + per-shape bias rows (zero rows stand in), nk >= 6.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void gstore16_s(unsigned voff, u32x4_t data, const half_t* sbase) {
+    // (s_nop: a VALU write of the data registers needs one wait state behind a > 8-byte store; the compiler does not look into the asm)
+    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 0" ::"v"(voff), "v"(data), "s"(sbase) : "memory");
+}
+
+__device__ __forceinline__ const half_t* uniform_ptr(const half_t* q) {
+    const uint64_t v = (uint64_t)q;
+    return (const half_t*)(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+}
+
+template <int R, bool ABL = false>
+__global__ __launch_bounds__(512) void gemm_xs_kernel(GemmParams p, const half_t* __restrict__ wfrag) {
+    constexpr int NCH = 16;                                // 1-KB output chunks of a wave's 128 x 64 tile: chunk c = rows i = c / 2 (16 each), column pair c % 2
+    constexpr int NDRIP = R == 1 ? 11 : 10;                // chunks parked in LDS, R of them stored per K tile of the next tile
+    constexpr int ND = NCH - NDRIP;                        // chunks stored straight from the epilogue (they count in vmcnt)
+    constexpr int BM = 256, BN = 256, BKT = 64, ROWB = 128, WGN = 4;
+    constexpr int WM = 128, WN = 64, MI = 8, NI = 4;
+    constexpr int STAGE_BYTES = BM * ROWB;                 // activation panel only
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) float bias_lds[2][2][BN];
+    __shared__ __attribute__((aligned(16))) char drip[8 * NDRIP * 1024];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave - wm * WGN;
+    const int tiles_mn = p.tiles_m * p.tiles_n;
+    const int nk1 = p.k1 / BKT, nk = (p.k1 + p.k2) / BKT;
+    // Scalar registers are this kernel's scarce resource (the compiler moves scalar values it cannot hold into VECTOR registers, and there are none to
+    // spare next to 128 accumulators + 64 operand registers + the drip): leading dimensions as 32-bit values (the host checks the ranges), per-tile bases
+    // formed once, and the K loop's address arithmetic kept dependent on an opaque copy of its counter so that it is not hoisted into more live values.
+    const int lda = (int)p.lda1, ldo = (int)p.ldo;
+    const int abl = ABL ? p.xp_depth : 0;                  // timing ablations (a separate instance: the product kernel carries none of it) (pcd_gemm_set_config(16 + bits); outputs are then WRONG): 1 no direct stores, 2 no drip
+                                                           // stores, 4 no LDS parking, 8 no epilogue arithmetic
+
+    // staging: round r covers rows r * 64 + wave * 8 + lane / 8 of the 256-row panel, 16-byte chunk swz(row, lane % 8); the swizzle does not see r * 64
+    const int srow = wave * 8 + (lane >> 3);
+    const unsigned voa = (unsigned)(srow * lda * 2 + swz<BKT>(srow, lane & 7) * 16);
+    const unsigned lds0 = (unsigned)(size_t)smem + wave * 8 * ROWB;
+    // K tile kt of the panel whose row-0 bases are (r1, r2): r1 = a1 + m0 * lda, r2 = a2 + m0 * lda - k1 (so that r2 + kt * 64 is K tile kt - nk1 of a2)
+    auto stage = [&](const half_t* r1, const half_t* r2, int kt, int buf) __attribute__((always_inline)) {
+        const half_t* ab = uniform_ptr((kt < nk1 ? r1 : r2) + kt * BKT);
+        const unsigned la = lds0 + buf * STAGE_BYTES;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) glds16_s(voa, ab + (int64_t)(r * 64) * lda, la + r * 64 * ROWB);
+    };
+    const unsigned lds_b = (unsigned)(size_t)&bias_lds[0][0][0] + wn * WN * 4;
+    auto stage_bias = [&](int m0, int n0, int par) __attribute__((always_inline)) {
+        const unsigned dst = lds_b + par * (2 * BN * 4);
+        glds4_s((unsigned)(lane * 4), p.bias + n0 + wn * WN, dst);
+        glds4_s((unsigned)(lane * 4), p.shape_bias + (int64_t)(m0 / p.rows_per_shape) * p.c + n0 + wn * WN, dst + BN * 4);
+    };
+    auto tile_coords = [&](int tile, int& tm, int& tn) {
+        if (p.patch_pn > 0) {
+            const int pn = p.patch_pn, pm = 32 / pn, xn = p.patch_xn, xm = 8 / xn;
+            const int round = tile >> 8, b = tile & 255;
+            const int xcd = b & 7, slot = b >> 3;
+            const int sbn = p.tiles_n / (xn * pn);
+            const int sb_m = round / sbn, sb_n = round - sb_m * sbn;
+            tm = (sb_m * xm + xcd / xn) * pm + slot / pn;
+            tn = (sb_n * xn + xcd % xn) * pn + slot % pn;
+        } else {
+            tm = tile / p.tiles_n;
+            tn = tile - tm * p.tiles_n;
+        }
+        // (wave-uniform by construction; say so -- the divergence analysis loses it through the tile walk and would keep every tile-derived base in VGPRs)
+        tm = __builtin_amdgcn_readfirstlane(tm);
+        tn = __builtin_amdgcn_readfirstlane(tn);
+    };
+    // this wave's weight fragments of K tile kt of column tile tn: 8 KB at wfrag + ((tn * nk + kt) * 4 + wn) * 4096 halfs, [ks][j][lane][8]: a scalar base per
+    // k step + the lane's 16-byte slot + an immediate (no per-lane 64-bit pointers)
+    const unsigned vlane16 = (unsigned)(lane * 16);
+    auto wload = [&](const half_t* wks, auto jc) __attribute__((always_inline)) {
+        constexpr int J = decltype(jc)::value;
+        half8 v;
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v) : "v"(vlane16), "s"(wks), "n"(J * 1024) : "memory");
+        return v;
+    };
+    auto wload4 = [&](half8 (&dst)[NI], const half_t* wks) __attribute__((always_inline)) {
+        dst[0] = wload(wks, std::integral_constant<int, 0>{});
+        dst[1] = wload(wks, std::integral_constant<int, 1>{});
+        dst[2] = wload(wks, std::integral_constant<int, 2>{});
+        dst[3] = wload(wks, std::integral_constant<int, 3>{});
+    };
+
+    const int ra = wm * WM + (lane & 15), q = lane >> 4;
+    int offa[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) offa[ks] = ra * ROWB + (swz<BKT>(ra, ks * 4 + q) << 4);
+    // output: accumulator element (i, j, r) = point row wm*WM + i*16 + (lane & 15), channel wn*WN + j*16 + 4 (lane >> 4) + r; after the half swap a lane
+    // holds 8 consecutive channels: chunk (i, jp) goes to row i*16 + (lane & 15), column (2 jp + (q & 1)) * 16 + (q >> 1) * 8 of the wave's tile
+    const unsigned vout = (unsigned)((((wm * WM + (lane & 15)) * ldo) + wn * WN + (q & 1) * 16 + (q >> 1) * 8) * 2);
+    char* const my_drip = drip + (wave * NDRIP * 64 + lane) * 16;
+    f32x4 acc[MI][NI];
+    half8 wq[2][NI];
+
+    int tile = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
+    if (tile >= tiles_mn) return;
+    int tm, tn;
+    tile_coords(tile, tm, tn);
+    int m0 = tm * BM, n0 = tn * BN;
+    const half_t* r1 = p.a1 + (int64_t)m0 * lda;
+    const half_t* r2 = p.a2 + (int64_t)m0 * lda - p.k1;
+    const half_t* wt = wfrag + ((int64_t)tn * nk * 4 + wn) * 4096;       // this wave's fragments of the tile's K tile 0
+    stage(r1, r2, 0, 0);
+    stage_bias(m0, n0, 0);
+    wload4(wq[0], uniform_ptr(wt));
+    wload4(wq[1], uniform_ptr(wt + 2048));
+    int it = 0;
+    int par = 0;
+    bool behind = false;                                   // this tile follows an epilogue: ND stores behind its K tile 0's operands, NDRIP chunks waiting in LDS
+    const half_t* prev_out = p.out16;                      // output tile of the tile whose chunks are being dripped
+    for (;;) {
+        const int next = tile + (int)gridDim.x;
+        const bool has_next = next < tiles_mn;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int dnext = behind ? 0 : NDRIP;                    // next parked chunk to store
+        bool prev_drip = false;                            // the previous K tile issued R drip stores
+        int m1 = m0, n1 = n0;
+        for (int kt = 0; kt < nk; ++kt) {
+            // issue order of a K tile: [A x 4 (+ bias x 2)] [w0 x 4] [drip x R] [w1 x 4].  Top: the activation pieces and k step 0's weights of this K tile have
+            // landed; younger than those: [the previous K tile's drip x R] w1 x 4 [the epilogue's ND stores in front of a tile's K tile 0]
+            if (kt == 0) { if (behind) wait_vmcnt<4 + ND>(); else wait_vmcnt<4>(); }
+            else if (prev_drip) wait_vmcnt<4 + R>();
+            else wait_vmcnt<4>();
+            __builtin_amdgcn_s_barrier();
+            int ktv = kt;
+            asm volatile("" : "+s"(ktv));                  // opaque: what follows is recomputed per K tile, not carried in registers across the loop
+            const bool last = ktv + 1 == nk;
+            const half_t* wnext;                           // this wave's fragments of the next K tile (of the next output tile behind the last one)
+            if (!last) {
+                stage(r1, r2, ktv + 1, (it + 1) & 1);
+                wnext = wt + (int64_t)(ktv + 1) * 16384;
+            } else {
+                int tm1 = tm, tn1 = tn;                    // without a next tile the look-ahead re-requests this tile's first K tile (harmless)
+                if (has_next) tile_coords(next, tm1, tn1);
+                m1 = tm1 * BM; n1 = tn1 * BN;
+                tm = tm1; tn = tn1;
+                r1 = p.a1 + (int64_t)m1 * lda;
+                r2 = p.a2 + (int64_t)m1 * lda - p.k1;
+                wt = wfrag + ((int64_t)tn1 * nk * 4 + wn) * 4096;
+                stage(r1, r2, 0, (it + 1) & 1);
+                stage_bias(m1, n1, par ^ 1);
+                wnext = wt;
+            }
+            wnext = uniform_ptr(wnext);
+            const char* base = smem + (it & 1) * STAGE_BYTES;
+            const bool dripping = dnext < NDRIP;
+            u32x4_t dv;                                    // (R = 2: the second chunk is read once the first has been stored -- the same four registers)
+            if (dripping) dv = *(const u32x4_t*)(my_drip + dnext * 1024);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                half8 af[MI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[i] = *(const half8*)(base + offa[ks] + i * 16 * ROWB);
+                if (ks == 1) {
+                    // k step 1's weights of this K tile; younger: [the epilogue's ND stores, at kt == 0 behind one] A x 4 [+ bias x 2] w0 x 4 [drip x R]
+                    if (kt == 0 && behind) { if (dripping) wait_vmcnt<8 + ND + R>(); else wait_vmcnt<8 + ND>(); }
+                    else if (last) { if (dripping) wait_vmcnt<10 + R>(); else wait_vmcnt<10>(); }
+                    else { if (dripping) wait_vmcnt<8 + R>(); else wait_vmcnt<8>(); }
+                }
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[ks][j], af[i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                wload4(wq[ks], wnext + ks * 2048);         // this k step's registers take the next K tile's fragments (the MFMAs that read them have been issued)
+                if (ks == 0 && dripping) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int c = ND + dnext + r;
+                        if (r > 0) dv = *(const u32x4_t*)(my_drip + (dnext + r) * 1024);
+                        if (abl & 2) { asm volatile("global_load_dword %0, %1, %2" : "=v"(dv[0]) : "v"(vlane16), "s"(wnext) : "memory"); continue; }   // (same vmcnt count)
+                        gstore16_s(vout, dv, uniform_ptr(prev_out + (int64_t)((c >> 1) * 16) * ldo + (c & 1) * 32));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            prev_drip = dripping;
+            if (dripping) dnext += R;
+            ++it;
+        }
+        // ---- epilogue: bias + ReLU + fp16, half swap -> sixteen 16-byte-per-lane chunks; ND stored now, NDRIP parked for the next tile's K loop
+        const half_t* tile_out = uniform_ptr(p.out16 + (int64_t)m0 * ldo + n0);
+        if (abl & 8) {
+            // (keep the accumulators alive and the vmcnt count: ND dummy loads)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(acc[i][j]));
+#pragma unroll
+            for (int c = 0; c < (has_next ? ND : NCH); ++c) { unsigned junk; asm volatile("global_load_dword %0, %1, %2" : "=v"(junk) : "v"(vlane16), "s"(tile_out) : "memory"); }
+        } else {
+            const int q4 = q * 4;
+            f32x4 bv[NI];
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                bv[j] = *(const f32x4*)&bias_lds[par][0][wn * WN + j * 16 + q4] + *(const f32x4*)&bias_lds[par][1][wn * WN + j * 16 + q4];
+            const float lo = p.relu ? 0.f : -65504.f;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int j = 0; j < NI; j += 2) {
+                    unsigned pk[2][2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const f32x4 v = acc[i][j + t] + bv[j + t];
+                        half2_ lo2, hi2;
+                        lo2[0] = (half_t)__builtin_amdgcn_fmed3f(v[0], lo, 65504.f);
+                        lo2[1] = (half_t)__builtin_amdgcn_fmed3f(v[1], lo, 65504.f);
+                        hi2[0] = (half_t)__builtin_amdgcn_fmed3f(v[2], lo, 65504.f);
+                        hi2[1] = (half_t)__builtin_amdgcn_fmed3f(v[3], lo, 65504.f);
+                        pk[t][0] = __builtin_bit_cast(unsigned, lo2);
+                        pk[t][1] = __builtin_bit_cast(unsigned, hi2);
+                    }
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                    const u32x4_t o = {s0[0], s1[0], s0[1], s1[1]};
+                    const int c = i * 2 + (j >> 1);
+                    if (c < ND || !has_next) {
+                        if (abl & 1) { unsigned junk; asm volatile("global_load_dword %0, %1, %2" : "=v"(junk) : "v"(vlane16), "s"(tile_out), "v"(o) : "memory"); }
+                        else gstore16_s(vout, o, tile_out + (int64_t)(i * 16) * ldo + (j >> 1) * 32);
+                    } else if (!(abl & 4)) *(u32x4_t*)(my_drip + (c - ND) * 1024) = o;
+                    else asm volatile("" ::"v"(o));
+                }
+            }
+        }
+        if (!has_next) break;
+        behind = true;
+        prev_out = tile_out;
+        par ^= 1;
+        tile = next; m0 = m1; n0 = n1;
+    }
+    wait_vmcnt<0>();                                       // the look-ahead's loads: nothing may land after the wave has gone
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(wq[ks][j]));
+}
+
 // fragment-order copy of W [c][ldw] for gemm_xw_kernel: one thread per 16-byte piece
 __global__ __launch_bounds__(256) void gemm_pack_wfrag_kernel(const half_t* __restrict__ w, int64_t ldw, int k, int c, half_t* __restrict__ out) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -792,6 +1052,8 @@ __global__ __launch_bounds__(256) void gemm_pack_wfrag_kernel(const half_t* __re
 }
 
 static int g_xw = 1;            // tuning hook (pcd_gemm_set_config(8) / (9)): callers that hold a fragment-order weight copy use gemm_xw_kernel: off / on
+static int g_xs_abl = 0;        // timing ablations of gemm_xs_kernel (pcd_gemm_set_config(16 + bits)): see the kernel; outputs are wrong while set
+static int g_xs = 1;            // tuning hook (pcd_gemm_set_config(10) / (11)): pcd_gemm_f16_wfrag uses gemm_xs_kernel (output dripped through LDS): off / on
 static int g_xp = 1;            // tuning hook (pcd_gemm_set_config(5) / (6) / (7)): the cross-tile prefetching store kernel off / 2 K tiles ahead / 1
 
 static int num_cus() {
@@ -1038,10 +1300,50 @@ extern "C" int pcd_gemm_f16_colmax_wfrag(const pcd_gemm_desc_t* d, const void* w
     return PCD_OK;
 }
 
+// Store GEMM with a fragment-order weight copy (pcd_gemm_pack_wfrag of the SAME weights as d->w): gemm_xs_kernel where its launch shape holds
+// (whole 256 x 256 tiles, a multiple of 256 of them, 6 or more K tiles, one A layout), pcd_gemm_f16's dispatch otherwise -- same bits either way.
+extern "C" int pcd_gemm_f16_wfrag(const pcd_gemm_desc_t* d, const void* wfrag, void* out, int64_t ldo, void* stream) {
+    GemmParams p;
+    int rc = fill(d, p);
+    if (rc) return rc;
+    PCD_CHECK_ARG(out != nullptr && ldo >= d->c && ldo % 8 == 0 && d->c % 8 == 0);
+    p.out16 = (half_t*)out; p.ldo = ldo;
+    const int nk = (p.k1 + p.k2) / 64;
+    const int64_t tiles = (int64_t)(p.m / 256) * (p.c / 256);
+    bool ok = g_xs && wfrag != nullptr && p.m % 256 == 0 && p.c % 256 == 0 && nk >= 6 && (p.k2 == 0 || p.lda2 == p.lda1) &&
+              (p.shape_bias == nullptr || p.rows_per_shape % 256 == 0) && tiles >= 256 && tiles % 256 == 0 && num_cus() == 256 &&
+              (int64_t)255 * p.lda1 * 2 + 128 < 0x7fffffffLL && ((int64_t)255 * p.ldo + 256) * 2 < 0x7fffffffLL;
+    if (ok && (p.bias == nullptr || p.shape_bias == nullptr)) {
+        float* zeros = zero_row(p.c, (hipStream_t)stream);
+        if (zeros == nullptr) ok = false;
+        else {
+            if (p.bias == nullptr) p.bias = zeros;
+            if (p.shape_bias == nullptr) { p.shape_bias = zeros; p.rows_per_shape = p.m; }
+        }
+    }
+    if (!ok) return dispatch<EPI_F16>(p, (hipStream_t)stream);
+    p.tiles_m = p.m / 256; p.tiles_n = p.c / 256;
+    p.patch_pn = p.patch_xn = 0;
+    const int pn = p.tiles_n >= 8 ? 8 : p.tiles_n, xn = p.tiles_n >= 16 ? 2 : 1;
+    if ((pn & (pn - 1)) == 0 && p.tiles_n % (xn * pn) == 0 && p.tiles_m % ((8 / xn) * (32 / pn)) == 0) { p.patch_pn = pn; p.patch_xn = xn; }
+    p.xp_depth = g_xs_abl;
+    if (g_xs_abl) {
+        if (nk >= 12) hipLaunchKernelGGL((gemm_xs_kernel<1, true>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
+        else hipLaunchKernelGGL((gemm_xs_kernel<2, true>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
+    } else if (nk >= 12) hipLaunchKernelGGL((gemm_xs_kernel<1, false>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
+    else hipLaunchKernelGGL((gemm_xs_kernel<2, false>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
 extern "C" int pcd_gemm_wfrag_enabled(void) { return g_xw; }
+extern "C" int pcd_gemm_store_wfrag_enabled(void) { return g_xs; }
 
 extern "C" int pcd_gemm_set_config(int cfg) {
-    PCD_CHECK_ARG(cfg >= -1 && cfg <= 9);
+    PCD_CHECK_ARG(cfg >= -1 && cfg <= 31);
+    if (cfg >= 16) { g_xs_abl = cfg - 16; return PCD_OK; }                          // timing ablations of gemm_xs_kernel (dev tools only)
+    PCD_CHECK_ARG(cfg <= 11);
+    if (cfg >= 10) { g_xs = cfg - 10; return PCD_OK; }                              // A/B switch of gemm_xs_kernel (pcd_gemm_f16_wfrag)
     if (cfg >= 8) { g_xw = cfg - 8; return PCD_OK; }                                // A/B switch of gemm_xw_kernel (pcd_gemm_wfrag_enabled)
     if (cfg >= 5) { g_xp = cfg == 5 ? 0 : (cfg == 6 ? 2 : 1); return PCD_OK; }      // A/B switch of gemm_xp_kernel; the tile choice is left as it is
     g_force_cfg = cfg;

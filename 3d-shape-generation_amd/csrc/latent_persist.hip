@@ -1225,10 +1225,12 @@ extern "C" int pcd_latent_persist_ddim(pcd_latent_persist_t* h, float* z, float*
     return lp_launch(h, a, workspace, workspace_bytes, stream);
 }
 
-extern "C" int pcd_latent_persist_status(const void* workspace, unsigned* status_host) {
+extern "C" int pcd_latent_persist_status(const void* workspace, unsigned* status_host, void* stream) {
     PCD_CHECK_ARG(workspace && status_host);
-    // the launch may sit on a non-blocking stream, which a null-stream copy does not wait for: drain the device first
-    PCD_CHECK_HIP(hipDeviceSynchronize());
-    PCD_CHECK_HIP(hipMemcpy(status_host, workspace, sizeof(unsigned), hipMemcpyDeviceToHost));
+    // the copy is ordered behind the launch on the launch's own stream and only that stream is waited for: other streams of the
+    // process (another model, a copy engine) keep running
+    hipStream_t s = (hipStream_t)stream;
+    PCD_CHECK_HIP(hipMemcpyAsync(status_host, workspace, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    PCD_CHECK_HIP(hipStreamSynchronize(s));
     return PCD_OK;
 }

@@ -348,6 +348,8 @@ __global__ __launch_bounds__(ST_THREADS, 2) void sab_head_kernel(SabHeadParams p
             }
         }
         {
+            // variance about the mean in a second pass over the packed fp16 pairs (sum(x^2) - C mean^2 cancels when |mean| >> std): subtract
+            // mh = fp16(mean) in packed fp16 and remove the shift exactly, sum (x - mh)^2 = sum (x - mean)^2 + C (mean - mh)^2  (widechain.hip)
             float sum = 0.f, sq = 0.f;
             half2_ one2; one2.x = one2.y = (half_t)1.f;
 #pragma unroll
@@ -356,12 +358,22 @@ __global__ __launch_bounds__(ST_THREADS, 2) void sab_head_kernel(SabHeadParams p
                 for (int e = 0; e < 4; ++e) {
                     half2_ v; v.x = bf[s][2 * e]; v.y = bf[s][2 * e + 1];
                     sum = __builtin_amdgcn_fdot2(v, one2, sum, false);
-                    sq = __builtin_amdgcn_fdot2(v, v, sq, false);
                 }
             sum += __shfl_xor(sum, 32);
-            sq += __shfl_xor(sq, 32);
             const float mean = sum * (1.f / C);
-            const float rstd = rsqrtf(fmaxf(sq - C * mean * mean, 0.f) * (1.f / C) + 1e-5f);
+            const half_t mh = (half_t)__builtin_amdgcn_fmed3f(mean, -65504.f, 65504.f);
+            half2_ mh2; mh2.x = mh2.y = mh;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    half2_ v; v.x = bf[s][2 * e]; v.y = bf[s][2 * e + 1];
+                    const half2_ d = v - mh2;
+                    sq = __builtin_amdgcn_fdot2(d, d, sq, false);
+                }
+            sq += __shfl_xor(sq, 32);
+            const float shift = mean - (float)mh;
+            const float rstd = rsqrtf(fmaxf(sq - C * shift * shift, 0.f) * (1.f / C) + 1e-5f);
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const f32x4 g0 = *(const f32x4*)&par[K::HGA + 16 * s + 8 * hh], g1 = *(const f32x4*)&par[K::HGA + 16 * s + 8 * hh + 4];

@@ -40,6 +40,8 @@ struct pcd_unet {
     void* wide[2] = {nullptr, nullptr};
     // fragment-order copy of global_feat.3's weights for gemm_xw_kernel (csrc/gemm_f16.hip), made at create; null: the LDS-staged kernel runs
     void* gf3_frag = nullptr;
+    // the same for the store GEMMs with K >= 512 and C >= 256 (enc4.conv1-3, global_feat.0, dec4.conv1-3, dec3.conv1-3: gemm_xs_kernel); null: pcd_gemm_f16
+    void* lin_frag[PCD_UNET_NLIN] = {};
     // parity-test capture of the decoder blocks' outputs (pcd_unet_capture): dec4 [M][512], dec3 [M][256], dec2 [M][128], dec1 [M][64]
     void* dec_tap[4] = {nullptr, nullptr, nullptr, nullptr};
 };
@@ -142,6 +144,16 @@ extern "C" int pcd_unet_create(const pcd_unet_desc_t* desc, pcd_unet_t** out) {
         (void)hipGetLastError();
         h->gf3_frag = nullptr;
     }
+    // the ten store GEMMs that run as 256 x 256 tiles (K >= 512): fragment-order copies (29 MB in all) for gemm_xs_kernel; hi / lo layers keep pcd_gemm_f16_hilo
+    for (int i = 8; here && i <= 18; ++i) {
+        if (i == 12 || ((desc->hilo_mask >> i) & 1u) || kLinK[i] < 384 || kLinC[i] % 256 != 0) continue;
+        if (hipMalloc(&h->lin_frag[i], (size_t)kLinK[i] * kLinC[i] * 2) != hipSuccess ||
+            pcd_gemm_pack_wfrag(desc->lin[i].w, kLinK[i], kLinK[i], kLinC[i], h->lin_frag[i], nullptr) != PCD_OK || hipStreamSynchronize(nullptr) != hipSuccess) {
+            (void)hipGetLastError();
+            if (h->lin_frag[i]) (void)hipFree(h->lin_frag[i]);
+            h->lin_frag[i] = nullptr;
+        }
+    }
     *out = h;
     return PCD_OK;
 }
@@ -149,6 +161,7 @@ extern "C" int pcd_unet_create(const pcd_unet_desc_t* desc, pcd_unet_t** out) {
 extern "C" void pcd_unet_destroy(pcd_unet_t* h) {
     if (h == nullptr) return;
     if (h->gf3_frag) (void)hipFree(h->gf3_frag);
+    for (int i = 0; i < PCD_UNET_NLIN; ++i) if (h->lin_frag[i]) (void)hipFree(h->lin_frag[i]);
     for (int k = 0; k < 2; ++k) if (h->wide[k]) (void)hipFree(h->wide[k]);
     for (int i = 0; i < h->ev_created; ++i) { (void)hipEventDestroy(h->ev0[i]); (void)hipEventDestroy(h->ev1[i]); }
     delete h;
@@ -187,7 +200,7 @@ extern "C" size_t pcd_unet_workspace_bytes(int batch, int n_points) {
 }
 
 static int run_lin(const pcd_unet_desc_t& d, int idx, int64_t m, const void* a1, const void* a2, int k2,
-                   const float* shape_bias, int rps, void* out, hipStream_t s) {
+                   const float* shape_bias, int rps, void* out, hipStream_t s, const void* wfrag = nullptr) {
     pcd_gemm_desc_t g{};
     const pcd_linear_desc_t& L = d.lin[idx];
     g.a1 = a1; g.k1 = L.k - k2; g.lda1 = g.k1;
@@ -197,7 +210,8 @@ static int run_lin(const pcd_unet_desc_t& d, int idx, int64_t m, const void* a1,
     g.bias = shape_bias ? nullptr : L.b;
     g.shape_bias = shape_bias; g.rows_per_shape = rps;
     g.relu = 1; g.m = (int)m; g.c = L.c;
-    return hilo ? pcd_gemm_f16_hilo(&g, out, L.c, s) : pcd_gemm_f16(&g, out, L.c, s);
+    if (hilo) return pcd_gemm_f16_hilo(&g, out, L.c, s);
+    return wfrag != nullptr ? pcd_gemm_f16_wfrag(&g, wfrag, out, L.c, s) : pcd_gemm_f16(&g, out, L.c, s);
 }
 
 extern "C" int pcd_unet_forward(pcd_unet_t* h, const float* x, int batch, int n_points, const float* tbias,
@@ -253,10 +267,10 @@ extern "C" int pcd_unet_forward(pcd_unet_t* h, const float* x, int batch, int n_
         RUN(run_lin(d, 6, m, s0, nullptr, 0, nullptr, 0, s1, s));
         RUN(run_lin(d, 7, m, s1, nullptr, 0, nullptr, 0, x3, s));
     }
-    RUN(run_lin(d, 8, m, x3, nullptr, 0, nullptr, 0, s0, s));
-    RUN(run_lin(d, 9, m, s0, nullptr, 0, nullptr, 0, s1, s));
-    RUN(run_lin(d, 10, m, s1, nullptr, 0, nullptr, 0, x4, s));
-    RUN(run_lin(d, 11, m, x4, nullptr, 0, nullptr, 0, s0, s));
+    RUN(run_lin(d, 8, m, x3, nullptr, 0, nullptr, 0, s0, s, h->lin_frag[8]));
+    RUN(run_lin(d, 9, m, s0, nullptr, 0, nullptr, 0, s1, s, h->lin_frag[9]));
+    RUN(run_lin(d, 10, m, s1, nullptr, 0, nullptr, 0, x4, s, h->lin_frag[10]));
+    RUN(run_lin(d, 11, m, x4, nullptr, 0, nullptr, 0, s0, s, h->lin_frag[11]));
     {   // global_feat.3 + max over the N points of each shape
         if (!pooled_cleared) RUN(pcd_fill_zero(pooled, (size_t)batch * 4096 * sizeof(float), s));
         pcd_gemm_desc_t g{};
@@ -293,15 +307,15 @@ extern "C" int pcd_unet_forward(pcd_unet_t* h, const float* x, int batch, int n_
             RUN(pcd_gemm_f16_out32(&g, gbias, 1024, s));
         }
     }
-    RUN(run_lin(d, 13, m, x4, nullptr, 0, gbias, n_points, s1, s));
-    RUN(run_lin(d, 14, m, s1, nullptr, 0, nullptr, 0, s0, s));
-    RUN(run_lin(d, 15, m, s0, nullptr, 0, nullptr, 0, s1, s));
+    RUN(run_lin(d, 13, m, x4, nullptr, 0, gbias, n_points, s1, s, h->lin_frag[13]));
+    RUN(run_lin(d, 14, m, s1, nullptr, 0, nullptr, 0, s0, s, h->lin_frag[14]));
+    RUN(run_lin(d, 15, m, s0, nullptr, 0, nullptr, 0, s1, s, h->lin_frag[15]));
 #define TAP(i, buf, ch) do { if (h->dec_tap[i]) PCD_CHECK_HIP(hipMemcpyAsync(h->dec_tap[i], buf, (size_t)m * (ch) * 2, \
                                                                              hipMemcpyDeviceToDevice, s)); } while (0)
     TAP(0, s1, 512);
-    RUN(run_lin(d, 16, m, s1, x3, 512, nullptr, 0, s0, s));
-    RUN(run_lin(d, 17, m, s0, nullptr, 0, nullptr, 0, s1, s));
-    RUN(run_lin(d, 18, m, s1, nullptr, 0, nullptr, 0, s0, s));
+    RUN(run_lin(d, 16, m, s1, x3, 512, nullptr, 0, s0, s, h->lin_frag[16]));
+    RUN(run_lin(d, 17, m, s0, nullptr, 0, nullptr, 0, s1, s, h->lin_frag[17]));
+    RUN(run_lin(d, 18, m, s1, nullptr, 0, nullptr, 0, s0, s, h->lin_frag[18]));
     TAP(1, s0, 256);
     if (wide) {
         RUN(pcd_pw_wide_chain(1, s0, x2, m, h->wide[1], s1, s));

@@ -126,8 +126,10 @@ __global__ __launch_bounds__(WC_THREADS, 2) void pw_wide_chain_kernel(WcParams p
                     // LayerNorm of the point's 256 channels (this lane holds 128 of them, lane ^ 32 the others): fp32 statistics, result in fp16
                     // like pcd_layernorm_f16's.  (The first barrier below orders these reads of ln_lds behind its fill; at the first tile of a
                     // workgroup the fill is ordered by the __syncthreads() in front of the tile loop.)
-                    // (statistics straight from the packed fp16 pairs by v_dot2_f32_f16, fp32 accumulation: sum and sum of squares in one pass -- a second
-                    // pass over converted values keeps 128 more registers alive and spills)
+                    // Statistics straight from the packed fp16 pairs by v_dot2_f32_f16 with fp32 accumulation (a pass over converted values would keep
+                    // 128 more registers alive and spill).  Two passes, the variance about the mean: sum(x^2) - 256 mean^2 cancels when |mean| >> std
+                    // (post-ReLU rows near the fp16 range).  The second pass subtracts mh = fp16(mean) in packed fp16 (exact or 1 ulp of a small
+                    // difference) and removes the shift exactly: sum (x - mh)^2 = sum (x - mean)^2 + 256 (mean - mh)^2 because sum (x - mean) = 0.
                     float sum = 0.f, sq = 0.f;
                     half2_ one2; one2.x = one2.y = (half_t)1.f;
 #pragma unroll
@@ -136,12 +138,22 @@ __global__ __launch_bounds__(WC_THREADS, 2) void pw_wide_chain_kernel(WcParams p
                         for (int e = 0; e < 4; ++e) {
                             half2_ v; v.x = bf[s][2 * e]; v.y = bf[s][2 * e + 1];
                             sum = __builtin_amdgcn_fdot2(v, one2, sum, false);
-                            sq = __builtin_amdgcn_fdot2(v, v, sq, false);
                         }
                     sum += __shfl_xor(sum, 32);
-                    sq += __shfl_xor(sq, 32);
                     const float mean = sum * (1.f / 256.f);
-                    const float ssq = fmaxf(sq - 256.f * mean * mean, 0.f);
+                    const half_t mh = (half_t)__builtin_amdgcn_fmed3f(mean, -65504.f, 65504.f);
+                    half2_ mh2; mh2.x = mh2.y = mh;
+#pragma unroll
+                    for (int s = 0; s < 16; ++s)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            half2_ v; v.x = bf[s][2 * e]; v.y = bf[s][2 * e + 1];
+                            const half2_ d = v - mh2;
+                            sq = __builtin_amdgcn_fdot2(d, d, sq, false);
+                        }
+                    sq += __shfl_xor(sq, 32);
+                    const float shift = mean - (float)mh;
+                    const float ssq = fmaxf(sq - 256.f * shift * shift, 0.f);
                     const float rstd = rsqrtf(ssq * (1.f / 256.f) + 1e-5f);
 #pragma unroll
                     for (int s = 0; s < 16; ++s) {

@@ -159,11 +159,12 @@ class PointCloudDataset(Dataset):
     @staticmethod
     def point_cloud_to_voxel(point_cloud, resolution):
         """data.py:220-228: [-1,1] coordinates -> occupancy, written as grid[z,y,x] from columns (x,y,z)."""
-        points = (point_cloud + 1) * (resolution - 1) / 2
-        points = np.clip(points, 0, resolution - 1).astype(int)
-        voxel_grid = np.zeros((resolution, resolution, resolution), dtype=np.float32)
-        voxel_grid[points[:, 2], points[:, 1], points[:, 0]] = 1
-        return voxel_grid
+        top = resolution - 1
+        cell = np.clip((point_cloud + 1) * top / 2, 0, top).astype(int)          # truncation, after the clip, as the reference does
+        x, y, z = cell[:, 0], cell[:, 1], cell[:, 2]
+        grid = np.zeros((resolution,) * 3, dtype=np.float32)
+        grid[z, y, x] = 1
+        return grid
 
     @staticmethod
     def normalize_point_cloud(point_cloud):
@@ -182,6 +183,23 @@ class PointCloudDataset(Dataset):
             return point_cloud[random.sample(range(len(point_cloud)), num_points)]
         extra = np.random.choice(len(point_cloud), num_points - len(point_cloud), replace=True)
         return point_cloud[list(range(len(point_cloud))) + extra.tolist()]
+
+    @staticmethod
+    def farthest_point_sample(point_cloud, num_points):
+        """data.py:256-287 (the reference's own pipeline does not call it: "makes dataloading very slow"): greedy farthest-point subset, first
+        point from `np.random.randint`.  `nearest` = squared distance of every point to the subset so far (starts at 1e10)."""
+        n = len(point_cloud)
+        if n == num_points:
+            return point_cloud
+        xyz = point_cloud[:, :3]
+        nearest = np.full((n,), 1e10)
+        chosen = np.empty((num_points,), np.int32)
+        nxt = np.random.randint(0, n)
+        for k in range(num_points):
+            chosen[k] = nxt
+            np.minimum(nearest, np.sum((xyz - xyz[nxt, :]) ** 2, axis=-1), out=nearest)
+            nxt = np.argmax(nearest, axis=-1)
+        return point_cloud[chosen]
 
     @staticmethod
     def jitter_points(points, sigma=0.01, clip=0.05):

@@ -627,11 +627,11 @@ class SimpleLatentUNetPointNet(_HipModule):
         return self._persist, self._persist_ws
 
     def persist_status(self) -> int:
-        """Drains the device and returns the status word of the last persistent launch: 0 = every wait was met, else
+        """Waits for the current stream (the one the launch was enqueued on) and returns the status word of the last persistent launch: 0 = every wait was met, else
         (wait kind << 16) | workgroup -- the launch was abandoned (0.2 s bound per wait) and its outputs are undefined."""
         h, ws = self._persist_handle()
         st = C.c_uint(0)
-        _lib.check(_lib.load().pcd_latent_persist_status(ws.data_ptr(), C.byref(st)), "latent_persist_status")
+        _lib.check(_lib.load().pcd_latent_persist_status(ws.data_ptr(), C.byref(st), _lib.stream_ptr()), "latent_persist_status")
         return int(st.value)
 
     def check_persist_status(self):

@@ -778,6 +778,12 @@ def fit(model, data_module, max_epochs: int = 500, ckpt_dir: Optional[str] = Non
     # RandomSampler seeds itself from the global torch RNG).  So the global RNG stays shared, and only the model's own draws --
     # torch.rand for t, the on-device Philox stream seeded by torch.initial_seed() -- run under a per-rank RNG state that is
     # swapped in around training_step / validation_step and swapped out again (it does not leak out of fit() either).
+    if world > 1:
+        # ... which only holds if every rank ENTERS with the same global RNG state: nothing upstream enforces that (a caller that seeded per rank,
+        # or not at all, would make each rank shuffle differently -- an epoch would no longer partition the dataset, silently).  Rank 0's seed wins.
+        seed = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=model.device if dist.get_backend() == "nccl" else "cpu")
+        _collective_inplace(dist.broadcast, seed, 0)
+        torch.manual_seed(int(seed.item()))
     rank_rng = _RankRng(model.device, rank) if world > 1 else contextlib.nullcontext()
     kept: List[Tuple[float, str]] = []
     steps = 0

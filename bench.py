@@ -70,8 +70,10 @@ def parse_args():
     ap.add_argument("--no-attention", action="store_true", help="skip the roofline_attention leg")
     ap.add_argument("--graph", action="store_true",
                     help="time the hipGraph replay path in the headline region instead of eager launches (the eager "
-                         "default lets the dominant kernel be timed by HIP events inside the timed region; the graph "
-                         "number is reported beside it either way)")
+                         "default at N = 1 lets the dominant kernel be timed by HIP events inside the timed region; the "
+                         "other launch mode's number is reported beside it either way).  With N > 1 graph replay -- what "
+                         "sample2() itself drives -- is the default: a rank's step then costs its host one launch, not 29")
+    ap.add_argument("--eager", action="store_true", help="N > 1: time eager launches in the headline region")
     return ap.parse_args()
 
 
@@ -270,6 +272,16 @@ class Ranks:
         tt = torch.tensor([seconds], dtype=torch.float64, device="cpu" if self.shared else self.device)
         self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
         return float(tt.item())
+
+    def gather_seconds(self, seconds: float):
+        """Every rank's own elapsed time, in rank order (one all-gather of a double per rank)."""
+        import torch
+        if self.dist is None:
+            return [seconds]
+        mine = torch.tensor([seconds], dtype=torch.float64, device="cpu" if self.shared else self.device)
+        got = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(got, mine)
+        return [float(g.item()) for g in got]
 
     def collective_ranks(self):
         """World size as seen by a collective on the data-path backend (an all-gather of one int per rank)."""
@@ -556,14 +568,15 @@ def run_cfg2(args, R: Ranks):
             _lib.check(lib.pcd_unet_profile(handle, 0))
         if not torch.isfinite(x).all():
             raise SystemExit("non-finite state after the timed steps")
-        return R.max_over_ranks(elapsed), tot_ms.value, launches.value
+        return R.max_over_ranks(elapsed), tot_ms.value, launches.value, elapsed
 
     # the set-attention kernel's own roofline first, on an idle chip (100 launches = 27 ms; after the ~1 s of the two legs below
     # the chip is power-throttled, which is a statement about the GEMM run that heated it, not about this kernel)
     att = attention_roofline(R.device) if (R.world == 1 and not args.no_attention) else None
-    head_graph = args.graph
-    elapsed, tot_ms, launches = leg(head_graph, 24 + R.rank)
-    other_elapsed, o_ms, o_launches = leg(not head_graph, 24 + R.rank)      # the other launch mode, same K steps
+    head_graph = args.graph or (R.world > 1 and not args.eager)
+    elapsed, tot_ms, launches, own = leg(head_graph, 24 + R.rank)
+    other_elapsed, o_ms, o_launches, _ = leg(not head_graph, 24 + R.rank)      # the other launch mode, same K steps
+    per_rank = R.gather_seconds(own)
     if head_graph:           # HIP events cannot be recorded inside a captured step: the eager leg carries them
         tot_ms, launches = o_ms, o_launches
     rccl_ranks = R.collective_ranks()
@@ -586,7 +599,11 @@ def run_cfg2(args, R: Ranks):
                    "launch": "hipGraph replay" if head_graph else "eager",
                    ("eager" if head_graph else "graph_replay") + "_steps_per_sec": world * args.steps / other_elapsed,
                    "point_steps_per_sec": world * args.steps * B_PER_GPU * N_POINTS / elapsed,
-                   "rccl_ranks": rccl_ranks, "collective_backend": R.backend},
+                   "rccl_ranks": rccl_ranks, "collective_backend": R.backend,
+                   # every rank's own clock over the same K steps: an efficiency loss at N > 1 is attributable to a rank
+                   "per_rank_steps_per_sec": {"min": args.steps / max(per_rank), "max": args.steps / min(per_rank),
+                                              "slowest_rank": per_rank.index(max(per_rank))},
+                   "rank_cpus": os.environ.get("PCD_RANK_CPUS"), "rank_host_threads": os.environ.get("OMP_NUM_THREADS")},
     }
     if pointnet:
         out["roofline"] = gf3_roofline(tot_ms / max(launches, 1), launches)
@@ -785,6 +802,11 @@ def main():
     # a job share a device -- LatentDiffusion._persistent_allowed -- and falls back if a launch cannot complete)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_children(args))           # the parent stays GPU-free
+    if args.gpus > 1:
+        # a rank that `python -m torch.distributed.run` started (the driver's N > 1 form): its CPU slice and thread budget, before torch
+        # is imported (ranks of launch_children come pinned already and this is a no-op)
+        from shapegen_amd import launcher
+        launcher.apply_rank_affinity()
 
     import torch
     import shapegen_amd  # noqa: F401

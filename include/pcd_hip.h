@@ -33,8 +33,13 @@ extern "C" {
 #define PCD_ERR_HIP (-2)
 #define PCD_ERR_WORKSPACE (-3)
 
+/* The ABI version this header describes: bumped whenever a signature or a descriptor struct changes (2: pcd_latent_persist_status takes the
+ * launch stream; the descriptor structs pcd_unet_desc_t / pcd_sab_desc_t / pcd_conv3d_desc_t / the VAE residual descriptor as they stand since round 4).
+ * A binding compares pcd_abi_version() of the library it loaded with the PCD_ABI_VERSION it was written against and refuses a mismatch. */
+#define PCD_ABI_VERSION 2
+
 const char* pcd_last_error(void);
-/* library/ABI version, bumped when a signature changes */
+/* the PCD_ABI_VERSION the library was built from */
 int pcd_abi_version(void);
 /* 0 if a gfx950 device is usable by this process, negative otherwise */
 int pcd_device_check(void);
@@ -86,11 +91,18 @@ int pcd_gemm_pack_wfrag(const void* w, int64_t ldw, int k, int c, void* wfrag, v
 int pcd_gemm_f16_colmax_wfrag(const pcd_gemm_desc_t* d, const void* wfrag, float* colmax, int rows_per_shape, void* stream);
 /* 1 unless pcd_gemm_set_config(8) switched the fragment-order path off (9: on): callers that hold a copy ask before they use it */
 int pcd_gemm_wfrag_enabled(void);
+/* pcd_gemm_f16 (bias [+ per-shape bias] [+ ReLU], fp16 store) for a caller that holds wfrag = pcd_gemm_pack_wfrag's copy of d->w: where the launch shape
+ * allows (whole 256 x 256 tiles, a multiple of 256 of them, k1 + k2 >= 384, one A layout) gemm_xs_kernel runs -- weights straight from global memory,
+ * and most of each output tile leaves through LDS DURING the next tile's K loop instead of as one store burst behind it; otherwise pcd_gemm_f16's
+ * kernels run.  Bitwise the same output either way.  pcd_gemm_set_config(10) / (11): that kernel off / on (default on); pcd_gemm_store_wfrag_enabled reads it. */
+int pcd_gemm_f16_wfrag(const pcd_gemm_desc_t* d, const void* wfrag, void* out, int64_t ldo, void* stream);
+int pcd_gemm_store_wfrag_enabled(void);
 /* tuning/benchmark hook: force a tile configuration for every following GEMM launch of this
  * process (-1 = shape heuristic; 0: 128x64, 1: 128x128, 2: 256x128 3-stage, 3: 256x256, 4: 128x128 3-stage).
  * 5 / 7 / 6 leave the tile choice alone and switch the 256x256 store / column-max kernel that requests the next tile's first
  * K tile(s) before the epilogue's stores (whole tiles only): off / one K tile ahead (default) / two (store epilogue only).
- * 8 / 9: pcd_gemm_wfrag_enabled() off / on (default on). */
+ * 8 / 9: pcd_gemm_wfrag_enabled() off / on (default on).  10 / 11: pcd_gemm_store_wfrag_enabled() off / on (default on).
+ * TEST / BENCHMARK ONLY: process-global, read by every handle at every launch -- not for use while another thread is launching. */
 int pcd_gemm_set_config(int cfg);
 
 int pcd_fill_zero(void* p, size_t bytes, void* stream);
@@ -352,8 +364,8 @@ int pcd_latent_f32_forward(pcd_latent_f32_t* h, const float* z, int batch, const
  *    updated in place, x0 (may be NULL) receives the last step's x0.  rate_tables is (4, n_steps_table, rate_width)
  *    fp32 = (n, s, n_next, s_next) like pcd_ddim_update's operands, rate_width 1 or batch.  The update is bitwise
  *    pcd_ddim_update's.
- *  - every in-kernel wait is bounded (0.2 s); pcd_latent_persist_status copies the status word to the host after the
- *    caller has synchronised: 0 = ok, otherwise (wait kind << 16 | workgroup) of the first wait that gave up (outputs
+ *  - every in-kernel wait is bounded (0.2 s); pcd_latent_persist_status waits for the launch stream and copies the status word to the
+ *    host: 0 = ok, otherwise (wait kind << 16 | workgroup) of the first wait that gave up (outputs
  *    are then undefined).
  *  - pcd_latent_persist_config: tuning hooks: poll back-off (s_sleep count between polls); predict_waits = 1 (default): a wait
  *    sleeps through 7/8 of the time the same wait took in the previous step before it starts probing. */
@@ -370,10 +382,11 @@ int pcd_latent_persist_forward(pcd_latent_persist_t* h, const float* z, int batc
 int pcd_latent_persist_ddim(pcd_latent_persist_t* h, float* z, float* x0, int batch, const float* tb_table, int tb_elems,
                             const float* rate_tables, int rate_width, int n_steps_table, int* counter, int nsteps,
                             void* workspace, size_t workspace_bytes, void* stream);
-/* drains the device, then reads the status word of the last launch: 0 = every wait was met; else (wait kind << 16) | workgroup.
+/* waits for `stream` (the stream the launch was enqueued on; nothing else is synchronised), then reads the status word of the last launch:
+ * 0 = every wait was met; else (wait kind << 16) | workgroup.
  * A non-zero status means the launch was ABANDONED (its outputs are undefined): the caller re-runs from its saved input on
  * the per-layer path (shapegen_amd.diffusion.LatentDiffusion._run does). */
-int pcd_latent_persist_status(const void* workspace, unsigned* status_host);
+int pcd_latent_persist_status(const void* workspace, unsigned* status_host, void* stream);
 /* fault injection for the recovery tests: in the following launches workgroup `workgroup` (role index 0..255) leaves at the
  * start of step `step`, as a workgroup that never became resident would; workgroup < 0 switches it off. */
 int pcd_latent_persist_inject_fault(pcd_latent_persist_t* h, int workgroup, int step);

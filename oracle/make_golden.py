@@ -21,7 +21,9 @@ G24 attention_n2048.npz (`make_golden.py g24`: `SetAttentionBlock(256, 4)` and `
 G23 latent_ddpm.npz (`make_golden.py g23`: `LatentDiffusion.sample2(8, num_steps=1000)` with hashed per-step noise),
 G22 point_cfg1_ddpm.npz (`make_golden.py g22`: BASELINE configs[0] through `sample2`: 512 points, 100 steps, batch 4),
 G19-G21 point_t1000_{ddim,ddpm,recon}.npz (`make_golden.py g19|g20|g21`: the three point samplers at N = 2048 over the full
-1000-step horizon, see `capture_t1000`).
+1000-step horizon, see `capture_t1000`),
+G25 point_b64.npz (`make_golden.py g25`: the DDIM sampler at the full launch batch, (64, 2048), 50 steps, hashed x_T),
+G26 attention_t1000_{ddim,ddpm}.npz (`make_golden.py g26a|g26b`: the sampling loops over `UNetAttentionPointExperimental` at (2, 2048), 1000 steps).
 """
 from __future__ import annotations
 
@@ -320,6 +322,73 @@ def capture_attention_n2048(rn):
     print("attention_n2048.npz", os.path.getsize(os.path.join(OUT, "attention_n2048.npz")), "|eps| max", float(np.abs(g["una_eps"]).max()))
 
 
+def _hashed_draws(tag):
+    """Stand-ins for `torch.randn` / `torch.randn_like` during a capture: draw k of the call comes from the integer hash
+    (`specs.hash_normal(f"{tag}.xT" | f"{tag}.z<k>")`), so a test rebuilds the start noise and every per-step draw instead of loading them."""
+    count = [0]
+
+    def randn(*shape, **k):
+        shape = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape)
+        return torch.from_numpy(specs.hash_normal(f"{tag}.xT", int(np.prod(shape)), 0).astype(np.float32).reshape(shape))
+
+    def randn_like(x, *a, **k):
+        z = specs.hash_normal(f"{tag}.z{count[0]}", x.numel(), 0).astype(np.float32).reshape(tuple(x.shape))
+        count[0] += 1
+        return torch.from_numpy(z)
+
+    return randn, randn_like, count
+
+
+def capture_full_batch(rd):
+    """G25: the reference's DDIM sampler at the batch one GPU runs in BASELINE configs[2] and bench.py times:
+    `PointCloudDiffusion.sample(64, 2048, num_steps=50)` (diffusion.py:261-289), x_T = `specs.hash_normal("g25.xT")` (the start draw of
+    diffusion.py:275 replaced during the capture; the test rebuilds it), only `out` stored (1.5 MB) -> tests/golden/point_b64.npz."""
+    pspec = specs.unet_pointnet_large_spec(prefix="model.")
+    pcd = rd.PointCloudDiffusion(num_points=2048).eval()
+    pcd.load_state_dict(T(specs.synth_state_dict(pspec, seed=0, gain=POINT_GAIN)), strict=True)
+    randn, _, _ = _hashed_draws("g25")
+    real = torch.randn
+    t0 = time.time()
+    torch.randn = randn
+    try:
+        out = pcd.sample(64, 2048, num_steps=50)
+    finally:
+        torch.randn = real
+    print("g25 seconds", time.time() - t0, "|out| max", float(out.abs().max()), "finite", bool(torch.isfinite(out).all()))
+    np.savez_compressed(os.path.join(OUT, "point_b64.npz"), out=out.numpy(), gain=np.float64(POINT_GAIN))
+    print("point_b64.npz", os.path.getsize(os.path.join(OUT, "point_b64.npz")))
+
+
+def capture_attention_t1000(rd, rn, which):
+    """G26: the reference's sampling loops (diffusion.py:225-289) over the attention denoiser: `pcd.model` replaced by
+    `UNetAttentionPointExperimental(2048)` (networks.py:597-722), (2, 2048), 1000 steps.  `g26a`: DDIM `sample`; `g26b`: DDPM `sample2` with
+    per-step draws from the integer hash.  x_T hashed too; the state handed to the denoiser at T1000_CHECKPOINTS is stored as in G19 / G20
+    -> tests/golden/attention_t1000_{ddim,ddpm}.npz."""
+    pcd = rd.PointCloudDiffusion(num_points=2048).eval()
+    una = rn.UNetAttentionPointExperimental(2048).eval()
+    una.load_state_dict(T(specs.synth_state_dict(specs.unet_attention_spec(), seed=0, gain=ATTN_GAIN)), strict=True)
+    pcd.model = una
+    tag = which
+    randn, randn_like, count = _hashed_draws(tag)
+    real, real_like = torch.randn, torch.randn_like
+    rec, h = _spy_states(pcd.model, 2)
+    t0 = time.time()
+    torch.randn, torch.randn_like = randn, randn_like
+    try:
+        out = pcd.sample(2, 2048) if which == "g26a" else pcd.sample2(2, 2048)
+    finally:
+        torch.randn, torch.randn_like = real, real_like
+    h.remove()
+    assert count[0] == (0 if which == "g26a" else 999)
+    g = {"out": out.numpy(), "ckpt_calls": np.array(sorted(rec), np.int64), "ckpt_x": np.stack([rec[k] for k in sorted(rec)]),
+         "n_draws": np.int64(count[0]), "gain": np.float64(ATTN_GAIN)}
+    name = "attention_t1000_ddim.npz" if which == "g26a" else "attention_t1000_ddpm.npz"
+    print(which, "seconds", time.time() - t0, "|out| max", float(out.abs().max()), "rms", float(out.pow(2).mean().sqrt()),
+          "finite", bool(torch.isfinite(out).all()))
+    np.savez_compressed(os.path.join(OUT, name), **g)
+    print(name, os.path.getsize(os.path.join(OUT, name)))
+
+
 def capture_cfg4(rd, rn, ru):
     """G17: the reference at BASELINE configs[3]'s launch shape (diffusion.py:619-653, networks.py:2299-2339): B = 32,
     T = 1000.  The 32 input grids are `synth_voxels(32, 4)` (the test rebuilds them from the same integer hash; the
@@ -598,6 +667,13 @@ def main():
     for which in ("g19", "g20b", "g20", "g21"):
         if which in sys.argv[1:]:
             capture_t1000(rd, rm, which)
+            return
+    if "g25" in sys.argv[1:]:
+        capture_full_batch(rd)
+        return
+    for which in ("g26a", "g26b"):
+        if which in sys.argv[1:]:
+            capture_attention_t1000(rd, rn, which)
             return
     if "g24" in sys.argv[1:]:
         capture_attention_n2048(rn)

@@ -26,7 +26,7 @@ def test_library_builds_and_exports_header_symbols():
         assert hasattr(lib, n), f"{n} declared in include/pcd_hip.h but not exported"
         assert n in _lib._SIGS, f"{n} has no ctypes prototype"
     assert set(_lib._SIGS) == set(names)
-    assert lib.pcd_abi_version() >= 1
+    assert lib.pcd_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_arg_validation_without_gpu():

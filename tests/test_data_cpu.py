@@ -61,7 +61,7 @@ def test_augmented_voxel_output_and_helpers(sample_dir, golden):
     assert np.array_equal(D.PointCloudDataset.normalize_point_cloud(pts), g["helper_norm"])
     assert np.array_equal(D.PointCloudDataset.point_cloud_to_voxel(g["helper_norm"], 32), g["helper_vox"])
     np.random.seed(13)
-    # (`farthest_point_sample` is not rebuilt: the reference never calls it and SURVEY section 2 #16 puts it out of scope)
+    assert np.array_equal(D.PointCloudDataset.farthest_point_sample(pts, 64), g["helper_fps"])       # golden from the reference's data.py:256-287
     # [z,y,x] scan order of voxel_to_point_cloud == the order utils.voxel_tensor_to_point_clouds reads grids in
     v = np.zeros((4, 4, 4)); v[1, 2, 3] = 1; v[0, 3, 1] = 1
     assert D.PointCloudDataset.voxel_to_point_cloud(v).tolist() == [[0, 3, 1], [1, 2, 3]]

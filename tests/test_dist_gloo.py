@@ -233,6 +233,124 @@ def test_launcher_kills_siblings_of_a_dead_rank_and_enforces_the_timeout(tmp_pat
     assert (tmp_path / "rank1.err").exists()              # per-rank logs, not DEVNULL
 
 
+def test_launcher_gives_every_rank_a_thread_budget_and_a_disjoint_cpu_slice(tmp_path):
+    """World 8 over gloo: every rank reports the environment and the affinity mask it actually runs with.  The slices are disjoint, equal in size,
+    inside the launcher's own usable CPUs, applied before the rank's first instruction (`sched_getaffinity` in the rank == PCD_RANK_CPUS), and the
+    thread budget equals the slice."""
+    import json
+    import sys
+    from shapegen_amd import launcher
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "OMP_NUM_THREADS", "MKL_NUM_THREADS")}
+    env.update(FAULT_MODE="none", PYTHONPATH=root, PCD_ENV_DUMP_DIR=str(tmp_path))
+    world = 8
+    code, out0, report = launcher.launch_ranks([sys.executable, os.path.join(root, "tests", "launch_worker.py")], world,
+                                               timeout_s=240.0, log_dir=str(tmp_path), env=env)
+    assert code == 0, report
+    usable = launcher.usable_cpus()
+    per = len(usable) // world
+    seen = []
+    for r in range(world):
+        got = json.load(open(tmp_path / f"env{r}.json"))
+        want = usable[r * per:(r + 1) * per] if per >= 1 else usable
+        assert got["PCD_RANK_CPUS"] == launcher.cpu_list(want) and got["affinity"] == want, (r, got)
+        assert got["OMP_NUM_THREADS"] == got["MKL_NUM_THREADS"] == str(len(want))
+        assert got["LOCAL_WORLD_SIZE"] == str(world) and got["LOCAL_RANK"] == str(r) and got["MASTER_ADDR"] == "127.0.0.1"
+        assert got["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+        seen += want
+    if per >= 1:
+        assert len(set(seen)) == len(seen) == per * world          # disjoint
+    # slices by hand: 20 CPUs over 8 ranks -> 2 each, 4 left over; fewer CPUs than ranks -> nothing to partition
+    assert [launcher.rank_cpus(r, 8, range(20)) for r in (0, 7)] == [[0, 1], [14, 15]]
+    assert launcher.rank_cpus(5, 8, [3, 4]) == [3, 4]
+
+
+def test_rank_started_by_torchrun_pins_itself(tmp_path):
+    """The driver starts the N > 1 bench through `python -m torch.distributed.run`: bench.py's ranks then call `launcher.apply_rank_affinity()` before
+    importing torch.  A child with LOCAL_RANK=1, LOCAL_WORLD_SIZE=2 must end up on the second half of its CPUs with a matching thread budget; a one-rank
+    world and a rank the launcher already pinned are left alone."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import json, os, sys; sys.path.insert(0, %r); from shapegen_amd import launcher; before = launcher.usable_cpus(); "
+            "got = launcher.apply_rank_affinity(); print(json.dumps({'before': before, 'got': got, 'aff': sorted(os.sched_getaffinity(0)), "
+            "'omp': os.environ.get('OMP_NUM_THREADS')}))" % root)
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "PCD_RANK_CPUS", "OMP_NUM_THREADS")}
+
+    def run(**extra):
+        p = subprocess.run([sys.executable, "-c", code], env={**base, **extra}, capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stderr
+        return json.loads(p.stdout.strip().splitlines()[-1])
+
+    r = run(LOCAL_RANK="1", LOCAL_WORLD_SIZE="2", WORLD_SIZE="2", RANK="1")
+    half = len(r["before"]) // 2
+    if half >= 1:
+        assert r["aff"] == r["before"][half:2 * half] and r["omp"] == str(half) and r["got"]["PCD_RANK_CPUS"]
+    assert run(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")["got"] is None
+    already = run(LOCAL_RANK="1", LOCAL_WORLD_SIZE="2", WORLD_SIZE="2", RANK="1", PCD_RANK_CPUS="0")
+    assert already["got"] is None and already["aff"] == already["before"]
+
+
+def test_launcher_told_to_stop_takes_its_ranks_with_it(tmp_path):
+    """ranks are session leaders, so a SIGTERM to the launcher (a scheduler, `timeout`, a CI driver) no longer reaches them by itself.
+    The launcher's handler must run `_stop`: after SIGTERM to a launcher whose rank 1 hangs, no rank is left alive."""
+    import json
+    import signal
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.path.insert(0, %r); from shapegen_amd import launcher; "
+            "launcher.launch_ranks([sys.executable, %r], 2, timeout_s=300.0, log_dir=%r)"
+            % (root, os.path.join(root, "tests", "launch_worker.py"), str(tmp_path)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(FAULT_MODE="hang", FAULT_RANK="1", PYTHONPATH=root, PCD_ENV_DUMP_DIR=str(tmp_path), PCD_DUMP_EARLY="1")
+    parent = subprocess.Popen([sys.executable, "-c", code], env=env)
+    try:
+        t_end = time.monotonic() + 120
+        while not all((tmp_path / f"pid{r}").exists() for r in range(2)):
+            assert time.monotonic() < t_end and parent.poll() is None, "ranks did not come up"
+            time.sleep(0.1)
+        pids = [int(open(tmp_path / f"pid{r}").read()) for r in range(2)]
+        parent.send_signal(signal.SIGTERM)
+        assert parent.wait(timeout=60) == 128 + signal.SIGTERM
+        t_end = time.monotonic() + 20
+        alive = pids
+        while alive and time.monotonic() < t_end:
+            alive = [p for p in alive if os.path.exists(f"/proc/{p}") and open(f"/proc/{p}/stat").read().split(")")[-1].split()[0] != "Z"]
+            time.sleep(0.1)
+        assert not alive, f"ranks left behind: {alive}"
+    finally:
+        if parent.poll() is None:
+            parent.kill()
+
+
+def test_launcher_does_not_signal_a_group_it_has_reaped():
+    """`_stop` used to `killpg` the pid of a rank it had already reaped -- a pid the kernel may have given to an unrelated session leader.
+    A finished rank stays an unreaped zombie until `_stop` has swept its group; after the reap `_signal_group` refuses."""
+    import subprocess
+    import sys
+    import time
+    from shapegen_amd import launcher
+    p = subprocess.Popen([sys.executable, "-c", "import sys; sys.exit(7)"], start_new_session=True)
+    t_end = time.monotonic() + 30
+    while launcher._exit_code(p) is None and time.monotonic() < t_end:
+        time.sleep(0.02)
+    assert launcher._exit_code(p) == 7 and p.returncode is None           # known to have exited, NOT reaped: the pid is still ours
+    assert os.path.exists(f"/proc/{p.pid}")
+    launcher._stop([p])
+    assert p.returncode == 7
+    called = []
+    real = os.killpg
+    os.killpg = lambda *a: called.append(a)
+    try:
+        launcher._signal_group(p, 9)
+    finally:
+        os.killpg = real
+    assert called == []
+
+
 class _ToyModel(torch.nn.Module):
     """Stands in for a HIP-trained module in `training.fit`: the control flow under test (how batches are dealt to ranks,
     which collectives pair up, what is broadcast) does not depend on the kernels."""
@@ -297,7 +415,13 @@ def _fit_worker(rank, world, port, tmp):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     D.init_from_env("gloo")
     model = _ToyModel(rank)
+    torch.manual_seed(1000 + 17 * rank)                                     # ranks enter fit() seeded DIFFERENTLY ...
     hist = fit(model, _ToyData(5), max_epochs=2, log=lambda *_: None)       # 5 batches, 2 ranks: the odd one is dropped
+    drew = torch.tensor([float(torch.rand(1))])                             # ... and leave it on ONE shared stream (rank 0's seed, broadcast):
+    both = [torch.zeros(1), torch.zeros(1)]                                 # the loaders' RandomSampler seeds itself from it, so the ranks
+    dist.all_gather(both, drew)                                             # enumerate one permutation
+    assert torch.equal(both[0], both[1]), "ranks left fit() on different global RNG streams"
+    assert torch.initial_seed() == 1000
     assert torch.equal(model.w.detach(), torch.ones(3)) and torch.equal(model.stat, torch.full((2,), 10.0))   # rank 0's values
     assert model.steps == 4 and model.seen == ([0, 2, 0, 2] if rank == 0 else [1, 3, 1, 3])
     assert abs(hist[-1][2] - 0.5) < 1e-12 and abs(model.sched_metric - 0.5) < 1e-12      # val_loss = mean over ranks of (0, 1)

@@ -376,6 +376,46 @@ def test_wide_chain_layernorm_linear_against_fp64(passes, relu, rows):
     assert lib.pcd_pw_wide_ln_linear(packed.data_ptr(), 5, relu, xd.data_ptr(), rows, out.data_ptr(), _lib.stream_ptr()) != 0
 
 
+@pytest.mark.parametrize("C", [64, 128, 256])
+def test_fused_layernorm_rows_with_a_large_mean(C):
+    """rows with |mean| >> std (x = 50 + 0.1 randn, as post-ReLU activations near the fp16 range are): a one-pass variance
+    sum(x^2) - C mean^2 cancels in fp32 and rstd is badly wrong.  The fused LayerNorm + Linear launches (C = 256: pcd_pw_wide_ln_linear; C <= 128:
+    pcd_sab_head_f16) compute the variance about the mean; against float64 from the fp16-rounded operands, with pcd_layernorm_f16 beside it."""
+    from shapegen_amd import _lib, ops
+    from shapegen_amd.networks import _PackedSAB
+    lib = _lib.load()
+    rows = 512
+    g = torch.Generator().manual_seed(1000 + C)
+    x = (50.0 + 0.1 * torch.randn(rows, C, generator=g)).half()
+    x[7] = (-300.0 + 0.5 * torch.randn(C, generator=g)).half()
+    x[8] = (0.02 * torch.randn(C, generator=g)).half()
+    sd = sab_sd(C)
+    w, b = sd["attention.in_proj_weight"].half(), sd["attention.in_proj_bias"]
+    ga, be = sd["ln1.weight"], sd["ln1.bias"]
+    xd = x.cuda()
+    if C == 256:
+        w, b = w[:256].contiguous(), b[:256].contiguous()
+        dev = lambda t: t.cuda().contiguous()
+        wd, bd, gd, bed = dev(w), dev(b), dev(ga), dev(be)
+        out = torch.full((rows, 256), float("nan"), dtype=torch.float16, device="cuda")
+        packed = torch.empty(lib.pcd_pw_wide_ln_linear_packed_bytes(1), dtype=torch.uint8, device="cuda")
+        _lib.check(lib.pcd_pw_wide_ln_linear_pack(wd.data_ptr(), bd.data_ptr(), 1, gd.data_ptr(), bed.data_ptr(), packed.data_ptr(), _lib.stream_ptr()))
+        _lib.check(lib.pcd_pw_wide_ln_linear(packed.data_ptr(), 1, 0, xd.data_ptr(), rows, out.data_ptr(), _lib.stream_ptr()))
+    else:
+        pk = _PackedSAB(sd, "", C, torch.device("cuda"))
+        desc = pk.fill(_lib.SabDesc())
+        out = torch.full((rows, 3 * C), float("nan"), dtype=torch.float16, device="cuda")
+        _lib.check(lib.pcd_sab_head_f16(C, desc.tail_packed, xd.data_ptr(), rows, out.data_ptr(), _lib.stream_ptr()))
+    ln = torch.nn.functional.layer_norm(x.double(), (C,), ga.double(), be.double(), 1e-5)
+    want = ln.half().double() @ w.double().T + b.double()
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    err = rel_l2(got, want)
+    err_ln = rel_l2(ops.layernorm_f16(xd, ga.cuda(), be.cuda()).cpu().double(), ln)          # the unfused kernel on the same rows
+    print(f"C = {C}: fused LayerNorm + Linear on large-mean rows rel-L2 {err:.2e} (pcd_layernorm_f16 alone {err_ln:.2e})")
+    assert err < 2e-3 and err_ln < 2e-3
+
+
 def test_set_attention_block_256_layernorm_in_the_linear_launches():
     """C = 256: LN1 + in_proj and LN2 + ff.0 as one launch each (default where rows % 256 == 0) against the separate launches and the oracle."""
     from shapegen_amd import _lib

@@ -152,6 +152,85 @@ def test_gemm_colmax_with_fragment_order_weights_exact(ops):
     assert torch.equal(on, off)
 
 
+def test_gemm_store_with_fragment_order_weights_exact(ops):
+    """gemm_xs_kernel (round 5: the store GEMMs of the point U-Net with K >= 512: weights straight from global memory, 5 / 6 of a wave's sixteen 1-KB output
+    chunks stored from the epilogue, 11 / 10 parked in LDS and stored one / two per K tile of the NEXT output tile, every vmcnt wait counted over LDS-DMA
+    pieces, asm weight loads and asm stores): exact on small integers and bitwise pcd_gemm_f16's output -- both drip rates (nk >= 12 and 6 <= nk < 12), one
+    / two / eight output tiles per workgroup (the last tile of a workgroup stores all sixteen chunks itself), two K sources, per-shape bias, no bias, no
+    ReLU; every launch repeated (a miscounted wait or a drip slot overwritten early shows as rows that differ between launches or from the reference)."""
+    from shapegen_amd import _lib
+    lib = _lib.load()
+    assert lib.pcd_gemm_store_wfrag_enabled() == 1
+    g = torch.Generator(device="cuda").manual_seed(12)
+    cases = [  # m, k1, k2, c, rows_per_shape of a per-shape bias (0: none), bias, relu
+        (65536, 1024, 0, 256, 0, True, True),         # 256 tiles: one per workgroup (all chunks direct), R = 1
+        (65536, 1024, 0, 512, 2048, True, True),      # 512 tiles: the first tile drips, per-shape bias
+        (32768, 512, 512, 2048, 0, True, True),       # two K sources, 1024 tiles: four per workgroup
+        (131072, 512, 0, 1024, 0, True, True),        # R = 2 (8 K tiles), eight tiles per workgroup
+        (65536, 384, 0, 512, 0, False, False),        # R = 2 at its smallest K (6 K tiles), no bias, no ReLU: negative outputs survive
+        (65536, 768, 0, 512, 512, True, False),       # nk = 12: R = 1 at its smallest K
+    ]
+    for m, k1, k2, c, rps, has_bias, relu in cases:
+        a1 = torch.randint(-3, 4, (m, k1), generator=g, device="cuda").half()
+        a2 = torch.randint(-3, 4, (m, k2), generator=g, device="cuda").half() if k2 else None
+        w = torch.randint(-2, 3, (c, k1 + k2), generator=g, device="cuda").half()
+        bias = torch.randint(-3, 4, (c,), generator=g, device="cuda").float() if has_bias else None
+        sb = torch.randint(-3, 4, (m // rps, c), generator=g, device="cuda").float() if rps else None
+        wfrag = torch.empty_like(w)
+        _lib.check(lib.pcd_gemm_pack_wfrag(w.data_ptr(), k1 + k2, k1 + k2, c, wfrag.data_ptr(), _lib.stream_ptr()))
+        d = ops._desc(a1, w, bias, a2, sb, rps, relu=relu)
+        ref = ops.gemm_f16(a1, w, bias, a2, sb, rps, relu)                      # gemm_xp_kernel / the generic kernel
+        pick = torch.cat([torch.arange(0, 512), torch.arange(m // 2 - 256, m // 2 + 256), torch.arange(m - 512, m)]).cuda()
+        want = (torch.cat([a1, a2], 1) if k2 else a1)[pick].float() @ w.float().t()
+        if has_bias:
+            want = want + bias
+        if rps:
+            want = want + sb[pick // rps]
+        want = (want.clamp_min(0) if relu else want).clamp(-65504, 65504).half()
+        assert torch.equal(ref[pick], want), (m, k1, k2, c, "reference kernel")
+        for rep in range(3):
+            out = torch.full((m, c), float("nan"), dtype=torch.float16, device="cuda")
+            _lib.check(lib.pcd_gemm_f16_wfrag(d, wfrag.data_ptr(), out.data_ptr(), c, _lib.stream_ptr()), "gemm_f16_wfrag")
+            assert torch.equal(out, ref), (m, k1, k2, c, rep, int((out != ref).any(1).sum()))
+        if not relu:
+            assert float(out.min()) < 0
+    # random fp16 operands (every bit of the fp32 sums matters): bitwise the LDS-staged kernel, at the U-Net's widest store layer
+    a = torch.randn(131072, 1024, generator=g, device="cuda").clamp_min(0).half()
+    w = (torch.randn(2048, 1024, generator=g, device="cuda") / 32).half()
+    bias = torch.randn(2048, generator=g, device="cuda") * 0.1
+    wfrag = torch.empty_like(w)
+    _lib.check(lib.pcd_gemm_pack_wfrag(w.data_ptr(), 1024, 1024, 2048, wfrag.data_ptr(), _lib.stream_ptr()))
+    d = ops._desc(a, w, bias, relu=True)
+    ref = ops.gemm_f16(a, w, bias, relu=True)
+    out = torch.empty_like(ref)
+    for rep in range(5):
+        out.fill_(float("nan"))
+        _lib.check(lib.pcd_gemm_f16_wfrag(d, wfrag.data_ptr(), out.data_ptr(), 2048, _lib.stream_ptr()))
+        assert torch.equal(out, ref), rep
+    # a shape the kernel does not take runs pcd_gemm_f16's kernels from the same entry point (fewer than 256 tiles; K = 128)
+    a = torch.randint(-3, 4, (8192, 128), generator=g, device="cuda").half()
+    w = torch.randint(-2, 3, (256, 128), generator=g, device="cuda").half()
+    d = ops._desc(a, w, None, relu=True)
+    out = torch.empty(8192, 256, dtype=torch.float16, device="cuda")
+    _lib.check(lib.pcd_gemm_f16_wfrag(d, w.data_ptr(), out.data_ptr(), 256, _lib.stream_ptr()))
+    assert torch.equal(out, ops.gemm_f16(a, w, None, relu=True))
+    # the U-Net forward with the kernel on (default) and off: bit-identical
+    from shapegen_amd.diffusion import PointCloudDiffusion
+    from helpers import point_sd
+    model = PointCloudDiffusion(num_points=2048)
+    model.load_state_dict(point_sd(), strict=True)
+    model = model.to("cuda").eval()
+    x, t = torch.randn(16, 2048, 3, generator=torch.Generator().manual_seed(3)).cuda(), torch.rand(16, generator=torch.Generator().manual_seed(4)).cuda()
+    on = model.model(x, t).clone()
+    lib.pcd_gemm_set_config(10)
+    try:
+        assert lib.pcd_gemm_store_wfrag_enabled() == 0
+        off = model.model(x, t).clone()
+    finally:
+        lib.pcd_gemm_set_config(11)
+    assert torch.equal(on, off)
+
+
 def test_gemm_dual_source_shape_bias_residual(ops):
     m, k1, k2, c, rps = 384, 128, 64, 136, 96
     a1, a2, w = _int_mat(m, k1, 4), _int_mat(m, k2, 5), _int_mat(c, k1 + k2, 6)
