@@ -343,9 +343,11 @@ def attention_roofline(device, launches=100):
         m2, a2, k2 = run(chan, launches, 200)
         by_d[str(chan // ATT_HEADS)] = {"achieved": a2, "frac": a2 / MFMA_F16_DENSE_PEAK_TFLOPS, "avg_launch_ms": m2, "kernel": k2,
                                         "note": "exp-issue bound: <= ~42 % / ~21 % of the MFMA peak at d 32 / 16"}
+    busy, busy_head, busy_stale = measured_mfma_busy("set_attention_sp_kernel", "attention.hip")
     return {"bound": "mfma", "kernel": kname + " (QK^T, softmax, PV; d_head 64; software-pipelined, 2 query blocks per wave)",
             "achieved": achieved, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": None,
+            "mfma_busy": busy, "mfma_busy_measured_at": busy_head, "mfma_busy_stale": busy_stale,
             "avg_launch_ms": ms, "launches_timed": launches, "flop_per_launch": ATT_FLOP_PER_LAUNCH,
             "shape": {"batch": B_PER_GPU, "points": N_POINTS, "channels": ATT_C, "heads": ATT_HEADS}, "by_d": by_d}
 
@@ -371,6 +373,18 @@ def measured_traffic():
     now = _sha16(os.path.join(ROOT, "3d-shape-generation_amd", "csrc", "gemm_f16.hip"))
     stale = rec.get("kernel_source_sha16") is None or rec.get("kernel_source_sha16") != now
     return rec.get("hbm_bytes_per_launch"), rec.get("git_head"), stale
+
+
+def measured_mfma_busy(kernel, source):
+    """MFMA-pipe utilisation of `kernel` from the committed SQ-counter recipe (tools/pmc_sq.sh -> profiles/sq_pmc_latest.json), with the same staleness rule as
+    `measured_traffic`: (fraction, git_head, stale)."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "sq_pmc_latest.json")))
+        k = rec["kernels"][kernel]
+    except Exception:
+        return None, None, None
+    now = _sha16(os.path.join(ROOT, "3d-shape-generation_amd", "csrc", source))
+    return k.get("mfma_busy"), rec.get("git_head"), (k.get("kernel_source_sha16") != now)
 
 
 LATENT_WEIGHT_BYTES = 38174720.0              # SURVEY 8(d): 19 087 360 fp16 weights streamed per latent step
@@ -490,10 +504,11 @@ def latent_rooflines(legs):
 def gf3_roofline(gf3_ms, launches, how=None):
     achieved = GF3_FLOP_PER_LAUNCH / (gf3_ms * 1e-3) / 1e12
     traffic, traffic_head, stale = measured_traffic()
+    busy, busy_head, busy_stale = measured_mfma_busy("gemm_xw_kernel", "gemm_f16.hip")
     r = {"bound": "mfma", "kernel": "gemm_xw_kernel = the 256x256 tile, 2x4 waves, persistent; activation panel through LDS, fragment-order weights straight from global memory (global_feat.3 2048->4096 + max over N)",
          "achieved": achieved, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
          "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": traffic, "traffic_measured_at": traffic_head,
-         "traffic_stale": stale, "avg_launch_ms": gf3_ms, "launches_timed": launches, "flop_per_launch": GF3_FLOP_PER_LAUNCH}
+         "traffic_stale": stale, "mfma_busy": busy, "mfma_busy_measured_at": busy_head, "mfma_busy_stale": busy_stale, "avg_launch_ms": gf3_ms, "launches_timed": launches, "flop_per_launch": GF3_FLOP_PER_LAUNCH}
     if how:
         r["measured"] = how
     return r

@@ -16,10 +16,28 @@ from shapegen_amd import dist as D  # noqa: E402
 from shapegen_amd.diffusion import PointCloudDiffusion  # noqa: E402
 
 
+def full_batch(rank, world):
+    """tests/test_gpu_full_batch.py: the G25 launch (64 x 2048, DDIM 50) as `world` shards; rank 0 saves the gathered clouds."""
+    from shapegen_amd import specs
+    B, N, T = 64, 2048, 50
+    model = PointCloudDiffusion(num_points=N)
+    model.load_state_dict(point_sd(), strict=True)
+    model = model.to("cuda").eval()
+    x_T = torch.from_numpy(specs.hash_normal("g25.xT", B * N * 3, 0).astype(np.float32).reshape(B, N, 3))
+    out = D.sample_sharded(model, B, N, T, x_T_global=x_T)
+    if rank == 0:
+        np.save(os.environ["DIST_OUT"], out.cpu().numpy())
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     torch.set_grad_enabled(False)
     rank, world, _ = D.init_from_env("gloo")
     torch.cuda.set_device(0)
+    if os.environ.get("DIST_CASE") == "g25":
+        return full_batch(rank, world)
     model = PointCloudDiffusion(num_points=128)
     model.load_state_dict(point_sd(), strict=True)
     model = model.to("cuda").eval()

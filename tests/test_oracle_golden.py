@@ -140,6 +140,18 @@ def test_ddim_sampler_at_baseline_point_count(golden):
     assert rel_l2(out, g["out"]) < 1e-5
 
 
+def test_ddim_sampler_rows_of_the_full_launch_batch(golden):
+    """G25 (`make_golden.py g25`): `sample(64, 2048, num_steps=50)` of the reference, start noise from the integer hash.  Shapes are independent in eval
+    mode, so the oracle re-runs three of the 64 on their own and must land on the reference's rows of the batched run."""
+    g = golden("point_b64.npz")
+    xT = torch.from_numpy(specs.hash_normal("g25.xT", 64 * 2048 * 3, 0).astype(np.float32).reshape(64, 2048, 3))
+    sd = point_sd()
+    rows = [0, 37, 63]
+    out = O.ddim_sample(lambda x, t: O.unet_pointnet_large(sd, "model.", x, t), xT[rows], 50)
+    for k, r in enumerate(rows):
+        assert rel_l2(out[k], g["out"][r]) < 1e-5, r
+
+
 def test_cfg4_launch_shape_rows(golden):
     """G17 (`make_golden.py cfg4`): the reference at BASELINE configs[3]'s shape, B = 32, T = 1000.  Every sample is
     independent (GroupNorm per sample, eval BatchNorm3d), so the oracle runs the four decoded rows only."""
