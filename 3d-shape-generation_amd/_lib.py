@@ -120,6 +120,7 @@ _SIGS = {
     "pcd_gemm_wfrag_enabled": (i32, []),
     "pcd_gemm_f16_wfrag": (i32, [C.POINTER(GemmDesc), vp, vp, i64, vp]),
     "pcd_gemm_store_wfrag_enabled": (i32, []),
+    "pcd_gemm_wfrag_stamps": (i32, [vp]),
     "pcd_gemm_set_config": (i32, [i32]),
     "pcd_fill_zero": (i32, [vp, sz, vp]),
     "pcd_f32_to_f16": (i32, [vp, vp, i64, vp]),

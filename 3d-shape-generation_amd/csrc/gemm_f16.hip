@@ -625,6 +625,7 @@ __device__ __forceinline__ half8 gload16_v(const half_t* g) {
     return v;
 }
 
+template <bool MID = false>
 __global__ __launch_bounds__(512) void gemm_xw_kernel(GemmParams p, const half_t* __restrict__ wfrag) {
     constexpr int NST = 4;                                 // the epilogue's atomics per wave (they count in vmcnt)
     constexpr int BM = 256, BN = 256, BKT = 64, ROWB = 128, WGN = 4;
@@ -690,6 +691,9 @@ __global__ __launch_bounds__(512) void gemm_xw_kernel(GemmParams p, const half_t
 
     int tile = blockIdx.x;
     if (tile >= tiles_mn) return;
+    // diagnostic (tools/bench_gemm_clock.py; p.out32 is unused by this epilogue): shader-clock and 100-MHz stamps around the workgroup's whole tile walk
+    unsigned long long stamp_c0 = 0, stamp_r0 = 0;
+    if (p.out32 != nullptr) { stamp_c0 = __builtin_amdgcn_s_memtime(); stamp_r0 = __builtin_amdgcn_s_memrealtime(); }
     int tm, tn;
     tile_coords(tile, tm, tn);
     int m0 = tm * BM, n0 = tn * BN;
@@ -723,8 +727,12 @@ __global__ __launch_bounds__(512) void gemm_xw_kernel(GemmParams p, const half_t
             __builtin_amdgcn_s_barrier();
             const bool last = kt + 1 == nk;
             const int mN = last ? m1 : m0, tnN = last ? tn1 : tn, ktN = last ? 0 : kt + 1;
-            stage(mN, ktN, (it + 1) & 1);
-            if (last) stage_bias(m1, n1, par ^ 1);
+            // (MID: the next K tile's activation pieces behind k step 0's MFMAs instead of right behind the barrier, where both waves of a SIMD would be issuing
+            // LDS-DMA pieces -- 60-180 cycles of issue each -- with the matrix pipe idle; same issue ORDER, so every counted wait keeps its count)
+            if constexpr (!MID) {
+                stage(mN, ktN, (it + 1) & 1);
+                if (last) stage_bias(m1, n1, par ^ 1);
+            }
             const half_t* wb = wbase(tnN, ktN);
             const char* base = smem + (it & 1) * STAGE_BYTES;
 #pragma unroll
@@ -740,6 +748,12 @@ __global__ __launch_bounds__(512) void gemm_xw_kernel(GemmParams p, const half_t
                     for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], wq[ks][j], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (MID) {
+                    if (ks == 0) {
+                        stage(mN, ktN, (it + 1) & 1);
+                        if (last) stage_bias(m1, n1, par ^ 1);
+                    }
+                }
                 // this k step's registers take the next K tile's fragments (the MFMAs that read them have been issued)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) wq[ks][j] = gload16_v(wb + (ks * 4 + j) * 512);
@@ -774,6 +788,11 @@ __global__ __launch_bounds__(512) void gemm_xw_kernel(GemmParams p, const half_t
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(wq[ks][j]));
+    if (p.out32 != nullptr && tid == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.out32) + blockIdx.x * 2;
+        o[0] = __builtin_amdgcn_s_memtime() - stamp_c0;
+        o[1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -802,7 +821,7 @@ __device__ __forceinline__ const half_t* uniform_ptr(const half_t* q) {
     return (const half_t*)(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v));
 }
 
-template <int R, bool ABL = false>
+template <int R, bool ABL = false, bool MID = false>
 __global__ __launch_bounds__(512) void gemm_xs_kernel(GemmParams p, const half_t* __restrict__ wfrag) {
     constexpr int NCH = 16;                                // 1-KB output chunks of a wave's 128 x 64 tile: chunk c = rows i = c / 2 (16 each), column pair c % 2
     constexpr int NDRIP = R == 1 ? 11 : 10;                // chunks parked in LDS, R of them stored per K tile of the next tile
@@ -925,7 +944,6 @@ __global__ __launch_bounds__(512) void gemm_xs_kernel(GemmParams p, const half_t
             const bool last = ktv + 1 == nk;
             const half_t* wnext;                           // this wave's fragments of the next K tile (of the next output tile behind the last one)
             if (!last) {
-                stage(r1, r2, ktv + 1, (it + 1) & 1);
                 wnext = wt + (int64_t)(ktv + 1) * 16384;
             } else {
                 int tm1 = tm, tn1 = tn;                    // without a next tile the look-ahead re-requests this tile's first K tile (harmless)
@@ -935,11 +953,16 @@ __global__ __launch_bounds__(512) void gemm_xs_kernel(GemmParams p, const half_t
                 r1 = p.a1 + (int64_t)m1 * lda;
                 r2 = p.a2 + (int64_t)m1 * lda - p.k1;
                 wt = wfrag + ((int64_t)tn1 * nk * 4 + wn) * 4096;
-                stage(r1, r2, 0, (it + 1) & 1);
-                stage_bias(m1, n1, par ^ 1);
                 wnext = wt;
             }
             wnext = uniform_ptr(wnext);
+            // the next K tile's activation pieces (+ the next tile's bias rows): at the top of the K tile, or (MID) behind k step 0's MFMAs -- an LDS-DMA piece
+            // holds its wave's issue for 60-180 cycles, and right behind the barrier BOTH waves of a SIMD would be issuing pieces with the matrix pipe idle
+            auto request_next = [&]() __attribute__((always_inline)) {
+                stage(r1, r2, last ? 0 : ktv + 1, (it + 1) & 1);
+                if (last) stage_bias(m1, n1, par ^ 1);
+            };
+            if constexpr (!MID) request_next();
             const char* base = smem + (it & 1) * STAGE_BYTES;
             const bool dripping = dnext < NDRIP;
             u32x4_t dv;                                    // (R = 2: the second chunk is read once the first has been stored -- the same four registers)
@@ -962,6 +985,7 @@ __global__ __launch_bounds__(512) void gemm_xs_kernel(GemmParams p, const half_t
                     for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[ks][j], af[i], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (MID) { if (ks == 0) request_next(); }
                 wload4(wq[ks], wnext + ks * 2048);         // this k step's registers take the next K tile's fragments (the MFMAs that read them have been issued)
                 if (ks == 0 && dripping) {
 #pragma unroll
@@ -1051,6 +1075,8 @@ __global__ __launch_bounds__(256) void gemm_pack_wfrag_kernel(const half_t* __re
     *(half8*)(out + idx * 8) = *(const half8*)(w + (int64_t)col * ldw + kt * 64 + ks * 32 + (lane >> 4) * 8);
 }
 
+static int g_xs_mid = 0;        // pcd_gemm_set_config(12) / (13): gemm_xs_kernel / gemm_xw_kernel request the next K tile's activation pieces at the top of a K tile / behind k step 0's MFMAs
+static void* g_wfrag_stamps = nullptr;
 static int g_xw = 1;            // tuning hook (pcd_gemm_set_config(8) / (9)): callers that hold a fragment-order weight copy use gemm_xw_kernel: off / on
 static int g_xs_abl = 0;        // timing ablations of gemm_xs_kernel (pcd_gemm_set_config(16 + bits)): see the kernel; outputs are wrong while set
 static int g_xs = 1;            // tuning hook (pcd_gemm_set_config(10) / (11)): pcd_gemm_f16_wfrag uses gemm_xs_kernel (output dripped through LDS): off / on
@@ -1295,7 +1321,9 @@ extern "C" int pcd_gemm_f16_colmax_wfrag(const pcd_gemm_desc_t* d, const void* w
     p.patch_pn = p.patch_xn = 0;
     const int pn = p.tiles_n >= 8 ? 8 : p.tiles_n, xn = p.tiles_n >= 16 ? 2 : 1;
     if ((pn & (pn - 1)) == 0 && p.tiles_n % (xn * pn) == 0 && p.tiles_m % ((8 / xn) * (32 / pn)) == 0) { p.patch_pn = pn; p.patch_xn = xn; }
-    hipLaunchKernelGGL(gemm_xw_kernel, dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
+    p.out32 = (float*)g_wfrag_stamps;
+    if (g_xs_mid) hipLaunchKernelGGL(gemm_xw_kernel<true>, dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
+    else hipLaunchKernelGGL(gemm_xw_kernel<false>, dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }
@@ -1330,19 +1358,25 @@ extern "C" int pcd_gemm_f16_wfrag(const pcd_gemm_desc_t* d, const void* wfrag, v
     if (g_xs_abl) {
         if (nk >= 12) hipLaunchKernelGGL((gemm_xs_kernel<1, true>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
         else hipLaunchKernelGGL((gemm_xs_kernel<2, true>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
+    } else if (g_xs_mid) {
+        if (nk >= 12) hipLaunchKernelGGL((gemm_xs_kernel<1, false, true>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
+        else hipLaunchKernelGGL((gemm_xs_kernel<2, false, true>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
     } else if (nk >= 12) hipLaunchKernelGGL((gemm_xs_kernel<1, false>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
     else hipLaunchKernelGGL((gemm_xs_kernel<2, false>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }
 
+// diagnostic: the next pcd_gemm_f16_colmax_wfrag launches write (shader cycles, 100-MHz ticks) of each workgroup's tile walk to stamps[256][2] (u64); NULL = off
+extern "C" int pcd_gemm_wfrag_stamps(void* stamps) { g_wfrag_stamps = stamps; return PCD_OK; }
 extern "C" int pcd_gemm_wfrag_enabled(void) { return g_xw; }
 extern "C" int pcd_gemm_store_wfrag_enabled(void) { return g_xs; }
 
 extern "C" int pcd_gemm_set_config(int cfg) {
     PCD_CHECK_ARG(cfg >= -1 && cfg <= 31);
     if (cfg >= 16) { g_xs_abl = cfg - 16; return PCD_OK; }                          // timing ablations of gemm_xs_kernel (dev tools only)
-    PCD_CHECK_ARG(cfg <= 11);
+    PCD_CHECK_ARG(cfg <= 13);
+    if (cfg >= 12) { g_xs_mid = cfg - 12; return PCD_OK; }
     if (cfg >= 10) { g_xs = cfg - 10; return PCD_OK; }                              // A/B switch of gemm_xs_kernel (pcd_gemm_f16_wfrag)
     if (cfg >= 8) { g_xw = cfg - 8; return PCD_OK; }                                // A/B switch of gemm_xw_kernel (pcd_gemm_wfrag_enabled)
     if (cfg >= 5) { g_xp = cfg == 5 ? 0 : (cfg == 6 ? 2 : 1); return PCD_OK; }      // A/B switch of gemm_xp_kernel; the tile choice is left as it is

@@ -97,11 +97,16 @@ int pcd_gemm_wfrag_enabled(void);
  * kernels run.  Bitwise the same output either way.  pcd_gemm_set_config(10) / (11): that kernel off / on (default on); pcd_gemm_store_wfrag_enabled reads it. */
 int pcd_gemm_f16_wfrag(const pcd_gemm_desc_t* d, const void* wfrag, void* out, int64_t ldo, void* stream);
 int pcd_gemm_store_wfrag_enabled(void);
+/* diagnostic (dev tools): the following pcd_gemm_f16_colmax_wfrag launches write, per workgroup, (shader-clock cycles, 100-MHz ticks) of its whole tile walk to
+ * stamps[256][2] (uint64, device memory); NULL switches it off.  In-kernel clock = cycles / ticks x 100 MHz (MI355X_MICROARCH.md, DVFS item 6). */
+int pcd_gemm_wfrag_stamps(void* stamps);
 /* tuning/benchmark hook: force a tile configuration for every following GEMM launch of this
  * process (-1 = shape heuristic; 0: 128x64, 1: 128x128, 2: 256x128 3-stage, 3: 256x256, 4: 128x128 3-stage).
  * 5 / 7 / 6 leave the tile choice alone and switch the 256x256 store / column-max kernel that requests the next tile's first
  * K tile(s) before the epilogue's stores (whole tiles only): off / one K tile ahead (default) / two (store epilogue only).
  * 8 / 9: pcd_gemm_wfrag_enabled() off / on (default on).  10 / 11: pcd_gemm_store_wfrag_enabled() off / on (default on).
+ * 12 / 13: the fragment-order kernels request a K tile's LDS-DMA pieces at its top (default) / behind its first 32 MFMAs (measured: 14 % slower; kept as the
+ * experiment that shows the K loop waits on those pieces).  16 + bits: timing ablations of gemm_xs_kernel.
  * TEST / BENCHMARK ONLY: process-global, read by every handle at every launch -- not for use while another thread is launching. */
 int pcd_gemm_set_config(int cfg);
 

@@ -35,10 +35,16 @@ for K, C, n in [(1024, 2048, 1), (1024, 1024, 2), (1024, 512, 2), (512, 1024, 1)
     _lib.check(lib.pcd_gemm_f16_wfrag(d, wfrag.data_ptr(), out.data_ptr(), C, _lib.stream_ptr()))
     same = torch.equal(out, ref)
     t_s = ev(lambda: lib.pcd_gemm_f16_wfrag(d, wfrag.data_ptr(), out.data_ptr(), C, _lib.stream_ptr()))
+    lib.pcd_gemm_set_config(13)        # the next K tile's activation pieces requested behind k step 0's MFMAs instead of at the top of the K tile
+    out.zero_()
+    _lib.check(lib.pcd_gemm_f16_wfrag(d, wfrag.data_ptr(), out.data_ptr(), C, _lib.stream_ptr()))
+    same_mid = torch.equal(out, ref)
+    t_m = ev(lambda: lib.pcd_gemm_f16_wfrag(d, wfrag.data_ptr(), out.data_ptr(), C, _lib.stream_ptr()))
+    lib.pcd_gemm_set_config(12)
     t_p = ev(lambda: lib.pcd_gemm_f16(d, out.data_ptr(), C, _lib.stream_ptr()))
     tot_s += n * t_s; tot_p += n * t_p
     fl = 2.0 * M * K * C
-    print(f"K={K:5d} C={C:5d}: gemm_xs_kernel {t_s:8.1f} us {fl / t_s / 1e6:6.0f} TF/s | gemm_xp_kernel {t_p:8.1f} us {fl / t_p / 1e6:6.0f} TF/s | bitwise equal {same}", flush=True)
+    print(f"K={K:5d} C={C:5d}: gemm_xs_kernel {t_s:8.1f} us {fl / t_s / 1e6:6.0f} TF/s | mid-tile requests {t_m:8.1f} us {fl / t_m / 1e6:6.0f} TF/s (equal {same_mid}) | gemm_xp_kernel {t_p:8.1f} us {fl / t_p / 1e6:6.0f} TF/s | bitwise equal {same}", flush=True)
     del a, w, out, ref
 print(f"the ten store GEMMs of one forward: gemm_xs_kernel {tot_s:8.1f} us | gemm_xp_kernel {tot_p:8.1f} us", flush=True)
 if "--forward" in sys.argv:

@@ -34,6 +34,11 @@ for M, K, C in [(131072, 2048, 4096), (131072, 1024, 2048), (131072, 512, 512)]:
     ref = ops.gemm_f16_colmax(a, w, bias, 2048)
     same = torch.equal(out, ref)
     t_w = ev(lambda: lib.pcd_gemm_f16_colmax_wfrag(d, wfrag.data_ptr(), out.data_ptr(), 2048, _lib.stream_ptr()))
+    lib.pcd_gemm_set_config(13)        # activation pieces of the next K tile requested behind k step 0's MFMAs
+    xw()
+    same_mid = torch.equal(out, ref)
+    t_m = ev(lambda: lib.pcd_gemm_f16_colmax_wfrag(d, wfrag.data_ptr(), out.data_ptr(), 2048, _lib.stream_ptr()))
+    lib.pcd_gemm_set_config(12)
     t_p = ev(lambda: lib.pcd_gemm_f16_colmax(d, out.data_ptr(), 2048, _lib.stream_ptr()))
     fl = 2.0 * M * K * C
-    print(f"M={M} K={K} C={C}: weights from global {t_w:8.1f} us {fl / t_w / 1e6:6.0f} TF/s | gemm_xp_kernel {t_p:8.1f} us {fl / t_p / 1e6:6.0f} TF/s | bitwise equal {same}", flush=True)
+    print(f"M={M} K={K} C={C}: weights from global {t_w:8.1f} us {fl / t_w / 1e6:6.0f} TF/s | mid-tile requests {t_m:8.1f} us {fl / t_m / 1e6:6.0f} TF/s (equal {same_mid}) | gemm_xp_kernel {t_p:8.1f} us {fl / t_p / 1e6:6.0f} TF/s | bitwise equal {same}", flush=True)
