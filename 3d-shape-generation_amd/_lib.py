@@ -56,7 +56,7 @@ class SabDesc(C.Structure):
     _fields_ = [("dim", i32), ("w_in", vp), ("b_in", vp), ("w_out", vp), ("b_out", vp),
                 ("ln1_g", vp), ("ln1_b", vp), ("ln2_g", vp), ("ln2_b", vp),
                 ("w_ff1", vp), ("b_ff1", vp), ("w_ff2", vp), ("b_ff2", vp),
-                ("ln_in_packed", vp), ("ln_ff1_packed", vp), ("tail_packed", vp)]
+                ("ln_in_packed", vp), ("ln_ff1_packed", vp), ("ffn_packed", vp), ("tail_packed", vp)]
 
 
 PCD_ATTN_UNET_NLIN, PCD_ATTN_UNET_NSAB, PCD_ATTN_UNET_NEMB, PCD_ATTN_UNET_TB = 14, 7, 6, 704
@@ -230,6 +230,10 @@ _SIGS = {
     "pcd_pw_wide_ln_linear_pack": (i32, [vp, vp, i32, vp, vp, vp, vp]),
     "pcd_pw_wide_ln_linear_supported": (i32, [i32, i64]),
     "pcd_pw_wide_ln_linear": (i32, [vp, i32, i32, vp, i64, vp, vp]),
+    "pcd_wide_ffn_packed_bytes": (sz, []),
+    "pcd_wide_ffn_supported": (i32, [i32, i64]),
+    "pcd_wide_ffn_pack": (i32, [vp, vp, vp, vp, vp, vp, vp, vp]),
+    "pcd_wide_ffn_f16": (i32, [vp, vp, i64, vp, vp]),
     "pcd_sab_tail_packed_bytes": (sz, [i32]),
     "pcd_sab_tail_supported": (i32, [i32, i64]),
     "pcd_sab_tail_pack": (i32, [C.POINTER(SabDesc), vp, vp]),

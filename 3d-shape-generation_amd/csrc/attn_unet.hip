@@ -67,6 +67,8 @@ static int sab_run(const pcd_sab_desc_t& d, const void* x, int batch, int n, int
     if (fused128)
         return pcd_sab_tail_bias_f16(C, d.tail_packed, t2, x, m, rps, pre_e, post_e, estride, y, s);                   // C <= 128: the rest of the block as one launch (sab_tail.hip)
     RUN(gemm(t2, C, nullptr, 0, d.w_out, d.b_out, 0, m, C, x, t1, s));               // x + out_proj(.)
+    if (d.ffn_packed != nullptr && pcd_sab_tail_enabled() && pcd_wide_ffn_supported(C, m))
+        return pcd_wide_ffn_f16(d.ffn_packed, t1, m, y, s);                              // C = 256: LN2 + FFN + residual as one launch (wideffn.hip), no hidden tensor
     if (lnlin && d.ln_ff1_packed != nullptr) {
         RUN(pcd_pw_wide_ln_linear(d.ln_ff1_packed, 4, 1, t1, m, ffh, s));                // LN2 + Linear(C,4C) + ReLU
     } else {

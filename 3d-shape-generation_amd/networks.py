@@ -327,6 +327,7 @@ class _PackedSAB:
         self.w_ff2, self.b_ff2 = devw(g("ff.2.weight"), dev), _dev32(g("ff.2.bias"), dev)
         self.tail = None
         self.lnlin = None
+        self.ffn = None
         self.f32 = f32
 
     def fill(self, d: "_lib.SabDesc") -> "_lib.SabDesc":
@@ -334,7 +335,7 @@ class _PackedSAB:
         for k in ("w_in", "b_in", "w_out", "b_out", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "w_ff1", "b_ff1", "w_ff2", "b_ff2"):
             setattr(d, k, getattr(self, k).data_ptr())
         d.tail_packed = None
-        d.ln_in_packed = d.ln_ff1_packed = None
+        d.ln_in_packed = d.ln_ff1_packed = d.ffn_packed = None
         packed_now = False
         # C <= 128, fp16: the block's tail (out_proj + residual + LN2 + FFN + residual) as one launch needs its weights in fragment-order stage images
         lib = _lib.load()
@@ -357,6 +358,13 @@ class _PackedSAB:
                 self.lnlin = bufs
                 packed_now = True
             d.ln_in_packed, d.ln_ff1_packed = self.lnlin[0].data_ptr(), self.lnlin[1].data_ptr()
+            # ... and LN2 + ff.0 + ReLU + ff.2 + residual as ONE launch (csrc/wideffn.hip): the 4C-wide hidden tensor is never written
+            if self.ffn is None:
+                self.ffn = torch.empty(lib.pcd_wide_ffn_packed_bytes(), dtype=torch.uint8, device=self.w_out.device)
+                _lib.check(lib.pcd_wide_ffn_pack(self.w_ff1.data_ptr(), self.b_ff1.data_ptr(), self.w_ff2.data_ptr(), self.b_ff2.data_ptr(),
+                                                 self.ln2_g.data_ptr(), self.ln2_b.data_ptr(), self.ffn.data_ptr(), _lib.stream_ptr()), "wide_ffn_pack")
+                packed_now = True
+            d.ffn_packed = self.ffn.data_ptr()
         if packed_now:
             # the images were written by pack kernels on the CURRENT stream; a forward enqueued on another stream (a side stream, a capture) must find them
             # complete: one synchronisation per model packing

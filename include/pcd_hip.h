@@ -575,10 +575,20 @@ typedef struct {
     const void* w_ff2; const float* b_ff2;           /* ff.2 [C][4C] */
     const void* ln_in_packed; const void* ln_ff1_packed;   /* optional (dim 256): pcd_pw_wide_ln_linear_pack images of (ln1, in_proj: 3 passes) and
                                                       * (ln2, ff.0: 4 passes): pcd_sab_forward then runs LN + Linear as one launch each when rows % 256 == 0 */
+    const void* ffn_packed;                          /* optional (dim 256): pcd_wide_ffn_pack's image of ln2, ff.0, ff.2: LN2 + Linear + ReLU + Linear + residual as ONE launch
+                                                      * (csrc/wideffn.hip; the 4C-wide hidden tensor is never written); rows % 128 == 0 */
     const void* tail_packed;                         /* optional (dim 64 / 128): pcd_sab_tail_pack's image of w_out .. b_ff2; pcd_sab_forward then runs
                                                       * out_proj + residual + LN2 + FFN + residual as ONE launch when rows % 256 == 0.  NULL: four launches.
                                                       * Ignored by the fp32 parity entry points */
 } pcd_sab_desc_t;
+/* The feed-forward half of the block at dim 256 as one launch (csrc/wideffn.hip; reference networks.py:62-68, 82):  y = x1 + W2 relu(W1 LN2(x1) + b1) + b2,
+ * x1, y fp16 [rows][256] (y may not alias x1), rows % 128 == 0.  Two waves share 32 points and split the channels of both products, the 1024-wide hidden row lives in
+ * registers / LDS 128 channels at a time, only the weights stream (pcd_wide_ffn_pack: 32 fragment-order stage images + b1 | b2 | gamma | beta,
+ * pcd_wide_ffn_packed_bytes() bytes).  w1 [1024][256], w2 [256][1024] fp16; biases and the LayerNorm affine fp32. */
+size_t pcd_wide_ffn_packed_bytes(void);
+int pcd_wide_ffn_supported(int dim, int64_t rows);
+int pcd_wide_ffn_pack(const void* w1, const float* b1, const void* w2, const float* b2, const float* ln_g, const float* ln_b, void* packed, void* stream);
+int pcd_wide_ffn_f16(const void* packed, const void* x, int64_t rows, void* y, void* stream);
 /* bytes of scratch one block needs for `rows` = B*N points */
 size_t pcd_sab_workspace_bytes(int64_t rows, int dim);
 /* the block's tail behind the attention kernel as one launch (csrc/sab_tail.hip; reference networks.py:78-83, the second half of SetAttentionBlock.forward):

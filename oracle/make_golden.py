@@ -46,6 +46,7 @@ POINT_GAIN = 1.3
 LATENT_GAIN = 1.3
 VAE_GAIN = 1.3
 ATTN_GAIN = 1.0
+ATTN_DDPM_GAIN = 0.6
 
 
 def T(sd):
@@ -366,7 +367,11 @@ def capture_attention_t1000(rd, rn, which):
     -> tests/golden/attention_t1000_{ddim,ddpm}.npz."""
     pcd = rd.PointCloudDiffusion(num_points=2048).eval()
     una = rn.UNetAttentionPointExperimental(2048).eval()
-    una.load_state_dict(T(specs.synth_state_dict(specs.unet_attention_spec(), seed=0, gain=ATTN_GAIN)), strict=True)
+    # g26b: with the gain every other attention fixture uses (1.0) the reference's DDPM loop over this untrained denoiser runs away (rms 3.8e3 at call 100, NaN before
+    # call 900: SURVEY A.9; a first capture recorded exactly that).  At gain 0.6 the state stays at the scale the loop's own noise accumulation gives (rms ~ 350,
+    # eps rms ~ 0.5: the denoiser still matters), like G20b for the point denoiser.
+    gain = ATTN_DDPM_GAIN if which == "g26b" else ATTN_GAIN
+    una.load_state_dict(T(specs.synth_state_dict(specs.unet_attention_spec(), seed=0, gain=gain)), strict=True)
     pcd.model = una
     tag = which
     randn, randn_like, count = _hashed_draws(tag)
@@ -381,7 +386,7 @@ def capture_attention_t1000(rd, rn, which):
     h.remove()
     assert count[0] == (0 if which == "g26a" else 999)
     g = {"out": out.numpy(), "ckpt_calls": np.array(sorted(rec), np.int64), "ckpt_x": np.stack([rec[k] for k in sorted(rec)]),
-         "n_draws": np.int64(count[0]), "gain": np.float64(ATTN_GAIN)}
+         "n_draws": np.int64(count[0]), "gain": np.float64(gain)}
     name = "attention_t1000_ddim.npz" if which == "g26a" else "attention_t1000_ddpm.npz"
     print(which, "seconds", time.time() - t0, "|out| max", float(out.abs().max()), "rms", float(out.pow(2).mean().sqrt()),
           "finite", bool(torch.isfinite(out).all()))

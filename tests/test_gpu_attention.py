@@ -416,6 +416,46 @@ def test_fused_layernorm_rows_with_a_large_mean(C):
     assert err < 2e-3 and err_ln < 2e-3
 
 
+@pytest.mark.parametrize("rows", [128, 128 * 7, 128 * 600])
+def test_wide_ffn_one_launch_against_fp64(rows):
+    """pcd_wide_ffn_f16 (round 5, csrc/wideffn.hip): y = x1 + W2 relu(W1 LN2(x1) + b1) + b2 at C = 256 as ONE launch -- wave pairs share 32 points and split the
+    channels of both products, the 1024-wide hidden row exists 128 channels at a time in registers / LDS -- against float64 from the fp16-rounded operands with the
+    kernel's own rounding points (LayerNorm result, hidden activations and the FFN output rounded to fp16, then the fp16 residual add).  One to five tiles per
+    workgroup (600 tiles on 256 workgroups: uneven), bitwise repeatable, arguments checked."""
+    from shapegen_amd import _lib
+    lib = _lib.load()
+    sd = sab_sd(256)
+    g = torch.Generator().manual_seed(31 + rows)
+    x = (torch.randn(rows, 256, generator=g) * 1.4 + 0.2).half()
+    x[3] = (40.0 + 0.2 * torch.randn(256, generator=g)).half()                 # a row with |mean| >> std (two-pass variance)
+    w1, b1 = sd["ff.0.weight"].half(), sd["ff.0.bias"].float()
+    w2, b2 = sd["ff.2.weight"].half(), sd["ff.2.bias"].float()
+    ga, be = sd["ln2.weight"].float(), sd["ln2.bias"].float()
+    dev = lambda t: t.cuda().contiguous()
+    xd, w1d, b1d, w2d, b2d, gd, bd = dev(x), dev(w1), dev(b1), dev(w2), dev(b2), dev(ga), dev(be)
+    assert lib.pcd_wide_ffn_supported(256, rows) == 1 and lib.pcd_wide_ffn_supported(128, rows) == 0 and lib.pcd_wide_ffn_supported(256, rows + 64) == 0
+    packed = torch.empty(lib.pcd_wide_ffn_packed_bytes(), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.pcd_wide_ffn_pack(w1d.data_ptr(), b1d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(), gd.data_ptr(), bd.data_ptr(), packed.data_ptr(), _lib.stream_ptr()))
+    y = torch.full((rows, 256), float("nan"), dtype=torch.float16, device="cuda")
+    _lib.check(lib.pcd_wide_ffn_f16(packed.data_ptr(), xd.data_ptr(), rows, y.data_ptr(), _lib.stream_ptr()), "wide_ffn")
+    pick = torch.arange(rows) if rows <= 4096 else torch.cat([torch.arange(0, 512), torch.arange(rows // 2 - 256, rows // 2 + 256), torch.arange(rows - 512, rows)])
+    xp = x[pick].double()
+    ln = torch.nn.functional.layer_norm(xp, (256,), ga.double(), be.double(), 1e-5).half().double()
+    hid = torch.relu(ln @ w1.double().T + b1.double()).half().double()
+    want = ((hid @ w2.double().T + b2.double()).half().double() + xp).half().double()
+    got = y.cpu().double()
+    assert torch.isfinite(got).all()
+    err = rel_l2(got[pick] - xp, want - xp)                                     # on the FFN's own contribution, not on x1 + it
+    print(f"wide FFN, {rows} rows: rel-L2 of the FFN term {err:.2e}, of y {rel_l2(got[pick], want):.2e}")
+    assert err < 2e-3 and rel_l2(got[pick], want) < 1e-3
+    y2 = torch.empty_like(y)
+    for _ in range(3):
+        _lib.check(lib.pcd_wide_ffn_f16(packed.data_ptr(), xd.data_ptr(), rows, y2.data_ptr(), _lib.stream_ptr()))
+        assert torch.equal(y, y2)
+    assert lib.pcd_wide_ffn_f16(packed.data_ptr(), xd.data_ptr(), rows + 8, y.data_ptr(), _lib.stream_ptr()) != 0
+    assert lib.pcd_wide_ffn_f16(None, xd.data_ptr(), rows, y.data_ptr(), _lib.stream_ptr()) != 0
+
+
 def test_set_attention_block_256_layernorm_in_the_linear_launches():
     """C = 256: LN1 + in_proj and LN2 + ff.0 as one launch each (default where rows % 256 == 0) against the separate launches and the oracle."""
     from shapegen_amd import _lib

@@ -329,6 +329,26 @@ def test_t1000_ddpm_fixtures_last_step_with_the_oracle(golden):
     assert float(np.abs(golden("point_t1000_ddpm_stable.npz")["out"]).max()) < 5e3
 
 
+def test_attention_t1000_fixtures_last_step_with_the_oracle(golden):
+    """G26 (`make_golden.py g26a | g26b`): the reference's `sample` / `sample2` loops over `UNetAttentionPointExperimental` at (2, 2048), 1000 steps.  One oracle
+    forward from the stored call-999 state must land on the reference's returned cloud (diffusion.py:246, 283): the attention oracle pinned at the far end of the
+    horizon, on the DDIM fixture (gain 1.0) and on the DDPM fixture (gain 0.6, hashed draws)."""
+    from helpers import as_torch
+    for name, gain, ddpm in (("attention_t1000_ddim.npz", 1.0, False), ("attention_t1000_ddpm.npz", 0.6, True)):
+        g = golden(name)
+        assert float(g["gain"]) == gain and int(g["ckpt_calls"][-1]) == 999 and int(g["n_draws"]) == (999 if ddpm else 0)
+        tag = "g26b" if ddpm else "g26a"
+        xT = specs.hash_normal(f"{tag}.xT", 2 * 2048 * 3, 0).astype(np.float32).reshape(2, 2048, 3)
+        assert np.array_equal(g["ckpt_x"][0], xT)                      # the start noise the reference drew is the hashed tensor the GPU test rebuilds
+        sd = as_torch(specs.synth_state_dict(specs.unet_attention_spec(), seed=0, gain=gain))
+        x = torch.from_numpy(g["ckpt_x"][-1])
+        t = torch.zeros(2) if ddpm else torch.ones(2) - 999 * (1.0 / 1000)
+        n, s = O.offset_cosine_schedule(t)
+        out = O.remove_noise(x, O.unet_attention(sd, "", x, t), n, s)
+        assert np.isfinite(g["out"]).all()
+        assert rel_l2(out, g["out"]) < 2e-6, name
+
+
 def test_baseline_config0_as_ddpm_with_the_oracle(golden):
     """G22 (configs[0] through `sample2`: 512 points, 100 steps, batch 4, hashed per-step noise, weights at gain 1.0): the oracle's whole loop
     against the reference's returned cloud."""
