@@ -17,8 +17,10 @@ from shapegen_amd import specs
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 
-# measured (round 5, first run): see the test output; the fp32 mode follows the reference to a few 1e-6, the fp16 path to a few 1e-3 after 1000 dependent steps
-TOL = {"fp16": dict(rel=1e-2), "fp32": dict(rel=5e-5)}
+# the point path's bounds.  Measured (round 5): fp16 cloud rel-L2 4.5e-4 (DDIM) / 4.3e-4 (DDPM), |dCD| 2.8e-6 / 2.4e-5 against the 1e-4 gate, growing smoothly over the
+# horizon (3.8e-4 at call 100 -> 4.4e-4 at call 999; DDPM 1.9e-5 -> 4.3e-4); fp32 mode 2.2e-6 / 7.9e-7.  The per-forward 1.5e-3 of G24 does not compound: no hi / lo
+# weights were needed on this backbone.
+TOL = {"fp16": dict(rel=2e-3), "fp32": dict(rel=5e-5)}
 
 
 def hashed(tag, shape):
@@ -36,7 +38,9 @@ class HashedNoises:
 def build(gain, prec):
     from shapegen_amd.diffusion import PointCloudDiffusion
     m = PointCloudDiffusion(num_points=2048, backbone="attention")
-    m.load_state_dict(as_torch(specs.synth_state_dict(specs.unet_attention_spec(prefix="model."), seed=0, gain=gain)), strict=True)
+    # (the synthetic generator hashes the KEY: generate under the names the reference capture used -- `UNetAttentionPointExperimental`'s own -- then prefix)
+    sd = as_torch(specs.synth_state_dict(specs.unet_attention_spec(), seed=0, gain=gain))
+    m.load_state_dict({"model." + k: v for k, v in sd.items()}, strict=True)
     m = m.to("cuda").eval()
     m.model.set_precision(prec)
     return m

@@ -29,6 +29,8 @@ from shapegen_amd import specs
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 
+SINKHORN_REL = 3e-4        # Sinkhorn EMD of the reconstructed cloud against the reference's: 3 x the measured deviation (fp16 path 3.4e-5 ... 8.9e-5 over G21's four
+                           # samples, fp32 mode 1.6e-6 ... 7.5e-6); was 2 % until round 5
 TOL = {"fp16": dict(rel=2e-3, maxabs=None), "fp32": dict(rel=5e-5, maxabs=1e-3)}      # measured: fp16 9.8e-5 ... 3.1e-4, fp32 1.4e-6 ... 2.3e-6
 
 
@@ -224,6 +226,8 @@ def test_reconstruction_flow_with_metrics_at_2048_points(models, golden, prec):
         assert abs(emd - remd) < 1e-2 * remd
         assert abs(rec - rrec) <= 8 * 100.0 / 32768 + 1e-6
         _, semd, _ = (float(v) for v in M.compute_metrics(x0[i], out[i], use_approximate_gpu_emd=True))
-        assert abs(semd - g["triples_sinkhorn"][i][1]) < 2e-2 * abs(g["triples_sinkhorn"][i][1]) + 1e-5
+        sref = float(g["triples_sinkhorn"][i][1])
+        print(f"      sinkhorn emd {semd:.6f} / {sref:.6f}: relative deviation {abs(semd - sref) / abs(sref):.2e}")
+        assert abs(semd - sref) < SINKHORN_REL * abs(sref) + 1e-6
         cd1 = float(M.chamfer_distance(x0[i], out[i], 1))
         assert abs(cd1 - g["cd_s1"][i]) < 1e-4
