@@ -209,6 +209,9 @@ _SIGS = {
     "pcd_convt3d_last_sigmoid": (i32, [vp, i32, i32, i32, i32, i32, vp, f32, vp, vp]),
     "pcd_conv3d_config": (i32, [i32]),
     "pcd_conv3d_last_sigmoid": (i32, [vp, i32, i32, i32, i32, i32, vp, f32, vp, vp]),
+    "pcd_conv3d_last_packed_bytes": (sz, []),
+    "pcd_conv3d_last_pack": (i32, [vp, vp, vp]),
+    "pcd_conv3d_last_sigmoid_packed": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, f32, vp, vp]),
     "pcd_reparameterize": (i32, [vp, vp, vp, vp, i64, vp]),
     "pcd_vae_config": (i32, [i32]),
     "pcd_vae_create": (i32, [C.POINTER(VaeDesc), C.POINTER(vp)]),

@@ -1553,6 +1553,89 @@ __global__ __launch_bounds__(64 * TZ) void conv3d_last_halo8_kernel(const half_t
     out[(((int64_t)b * D + z0 + z) * H + y0 + y) * W + x0 + x] = 1.f / (1.f + expf(-a));
 }
 
+// fp32 weights [27][32] -> the MFMA A operand of every tap for conv3d_last_mfma8_kernel: [27][64 lanes][8 halfs]
+__global__ __launch_bounds__(64) void conv3d_last_pack_kernel(const float* __restrict__ w, half_t* __restrict__ wfrag) {
+    const int tap = blockIdx.x, lane = threadIdx.x, m = lane & 15, kq = lane >> 4;
+    half8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float wf = w[tap * 32 + kq * 8 + e];
+        const half_t hi = (half_t)wf;
+        const half_t lo = (half_t)(wf - (float)hi);
+        const half_t lo2 = (half_t)((wf - (float)hi) - (float)lo);
+        v[e] = m == 0 ? hi : (m == 1 ? lo : (m == 2 ? lo2 : (half_t)0.f));
+    }
+    *(half8*)(wfrag + (tap * 64 + lane) * 8) = v;
+}
+
+// The same 8 x 8 x 8 block with the 864 multiply-adds per voxel on the MATRIX pipe (round 5).  The layer has ONE output channel, so as a product it is
+// D[3][voxel] = Wt[3][K = 27 x 32] . X[K][voxel] with the three rows = the fp16 head of the fp32 weights and two successive fp16 rounding residuals (hi + lo + lo2: the
+// fp32 weights to their last bit, fp32 accumulation; the other 13 rows of the 16 x 16 x 32 MFMA are zeros -- wasted, and still 4 x faster than 864 v_fma_mix per voxel:
+// 108 MFMAs of 16 cycles per wave and 64 voxels against ~3500 VALU cycles).  A k step is one tap: the B operand of voxel n is its 32 input channels at the tap's
+// halo row (the same 16-byte LDS reads as the VALU form); the A operand of tap t is 1 KB of a fragment-order copy of the weights (pcd_conv3d_last_pack, made once).
+// Lanes 0-15 hold rows 0-2 (the three partial sums) of their voxel: out = sigmoid(hi + (lo + lo2) + bias).
+__global__ __launch_bounds__(512, 4) void conv3d_last_mfma8_kernel(const half_t* __restrict__ in, int B, int D, int H, int W, const half_t* __restrict__ wfrag,
+                                                                   float bias, float* __restrict__ out, int ntz, int nty, int ntx) {
+    constexpr int CIN = 32, RB = CIN * 2, P = RB + 16, CPR = RB / 16, T = 8, TZ = 8, HH = T + 2, ROWS = (TZ + 2) * HH * HH, NTH = 64 * TZ;
+    constexpr int HIT = (ROWS * CPR + NTH - 1) / NTH;
+    __shared__ __attribute__((aligned(16))) char smem[ROWS * P];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    int t = blockIdx.x;
+    const int tx = t % ntx; t /= ntx;
+    const int ty = t % nty; t /= nty;
+    const int tz = t % ntz; const int b = t / ntz;
+    const int z0 = tz * TZ, y0 = ty * T, x0 = tx * T;
+    {
+        half8 hv[HIT];
+#pragma unroll
+        for (int it = 0; it < HIT; ++it) {                       // every load of the halo in flight before the first LDS store
+            const int c = it * NTH + tid;
+            const int row = c / CPR, ch = c - row * CPR;
+            const int hx = row % HH; const int r2 = row / HH;
+            const int hy = r2 % HH, hz = r2 / HH;
+            const int iz = z0 - 1 + hz, iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+            const bool ok = row < ROWS && (unsigned)iz < (unsigned)D && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            hv[it] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (ok) hv[it] = *(const half8*)(in + ((((int64_t)b * D + iz) * H + iy) * W + ix) * CIN + ch * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < HIT; ++it) {
+            const int c = it * NTH + tid;
+            const int row = c / CPR, ch = c - row * CPR;
+            if (row < ROWS) *(half8*)(smem + row * P + ch * 16) = hv[it];
+        }
+    }
+    // A operand of tap t: wfrag[t][lane][8] (conv3d_last_pack_kernel: lane (m = lane & 15, k = 8 (lane >> 4) .. + 7), rows 0-2 = hi / lo / lo2, rows 3-15 zero),
+    // one coalesced 1-KB load per tap and wave from 27 KB that every workgroup reads (L1 / L2 resident)
+    const int m = lane & 15, kq = lane >> 4;
+    const half_t* wl = wfrag + lane * 8;
+    __syncthreads();
+    const int z = tid >> 6;                                       // the wave's z slice: 64 voxels = four groups of 16 (two x rows of 8 each)
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 3
+    for (int tap = 0; tap < 27; ++tap) {
+        const int toff = ((tap / 9) * HH + (tap / 3) % 3) * HH + tap % 3;
+        const half8 wa = *(const half8*)(wl + tap * 512);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int v = g * 16 + m, x = v & 7, y = v >> 3;
+            const half8 xb = *(const half8*)(smem + ((z * HH + y) * HH + x + toff) * P + kq * 16);
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, xb, acc[g], 0, 0, 0);
+        }
+    }
+    if (kq == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int v = g * 16 + m, x = v & 7, y = v >> 3;
+            const float a = (acc[g][0] + (acc[g][1] + acc[g][2])) + bias;
+            out[(((int64_t)b * D + z0 + z) * H + y0 + y) * W + x0 + x] = 1.f / (1.f + expf(-a));
+        }
+    }
+}
+
 // VAE3D's last layer (networks.py:2018-2019): ConvTranspose3d(CIN, 1, k3, s2, p1, output_padding 1) + Sigmoid.
 // o = 2 i - 1 + k per dimension: even o takes (k=1, i=o/2); odd o takes (k=0, i=(o+1)/2) and (k=2, i=(o-1)/2).
 // in fp16 NDHWC [B][D][H][W][CIN]; w fp32 [27][CIN] (tap-major); out fp32 [B][2D][2H][2W].
@@ -1712,12 +1795,13 @@ extern "C" int pcd_conv3d_f16(const pcd_conv3d_desc_t* d, void* stream) {
 }
 
 static int g_halo_tall = 1;          // tuning / testing hook (pcd_conv3d_config)
-static int g_last8 = 1;       // pcd_conv3d_config + 8: the 4 x 4 x 8 block form of the last layer instead of the 8 x 8 x 8 one
+static int g_last8 = 2;       // the last layer (Conv3d 32 -> 1 + sigmoid): 2 = 8 x 8 x 8 blocks on the matrix pipe (default), 1 = 8 x 8 x 8 on the VALU (pcd_conv3d_config
+                              // + 16), 0 = 4 x 4 x 8 blocks (+ 8)
 
 extern "C" int pcd_conv3d_config(int tall_halo_tiles) {
-    PCD_CHECK_ARG(tall_halo_tiles >= 0 && (tall_halo_tiles & 7) <= 2 && tall_halo_tiles < 16);
+    PCD_CHECK_ARG(tall_halo_tiles >= 0 && (tall_halo_tiles & 7) <= 2 && tall_halo_tiles < 32);
     g_halo_tall = tall_halo_tiles & 7;
-    g_last8 = (tall_halo_tiles & 8) ? 0 : 1;
+    g_last8 = (tall_halo_tiles & 8) ? 0 : ((tall_halo_tiles & 16) ? 1 : 2);
     return PCD_OK;
 }
 
@@ -1914,6 +1998,29 @@ extern "C" int pcd_conv3d_last_sigmoid(const void* in, int batch, int d, int h, 
         hipLaunchKernelGGL((conv3d_last_kernel<32>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0,
                            (hipStream_t)stream, (const half_t*)in, batch, d, h, w, wgt, bias, out);
     }
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+extern "C" size_t pcd_conv3d_last_packed_bytes(void) { return (size_t)27 * 64 * 8 * sizeof(half_t); }
+
+extern "C" int pcd_conv3d_last_pack(const float* wgt, void* wfrag, void* stream) {
+    PCD_CHECK_ARG(wgt && wfrag);
+    hipLaunchKernelGGL(conv3d_last_pack_kernel, dim3(27), dim3(64), 0, (hipStream_t)stream, wgt, (half_t*)wfrag);
+    PCD_CHECK_LAUNCH();
+    return PCD_OK;
+}
+
+// the same layer from pcd_conv3d_last_pack's copy of the weights, on the matrix pipe (d, h, w multiples of 8; otherwise, or with pcd_conv3d_config(+ 8 | + 16),
+// pcd_conv3d_last_sigmoid's kernels run from the fp32 weights)
+extern "C" int pcd_conv3d_last_sigmoid_packed(const void* in, int batch, int d, int h, int w, int cin, const float* wgt, const void* wfrag, float bias, float* out,
+                                              void* stream) {
+    PCD_CHECK_ARG(in && wgt && out && batch > 0 && d > 0 && h > 0 && w > 0 && cin == 32);
+    const int64_t total = (int64_t)batch * d * h * w;
+    if (wfrag == nullptr || g_last8 != 2 || d % 8 || h % 8 || w % 8 || total / 512 > 0x7fffffff)
+        return pcd_conv3d_last_sigmoid(in, batch, d, h, w, cin, wgt, bias, out, stream);
+    hipLaunchKernelGGL(conv3d_last_mfma8_kernel, dim3((unsigned)(total / 512)), dim3(512), 0, (hipStream_t)stream, (const half_t*)in, batch, d, h, w,
+                       (const half_t*)wfrag, bias, out, d / 8, h / 8, w / 8);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

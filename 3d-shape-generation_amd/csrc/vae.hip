@@ -22,6 +22,7 @@ struct pcd_vae {
     void* wf_dec5c2 = nullptr;
     void* wf_dec8c1 = nullptr;
     void* wf_dec8c2 = nullptr;
+    void* wf_last = nullptr;            // decoder.12's weights as MFMA A operands (pcd_conv3d_last_pack)
 };
 
 namespace pcd {
@@ -198,12 +199,25 @@ extern "C" int pcd_vae_create(const pcd_vae_desc_t* desc, pcd_vae_t** out) {
         }
         *pk.dst = buf;
     }
+    {   // decoder.12's weights as MFMA A operands (27 KB); a failure leaves the VALU form
+        hipPointerAttribute_t at;
+        int cur = -1;
+        void* buf = nullptr;
+        if (hipGetDevice(&cur) == hipSuccess && hipPointerGetAttributes(&at, desc->last_w) == hipSuccess && at.device == cur &&
+            hipMalloc(&buf, pcd_conv3d_last_packed_bytes()) == hipSuccess) {
+            if (pcd_conv3d_last_pack(desc->last_w, buf, nullptr) == PCD_OK && hipStreamSynchronize(nullptr) == hipSuccess) h->wf_last = buf;
+            else { (void)hipGetLastError(); (void)hipFree(buf); }
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     *out = h;
     return PCD_OK;
 }
 
 extern "C" void pcd_vae_destroy(pcd_vae_t* h) {
     if (h == nullptr) return;
+    if (h->wf_last) (void)hipFree(h->wf_last);
     for (void* b : {h->wf_enc2c1, h->wf_enc2c2, h->wf_enc5c1, h->wf_enc5c2, h->wf_dec5c1, h->wf_dec5c2, h->wf_dec8c1, h->wf_dec8c2, h->wf_dec9, h->wf_dec11c1, h->wf_dec11c2})
         if (b != nullptr) (void)hipFree(b);
     delete h;
@@ -297,7 +311,7 @@ extern "C" int pcd_vae_decode(pcd_vae_t* h, const float* z, int batch, float* ou
     RUN(R.conv(d.dec_conv9, x, 32, 1, d.taps3, 32, 1, nullptr, hb, nullptr, 0, h->wf_dec9));   // decoder.9/10  64 -> 32
     SWAP(x, hb);
     RUN(R.res(d.dec_res[3], x, 32, hb, r, h->wf_dec11c1, h->wf_dec11c2));         // decoder.11
-    RUN(pcd_conv3d_last_sigmoid(x, batch, 32, 32, 32, 32, d.last_w, d.last_b, out, s));   // decoder.12/13
+    RUN(pcd_conv3d_last_sigmoid_packed(x, batch, 32, 32, 32, 32, d.last_w, h->wf_last, d.last_b, out, s));   // decoder.12/13
     return PCD_OK;
 }
 #undef SWAP

@@ -439,8 +439,8 @@ int pcd_conv3d_f16_multi(const pcd_conv3d_desc_t* descs, int n, void* workspace,
                          void* stream);
 /* testing / tuning hook for pcd_conv3d_k3s1_f16 at C_in = 32, C_out <= 32: 0 = 128-row workgroups, 1 (default) = 256-row workgroups
  * (4 x 8 x 8 voxels, eight waves) where the grid has at least 512 of them, 2 = wherever H % 8 == 0 (tests).  Same bits.
- * + 8: pcd_conv3d_last_sigmoid on 4 x 4 x 8 output blocks instead of 8 x 8 x 8 (the same sums in the same order per voxel up to the split of
- * the taps over two threads: results agree to 1e-6). */
+ * pcd_conv3d_last_sigmoid: default = 8 x 8 x 8 output blocks on the matrix pipe (the fp32 weights as fp16 hi + lo + lo2 rows); + 16: the same blocks on the
+ * VALU (fp32 weights); + 8: 4 x 4 x 8 blocks on the VALU.  The three forms agree to 1e-6.  TEST / BENCHMARK ONLY: process-global. */
 int pcd_conv3d_config(int tall_halo_tiles);
 /* Conv3d(k3, stride 1, pad 1) (+ folded BN, residual, ReLU) with the input halo of a 4x4x8 output block held in
  * LDS and reused by all 27 taps -- the 32^3 layers of VAE3DLarge (encoder.2, decoder.8-11; networks.py:2227,
@@ -486,6 +486,12 @@ int pcd_conv3d_first(const float* x, int batch, int d, int h, int w, int stride,
 /* decoder.12 + decoder.13: Conv3d(32, 1, k3, p1) + Sigmoid -> fp32 [B][D][H][W]; w fp32 [27][cin]. */
 int pcd_conv3d_last_sigmoid(const void* in, int batch, int d, int h, int w, int cin, const float* wgt,
                             float bias, float* out, void* stream);
+/* the same layer on the matrix pipe: wfrag = pcd_conv3d_last_pack's copy of wgt (pcd_conv3d_last_packed_bytes() bytes: the fp32 weights as fp16 hi / lo / lo2 rows of
+ * the MFMA A operand of every tap); d, h, w multiples of 8, otherwise (or wfrag NULL, or pcd_conv3d_config + 8 / + 16) pcd_conv3d_last_sigmoid's kernels run from wgt */
+size_t pcd_conv3d_last_packed_bytes(void);
+int pcd_conv3d_last_pack(const float* wgt, void* wfrag, void* stream);
+int pcd_conv3d_last_sigmoid_packed(const void* in, int batch, int d, int h, int w, int cin, const float* wgt, const void* wfrag, float bias, float* out,
+                                   void* stream);
 /* VAE3D's last layer (networks.py:2018-2019): ConvTranspose3d(32, 1, k3, s2, p1, output_padding 1) + Sigmoid;
  * in fp16 NDHWC [B][d][h][w][32], w fp32 [27][32] tap-major, out fp32 [B][2d][2h][2w]. */
 int pcd_convt3d_last_sigmoid(const void* in, int batch, int d, int h, int w, int cin, const float* wgt,

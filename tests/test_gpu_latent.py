@@ -312,14 +312,24 @@ def test_conv3d_first_and_last_layers(dims, stride):
         _lib.check(lib.pcd_conv3d_last_sigmoid(h.data_ptr(), b, dims[0], dims[1], dims[2], 32, dwl.data_ptr(), bl,
                                                o2.data_ptr(), _lib.stream_ptr()))
         assert (o2.cpu().double() - want2).abs().max() <= 2e-6
-        _lib.check(lib.pcd_conv3d_config(8 + 1))           # the 4 x 4 x 8 block form of the last layer (8 x 8 x 8 is the default where it divides)
-        try:
-            o3 = torch.empty_like(o2)
-            _lib.check(lib.pcd_conv3d_last_sigmoid(h.data_ptr(), b, dims[0], dims[1], dims[2], 32, dwl.data_ptr(), bl,
-                                                   o3.data_ptr(), _lib.stream_ptr()))
-        finally:
-            _lib.check(lib.pcd_conv3d_config(1))           # the library's default
-        assert (o3.cpu().double() - want2).abs().max() <= 2e-6
+        # the matrix-pipe form (what pcd_vae_decode launches where the grid divides by 8; elsewhere the call falls back to the kernels above)
+        wf = torch.empty(lib.pcd_conv3d_last_packed_bytes(), dtype=torch.uint8, device="cuda")
+        _lib.check(lib.pcd_conv3d_last_pack(dwl.data_ptr(), wf.data_ptr(), _lib.stream_ptr()))
+        o4 = torch.empty_like(o2)
+        _lib.check(lib.pcd_conv3d_last_sigmoid_packed(h.data_ptr(), b, dims[0], dims[1], dims[2], 32, dwl.data_ptr(), wf.data_ptr(), bl,
+                                                      o4.data_ptr(), _lib.stream_ptr()))
+        assert (o4.cpu().double() - want2).abs().max() <= 2e-6
+        # the default where the grid divides by 8: 8 x 8 x 8 blocks on the matrix pipe (hi / lo / lo2 rows of the fp32 weights); + 16: the same blocks on the VALU;
+        # + 8: 4 x 4 x 8 blocks
+        for cfg in (16 + 1, 8 + 1):
+            _lib.check(lib.pcd_conv3d_config(cfg))
+            try:
+                o3 = torch.empty_like(o2)
+                _lib.check(lib.pcd_conv3d_last_sigmoid(h.data_ptr(), b, dims[0], dims[1], dims[2], 32, dwl.data_ptr(), bl,
+                                                       o3.data_ptr(), _lib.stream_ptr()))
+            finally:
+                _lib.check(lib.pcd_conv3d_config(1))           # the library's default
+            assert (o3.cpu().double() - want2).abs().max() <= 2e-6, cfg
 
 
 def test_conv_transpose3d_classes_exact():

@@ -12,7 +12,7 @@ B = 32
 g = torch.Generator().manual_seed(0)
 h = torch.randn(B * 32768, 32, generator=g).clamp_min(0).half().cuda()
 w32 = (torch.randn(27, 32, generator=g) * 0.1).cuda()
-o = [torch.empty(B, 1, 32, 32, 32, device="cuda") for _ in range(2)]
+o = [torch.empty(B, 1, 32, 32, 32, device="cuda") for _ in range(3)]
 
 
 def ev(fn, n=50):
@@ -28,10 +28,13 @@ def ev(fn, n=50):
     return e0.elapsed_time(e1) / n * 1e3
 
 
+wf = torch.empty(lib.pcd_conv3d_last_packed_bytes(), dtype=torch.uint8, device="cuda")
+_lib.check(lib.pcd_conv3d_last_pack(w32.data_ptr(), wf.data_ptr(), _lib.stream_ptr()))
 for rep in range(3):
     t = []
-    for k, cfg in enumerate((9, 1)):
+    for k, cfg in enumerate((9, 17, 1)):
         _lib.check(lib.pcd_conv3d_config(cfg))
-        t.append(ev(lambda: _lib.check(lib.pcd_conv3d_last_sigmoid(h.data_ptr(), B, 32, 32, 32, 32, w32.data_ptr(), 0.05, o[k].data_ptr(), _lib.stream_ptr()))))
-    print(f"4x4x8 blocks {t[0]:6.1f} us | 8x8x8 blocks {t[1]:6.1f} us | max diff {float((o[0]-o[1]).abs().max()):.1e}", flush=True)
+        t.append(ev(lambda: _lib.check(lib.pcd_conv3d_last_sigmoid_packed(h.data_ptr(), B, 32, 32, 32, 32, w32.data_ptr(), wf.data_ptr(), 0.05, o[k].data_ptr(),
+                                                                          _lib.stream_ptr()))))
+    print(f"4x4x8 blocks {t[0]:6.1f} us | 8x8x8 blocks, VALU {t[1]:6.1f} us | 8x8x8 blocks, matrix pipe (default) {t[2]:6.1f} us | max diff {float((o[0]-o[1]).abs().max()):.1e} {float((o[2]-o[1]).abs().max()):.1e}", flush=True)
 _lib.check(lib.pcd_conv3d_config(1))
