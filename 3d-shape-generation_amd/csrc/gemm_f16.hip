@@ -80,6 +80,17 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// the same with a wave-uniform run-time count (0 .. 31): a scalar branch tree in front of the immediate forms
+__device__ __forceinline__ void wait_vmcnt_rt(int n) {
+    switch (n) {
+#define PCD_W(k) case k: wait_vmcnt<k>(); break;
+        PCD_W(0) PCD_W(1) PCD_W(2) PCD_W(3) PCD_W(4) PCD_W(5) PCD_W(6) PCD_W(7) PCD_W(8) PCD_W(9) PCD_W(10) PCD_W(11) PCD_W(12) PCD_W(13) PCD_W(14) PCD_W(15)
+        PCD_W(16) PCD_W(17) PCD_W(18) PCD_W(19) PCD_W(20) PCD_W(21) PCD_W(22) PCD_W(23) PCD_W(24) PCD_W(25) PCD_W(26) PCD_W(27) PCD_W(28) PCD_W(29) PCD_W(30)
+#undef PCD_W
+        default: wait_vmcnt<0>(); break;          // (never reached with the counts of this file; waiting for everything is always safe)
+    }
+}
+
 // BM x BN x 64 tile, WGM x WGN waves (each wave (BM/WGM) x (BN/WGN)), STAGES LDS buffers.
 // STAGES == 2: one tile prefetched, plain barrier.  STAGES >= 3: STAGES-1 tiles prefetched, the
 // LDS-DMA of the younger ones stays in flight across the (raw) barrier behind a counted vmcnt.
@@ -625,7 +636,9 @@ __device__ __forceinline__ half8 gload16_v(const half_t* g) {
     return v;
 }
 
-template <bool MID = false>
+// SPLIT: the 32 LDS-DMA pieces of a K tile's activation panel are requested by ONE wave of each SIMD (waves 0-3 for even K tiles, 4-7 for odd ones: 8 pieces each)
+// instead of 4 pieces by every wave -- while one wave of a SIMD issues pieces (60-180 cycles each) its partner already issues MFMAs (csrc/wideffn.hip: +11 % there)
+template <bool MID = false, bool SPLIT = false>
 __global__ __launch_bounds__(512) void gemm_xw_kernel(GemmParams p, const half_t* __restrict__ wfrag) {
     constexpr int NST = 4;                                 // the epilogue's atomics per wave (they count in vmcnt)
     constexpr int BM = 256, BN = 256, BKT = 64, ROWB = 128, WGN = 4;
@@ -640,22 +653,23 @@ __global__ __launch_bounds__(512) void gemm_xw_kernel(GemmParams p, const half_t
     const int tiles_mn = p.tiles_m * p.tiles_n;
     const int nk1 = p.k1 / BKT, nk = (p.k1 + p.k2) / BKT;
 
-    unsigned voa[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = r * 64 + wave * 8 + (lane >> 3);
-        voa[r] = (unsigned)(row * (int)p.lda1 * 2 + swz<BKT>(row, lane & 7) * 16);
-    }
+    // staging: a piece = 8 rows x 128 bytes; by default wave w moves rows r * 64 + w * 8 + lane / 8 (r < 4) of the 256-row panel; SPLIT: the waves of the issuing
+    // group (w' = wave & 3) move rows r * 32 + w' * 8 + lane / 8 (r < 8).  The swizzle does not see the r term, so a lane's offsets differ by a scalar only.
+    constexpr int NPIECE = SPLIT ? 8 : 4, RSTEP = SPLIT ? 32 : 64;
+    const int srow = (SPLIT ? (wave & 3) : wave) * 8 + (lane >> 3);
+    const unsigned voa = (unsigned)(srow * (int)p.lda1 * 2 + swz<BKT>(srow, lane & 7) * 16);
     const unsigned lds0 = (unsigned)(size_t)smem;
-    auto stage = [&](int m0, int kt, int buf) __attribute__((always_inline)) {
+    // itn = the workgroup's running index of the K tile being requested (SPLIT: group itn & 1 requests it)
+    auto stage = [&](int m0, int kt, int buf, int itn) __attribute__((always_inline)) {
+        if (SPLIT && (wave >> 2) != (itn & 1)) return;
         const half_t* ab = kt < nk1 ? p.a1 + (int64_t)m0 * p.lda1 + kt * BKT : p.a2 + (int64_t)m0 * p.lda2 + (kt - nk1) * BKT;
-        const unsigned la = lds0 + buf * STAGE_BYTES + wave * 8 * ROWB;
+        const unsigned la = lds0 + buf * STAGE_BYTES + (SPLIT ? (wave & 3) : wave) * 8 * ROWB;
         // (the base is wave-uniform; say so: the divergence analysis loses it through the tile walk below and would hand the asm a VGPR pair)
         const uint64_t av = (uint64_t)ab;
         const half_t* abu = (const half_t*)(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(av >> 32)) << 32) |
                                             (unsigned)__builtin_amdgcn_readfirstlane((int)av));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) glds16_s(voa[r], abu, la + r * 64 * ROWB);
+        for (int r = 0; r < NPIECE; ++r) glds16_s(voa, abu + (int64_t)(r * RSTEP) * p.lda1, la + r * RSTEP * ROWB);
     };
     const unsigned lds_b = (unsigned)(size_t)&bias_lds[0][0][0];
     auto stage_bias = [&](int m0, int n0, int par) __attribute__((always_inline)) {
@@ -698,7 +712,7 @@ __global__ __launch_bounds__(512) void gemm_xw_kernel(GemmParams p, const half_t
     tile_coords(tile, tm, tn);
     int m0 = tm * BM, n0 = tn * BN;
     // prologue: K tile 0's activation pieces (4), bias rows (2), weight fragments of both k steps (8)
-    stage(m0, 0, 0);
+    stage(m0, 0, 0, 0);
     stage_bias(m0, n0, 0);
     {
         const half_t* wb = wbase(tn, 0);
@@ -730,7 +744,7 @@ __global__ __launch_bounds__(512) void gemm_xw_kernel(GemmParams p, const half_t
             // (MID: the next K tile's activation pieces behind k step 0's MFMAs instead of right behind the barrier, where both waves of a SIMD would be issuing
             // LDS-DMA pieces -- 60-180 cycles of issue each -- with the matrix pipe idle; same issue ORDER, so every counted wait keeps its count)
             if constexpr (!MID) {
-                stage(mN, ktN, (it + 1) & 1);
+                stage(mN, ktN, (it + 1) & 1, it + 1);
                 if (last) stage_bias(m1, n1, par ^ 1);
             }
             const half_t* wb = wbase(tnN, ktN);
@@ -740,7 +754,15 @@ __global__ __launch_bounds__(512) void gemm_xw_kernel(GemmParams p, const half_t
                 half8 af[MI];
 #pragma unroll
                 for (int i = 0; i < MI; ++i) af[i] = *(const half8*)(base + offa[ks] + i * 16 * ROWB);
-                if (ks == 1) { if (last) wait_vmcnt<10>(); else wait_vmcnt<8>(); }      // k step 1's weights: behind them the A pieces (4) [+ bias 2] and k step 0's reload (4)
+                if (ks == 1) {                                                         // k step 1's weights: behind them the A pieces (4; SPLIT: 8 or none) [+ bias 2] and k step 0's reload (4)
+                    if constexpr (SPLIT) {
+                        const bool issuer = (wave >> 2) == ((it + 1) & 1);
+                        if (issuer) { if (last) wait_vmcnt<14>(); else wait_vmcnt<12>(); }
+                        else { if (last) wait_vmcnt<6>(); else wait_vmcnt<4>(); }
+                    } else {
+                        if (last) wait_vmcnt<10>(); else wait_vmcnt<8>();
+                    }
+                }
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
@@ -750,7 +772,7 @@ __global__ __launch_bounds__(512) void gemm_xw_kernel(GemmParams p, const half_t
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (MID) {
                     if (ks == 0) {
-                        stage(mN, ktN, (it + 1) & 1);
+                        stage(mN, ktN, (it + 1) & 1, it + 1);
                         if (last) stage_bias(m1, n1, par ^ 1);
                     }
                 }
@@ -821,7 +843,7 @@ __device__ __forceinline__ const half_t* uniform_ptr(const half_t* q) {
     return (const half_t*)(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v));
 }
 
-template <int R, bool ABL = false, bool MID = false>
+template <int R, bool ABL = false, bool MID = false, bool SPLIT = true>
 __global__ __launch_bounds__(512) void gemm_xs_kernel(GemmParams p, const half_t* __restrict__ wfrag) {
     constexpr int NCH = 16;                                // 1-KB output chunks of a wave's 128 x 64 tile: chunk c = rows i = c / 2 (16 each), column pair c % 2
     constexpr int NDRIP = R == 1 ? 11 : 10;                // chunks parked in LDS, R of them stored per K tile of the next tile
@@ -845,16 +867,22 @@ __global__ __launch_bounds__(512) void gemm_xs_kernel(GemmParams p, const half_t
     const int abl = ABL ? p.xp_depth : 0;                  // timing ablations (a separate instance: the product kernel carries none of it) (pcd_gemm_set_config(16 + bits); outputs are then WRONG): 1 no direct stores, 2 no drip
                                                            // stores, 4 no LDS parking, 8 no epilogue arithmetic
 
-    // staging: round r covers rows r * 64 + wave * 8 + lane / 8 of the 256-row panel, 16-byte chunk swz(row, lane % 8); the swizzle does not see r * 64
-    const int srow = wave * 8 + (lane >> 3);
+    // staging: a piece = 8 rows x 128 bytes; 16-byte chunk swz(row, lane % 8), and the swizzle does not see the r term below.  SPLIT (default): the 32 pieces of a K
+    // tile are requested by ONE wave of each SIMD -- waves 0-3 for even K tiles of the workgroup's run, 4-7 for odd ones, rows r * 32 + (wave & 3) * 8 + lane / 8, r < 8 --
+    // so that its SIMD partner issues MFMAs meanwhile (a piece holds its wave's issue for 60-180 cycles; +1.5-2 % on the K loop, profiles/r05_d); otherwise every
+    // wave requests rows r * 64 + wave * 8 + lane / 8, r < 4.
+    constexpr int NPIECE = SPLIT ? 8 : 4, RSTEP = SPLIT ? 32 : 64;
+    const int srow = (SPLIT ? (wave & 3) : wave) * 8 + (lane >> 3);
     const unsigned voa = (unsigned)(srow * lda * 2 + swz<BKT>(srow, lane & 7) * 16);
-    const unsigned lds0 = (unsigned)(size_t)smem + wave * 8 * ROWB;
-    // K tile kt of the panel whose row-0 bases are (r1, r2): r1 = a1 + m0 * lda, r2 = a2 + m0 * lda - k1 (so that r2 + kt * 64 is K tile kt - nk1 of a2)
-    auto stage = [&](const half_t* r1, const half_t* r2, int kt, int buf) __attribute__((always_inline)) {
+    const unsigned lds0 = (unsigned)(size_t)smem + (SPLIT ? (wave & 3) : wave) * 8 * ROWB;
+    // K tile kt of the panel whose row-0 bases are (r1, r2): r1 = a1 + m0 * lda, r2 = a2 + m0 * lda - k1 (so that r2 + kt * 64 is K tile kt - nk1 of a2);
+    // itn = the workgroup's running index of the K tile being requested
+    auto stage = [&](const half_t* r1, const half_t* r2, int kt, int buf, int itn) __attribute__((always_inline)) {
+        if (SPLIT && (wave >> 2) != (itn & 1)) return;
         const half_t* ab = uniform_ptr((kt < nk1 ? r1 : r2) + kt * BKT);
         const unsigned la = lds0 + buf * STAGE_BYTES;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) glds16_s(voa, ab + (int64_t)(r * 64) * lda, la + r * 64 * ROWB);
+        for (int r = 0; r < NPIECE; ++r) glds16_s(voa, ab + (int64_t)(r * RSTEP) * lda, la + r * RSTEP * ROWB);
     };
     const unsigned lds_b = (unsigned)(size_t)&bias_lds[0][0][0] + wn * WN * 4;
     auto stage_bias = [&](int m0, int n0, int par) __attribute__((always_inline)) {
@@ -914,7 +942,7 @@ __global__ __launch_bounds__(512) void gemm_xs_kernel(GemmParams p, const half_t
     const half_t* r1 = p.a1 + (int64_t)m0 * lda;
     const half_t* r2 = p.a2 + (int64_t)m0 * lda - p.k1;
     const half_t* wt = wfrag + ((int64_t)tn * nk * 4 + wn) * 4096;       // this wave's fragments of the tile's K tile 0
-    stage(r1, r2, 0, 0);
+    stage(r1, r2, 0, 0, 0);
     stage_bias(m0, n0, 0);
     wload4(wq[0], uniform_ptr(wt));
     wload4(wq[1], uniform_ptr(wt + 2048));
@@ -959,7 +987,7 @@ __global__ __launch_bounds__(512) void gemm_xs_kernel(GemmParams p, const half_t
             // the next K tile's activation pieces (+ the next tile's bias rows): at the top of the K tile, or (MID) behind k step 0's MFMAs -- an LDS-DMA piece
             // holds its wave's issue for 60-180 cycles, and right behind the barrier BOTH waves of a SIMD would be issuing pieces with the matrix pipe idle
             auto request_next = [&]() __attribute__((always_inline)) {
-                stage(r1, r2, last ? 0 : ktv + 1, (it + 1) & 1);
+                stage(r1, r2, last ? 0 : ktv + 1, (it + 1) & 1, it + 1);
                 if (last) stage_bias(m1, n1, par ^ 1);
             };
             if constexpr (!MID) request_next();
@@ -973,10 +1001,16 @@ __global__ __launch_bounds__(512) void gemm_xs_kernel(GemmParams p, const half_t
 #pragma unroll
                 for (int i = 0; i < MI; ++i) af[i] = *(const half8*)(base + offa[ks] + i * 16 * ROWB);
                 if (ks == 1) {
-                    // k step 1's weights of this K tile; younger: [the epilogue's ND stores, at kt == 0 behind one] A x 4 [+ bias x 2] w0 x 4 [drip x R]
-                    if (kt == 0 && behind) { if (dripping) wait_vmcnt<8 + ND + R>(); else wait_vmcnt<8 + ND>(); }
-                    else if (last) { if (dripping) wait_vmcnt<10 + R>(); else wait_vmcnt<10>(); }
-                    else { if (dripping) wait_vmcnt<8 + R>(); else wait_vmcnt<8>(); }
+                    // k step 1's weights of this K tile; younger: [the epilogue's ND stores, at kt == 0 behind one] A x 4 (SPLIT: x 8 on the requesting waves, none on
+                    // the others) [+ bias x 2] w0 x 4 [drip x R]
+                    if constexpr (SPLIT) {
+                        const bool issuer = (wave >> 2) == ((it + 1) & 1);
+                        wait_vmcnt_rt(4 + (issuer ? 8 : 0) + (last ? 2 : 0) + (dripping ? R : 0) + (kt == 0 && behind ? ND : 0));
+                    } else {
+                        if (kt == 0 && behind) { if (dripping) wait_vmcnt<8 + ND + R>(); else wait_vmcnt<8 + ND>(); }
+                        else if (last) { if (dripping) wait_vmcnt<10 + R>(); else wait_vmcnt<10>(); }
+                        else { if (dripping) wait_vmcnt<8 + R>(); else wait_vmcnt<8>(); }
+                    }
                 }
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1075,6 +1109,7 @@ __global__ __launch_bounds__(256) void gemm_pack_wfrag_kernel(const half_t* __re
     *(half8*)(out + idx * 8) = *(const half8*)(w + (int64_t)col * ldw + kt * 64 + ks * 32 + (lane >> 4) * 8);
 }
 
+static int g_split = 1;         // pcd_gemm_set_config(14) / (15): the fragment-order kernels' LDS-DMA pieces requested by every wave / by one wave per SIMD (default)
 static int g_xs_mid = 0;        // pcd_gemm_set_config(12) / (13): gemm_xs_kernel / gemm_xw_kernel request the next K tile's activation pieces at the top of a K tile / behind k step 0's MFMAs
 static void* g_wfrag_stamps = nullptr;
 static int g_xw = 1;            // tuning hook (pcd_gemm_set_config(8) / (9)): callers that hold a fragment-order weight copy use gemm_xw_kernel: off / on
@@ -1322,8 +1357,9 @@ extern "C" int pcd_gemm_f16_colmax_wfrag(const pcd_gemm_desc_t* d, const void* w
     const int pn = p.tiles_n >= 8 ? 8 : p.tiles_n, xn = p.tiles_n >= 16 ? 2 : 1;
     if ((pn & (pn - 1)) == 0 && p.tiles_n % (xn * pn) == 0 && p.tiles_m % ((8 / xn) * (32 / pn)) == 0) { p.patch_pn = pn; p.patch_xn = xn; }
     p.out32 = (float*)g_wfrag_stamps;
-    if (g_xs_mid) hipLaunchKernelGGL(gemm_xw_kernel<true>, dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
-    else hipLaunchKernelGGL(gemm_xw_kernel<false>, dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
+    if (g_xs_mid) hipLaunchKernelGGL((gemm_xw_kernel<true, false>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
+    else if (g_split) hipLaunchKernelGGL((gemm_xw_kernel<false, true>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
+    else hipLaunchKernelGGL((gemm_xw_kernel<false, false>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }
@@ -1356,11 +1392,14 @@ extern "C" int pcd_gemm_f16_wfrag(const pcd_gemm_desc_t* d, const void* wfrag, v
     if ((pn & (pn - 1)) == 0 && p.tiles_n % (xn * pn) == 0 && p.tiles_m % ((8 / xn) * (32 / pn)) == 0) { p.patch_pn = pn; p.patch_xn = xn; }
     p.xp_depth = g_xs_abl;
     if (g_xs_abl) {
-        if (nk >= 12) hipLaunchKernelGGL((gemm_xs_kernel<1, true>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
-        else hipLaunchKernelGGL((gemm_xs_kernel<2, true>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
+        if (nk >= 12) hipLaunchKernelGGL((gemm_xs_kernel<1, true, false, false>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
+        else hipLaunchKernelGGL((gemm_xs_kernel<2, true, false, false>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
     } else if (g_xs_mid) {
-        if (nk >= 12) hipLaunchKernelGGL((gemm_xs_kernel<1, false, true>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
-        else hipLaunchKernelGGL((gemm_xs_kernel<2, false, true>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
+        if (nk >= 12) hipLaunchKernelGGL((gemm_xs_kernel<1, false, true, false>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
+        else hipLaunchKernelGGL((gemm_xs_kernel<2, false, true, false>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
+    } else if (g_split == 0) {
+        if (nk >= 12) hipLaunchKernelGGL((gemm_xs_kernel<1, false, false, false>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
+        else hipLaunchKernelGGL((gemm_xs_kernel<2, false, false, false>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
     } else if (nk >= 12) hipLaunchKernelGGL((gemm_xs_kernel<1, false>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
     else hipLaunchKernelGGL((gemm_xs_kernel<2, false>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
     PCD_CHECK_LAUNCH();
@@ -1375,6 +1414,7 @@ extern "C" int pcd_gemm_store_wfrag_enabled(void) { return g_xs; }
 extern "C" int pcd_gemm_set_config(int cfg) {
     PCD_CHECK_ARG(cfg >= -1 && cfg <= 31);
     if (cfg >= 16) { g_xs_abl = cfg - 16; return PCD_OK; }                          // timing ablations of gemm_xs_kernel (dev tools only)
+    if (cfg == 14 || cfg == 15) { g_split = cfg - 14; return PCD_OK; }              // gemm_xw / gemm_xs: every wave requests 4 activation pieces / one wave per SIMD 8 (default)
     PCD_CHECK_ARG(cfg <= 13);
     if (cfg >= 12) { g_xs_mid = cfg - 12; return PCD_OK; }
     if (cfg >= 10) { g_xs = cfg - 10; return PCD_OK; }                              // A/B switch of gemm_xs_kernel (pcd_gemm_f16_wfrag)

@@ -79,7 +79,9 @@ __device__ __forceinline__ half8 wc_regroup(const f32x16& acc, int gp, const flo
 
 // LN = false: the chains of UNetPointNetLarge; LN = true: LayerNorm + Linear (pcd_pw_wide_ln_linear) -- its own instantiation so that the chains keep their
 // register allocation (246 registers, no spill)
-template <bool LN>
+// SPLIT: an image's 32 LDS-DMA pieces are requested by ONE wave of each SIMD (waves 0-3 for even images of the workgroup's run, 4-7 for odd ones, 8 pieces each) instead of
+// 4 pieces by every wave, so that the requesting wave's SIMD partner issues MFMAs meanwhile (round 5, as csrc/wideffn.hip)
+template <bool LN, bool SPLIT>
 __global__ __launch_bounds__(WC_THREADS, 2) void pw_wide_chain_kernel(WcParams p) {
     extern __shared__ __attribute__((aligned(16))) char wc_smem[];          // [WC_RING][WC_STAGE] | bias copy
     const int lane = threadIdx.x & 63;
@@ -99,10 +101,20 @@ __global__ __launch_bounds__(WC_THREADS, 2) void pw_wide_chain_kernel(WcParams p
     // stage n of this workgroup's run = image (n % nstage_seq); wave w moves pieces 4 w .. 4 w + 3 of its 32
     auto issue = [&](int n) __attribute__((always_inline)) {
         if (n < total_stages) {
-            const char* src = p.wpacked + (size_t)(n % nstage_seq) * WC_STAGE + (size_t)(4 * wave) * 1024 + lane * 16;
-            const unsigned dst = lds0 + (n % WC_RING) * WC_STAGE + (4 * wave) * 1024;
+            if constexpr (SPLIT) {
+                if ((wave >> 2) == (n & 1)) {
+                    const int w4 = wave & 3;
+                    const char* src = p.wpacked + (size_t)(n % nstage_seq) * WC_STAGE + (size_t)(8 * w4) * 1024 + lane * 16;
+                    const unsigned dst = lds0 + (n % WC_RING) * WC_STAGE + (8 * w4) * 1024;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wc_dma(src + i * 1024, dst + i * 1024);
+                    for (int i = 0; i < 8; ++i) wc_dma(src + i * 1024, dst + i * 1024);
+                }
+            } else {
+                const char* src = p.wpacked + (size_t)(n % nstage_seq) * WC_STAGE + (size_t)(4 * wave) * 1024 + lane * 16;
+                const unsigned dst = lds0 + (n % WC_RING) * WC_STAGE + (4 * wave) * 1024;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wc_dma(src + i * 1024, dst + i * 1024);
+            }
         }
     };
     issue(0);
@@ -177,8 +189,14 @@ __global__ __launch_bounds__(WC_THREADS, 2) void pw_wide_chain_kernel(WcParams p
             for (int kt = 0; kt < 4; ++kt) {
                 // stage n has landed (all but this wave's 4 youngest LDS-DMA pieces), every wave is done with stage n - 1: its
                 // slot takes stage n + 2
-                if (n + 1 < total_stages) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");     // (lgkmcnt: tools/check_barrier_reads.py)
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                if constexpr (SPLIT) {
+                    // the group that requested stage n waits for all its pieces; the other group's pieces (stage n + 1) stay in flight; the barrier publishes
+                    if ((wave >> 2) == (n & 1)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                } else {
+                    if (n + 1 < total_stages) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");     // (lgkmcnt: tools/check_barrier_reads.py)
+                    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                }
                 __syncthreads();
                 issue(n + 2);
                 const char* img = wc_smem + (n % WC_RING) * WC_STAGE + lane * 16;
@@ -218,9 +236,11 @@ __global__ __launch_bounds__(WC_THREADS, 2) void pw_wide_chain_kernel(WcParams p
 // the largest dynamic LDS either launch form asks for (ring + bias rows of WC_MAXSEG passes + LayerNorm affine): set once, for both
 constexpr size_t WC_LDS_MAX = (size_t)WC_RING * WC_STAGE + (size_t)(WC_MAXSEG * 256 + 512) * sizeof(float);
 static hipError_t wc_allow_lds() {
-    static PcdLdsOnce once_chain, once_ln;
-    hipError_t e = pcd_allow_lds(once_chain, (const void*)pw_wide_chain_kernel<false>, (int)WC_LDS_MAX);
-    if (e == hipSuccess) e = pcd_allow_lds(once_ln, (const void*)pw_wide_chain_kernel<true>, (int)WC_LDS_MAX);
+    static PcdLdsOnce once[4];
+    hipError_t e = pcd_allow_lds(once[0], (const void*)pw_wide_chain_kernel<false, false>, (int)WC_LDS_MAX);
+    if (e == hipSuccess) e = pcd_allow_lds(once[1], (const void*)pw_wide_chain_kernel<true, false>, (int)WC_LDS_MAX);
+    if (e == hipSuccess) e = pcd_allow_lds(once[2], (const void*)pw_wide_chain_kernel<false, true>, (int)WC_LDS_MAX);
+    if (e == hipSuccess) e = pcd_allow_lds(once[3], (const void*)pw_wide_chain_kernel<true, true>, (int)WC_LDS_MAX);
     return e;
 }
 
@@ -241,6 +261,10 @@ __global__ __launch_bounds__(256) void wc_pack_kernel(const half_t* __restrict__
 }  // namespace pcd
 
 using namespace pcd;
+
+static int g_wc_split = 1;          // pcd_pw_wide_config: which waves request the weight images (0: every wave 4 pieces; 1, default: one wave per SIMD 8 in the chains;
+                                    // 2: in the LN + Linear launches too)
+extern "C" int pcd_pw_wide_config(int split) { g_wc_split = split < 0 ? 0 : (split > 2 ? 2 : split); return PCD_OK; }
 
 extern "C" size_t pcd_pw_wide_packed_bytes(int chain) {
     return (chain == 0 || chain == 1) ? (size_t)16 * WC_STAGE + (size_t)4 * 256 * sizeof(float) : 0;
@@ -302,7 +326,8 @@ extern "C" int pcd_pw_wide_chain(int chain, const void* in1, const void* in2, in
     PCD_CHECK_HIP(wc_allow_lds());
     const int64_t tiles = m / WC_TILE;
     const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
-    hipLaunchKernelGGL(pw_wide_chain_kernel<false>, dim3(grid), dim3(WC_THREADS), lds, (hipStream_t)stream, p);
+    if (g_wc_split) hipLaunchKernelGGL((pw_wide_chain_kernel<false, true>), dim3(grid), dim3(WC_THREADS), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((pw_wide_chain_kernel<false, false>), dim3(grid), dim3(WC_THREADS), lds, (hipStream_t)stream, p);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }
@@ -346,7 +371,10 @@ extern "C" int pcd_pw_wide_ln_linear(const void* packed, int passes, int relu, c
     PCD_CHECK_HIP(wc_allow_lds());
     const int64_t tiles = m / WC_TILE;
     const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
-    hipLaunchKernelGGL(pw_wide_chain_kernel<true>, dim3(grid), dim3(WC_THREADS), lds, (hipStream_t)stream, p);
+    // (the LN + Linear launches store a 256-wide output piece per pass: a requesting wave's vmcnt(0) would wait for those stores at every stage -- measured neutral to
+    // slightly slower in the attention U-Net's forward, so they keep "every wave requests" unless pcd_pw_wide_config(2) asks for the split form)
+    if (g_wc_split == 2) hipLaunchKernelGGL((pw_wide_chain_kernel<true, true>), dim3(grid), dim3(WC_THREADS), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((pw_wide_chain_kernel<true, false>), dim3(grid), dim3(WC_THREADS), lds, (hipStream_t)stream, p);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

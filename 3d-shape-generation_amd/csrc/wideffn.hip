@@ -62,6 +62,9 @@ __device__ __forceinline__ half8 wf_regroup(const f32x16& acc, int gp, const flo
     return __builtin_bit_cast(half8, (u4){f[0], f[1], f[2], f[3]});
 }
 
+// SPLIT: the 32 LDS-DMA pieces of an image are requested by ONE wave of each SIMD (waves 0-3 for even images, 4-7 for odd ones, 8 pieces each) instead of 4 pieces by
+// every wave: a piece holds its wave's issue for 60-180 cycles, and with every wave requesting behind the barrier no wave of a SIMD issues MFMAs meanwhile
+template <bool SPLIT>
 __global__ __launch_bounds__(WF_THREADS, 2) void wide_ffn_kernel(WfParams p) {
     extern __shared__ __attribute__((aligned(16))) char wf_smem[];          // [WF_RING][WF_STAGE] | exchange [8 waves][4 KB] | b1 | b2 | gamma | beta
     const int lane = threadIdx.x & 63;
@@ -79,23 +82,39 @@ __global__ __launch_bounds__(WF_THREADS, 2) void wide_ffn_kernel(WfParams p) {
     const int64_t ntiles = p.m / WF_TILE;
     const int my_tiles = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
     const int total_stages = my_tiles * WF_STAGES_PER_TILE;
-    // image n of this workgroup's run = stage image n % 32; wave w moves pieces 4 w .. 4 w + 3 of its 32
+    // image n of this workgroup's run = stage image n % 32; wave w moves pieces 4 w .. 4 w + 3 of its 32 (SPLIT: the waves of group n & 1 move 8 w' .. 8 w' + 7)
     auto issue = [&](int n) __attribute__((always_inline)) {
         if (n < total_stages) {
-            const char* src = p.wpacked + (size_t)(n % WF_STAGES_PER_TILE) * WF_STAGE + (size_t)(4 * wave) * 1024 + lane * 16;
-            const unsigned dst = lds0 + (n % WF_RING) * WF_STAGE + (4 * wave) * 1024;
+            if constexpr (SPLIT) {
+                if ((wave >> 2) == (n & 1)) {
+                    const int w4 = wave & 3;
+                    const char* src = p.wpacked + (size_t)(n % WF_STAGES_PER_TILE) * WF_STAGE + (size_t)(8 * w4) * 1024 + lane * 16;
+                    const unsigned dst = lds0 + (n % WF_RING) * WF_STAGE + (8 * w4) * 1024;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wf_dma(src + i * 1024, dst + i * 1024);
+                    for (int i = 0; i < 8; ++i) wf_dma(src + i * 1024, dst + i * 1024);
+                }
+            } else {
+                const char* src = p.wpacked + (size_t)(n % WF_STAGES_PER_TILE) * WF_STAGE + (size_t)(4 * wave) * 1024 + lane * 16;
+                const unsigned dst = lds0 + (n % WF_RING) * WF_STAGE + (4 * wave) * 1024;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wf_dma(src + i * 1024, dst + i * 1024);
+            }
         }
     };
     issue(0);
     issue(1);
     __syncthreads();                                           // the constants are read before the first stage barrier
     int n = 0;                                                 // next image to consume
-    // image n has landed (all but this wave's 4 youngest LDS-DMA pieces), every wave is done with image n - 1 (its LDS reads included): its slot takes image n + 2
+    // image n has landed (all but this wave's 4 youngest LDS-DMA pieces; SPLIT: every piece of the group that requested it), every wave is done with image n - 1
+    // (its LDS reads included): its slot takes image n + 2
     auto acquire = [&]() __attribute__((always_inline)) -> const char* {
-        if (n + 1 < total_stages) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if constexpr (SPLIT) {
+            if ((wave >> 2) == (n & 1)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+            if (n + 1 < total_stages) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
         __syncthreads();
         issue(n + 2);
         const char* img = wf_smem + (n % WF_RING) * WF_STAGE + lane * 16;
@@ -105,15 +124,21 @@ __global__ __launch_bounds__(WF_THREADS, 2) void wide_ffn_kernel(WfParams p) {
     char* const my_slot = exch + wave * 4096 + lane * 16;
     const char* const partner_slot = exch + (wave ^ 1) * 4096 + lane * 16;
 
+    // the pair's 32 points x 256 channels as B fragments; the rows of the NEXT tile are requested before a tile's epilogue (the registers are free by then), so
+    // their latency sits under the epilogue's arithmetic, loads and stores instead of in front of the next tile's first MFMA
+    half8 xin[16];
+    auto request_rows = [&](int ti) __attribute__((always_inline)) {
+        const int64_t pt = (blockIdx.x + (int64_t)ti * gridDim.x) * WF_TILE + pair * 32 + pnt;
+        const half_t* row = p.x + pt * 256 + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) xin[s] = *(const half8*)(row + 16 * s);
+    };
+    if (my_tiles > 0) request_rows(0);
     for (int ti = 0; ti < my_tiles; ++ti) {
         const int64_t tile = blockIdx.x + (int64_t)ti * gridDim.x;
         const int64_t pt = tile * WF_TILE + pair * 32 + pnt;
-        // ---- the pair's 32 points x 256 channels as B fragments, LayerNorm applied as they are loaded (widechain.hip's LN prologue: two passes, fp32 statistics)
-        half8 xin[16];
+        // ---- LayerNorm on the fragments (widechain.hip's LN prologue: two passes, fp32 statistics)
         {
-            const half_t* row = p.x + pt * 256 + 8 * hh;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) xin[s] = *(const half8*)(row + 16 * s);
             float sum = 0.f, sq = 0.f;
             half2_ one2; one2.x = one2.y = (half_t)1.f;
 #pragma unroll
@@ -210,6 +235,7 @@ __global__ __launch_bounds__(WF_THREADS, 2) void wide_ffn_kernel(WfParams p) {
                 }
             }
         }
+        if (ti + 1 < my_tiles) request_rows(ti + 1);
         // ---- epilogue: y = x1 + (accY + b2) rounded like the two-launch form (the GEMM's fp16 result, then the fp16 residual add)
         {
             const half_t* xrow = p.x + pt * 256 + 128 * h + 8 * hh;
@@ -240,6 +266,10 @@ __global__ __launch_bounds__(256) void wf_pack_kernel(const half_t* __restrict__
 
 using namespace pcd;
 
+static int g_wf_split = 1;          // pcd_wide_ffn_config: who requests the weight images (0: every wave 4 pieces; 1, default: one wave per SIMD 8 pieces, alternating
+                                    // groups: 187 v. 210 us at B = 64, N = 2048, same bits)
+extern "C" int pcd_wide_ffn_config(int split) { g_wf_split = split ? 1 : 0; return PCD_OK; }
+
 extern "C" size_t pcd_wide_ffn_packed_bytes(void) { return WF_IMG_BYTES + (size_t)WF_NCONST * sizeof(float); }
 
 extern "C" int pcd_wide_ffn_supported(int dim, int64_t rows) { return dim == 256 && rows > 0 && rows % WF_TILE == 0 ? 1 : 0; }
@@ -268,13 +298,15 @@ extern "C" int pcd_wide_ffn_pack(const void* w1, const float* b1, const void* w2
 
 extern "C" int pcd_wide_ffn_f16(const void* packed, const void* x, int64_t rows, void* y, void* stream) {
     PCD_CHECK_ARG(packed && x && y && rows > 0 && rows % WF_TILE == 0);
-    static PcdLdsOnce once;
-    PCD_CHECK_HIP(pcd_allow_lds(once, (const void*)wide_ffn_kernel, (int)WF_LDS));
+    static PcdLdsOnce once, once_split;
+    PCD_CHECK_HIP(pcd_allow_lds(once, (const void*)wide_ffn_kernel<false>, (int)WF_LDS));
+    PCD_CHECK_HIP(pcd_allow_lds(once_split, (const void*)wide_ffn_kernel<true>, (int)WF_LDS));
     WfParams p{};
     p.x = (const half_t*)x; p.wpacked = (const char*)packed; p.y = (half_t*)y; p.m = rows;
     const int64_t tiles = rows / WF_TILE;
     const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
-    hipLaunchKernelGGL(wide_ffn_kernel, dim3(grid), dim3(WF_THREADS), WF_LDS, (hipStream_t)stream, p);
+    if (g_wf_split) hipLaunchKernelGGL(wide_ffn_kernel<true>, dim3(grid), dim3(WF_THREADS), WF_LDS, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(wide_ffn_kernel<false>, dim3(grid), dim3(WF_THREADS), WF_LDS, (hipStream_t)stream, p);
     PCD_CHECK_LAUNCH();
     return PCD_OK;
 }

@@ -242,6 +242,9 @@ int pcd_unet_config(int use_chains);
 size_t pcd_pw_wide_packed_bytes(int chain);
 int pcd_pw_wide_pack(int chain, const void* const* w, const float* const* b, void* packed, void* stream);
 int pcd_pw_wide_chain(int chain, const void* in1, const void* in2, int64_t m, const void* packed, void* out, void* stream);
+/* A/B hook (TEST / BENCHMARK ONLY, process-global): which waves request the weight images of the wide-chain launches (1, default: one wave per SIMD,
+ * alternating groups per image; 0: every wave; 2: the split form in the LN + Linear launches too).  Same bits either way. */
+int pcd_pw_wide_config(int split);
 /* LayerNorm(256) + Linear(256, 256 passes) [+ ReLU] as one launch of the wide-chain kernel (csrc/widechain.hip): the B fragments are normalised as they
  * are loaded (two-pass fp32 statistics, eps 1e-5, fp16 result as pcd_layernorm_f16's), so the LayerNorm launch and its tensor disappear: attention in_proj
  * (passes 3, relu 0) and ff.0 (passes 4, relu 1) of the C = 256 SetAttentionBlocks (networks.py:61-66, 81-82).  w fp16 [256 passes][256], b fp32;
@@ -595,6 +598,8 @@ size_t pcd_wide_ffn_packed_bytes(void);
 int pcd_wide_ffn_supported(int dim, int64_t rows);
 int pcd_wide_ffn_pack(const void* w1, const float* b1, const void* w2, const float* b2, const float* ln_g, const float* ln_b, void* packed, void* stream);
 int pcd_wide_ffn_f16(const void* packed, const void* x, int64_t rows, void* y, void* stream);
+/* A/B hook (TEST / BENCHMARK ONLY, process-global): which waves request the weight images, see csrc/wideffn.hip; same bits either way */
+int pcd_wide_ffn_config(int split);
 /* bytes of scratch one block needs for `rows` = B*N points */
 size_t pcd_sab_workspace_bytes(int64_t rows, int dim);
 /* the block's tail behind the attention kernel as one launch (csrc/sab_tail.hip; reference networks.py:78-83, the second half of SetAttentionBlock.forward):

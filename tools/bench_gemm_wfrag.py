@@ -38,7 +38,11 @@ for M, K, C in [(131072, 2048, 4096), (131072, 1024, 2048), (131072, 512, 512)]:
     xw()
     same_mid = torch.equal(out, ref)
     t_m = ev(lambda: lib.pcd_gemm_f16_colmax_wfrag(d, wfrag.data_ptr(), out.data_ptr(), 2048, _lib.stream_ptr()))
+    lib.pcd_gemm_set_config(14)        # one wave per SIMD requests the activation pieces (8 each), alternating groups per K tile
+    xw()
+    same_split = torch.equal(out, ref)
+    t_s = ev(lambda: lib.pcd_gemm_f16_colmax_wfrag(d, wfrag.data_ptr(), out.data_ptr(), 2048, _lib.stream_ptr()))
     lib.pcd_gemm_set_config(12)
     t_p = ev(lambda: lib.pcd_gemm_f16_colmax(d, out.data_ptr(), 2048, _lib.stream_ptr()))
     fl = 2.0 * M * K * C
-    print(f"M={M} K={K} C={C}: weights from global {t_w:8.1f} us {fl / t_w / 1e6:6.0f} TF/s | mid-tile requests {t_m:8.1f} us {fl / t_m / 1e6:6.0f} TF/s (equal {same_mid}) | gemm_xp_kernel {t_p:8.1f} us {fl / t_p / 1e6:6.0f} TF/s | bitwise equal {same}", flush=True)
+    print(f"M={M} K={K} C={C}: weights from global {t_w:8.1f} us {fl / t_w / 1e6:6.0f} TF/s | mid-tile requests {t_m:8.1f} us {fl / t_m / 1e6:6.0f} TF/s (equal {same_mid}) | split requests {t_s:8.1f} us {fl / t_s / 1e6:6.0f} TF/s (equal {same_split}) | gemm_xp_kernel {t_p:8.1f} us {fl / t_p / 1e6:6.0f} TF/s | bitwise equal {same}", flush=True)
