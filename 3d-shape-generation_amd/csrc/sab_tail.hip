@@ -55,6 +55,7 @@ struct SabTailParams {
     // the attention U-Net's additive per-level time embeddings (networks.py:669-698) inside the launch: x is read as fp16(x + pre_e[shape]) (the block
     // runs on x + emb), y leaves as fp16(y + post_e[shape]) (the skip tensor is block(x) + emb); each exactly as pcd_add_shape_bias_strided_f16 rounds it
     const float* pre_e; const float* post_e; int64_t estride; int rps;
+    int split;                // 1: one wave per SIMD requests a stage's LDS-DMA pieces (pcd_sab_tail_config bit 1)
 };
 
 __device__ __forceinline__ void st_dma(const char* g, unsigned lds_addr) {
@@ -96,12 +97,25 @@ __global__ __launch_bounds__(ST_THREADS, 2) void sab_tail_kernel(SabTailParams p
     const int my_tiles = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
     const int total_stages = my_tiles * K::NSTG;
     // stage n of this workgroup's run = image n % NSTG; wave w moves pieces PPW w .. PPW w + PPW - 1
+    // (p.split: the pieces of stage n are requested by ONE wave of each SIMD -- waves 0-3 for even stages, 4-7 for odd ones, 2 PPW pieces each -- so that its SIMD partner
+    // issues MFMAs meanwhile: round 5, as csrc/wideffn.hip)
+    const bool split = p.split != 0;
     auto issue = [&](int n) __attribute__((always_inline)) {
         if (n < total_stages) {
-            const char* src = p.packed + (size_t)(n % K::NSTG) * K::STAGE + (size_t)(K::PPW * wave) * 1024 + lane * 16;
-            const unsigned dst = lds0 + (n % ST_RING) * K::STAGE + (K::PPW * wave) * 1024;
+            if (split) {
+                if ((wave >> 2) == (n & 1)) {
+                    const int w4 = wave & 3;
+                    const char* src = p.packed + (size_t)(n % K::NSTG) * K::STAGE + (size_t)(2 * K::PPW * w4) * 1024 + lane * 16;
+                    const unsigned dst = lds0 + (n % ST_RING) * K::STAGE + (2 * K::PPW * w4) * 1024;
 #pragma unroll
-            for (int i = 0; i < K::PPW; ++i) st_dma(src + i * 1024, dst + i * 1024);
+                    for (int i = 0; i < 2 * K::PPW; ++i) st_dma(src + i * 1024, dst + i * 1024);
+                }
+            } else {
+                const char* src = p.packed + (size_t)(n % K::NSTG) * K::STAGE + (size_t)(K::PPW * wave) * 1024 + lane * 16;
+                const unsigned dst = lds0 + (n % ST_RING) * K::STAGE + (K::PPW * wave) * 1024;
+#pragma unroll
+                for (int i = 0; i < K::PPW; ++i) st_dma(src + i * 1024, dst + i * 1024);
+            }
         }
     };
     issue(0);
@@ -110,7 +124,10 @@ __global__ __launch_bounds__(ST_THREADS, 2) void sab_tail_kernel(SabTailParams p
     // stage n has landed (all but this wave's PPW youngest pieces), this wave's reads of stage n - 1 have RETURNED (the refill of its slot is
     // issued right behind the barrier: tools/check_barrier_reads.py) and every wave is past them: the slot takes stage n + 2
     auto acquire = [&]() __attribute__((always_inline)) -> const char* {
-        if (n + 1 < total_stages) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(K::PPW) : "memory");
+        if (split) {
+            if ((wave >> 2) == (n & 1)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (n + 1 < total_stages) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(K::PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
         issue(n + 2);
@@ -288,6 +305,7 @@ struct SabHeadParams {
     half_t* qkv;              // [M][3C]
     int64_t m;
     const float* pre_e; int64_t estride; int rps;      // x is read as fp16(x + pre_e[shape]) (see SabTailParams)
+    int split;                // as SabTailParams
 };
 
 template <int C>
@@ -307,12 +325,23 @@ __global__ __launch_bounds__(ST_THREADS, 2) void sab_head_kernel(SabHeadParams p
     const int64_t ntiles = p.m / ST_TILE;
     const int my_tiles = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
     const int total_stages = my_tiles * 3;
+    const bool split = p.split != 0;
     auto issue = [&](int n) __attribute__((always_inline)) {
         if (n < total_stages) {
-            const char* src = p.packed + (size_t)(n % 3) * K::HSTAGE + (size_t)(K::HPPW * wave) * 1024 + lane * 16;
-            const unsigned dst = lds0 + (n % ST_RING) * K::HSTAGE + (K::HPPW * wave) * 1024;
+            if (split) {
+                if ((wave >> 2) == (n & 1)) {
+                    const int w4 = wave & 3;
+                    const char* src = p.packed + (size_t)(n % 3) * K::HSTAGE + (size_t)(2 * K::HPPW * w4) * 1024 + lane * 16;
+                    const unsigned dst = lds0 + (n % ST_RING) * K::HSTAGE + (2 * K::HPPW * w4) * 1024;
 #pragma unroll
-            for (int i = 0; i < K::HPPW; ++i) st_dma(src + i * 1024, dst + i * 1024);
+                    for (int i = 0; i < 2 * K::HPPW; ++i) st_dma(src + i * 1024, dst + i * 1024);
+                }
+            } else {
+                const char* src = p.packed + (size_t)(n % 3) * K::HSTAGE + (size_t)(K::HPPW * wave) * 1024 + lane * 16;
+                const unsigned dst = lds0 + (n % ST_RING) * K::HSTAGE + (K::HPPW * wave) * 1024;
+#pragma unroll
+                for (int i = 0; i < K::HPPW; ++i) st_dma(src + i * 1024, dst + i * 1024);
+            }
         }
     };
     issue(0);
@@ -320,7 +349,10 @@ __global__ __launch_bounds__(ST_THREADS, 2) void sab_head_kernel(SabHeadParams p
     __syncthreads();                                           // the LayerNorm affine is read before the first stage barrier
     int n = 0;
     auto acquire = [&]() __attribute__((always_inline)) -> const char* {
-        if (n + 1 < total_stages) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(K::HPPW) : "memory");
+        if (split) {
+            if ((wave >> 2) == (n & 1)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (n + 1 < total_stages) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(K::HPPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
         issue(n + 2);
@@ -431,6 +463,7 @@ __global__ __launch_bounds__(256) void st_pack_kernel(const half_t* __restrict__
     *(half8*)(img + (size_t)id * 16) = *(const half8*)(w + (int64_t)ch * ldw + k0 + 16 * q + 8 * (lane >> 5));
 }
 
+static int g_sab_split = 1;     // pcd_sab_tail_config + 2 switches it off: one wave per SIMD requests a stage's LDS-DMA pieces
 static int g_sab_tail = 1;      // pcd_sab_tail_config: 0 = pcd_sab_forward keeps the four launches even where the descriptor carries a packed tail
 
 template <int C>
@@ -471,6 +504,7 @@ static int head_launch(const void* packed, const void* x, int64_t m, void* qkv, 
     SabHeadParams p{};
     p.x = (const half_t*)x; p.packed = (const char*)packed + K::TAIL_BYTES; p.qkv = (half_t*)qkv; p.m = m;
     p.pre_e = pre_e; p.estride = estride; p.rps = rps > 0 ? rps : 1;
+    p.split = g_sab_split;
     static PcdLdsOnce once;
     const size_t lds = (size_t)ST_RING * K::HSTAGE + K::HNPAR * sizeof(float);
     PCD_CHECK_HIP(pcd_allow_lds(once, (const void*)sab_head_kernel<C>, (int)lds));
@@ -489,6 +523,7 @@ static int tail_launch(const void* packed, const void* a, const void* x, int64_t
     SabTailParams p{};
     p.a = (const half_t*)a; p.x = (const half_t*)x; p.packed = (const char*)packed; p.y = (half_t*)y; p.m = m;
     p.pre_e = pre_e; p.post_e = post_e; p.estride = estride; p.rps = rps > 0 ? rps : 1;
+    p.split = g_sab_split;
     static PcdLdsOnce once;
     const size_t lds = (size_t)ST_RING * K::STAGE + K::NPAR * sizeof(float);
     PCD_CHECK_HIP(pcd_allow_lds(once, (const void*)sab_tail_kernel<C>, (int)lds));
@@ -516,8 +551,9 @@ extern "C" int pcd_sab_tail_supported(int dim, int64_t rows) {
 }
 
 extern "C" int pcd_sab_tail_config(int fused) {
-    PCD_CHECK_ARG(fused == 0 || fused == 1);
-    g_sab_tail = fused;
+    PCD_CHECK_ARG(fused >= 0 && fused <= 3);
+    g_sab_tail = fused & 1;
+    g_sab_split = (fused & 2) ? 0 : 1;
     return PCD_OK;
 }
 

@@ -606,7 +606,8 @@ size_t pcd_sab_workspace_bytes(int64_t rows, int dim);
  *   y = x1 + W2 relu(W1 LN2(x1) + b1) + b2,  x1 = x + W_out a + b_out      a = the heads' outputs [rows][dim], x = the block's input, all fp16
  * pcd_sab_tail_pack writes the fragment-order stage images of w_out / w_ff1 / w_ff2 (and w_in, for pcd_sab_head_f16) and the fp32 biases / LayerNorm affine of `d` into `packed`
  * (pcd_sab_tail_packed_bytes(dim) bytes of device memory; 0 = dim not supported); pcd_sab_tail_supported: dim 64 or 128 and rows % 256 == 0.
- * pcd_sab_tail_config(0) makes pcd_sab_forward / pcd_attn_unet_forward keep the four launches (A/B, tests); pcd_sab_tail_enabled reads it back. */
+ * pcd_sab_tail_config(0) makes pcd_sab_forward / pcd_attn_unet_forward keep the four launches (A/B, tests); + 2: the fused launches with every wave requesting its
+ * share of a stage's LDS-DMA pieces instead of one wave per SIMD (A/B); pcd_sab_tail_enabled reads bit 0 back.  TEST / BENCHMARK ONLY: process-global. */
 size_t pcd_sab_tail_packed_bytes(int dim);
 int pcd_sab_tail_supported(int dim, int64_t rows);
 int pcd_sab_tail_pack(const pcd_sab_desc_t* d, void* packed, void* stream);

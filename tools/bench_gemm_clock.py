@@ -21,7 +21,7 @@ ktiles = (M // 256) * (C // 256) // 256 * (K // 64)
 def launch():
     _lib.check(lib.pcd_gemm_f16_colmax_wfrag(d, wfrag.data_ptr(), out.data_ptr(), 2048, _lib.stream_ptr()))
 for rnd in range(2):
-    for name, cfgs in (("gemm_xw_kernel", (12,)), ("xw, mid-tile requests", (13,)), ("xw, one requesting wave per SIMD", (14,))):
+    for name, cfgs in (("gemm_xw_kernel (one requesting wave per SIMD)", (12, 15)), ("  every wave requests", (12, 14)), ("  mid-tile requests", (13, 14))):
         for c in cfgs: lib.pcd_gemm_set_config(c)
         for _ in range(100): launch()
         torch.cuda.synchronize()
@@ -36,4 +36,4 @@ for rnd in range(2):
         s = stamps.cpu().double()
         cyc, ticks = s[:, 0].median().item(), s[:, 1].median().item()
         print(f"{name:36s} {e0.elapsed_time(e1) / 300 * 1e3:8.1f} us / launch | {cyc / ktiles:7.0f} cycles per K tile | in-kernel clock {cyc / ticks * 100:6.0f} MHz | stamped launch {ticks / 100:7.1f} us", flush=True)
-lib.pcd_gemm_set_config(12)
+lib.pcd_gemm_set_config(12); lib.pcd_gemm_set_config(15)

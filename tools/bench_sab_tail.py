@@ -24,15 +24,15 @@ for C in (64, 128, 256):
     blk = SetAttentionBlock(C, 4); blk.load_state_dict(sab_sd(C), strict=True); blk = blk.to("cuda").eval()
     x = torch.randn(64, 2048, C, generator=g).cuda().half()
     t = {}
-    for fused in (1, 0, 1, 0):
+    for fused in (1, 3, 0, 1, 3, 0):
         _lib.check(lib.pcd_sab_tail_config(fused))
         t.setdefault(fused, []).append(ev(lambda: blk(x)))
-    print(f"SetAttentionBlock C={C}, B=64, N=2048: fused launches {min(t[1]):7.1f} us | separate launches {min(t[0]):7.1f} us per block", flush=True)
+    print(f"SetAttentionBlock C={C}, B=64, N=2048: fused launches {min(t[1]):7.1f} us (every wave requesting its pieces: {min(t[3]):7.1f}) | separate launches {min(t[0]):7.1f} us per block", flush=True)
 _lib.check(lib.pcd_sab_tail_config(1))
 att = PointCloudDiffusion(num_points=2048, backbone="attention").to("cuda").eval()
 x = torch.randn(64, 2048, 3, generator=g).cuda(); tt = torch.rand(64, generator=g).cuda()
 for rnd in range(3):
-    for fused in (1, 0):
+    for fused in (1, 3, 0):
         _lib.check(lib.pcd_sab_tail_config(fused))
         print(f"attention U-Net forward, tails fused={fused}: {ev(lambda: att.model(x, tt)) / 1e3:.3f} ms", flush=True)
 _lib.check(lib.pcd_sab_tail_config(1))

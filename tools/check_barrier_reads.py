@@ -250,7 +250,11 @@ def check_vmem_kernel(body):
 # path-insensitive join of the queues cannot verify them and reports phantom pending loads.  They are listed, counted and not failed on; what covers
 # them is dynamic: bitwise equality with the LDS-staged kernel on every GEMM test shape and the repeated-launch screens.
 PATH_SENSITIVE = {
-    "gemm_xw_kernel": "wait_vmcnt<4 + NST> / <4> by `behind_atomics`, <8> / <10> by the bias pieces of a tile boundary (csrc/gemm_f16.hip)",
+    "gemm_xw_kernel": "wait_vmcnt<4 + NST> / <4> by `behind_atomics`, <8> / <10> by the bias pieces of a tile boundary, <12> / <4> by which wave group requested the "
+                      "K tile's pieces (csrc/gemm_f16.hip)",
+    "gemm_xs_kernel": "the same structure with the epilogue's ND stores and the R drip stores of a K tile in the counts; the k-step-1 wait takes its count at run time "
+                      "(wait_vmcnt_rt: requesting group, tile boundary, dripping, behind an epilogue); covered by "
+                      "tests/test_gpu_kernels.py::test_gemm_store_with_fragment_order_weights_exact (bitwise v. gemm_xp_kernel, every combination, repeated launches)",
 }
 
 
