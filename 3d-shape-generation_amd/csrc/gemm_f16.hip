@@ -638,7 +638,9 @@ __device__ __forceinline__ half8 gload16_v(const half_t* g) {
 
 // SPLIT: the 32 LDS-DMA pieces of a K tile's activation panel are requested by ONE wave of each SIMD (waves 0-3 for even K tiles, 4-7 for odd ones: 8 pieces each)
 // instead of 4 pieces by every wave -- while one wave of a SIMD issues pieces (60-180 cycles each) its partner already issues MFMAs (csrc/wideffn.hip: +11 % there)
-template <bool MID = false, bool SPLIT = false>
+// WLATE (a diagnostic, pcd_gemm_set_config(33)): k step 0's weight registers are reloaded at the END of the K tile (lead ~0.05 K tile instead of ~0.5): if the K loop
+// does not slow down, the weights are not what its top wait waits for
+template <bool MID = false, bool SPLIT = false, bool WLATE = false>
 __global__ __launch_bounds__(512) void gemm_xw_kernel(GemmParams p, const half_t* __restrict__ wfrag) {
     constexpr int NST = 4;                                 // the epilogue's atomics per wave (they count in vmcnt)
     constexpr int BM = 256, BN = 256, BKT = 64, ROWB = 128, WGN = 4;
@@ -755,7 +757,11 @@ __global__ __launch_bounds__(512) void gemm_xw_kernel(GemmParams p, const half_t
 #pragma unroll
                 for (int i = 0; i < MI; ++i) af[i] = *(const half8*)(base + offa[ks] + i * 16 * ROWB);
                 if (ks == 1) {                                                         // k step 1's weights: behind them the A pieces (4; SPLIT: 8 or none) [+ bias 2] and k step 0's reload (4)
-                    if constexpr (SPLIT) {
+                    if constexpr (SPLIT && WLATE) {                                      // (k step 0's reload has not been issued yet)
+                        const bool issuer = (wave >> 2) == ((it + 1) & 1);
+                        if (issuer) { if (last) wait_vmcnt<10>(); else wait_vmcnt<8>(); }
+                        else { if (last) wait_vmcnt<2>(); else wait_vmcnt<0>(); }
+                    } else if constexpr (SPLIT) {
                         const bool issuer = (wave >> 2) == ((it + 1) & 1);
                         if (issuer) { if (last) wait_vmcnt<14>(); else wait_vmcnt<12>(); }
                         else { if (last) wait_vmcnt<6>(); else wait_vmcnt<4>(); }
@@ -777,8 +783,17 @@ __global__ __launch_bounds__(512) void gemm_xw_kernel(GemmParams p, const half_t
                     }
                 }
                 // this k step's registers take the next K tile's fragments (the MFMAs that read them have been issued)
+                if constexpr (WLATE) {
+                    if (ks == 1) {
 #pragma unroll
-                for (int j = 0; j < NI; ++j) wq[ks][j] = gload16_v(wb + (ks * 4 + j) * 512);
+                        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                            for (int j = 0; j < NI; ++j) wq[k2][j] = gload16_v(wb + (k2 * 4 + j) * 512);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) wq[ks][j] = gload16_v(wb + (ks * 4 + j) * 512);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             ++it;
@@ -1357,7 +1372,8 @@ extern "C" int pcd_gemm_f16_colmax_wfrag(const pcd_gemm_desc_t* d, const void* w
     const int pn = p.tiles_n >= 8 ? 8 : p.tiles_n, xn = p.tiles_n >= 16 ? 2 : 1;
     if ((pn & (pn - 1)) == 0 && p.tiles_n % (xn * pn) == 0 && p.tiles_m % ((8 / xn) * (32 / pn)) == 0) { p.patch_pn = pn; p.patch_xn = xn; }
     p.out32 = (float*)g_wfrag_stamps;
-    if (g_xs_mid) hipLaunchKernelGGL((gemm_xw_kernel<true, false>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
+    if (g_xs_mid == 2) hipLaunchKernelGGL((gemm_xw_kernel<false, true, true>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
+    else if (g_xs_mid) hipLaunchKernelGGL((gemm_xw_kernel<true, false>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
     else if (g_split) hipLaunchKernelGGL((gemm_xw_kernel<false, true>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
     else hipLaunchKernelGGL((gemm_xw_kernel<false, false>), dim3(256), dim3(512), 0, (hipStream_t)stream, p, (const half_t*)wfrag);
     PCD_CHECK_LAUNCH();
@@ -1412,6 +1428,7 @@ extern "C" int pcd_gemm_wfrag_enabled(void) { return g_xw; }
 extern "C" int pcd_gemm_store_wfrag_enabled(void) { return g_xs; }
 
 extern "C" int pcd_gemm_set_config(int cfg) {
+    if (cfg == 33) { g_xs_mid = 2; return PCD_OK; }                                 // diagnostic: gemm_xw_kernel reloads k step 0's weights late (see the kernel)
     PCD_CHECK_ARG(cfg >= -1 && cfg <= 31);
     if (cfg >= 16) { g_xs_abl = cfg - 16; return PCD_OK; }                          // timing ablations of gemm_xs_kernel (dev tools only)
     if (cfg == 14 || cfg == 15) { g_split = cfg - 14; return PCD_OK; }              // gemm_xw / gemm_xs: every wave requests 4 activation pieces / one wave per SIMD 8 (default)

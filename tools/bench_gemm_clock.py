@@ -21,7 +21,7 @@ ktiles = (M // 256) * (C // 256) // 256 * (K // 64)
 def launch():
     _lib.check(lib.pcd_gemm_f16_colmax_wfrag(d, wfrag.data_ptr(), out.data_ptr(), 2048, _lib.stream_ptr()))
 for rnd in range(2):
-    for name, cfgs in (("gemm_xw_kernel (one requesting wave per SIMD)", (12, 15)), ("  every wave requests", (12, 14)), ("  mid-tile requests", (13, 14))):
+    for name, cfgs in (("gemm_xw_kernel (one requesting wave per SIMD)", (12, 15)), ("  every wave requests", (12, 14)), ("  mid-tile requests", (13, 14)), ("  k step 0's weights reloaded at the end of the K tile", (12, 15, 33))):
         for c in cfgs: lib.pcd_gemm_set_config(c)
         for _ in range(100): launch()
         torch.cuda.synchronize()

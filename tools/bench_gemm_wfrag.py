@@ -38,6 +38,11 @@ for M, K, C in [(131072, 2048, 4096), (131072, 1024, 2048), (131072, 512, 512)]:
     xw()
     same_mid = torch.equal(out, ref)
     t_m = ev(lambda: lib.pcd_gemm_f16_colmax_wfrag(d, wfrag.data_ptr(), out.data_ptr(), 2048, _lib.stream_ptr()))
+    lib.pcd_gemm_set_config(33)        # diagnostic: k step 0's weights reloaded late
+    xw()
+    same_late = torch.equal(out, ref)
+    lib.pcd_gemm_set_config(12)
+    print("      (late-weights diagnostic bitwise equal:", same_late, ")", flush=True)
     lib.pcd_gemm_set_config(14)        # one wave per SIMD requests the activation pieces (8 each), alternating groups per K tile
     xw()
     same_split = torch.equal(out, ref)
