@@ -685,6 +685,310 @@ __global__ __launch_bounds__(256, 2) void set_attention_sp_kernel(const half_t* 
 }
 
 
+// ------------------------------------------------------------ software-pipelined kernel for d = 32 / 16 (n % 256 == 0)
+// set_attention_om_kernel below keeps ONE 32-query block per wave: the score MFMAs, the 16 v_exp_f32, the packs, the row sum, the any() branch and the
+// PV MFMAs of a 32 x 32 score tile are one dependent chain, and two waves per SIMD do not hide it -- 441 cycles per tile and SIMD at d = 32 for 128 cycles of
+// MFMA and ~200 of VALU issue (profiles/r05_b: the matrix pipe and the VALU overlap, so the floor is the LARGER of the two, not their sum).  Here a wave
+// owns TWO 32-query blocks half a step apart, exactly as in set_attention_sp_kernel: while block A's scores are exponentiated the matrix pipe holds block
+// B's PV product and A's next score tile.  At d <= 32 a phase has 4 (d = 32) or 3 (d = 16) MFMAs beside the same 16 exponentials, so the VALU is the
+// busy unit (~205 issue cycles per phase: 16 x 8 v_exp_f32 + 8 packs + 8 packed adds) and the MFMAs ride in its shadow.
+//   d = 32: K / V tile rows are 64 bytes (4 + 4 one-KB LDS-DMA pieces per 64-key tile, two per wave), one O^T block of 32 rows;
+//   d = 16: 32-byte rows (2 + 2 pieces, one per wave); O^T rows 16 .. 31 multiply zeros: the lanes that would read them point into a zeroed LDS region
+//           as large as the ring, so the same immediate offsets apply and no lane needs a branch.
+// Softmax, rare path, ring, barriers and the XCD-aware block map are set_attention_sp_kernel's.
+// rare path: the tile's scores were overwritten by the next tile's (see spn_phase), so they are formed again from K(i), which is still in its ring slot;
+// then as sp_fix: raise the running max of the rows that need it, rescale everything that was formed against the old one (O, l, the -m accumulator seed, the
+// pending next score tile) and redo this tile's exponentials
+template <int D>
+__device__ __forceinline__ half2_ spn_fix(const char* (&kaddr)[D / 16], int koff_cur, const half8 (&qf)[D / 16], f32x16& s_nxt, f32x16& negm,
+                                          f32x16& o, float& l, half8& p0, half8& p1) {
+    f32x16 s_cur = SP_MF(*(const half8*)(kaddr[0] + koff_cur), qf[0], negm);
+    if constexpr (D == 32) s_cur = SP_MF(*(const half8*)(kaddr[1] + koff_cur), qf[1], s_cur);
+    const float delta = fmaxf(sp_rowmax(s_cur), 0.f);
+    const float alpha = __builtin_amdgcn_exp2f(-delta);
+    l *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        negm[r] -= delta; s_cur[r] -= delta; s_nxt[r] -= delta;
+        o[r] *= alpha;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        p0[j] = (half_t)__builtin_amdgcn_exp2f(s_cur[j]);
+        p1[j] = (half_t)__builtin_amdgcn_exp2f(s_cur[8 + j]);
+    }
+    return sp_tile_sum(p0, p1);
+}
+
+// One phase: the VALU work of sp_phase in its eight slices; the OTHER block's PV MFMAs (and mid(), the reload of V behind them) in front of fixed slices, and
+// this block's NEXT score tile last, INTO the registers the exponentials have just read (the matrix pipe works on it under the next phase; a separate
+// register set for it costs 32 registers = the third wave per SIMD):
+//   d = 32:  PV0 | . | PV1 | . | mid | . | . | . | S0 S1           d = 16:  PV0 | . | . | PV1 | . | mid | . | . | S0
+template <int D, typename Mid>
+__device__ __forceinline__ half2_ spn_phase(f32x16& s, half8& p0, half8& p1, const half8 (&kf)[D / 16], const half8 (&qf)[D / 16],
+                                            const f32x16& negm, f32x16& o, const half8 (&vf)[2], const half8& y0, const half8& y1,
+                                            half2_ t_other, float& l_other, Mid&& mid) {
+#define SPN_PV(j) o = SP_MF(vf[j], (j) ? y1 : y0, o)
+#define SPN_SLOT(k)                                                            \
+    do {                                                                       \
+        SP_SB();                                                               \
+        if constexpr ((k) == 0) SPN_PV(0);                                     \
+        if constexpr ((k) == (D == 32 ? 2 : 3)) SPN_PV(1);                     \
+        if constexpr ((k) == (D == 32 ? 4 : 5)) { mid(); SP_SB(); }            \
+    } while (0)
+    SPN_SLOT(0);
+    const float e0 = __builtin_amdgcn_exp2f(s[0]), e1 = __builtin_amdgcn_exp2f(s[1]);
+    SPN_SLOT(1);
+    const float e8 = __builtin_amdgcn_exp2f(s[8]), e9 = __builtin_amdgcn_exp2f(s[9]);
+    const half2_ c0 = sp_pk(e0, e1);
+    SPN_SLOT(2);
+    const float e2 = __builtin_amdgcn_exp2f(s[2]), e3 = __builtin_amdgcn_exp2f(s[3]);
+    const half2_ c4 = sp_pk(e8, e9);
+    SPN_SLOT(3);
+    const float e10 = __builtin_amdgcn_exp2f(s[10]), e11 = __builtin_amdgcn_exp2f(s[11]);
+    const half2_ c1 = sp_pk(e2, e3);
+    const half2_ a0 = c0 + c4;
+    SPN_SLOT(4);
+    const float e4 = __builtin_amdgcn_exp2f(s[4]), e5 = __builtin_amdgcn_exp2f(s[5]);
+    const half2_ c5 = sp_pk(e10, e11);
+    SPN_SLOT(5);
+    const float e12 = __builtin_amdgcn_exp2f(s[12]), e13 = __builtin_amdgcn_exp2f(s[13]);
+    const half2_ c2 = sp_pk(e4, e5);
+    const half2_ a1 = c1 + c5;
+    SPN_SLOT(6);
+    const float e6 = __builtin_amdgcn_exp2f(s[6]), e7 = __builtin_amdgcn_exp2f(s[7]);
+    const half2_ c6 = sp_pk(e12, e13);
+    const half2_ b0 = a0 + a1;
+    SPN_SLOT(7);
+    const float e14 = __builtin_amdgcn_exp2f(s[14]), e15 = __builtin_amdgcn_exp2f(s[15]);
+    const half2_ c3 = sp_pk(e6, e7);
+    const half2_ a2 = c2 + c6;
+    const half2_ b1 = b0 + a2;
+    SP_SB();
+    s = SP_MF(kf[0], qf[0], negm);                             // every score of this tile has been read: the next tile's take their place
+    if constexpr (D == 32) s = SP_MF(kf[1], qf[1], s);
+    SP_SB();
+#undef SPN_SLOT
+#undef SPN_PV
+    // tail as in sp_phase: the other block's pending row sum goes into its fp32 l in the wait states of the three dependent packed adds
+    const half2_ c7 = sp_pk(e14, e15);
+    half2_ a3, t, tt;
+    float lo;
+    asm volatile("v_pk_add_f16 %0, %5, %6\n\t"
+                 "v_cvt_f32_f16_e32 %3, %8\n\t"
+                 "v_pk_add_f16 %1, %7, %0\n\t"
+                 "v_add_f32_e32 %4, %4, %3\n\t"
+                 "v_pk_add_f16 %2, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]"
+                 : "=&v"(a3), "=&v"(t), "=&v"(tt), "=&v"(lo), "+v"(l_other)
+                 : "v"(c3), "v"(c7), "v"(b1), "v"(t_other));
+    p0 = __builtin_shufflevector(__builtin_shufflevector(c0, c1, 0, 1, 2, 3), __builtin_shufflevector(c2, c3, 0, 1, 2, 3),
+                                 0, 1, 2, 3, 4, 5, 6, 7);
+    p1 = __builtin_shufflevector(__builtin_shufflevector(c4, c5, 0, 1, 2, 3), __builtin_shufflevector(c6, c7, 0, 1, 2, 3),
+                                 0, 1, 2, 3, 4, 5, 6, 7);
+    return tt;
+}
+
+// ABL: timing ablations for tools/bench_attn_small_d.py (pcd_set_attention_config(16 + bits); outputs are wrong while set): 1 = no K/V restaging in the loop,
+// 2 = no rare-path test, 4 = no waits / barriers in the loop
+template <int D, int ABL = 0>
+__global__ __launch_bounds__(256, 3) void set_attention_spn_kernel(const half_t* __restrict__ qkv, int n, int c, int heads,
+                                                                    float scale_log2e, half_t* __restrict__ out) {
+    static_assert(D == 32 || D == 16, "d = 64 has set_attention_sp_kernel");
+    constexpr int KSTEPS = D / 16, KRB = 2 * D, NSLOT = 4;
+    constexpr int KBYTES = KT * KRB, STAGE = 2 * KBYTES;
+    constexpr int AHEAD = NSLOT - 2;                          // tiles in flight beyond the one being consumed
+    constexpr int RPP = 1024 / KRB;                           // rows of a K / V tile per 1-KB LDS-DMA piece (16 / 32)
+    constexpr int CPR = KRB / 16;                             // 16-byte chunks per row (4 / 2)
+    constexpr int PPW = 2 * (KT / RPP) / 4;                   // pieces per wave and tile (2 / 1)
+    constexpr int ZERO_BYTES = D == 16 ? NSLOT * STAGE : 0;   // d = 16: what the lanes of O^T rows 16 .. 31 read (every ring offset stays inside it)
+    __shared__ __attribute__((aligned(16))) char smem[NSLOT * STAGE + ZERO_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qr = lane & 31, hh = lane >> 5;
+    // XCD-aware block -> (shape, head, query block) map of set_attention_sp_kernel: the n / 256 query blocks of one (shape, head) run on one XCD
+    const int nqb = n >> 8;
+    int bh, qb;
+    {
+        const int L = blockIdx.x, total_bh = gridDim.x / nqb;
+        const int xcd = L & 7, i = L >> 3;
+        const int j = i / nqb;
+        bh = xcd + 8 * j;
+        qb = i - j * nqb;
+        if (bh >= total_bh || (total_bh & 7)) { bh = L / nqb; qb = L - bh * nqb; }
+    }
+    const int b = bh / heads, head = bh - b * heads;
+    const int q0 = qb * 256 + wave * 64;
+    const int64_t row_base = (int64_t)b * n;
+    const int ld = 3 * c;
+
+    if constexpr (D == 16) {
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        for (int i = tid * 16; i < ZERO_BYTES; i += 256 * 16) *(u32x4_*)(smem + NSLOT * STAGE + i) = (u32x4_){0u, 0u, 0u, 0u};
+    }
+
+    const half_t* kbase = qkv + row_base * ld + c + head * D;
+    const half_t* vbase = qkv + row_base * ld + 2 * c + head * D;
+    const int ntiles = n / KT;                                // a multiple of NSLOT (n % 256 == 0)
+    // LDS-DMA staging: a 1-KB piece is RPP rows; lane -> (row lane / CPR of the piece, chunk lane % CPR).  The K swizzle of a row only depends on the row
+    // inside its piece (pieces start at multiples of 16 rows), V rows are not swizzled at these row widths: one lane-constant offset each.
+    const unsigned lrow = lane / CPR, lch = lane % CPR;
+    const unsigned koff32 = lrow * (unsigned)ld * 2u + ((unsigned)k_swz<KRB>((int)lrow, (int)lch) << 4);
+    const unsigned voff32 = lrow * (unsigned)ld * 2u + (lch << 4);
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const size_t tile_bytes = (size_t)KT * ld * 2;
+    // d = 32: wave w moves K piece w and V piece w of a tile (rows 16 w ..); d = 16: waves 0, 1 move K pieces 0, 1, waves 2, 3 V pieces 0, 1 (rows 32 (w & 1) ..)
+    const int prow = D == 32 ? 16 * wave : 32 * (wave & 1);
+    const char* kwave = (const char*)kbase + (size_t)prow * ld * 2;
+    const char* vwave = (const char*)vbase + (size_t)prow * ld * 2;
+    auto dma = [&](const char* sbase, unsigned voff, unsigned lds_addr) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr)
+                     : "memory", "m0");
+    };
+    // piece j of this wave's PPW pieces of tile kt into ring slot `slot`
+    auto stage_piece = [&](int kt, int slot, int j) __attribute__((always_inline)) {
+        if constexpr (D == 32) {
+            const char* src = (j ? vwave : kwave) + (size_t)kt * tile_bytes;
+            dma(src, j ? voff32 : koff32, lds0 + slot * STAGE + (j ? KBYTES : 0) + wave * 1024);
+        } else {
+            if (j == 0) {
+                const bool is_v = wave >= 2;
+                const char* src = (is_v ? vwave : kwave) + (size_t)kt * tile_bytes;
+                dma(src, is_v ? voff32 : koff32, lds0 + slot * STAGE + (is_v ? KBYTES : 0) + (wave & 1) * 1024);
+            }
+        }
+    };
+#pragma unroll
+    for (int t = 0; t <= AHEAD; ++t)
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) stage_piece(t, t, j);
+
+    half8 qA[KSTEPS], qB[KSTEPS];
+    {
+        const half_t* qpA = qkv + (row_base + q0 + qr) * ld + head * D;
+        const half_t* qpB = qpA + (int64_t)32 * ld;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            const half8 ra = *(const half8*)(qpA + 16 * s + 8 * hh), rb = *(const half8*)(qpB + 16 * s + 8 * hh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                qA[s][e] = (half_t)((float)ra[e] * scale_log2e);
+                qB[s][e] = (half_t)((float)rb[e] * scale_log2e);
+            }
+        }
+    }
+
+    // lane-constant LDS addresses (slot 0, key sub-tile 0); every read adds a compile-time offset (the K swizzle of row qr + 32 i is that of row qr)
+    const int tq = (lane >> 2) & 3, tp = lane & 3, tg = lane >> 4;
+    const char* kaddr[KSTEPS];
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) kaddr[s] = smem + qr * KRB + (k_swz<KRB>(qr, 2 * s + hh) << 4);
+    const char* vaddr;
+    {
+        const int key = 4 * (tg >> 1) + tq;
+        const int ch = ((16 * (tg & 1)) >> 3) + (tp >> 1);
+        vaddr = smem + KBYTES + key * KRB + (ch << 4) + (tp & 1) * 8;
+        if (D == 16 && (tg & 1)) vaddr = smem + NSLOT * STAGE + (tp & 1) * 8;
+    }
+    auto load_k = [&](int off, half8 (&kf)[KSTEPS]) __attribute__((always_inline)) {         // off = slot * STAGE + sub * 32 * KRB
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) kf[s] = *(const half8*)(kaddr[s] + off);
+    };
+    auto load_v = [&](int off, half8 (&vf)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const char* a0 = vaddr + off + 16 * s2 * KRB;
+            const fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)a0);
+            const fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(a0 + 8 * KRB));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { vf[s2][e] = (half_t)lo[e]; vf[s2][4 + e] = (half_t)hi[e]; }
+        }
+    };
+
+    f32x16 oA, oB, negmA, negmB, sA, sB;
+    float lA = 0.f, lB = 0.f;
+    half8 pA0, pA1, pB0, pB1, kf[KSTEPS], vf[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oA[r] = oB[r] = 0.f; negmA[r] = negmB[r] = 0.f; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {                              // the first phase's O_B += V(-1)^T P_B(-1) adds zero
+        pB0[e] = pB1[e] = (half_t)0.f;
+        vf[0][e] = vf[1][e] = (half_t)0.f;
+    }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // the first 32 keys fix the running max exactly: S(0) - rowmax, seed accumulators = -rowmax
+    load_k(0, kf);
+    sA = SP_MF(kf[0], qA[0], negmA);
+    sB = SP_MF(kf[0], qB[0], negmB);
+#pragma unroll
+    for (int s = 1; s < KSTEPS; ++s) { sA = SP_MF(kf[s], qA[s], sA); sB = SP_MF(kf[s], qB[s], sB); }
+    {
+        const float ma = sp_rowmax(sA), mb = sp_rowmax(sB);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { negmA[r] = -ma; sA[r] -= ma; negmB[r] = -mb; sB[r] -= mb; }
+    }
+    load_k(32 * KRB, kf);                                     // K(1) for the first sub-tile's S(i+1) products
+
+    half2_ tA, tB;                                              // row sums of the last tile of A / B, not yet in lA / lB
+    tA.x = tA.y = tB.x = tB.y = (half_t)0.f;
+    // one key sub-tile i (32 keys): kf holds K(i+1), vf V(i-1), sA / sB the scores S(i) on entry; V(i) (and K(i), for the rare path) at voff, K(i+2) at koff;
+    // when stage_on, piece j of tile st leaves for ring slot sslot in front of the first phase
+    auto sub_iter = [&](int voff, int koff, bool stage_on, int st, int sslot, int j) __attribute__((always_inline)) {
+        if (!(ABL & 1) && stage_on && j < PPW) stage_piece(st, sslot, j);
+        tA = spn_phase<D>(sA, pA0, pA1, kf, qA, negmA, oB, vf, pB0, pB1, tB, lB, [&]() { load_v(voff, vf); });
+        asm volatile("" : "+v"(vf[0]), "+v"(vf[1]));           // V(i) is read HERE (the compiler would sink the reads to their use, the first MFMA of the next phase)
+        if (!(ABL & 2) && __builtin_expect(__any(__builtin_bit_cast(unsigned, tA) > SP_BIG_BITS), 0)) tA = spn_fix<D>(kaddr, voff, qA, sA, negmA, oA, lA, pA0, pA1);
+        tB = spn_phase<D>(sB, pB0, pB1, kf, qB, negmB, oA, vf, pA0, pA1, tA, lA, [&]() {});
+        load_k(koff, kf);                                      // behind the last product that reads K(i+1)
+        if (!(ABL & 2) && __builtin_expect(__any(__builtin_bit_cast(unsigned, tB) > SP_BIG_BITS), 0)) tB = spn_fix<D>(kaddr, voff, qB, sB, negmB, oB, lB, pB0, pB1);
+    };
+    auto tile_group = [&](int t0, auto last_tag) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_tag)::value;
+#pragma unroll
+        for (int u = 0; u < NSLOT; ++u) {
+            // tile t+1 has landed (all but the youngest stage's PPW LDS-DMA pieces of this wave), this wave's own fragment reads have returned
+            if constexpr (!(ABL & 4)) {
+                if (!LAST || u < 2) {
+                    if constexpr (PPW == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                }
+                __syncthreads();
+            }
+            const int cur = u * STAGE, nxt = ((u + 1) % NSLOT) * STAGE;   // last tile: nxt holds stale bytes, S(i+1) unused
+            const int st = t0 + u + AHEAD + 1, sslot = (u + AHEAD + 1) % NSLOT;   // tile to stage; its slot == slot of tile t-1
+            const bool on = !LAST || u == 0;
+            sub_iter(cur, nxt, on, st, sslot, 0);
+            sub_iter(cur + 32 * KRB, nxt + 32 * KRB, on, st, sslot, 1);
+        }
+    };
+    int t0 = 0;
+    for (; t0 + NSLOT < ntiles; t0 += NSLOT) tile_group(t0, std::false_type{});
+    tile_group(t0, std::true_type{});
+    oB = SP_MF(vf[0], pB0, oB);                               // O_B += V(last)^T P_B(last)
+    oB = SP_MF(vf[1], pB1, oB);
+
+    // epilogue: lane (query qr, half hh) holds O^T rows dd = (r & 3) + 8 (r >> 2) + 4 hh
+    auto store = [&](const f32x16& o, float l, int qi) {
+        const float l_tot = l + __shfl_xor(l, 32);
+        const float inv = 1.f / l_tot;
+        half_t* orow = out + (row_base + qi) * c + head * D;
+#pragma unroll
+        for (int g = 0; g < D / 8; ++g) {
+            half4 ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[e] = to_half_sat(o[4 * g + e] * inv);
+            *(half4*)(orow + 8 * g + 4 * hh) = ov;
+        }
+    };
+    store(oA, lA, q0 + qr);
+    store(oB, lB + (float)tB.x, q0 + 32 + qr);                 // B's last tile sum is still pending (A's went in with B's last phase)
+}
+
+
 // ------------------------------------------------------------ generic kernel without the running max (d = 16 / 32 / 64, any n)
 // set_attention_kernel above spends 66 VALU instructions per 32 x 32 score tile, 50 of them around the 16 v_exp_f32 (row max chain,
 // half-wave exchange, compare, fp32 row sums); at d = 32 / 16 a tile is only 4 / 3 MFMAs (128 / 96 matrix cycles), so the kernel is VALU
@@ -891,8 +1195,12 @@ extern "C" size_t pcd_set_attention_workspace_bytes(int batch, int n_points, int
 }
 
 static int g_attn_force_generic = 0;   // tuning/testing hook: 1 = always the round-1 generic kernel, 2 = always the max-free generic kernel
+static int g_attn_spn_abl = 0;         // timing ablations of set_attention_spn_kernel (pcd_set_attention_config(16 + bits)); outputs are wrong while set
+static int g_attn_spn = 1;             // tuning/testing hook (pcd_set_attention_config(3) / (4)): d = 32 / 16 on the software-pipelined kernel: off / on (default)
 
 extern "C" int pcd_set_attention_config(int force_generic) {
+    if (force_generic == 3 || force_generic == 4) { g_attn_spn = force_generic == 4; return PCD_OK; }
+    if (force_generic >= 16 && force_generic < 24) { g_attn_spn_abl = force_generic - 16; return PCD_OK; }
     g_attn_force_generic = force_generic < 0 ? 0 : (force_generic > 2 ? 2 : force_generic);
     return PCD_OK;
 }
@@ -918,6 +1226,24 @@ extern "C" int pcd_set_attention_f16(const void* qkv, int batch, int n_points, i
         hipLaunchKernelGGL(set_attention_sp_kernel, sgrid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads,
                            scale_log2e, (half_t*)out);
         g_attn_last_kernel = "set_attention_sp_kernel";
+        PCD_CHECK_LAUNCH();
+        return PCD_OK;
+    }
+    if ((d == 32 || d == 16) && n_points % 256 == 0 && g_attn_force_generic == 0 && g_attn_spn) {   // the same pipeline at d <= 32
+        dim3 sgrid((unsigned)((n_points / 256) * batch * heads));
+#define PCD_SPN_ABL(A)                                                                                                                                   \
+        if (g_attn_spn_abl == A) {                                                                                                                           \
+            if (d == 32) hipLaunchKernelGGL((set_attention_spn_kernel<32, A>), sgrid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads, scale_log2e, (half_t*)out); \
+            else hipLaunchKernelGGL((set_attention_spn_kernel<16, A>), sgrid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads, scale_log2e, (half_t*)out);          \
+            g_attn_last_kernel = "set_attention_spn_kernel (timing ablation)";                                                                               \
+            PCD_CHECK_LAUNCH();                                                                                                                              \
+            return PCD_OK;                                                                                                                                   \
+        }
+        PCD_SPN_ABL(1) PCD_SPN_ABL(2) PCD_SPN_ABL(3) PCD_SPN_ABL(7)
+#undef PCD_SPN_ABL
+        if (d == 32) hipLaunchKernelGGL((set_attention_spn_kernel<32>), sgrid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads, scale_log2e, (half_t*)out);
+        else hipLaunchKernelGGL((set_attention_spn_kernel<16>), sgrid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads, scale_log2e, (half_t*)out);
+        g_attn_last_kernel = d == 32 ? "set_attention_spn_kernel<32>" : "set_attention_spn_kernel<16>";
         PCD_CHECK_LAUNCH();
         return PCD_OK;
     }

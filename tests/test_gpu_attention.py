@@ -127,8 +127,47 @@ def test_attention_max_free_generic_kernel(pattern, C, N):
     assert torch.isfinite(outs[2]).all()
     assert rel_l2(outs[2], want) < 2e-3, (pattern, C, N)
     assert rel_l2(outs[2], outs[1]) < 2e-3
-    if not (C == 256 and N % 256 == 0):                         # the default dispatch is this kernel for these shapes
+    if N % 256 != 0:                                            # the default dispatch is this kernel for ragged lengths
         assert torch.equal(ops.set_attention_f16(qkv16.cuda(), B, N, C, H).float().cpu(), outs[2])
+
+
+@pytest.mark.parametrize("pattern", ["plain", "late_spike", "rising", "falling", "huge_first"])
+@pytest.mark.parametrize("C,N", [(64, 256), (64, 512), (128, 512), (128, 768), (64, 2048)])
+def test_attention_pipelined_kernel_d32_d16(pattern, C, N):
+    """d = 32 / 16 at N % 256 == 0 run the two-block software pipeline of the d = 64 kernel (set_attention_spn_kernel): one ring group only
+    (N = 256), several, the rare path in every position, against fp64 and against the one-block kernel it replaces."""
+    from shapegen_amd import _lib, ops
+    B, H = 2, 4
+    g = torch.Generator().manual_seed(11 + C + N)
+    qkv = torch.randn(B * N, 3 * C, generator=g)
+    k = qkv[:, C:2 * C]
+    if pattern == "late_spike":
+        k[N + N - 40] *= 14.0                    # shape 1, one of the last keys
+        k[37] *= 9.0                             # shape 0, second sub-tile
+        k[N + 64] *= 11.0                        # shape 1, first key of tile 1
+    elif pattern == "rising":
+        k *= torch.linspace(0.2, 6.0, N).repeat(B)[:, None]
+    elif pattern == "falling":
+        k *= torch.linspace(8.0, 0.1, N).repeat(B)[:, None]
+    elif pattern == "huge_first":
+        k[:32] *= 20.0
+    qkv16 = qkv.half()
+    want = _attention_fp64(qkv16, B, N, C, H)
+    lib = _lib.load()
+    got = ops.set_attention_f16(qkv16.cuda(), B, N, C, H).float().cpu()
+    assert lib.pcd_set_attention_last_kernel().decode() == f"set_attention_spn_kernel<{C // H}>"
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, want) < 2e-3, (pattern, C, N)
+    _lib.check(lib.pcd_set_attention_config(3))                  # the one-block kernel on the same input
+    try:
+        one = ops.set_attention_f16(qkv16.cuda(), B, N, C, H).float().cpu()
+        assert lib.pcd_set_attention_last_kernel().decode() == f"set_attention_om_kernel<{C // H}>"
+    finally:
+        _lib.check(lib.pcd_set_attention_config(4))
+    assert rel_l2(got, one) < 1e-3
+    # per-row check: no query row may be off (a wrong row hides in a whole-tensor norm)
+    rows = ((got - want).norm(dim=1) / want.norm(dim=1).clamp_min(1e-3))
+    assert float(rows.max()) < 2e-2, (pattern, C, N, int(rows.argmax()))
 
 
 @pytest.mark.parametrize("rows,c", [(4096 + 5, 64), (1000, 128), (777, 256), (64, 96), (3, 256)])
