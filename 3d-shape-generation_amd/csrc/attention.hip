@@ -487,7 +487,11 @@ __device__ __forceinline__ half2_ sp_phase(const f32x16& s, half8& p0, half8& p1
     return tt;
 }
 
-__global__ __launch_bounds__(256, 2) void set_attention_sp_kernel(const half_t* __restrict__ qkv, int n, int c, int heads,
+// ABL: timing ablations (pcd_set_attention_config(16 + bits), outputs wrong while set): 1 = no K/V restaging in the loop, 2 = no rare-path test
+// NW: waves per workgroup (4 or 8): the workgroup's 64 NW queries share one K/V ring -- restaging K/V costs 10 % of the kernel at NW = 4 (tools/bench_attn_small_d.py),
+// and at NW = 8 every wave moves 2 pieces per tile instead of 4
+template <int ABL = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void set_attention_sp_kernel(const half_t* __restrict__ qkv, int n, int c, int heads,
                                                                    float scale_log2e, half_t* __restrict__ out) {
     constexpr int D = 64, KSTEPS = 4, KRB = 128, NSLOT = 4;
     constexpr int KBYTES = KT * KRB, STAGE = 2 * KBYTES;
@@ -501,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void set_attention_sp_kernel(const half_t* 
     // (block L runs on XCD L % 8, speed only, never correctness), and the n/256 query blocks of one (shape, head)
     // all stream the same K/V: give them to ONE XCD, next to each other in time, so its L2 fetches that K/V once
     // instead of 8 L2s fetching it once each.
-    const int nqb = n >> 8;                                   // query blocks per (shape, head)
+    const int nqb = n / (64 * NW);                            // query blocks per (shape, head)
     int bh, qb;
     {
         const int L = blockIdx.x, total_bh = gridDim.x / nqb;
@@ -512,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void set_attention_sp_kernel(const half_t* 
         if (bh >= total_bh || (total_bh & 7)) { bh = L / nqb; qb = L - bh * nqb; }   // batch*heads not a multiple of 8: plain order
     }
     const int b = bh / heads, head = bh - b * heads;
-    const int q0 = qb * 256 + wave * 64;
+    const int q0 = qb * (64 * NW) + wave * 64;
     const int64_t row_base = (int64_t)b * n;
     const int ld = 3 * c;
 
@@ -537,9 +541,16 @@ __global__ __launch_bounds__(256, 2) void set_attention_sp_kernel(const half_t* 
     };
     // piece j (0..3) of tile kt into ring slot `slot`: K rows 8w.., K rows 8w+32.., V rows 8w.., V rows 8w+32..
     auto stage_piece = [&](int kt, int slot, int j) __attribute__((always_inline)) {
-        const char* src = ((j & 2) ? vwave : kwave) + (size_t)kt * tile_bytes + ((j & 1) ? half_bytes : 0);
-        const unsigned dst = lds0 + slot * STAGE + ((j & 2) ? KBYTES : 0) + (wave + 4 * (j & 1)) * 1024;
-        dma(src, (j & 2) ? voff32 : koff32, dst);
+        if constexpr (NW == 4) {
+            const char* src = ((j & 2) ? vwave : kwave) + (size_t)kt * tile_bytes + ((j & 1) ? half_bytes : 0);
+            const unsigned dst = lds0 + slot * STAGE + ((j & 2) ? KBYTES : 0) + (wave + 4 * (j & 1)) * 1024;
+            dma(src, (j & 2) ? voff32 : koff32, dst);
+        } else {                                               // eight waves: piece 0 = K rows 8 w .., piece 2 = V rows 8 w .. (one in front of each sub-tile)
+            if (j == 0 || j == 2) {
+                const char* src = (j ? vwave : kwave) + (size_t)kt * tile_bytes;
+                dma(src, j ? voff32 : koff32, lds0 + slot * STAGE + (j ? KBYTES : 0) + wave * 1024);
+            }
+        }
     };
     // K/V tiles 0 .. AHEAD go out first (4 LDS-DMA instructions per wave and tile), the Q rows behind them
 #pragma unroll
@@ -629,12 +640,12 @@ __global__ __launch_bounds__(256, 2) void set_attention_sp_kernel(const half_t* 
     // one key sub-tile i (32 keys): kf holds K(i+1) and vf V(i-1) on entry; V(i) at voff, K(i+2) at koff; when STAGE_ON,
     // pieces j0 and j0 + 1 of tile st leave for ring slot sslot, one in front of each phase
     auto sub_iter = [&](int voff, int koff, bool stage_on, int st, int sslot, int j0) __attribute__((always_inline)) {
-        if (stage_on) stage_piece(st, sslot, j0);
+        if (!(ABL & 1) && stage_on) stage_piece(st, sslot, j0);
         tA = sp_phase<true>(sA, pA0, pA1, kf, qA, negmA, sAn, oB, vf, pB0, pB1, tB, lB, [&]() { load_v(voff, vf); });
-        if (__builtin_expect(__any(__builtin_bit_cast(unsigned, tA) > SP_BIG_BITS), 0)) tA = sp_fix(sA, sAn, negmA, oA, lA, pA0, pA1);
-        if (stage_on) stage_piece(st, sslot, j0 + 1);
+        if (!(ABL & 2) && __builtin_expect(__any(__builtin_bit_cast(unsigned, tA) > SP_BIG_BITS), 0)) tA = sp_fix(sA, sAn, negmA, oA, lA, pA0, pA1);
+        if (!(ABL & 1) && stage_on) stage_piece(st, sslot, j0 + 1);
         tB = sp_phase<false>(sB, pB0, pB1, kf, qB, negmB, sBn, oA, vf, pA0, pA1, tA, lA, [&]() { load_k(koff, kf); });
-        if (__builtin_expect(__any(__builtin_bit_cast(unsigned, tB) > SP_BIG_BITS), 0)) tB = sp_fix(sB, sBn, negmB, oB, lB, pB0, pB1);
+        if (!(ABL & 2) && __builtin_expect(__any(__builtin_bit_cast(unsigned, tB) > SP_BIG_BITS), 0)) tB = sp_fix(sB, sBn, negmB, oB, lB, pB0, pB1);
         sA = sAn; sB = sBn;
     };
     // NSLOT tiles, tile t0 + u in ring slot u.  LAST = the final group: only its first tile still has a tile to stage
@@ -646,7 +657,10 @@ __global__ __launch_bounds__(256, 2) void set_attention_sp_kernel(const half_t* 
             // tile t+1 has landed (all but the youngest stage's 4 LDS-DMA) and every wave is done with tile t-1
             // (lgkmcnt(0): this wave's own fragment reads have RETURNED before the barrier behind which another wave's LDS-DMA refills a slot --
             // the compiler's barrier fence says so at three of the four barriers of a group, not at the loop-carried one: tools/check_barrier_reads.py)
-            if (!LAST || u < 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            if (!LAST || u < 2) {
+                if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            }
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __syncthreads();
             const int cur = u * STAGE, nxt = ((u + 1) % NSLOT) * STAGE;   // last tile: nxt holds stale bytes, S(i+1) unused
@@ -1196,10 +1210,12 @@ extern "C" size_t pcd_set_attention_workspace_bytes(int batch, int n_points, int
 
 static int g_attn_force_generic = 0;   // tuning/testing hook: 1 = always the round-1 generic kernel, 2 = always the max-free generic kernel
 static int g_attn_spn_abl = 0;         // timing ablations of set_attention_spn_kernel (pcd_set_attention_config(16 + bits)); outputs are wrong while set
+static int g_attn_sp_waves = 4;        // tuning hook (pcd_set_attention_config(5) / (6)): set_attention_sp_kernel with 4 / 8 waves per workgroup
 static int g_attn_spn = 1;             // tuning/testing hook (pcd_set_attention_config(3) / (4)): d = 32 / 16 on the software-pipelined kernel: off / on (default)
 
 extern "C" int pcd_set_attention_config(int force_generic) {
     if (force_generic == 3 || force_generic == 4) { g_attn_spn = force_generic == 4; return PCD_OK; }
+    if (force_generic == 5 || force_generic == 6) { g_attn_sp_waves = force_generic == 6 ? 8 : 4; return PCD_OK; }
     if (force_generic >= 16 && force_generic < 24) { g_attn_spn_abl = force_generic - 16; return PCD_OK; }
     g_attn_force_generic = force_generic < 0 ? 0 : (force_generic > 2 ? 2 : force_generic);
     return PCD_OK;
@@ -1223,7 +1239,13 @@ extern "C" int pcd_set_attention_f16(const void* qkv, int batch, int n_points, i
     constexpr int QT = 1;
     if (d == 64 && n_points % 256 == 0 && g_attn_force_generic == 0) {   // software-pipelined kernel: 64 queries per wave, 256 per workgroup
         dim3 sgrid((unsigned)((n_points / 256) * batch * heads));
-        hipLaunchKernelGGL(set_attention_sp_kernel, sgrid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads,
+        if (g_attn_spn_abl == 1) hipLaunchKernelGGL(set_attention_sp_kernel<1>, sgrid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads, scale_log2e, (half_t*)out);
+        else if (g_attn_spn_abl == 2) hipLaunchKernelGGL(set_attention_sp_kernel<2>, sgrid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads, scale_log2e, (half_t*)out);
+        else if (g_attn_spn_abl == 3) hipLaunchKernelGGL(set_attention_sp_kernel<3>, sgrid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads, scale_log2e, (half_t*)out);
+        else if (g_attn_sp_waves == 8 && n_points % 512 == 0)
+            hipLaunchKernelGGL((set_attention_sp_kernel<0, 8>), dim3(sgrid.x / 2), dim3(512), 0, s, (const half_t*)qkv, n_points, c, heads, scale_log2e, (half_t*)out);
+        else
+        hipLaunchKernelGGL((set_attention_sp_kernel<0, 4>), sgrid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads,
                            scale_log2e, (half_t*)out);
         g_attn_last_kernel = "set_attention_sp_kernel";
         PCD_CHECK_LAUNCH();

@@ -1681,9 +1681,11 @@ __global__ __launch_bounds__(256) void convT3d_last_kernel(const half_t* __restr
 using namespace pcd;
 
 // split-K factor for a launch of `blocks` workgroups over `nk` K tiles: aim for ~2 workgroups per CU
+static int g_split_target = 512;      // split-K aims at this many workgroups (tuning hook: pcd_conv3d_config + 64: 384, + 32: 768, + 96: 1024; VAE3DLarge encode at B = 32:
+                                      // 834 / 913 / 888 us against 817 at 512: tools/bench_vae.py with PCD_CONV3D_CONFIG)
 static int conv_splits(int64_t blocks, int nk) {
-    if (blocks >= 512 || nk < 8) return 1;
-    int s = (int)ceil_div((int64_t)512, blocks);
+    if (blocks >= g_split_target || nk < 8) return 1;
+    int s = (int)ceil_div((int64_t)g_split_target, blocks);
     s = s < nk / 4 ? s : nk / 4;
     s = s < 64 ? s : 64;
     return s < 1 ? 1 : s;
@@ -1799,7 +1801,8 @@ static int g_last8 = 2;       // the last layer (Conv3d 32 -> 1 + sigmoid): 2 = 
                               // + 16), 0 = 4 x 4 x 8 blocks (+ 8)
 
 extern "C" int pcd_conv3d_config(int tall_halo_tiles) {
-    PCD_CHECK_ARG(tall_halo_tiles >= 0 && (tall_halo_tiles & 7) <= 2 && tall_halo_tiles < 32);
+    PCD_CHECK_ARG(tall_halo_tiles >= 0 && (tall_halo_tiles & 7) <= 2 && tall_halo_tiles < 128);
+    g_split_target = (tall_halo_tiles & 96) == 96 ? 1024 : (tall_halo_tiles & 32) ? 768 : ((tall_halo_tiles & 64) ? 384 : 512);
     g_halo_tall = tall_halo_tiles & 7;
     g_last8 = (tall_halo_tiles & 8) ? 0 : ((tall_halo_tiles & 16) ? 1 : 2);
     return PCD_OK;

@@ -443,7 +443,8 @@ int pcd_conv3d_f16_multi(const pcd_conv3d_desc_t* descs, int n, void* workspace,
 /* testing / tuning hook for pcd_conv3d_k3s1_f16 at C_in = 32, C_out <= 32: 0 = 128-row workgroups, 1 (default) = 256-row workgroups
  * (4 x 8 x 8 voxels, eight waves) where the grid has at least 512 of them, 2 = wherever H % 8 == 0 (tests).  Same bits.
  * pcd_conv3d_last_sigmoid: default = 8 x 8 x 8 output blocks on the matrix pipe (the fp32 weights as fp16 hi + lo + lo2 rows); + 16: the same blocks on the
- * VALU (fp32 weights); + 8: 4 x 4 x 8 blocks on the VALU.  The three forms agree to 1e-6.  TEST / BENCHMARK ONLY: process-global. */
+ * VALU (fp32 weights); + 8: 4 x 4 x 8 blocks on the VALU.  The three forms agree to 1e-6.  + 64 / + 32 / + 96: split-K aims at 384 / 768 / 1024 workgroups
+ * instead of 512 (all measured slower on VAE3DLarge).  TEST / BENCHMARK ONLY: process-global. */
 int pcd_conv3d_config(int tall_halo_tiles);
 /* Conv3d(k3, stride 1, pad 1) (+ folded BN, residual, ReLU) with the input halo of a 4x4x8 output block held in
  * LDS and reused by all 27 taps -- the 32^3 layers of VAE3DLarge (encoder.2, decoder.8-11; networks.py:2227,
@@ -554,8 +555,13 @@ int pcd_layernorm_f16(const void* x, int64_t rows, int c, const float* gamma, co
 size_t pcd_set_attention_workspace_bytes(int batch, int n_points, int c);
 int pcd_set_attention_f16(const void* qkv, int batch, int n_points, int c, int heads,
                           void* out, void* workspace, size_t workspace_bytes, void* stream);
-/* testing / tuning hook: force_generic = 1 routes every call through the generic kernel (any N, d = 16/32/64)
- * instead of the software-pipelined d = 64 kernel that N % 256 == 0 selects; 0 restores the default. */
+/* testing / tuning hook.  Dispatch: N % 256 == 0 selects the software-pipelined kernels (two 32-query blocks per wave: set_attention_sp_kernel at d = 64,
+ * set_attention_spn_kernel at d = 32 / 16); every other length runs the one-block kernel with the same max-free softmax (set_attention_om_kernel).
+ *   0 default; 1 = always the round-1 kernel (running max per tile); 2 = always the one-block max-free kernel;
+ *   3 / 4 = d = 32 / 16 on the one-block kernel / on the pipelined kernel (default);
+ *   5 / 6 = the d = 64 kernel as workgroups of four (default) / eight waves (same bits, measured equal);
+ *   16 + bits = timing ablations of the pipelined kernels (1 no K/V restaging, 2 no rare-path test, 4 no waits / barriers): OUTPUTS ARE WRONG while set; 16 clears.
+ * TEST / BENCHMARK ONLY: process-global. */
 int pcd_set_attention_config(int force_generic);
 /* name of the kernel the last pcd_set_attention_f16 call of this process launched (measurement reports quote it) */
 const char* pcd_set_attention_last_kernel(void);

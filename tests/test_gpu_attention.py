@@ -85,6 +85,12 @@ def test_attention_pipelined_kernel_d64(pattern):
     assert torch.isfinite(got).all()
     assert rel_l2(got, want) < 2e-3, pattern
     lib = _lib.load()
+    _lib.check(lib.pcd_set_attention_config(6))                  # the same kernel as workgroups of eight waves (512 queries share a K/V ring): same bits
+    try:
+        got8 = ops.set_attention_f16(qkv16.cuda(), B, N, C, H).float().cpu()
+    finally:
+        _lib.check(lib.pcd_set_attention_config(5))
+    assert torch.equal(got8, got)
     _lib.check(lib.pcd_set_attention_config(1))                  # the generic kernel on the same input
     try:
         gen = ops.set_attention_f16(qkv16.cuda(), B, N, C, H).float().cpu()

@@ -9,13 +9,13 @@ lib = _lib.load()
 B, N, H = 64, 2048, 4
 LEGS = [("one block per wave (om)", [3]), ("two blocks per wave (spn)", [4]), ("  spn, no K/V restaging", [4, 17]), ("  spn, no rare-path test", [4, 18]),
         ("  spn, neither", [4, 19]), ("  spn, neither, no waits / barriers", [4, 23])]
-for C in (128, 64):
+for C in (256, 128, 64):
     g = torch.Generator(device="cuda").manual_seed(0)
     qkv = (torch.randn(B * N, 3 * C, device="cuda", generator=g) * 0.7).half()
     out = torch.empty(B * N, C, dtype=torch.float16, device="cuda")
     def fn():
         _lib.check(lib.pcd_set_attention_f16(qkv.data_ptr(), B, N, C, H, out.data_ptr(), 0, 0, _lib.stream_ptr()))
-    for name, cfgs in LEGS:
+    for name, cfgs in (LEGS if C < 256 else [("two blocks per wave (sp)", [4, 5]), ("  sp, eight waves per workgroup", [4, 6]), ("two blocks per wave (sp)", [4, 5]), ("  sp, eight waves per workgroup", [4, 6]), ("  sp, no K/V restaging", [4, 17]), ("  sp, no rare-path test", [4, 18]), ("  sp, neither", [4, 19])]):
         _lib.check(lib.pcd_set_attention_config(16))
         for c in cfgs:
             _lib.check(lib.pcd_set_attention_config(c))
@@ -32,4 +32,4 @@ for C in (128, 64):
             best = min(best, e0.elapsed_time(e1) / 10)
         fl = 4.0 * B * N * N * C
         print(f"d={C // H:2d} {name:40s} {best * 1e3:7.1f} us  {fl / best / 1e9:5.0f} TFLOP/s ({fl / best / 1e9 / 25:.1f} % of 2.5 PF)", flush=True)
-    _lib.check(lib.pcd_set_attention_config(16)); _lib.check(lib.pcd_set_attention_config(4))
+    _lib.check(lib.pcd_set_attention_config(16)); _lib.check(lib.pcd_set_attention_config(4)); _lib.check(lib.pcd_set_attention_config(5))

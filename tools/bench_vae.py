@@ -23,6 +23,9 @@ def timed(fn, n=10):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
+from shapegen_amd import _lib
+cfg = int(os.environ.get("PCD_CONV3D_CONFIG", "1"))
+_lib.check(_lib.load().pcd_conv3d_config(cfg))
 for rep in range(3):
     td, te = timed(lambda: vae.decode(z)), timed(lambda: vae.encode(x))
     print(f"B={B}: decode {td:7.1f} us = {40.20e9 * B / td / 1e6:5.0f} TFLOP/s = {40.20e9 * B / td / 1e6 / 25:4.1f} % of 2.5 PF | "

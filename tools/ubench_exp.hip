@@ -9,7 +9,7 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int KIND, int E>          // KIND 0: v_exp_f32; 1: v_exp_f16; 2: v_exp_f32 + v_cvt_pk (fp16 pack of two results); 3: v_add_f32 (a 4-cycle reference)
+template <int KIND, int E>          // KIND 4 / 5: as 3 / 0 with the MFMA accumulators in AGPRs; KIND 0: v_exp_f32; 1: v_exp_f16; 2: v_exp_f32 + v_cvt_pk (fp16 pack of two results); 3: v_add_f32 (a 4-cycle reference)
 __global__ void body(float* out, unsigned long long* cyc, int iters) {
     half8 a, b;
     for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(0.001f * (threadIdx.x + i)); b[i] = (_Float16)(0.002f * (threadIdx.x ^ i)); }
@@ -20,10 +20,12 @@ __global__ void body(float* out, unsigned long long* cyc, int iters) {
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
+            if constexpr (KIND >= 4) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));     // accumulators in AGPRs
+            else
             asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));     // (asm: the compiler may not move it across the fillers)
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                if constexpr (KIND == 0) asm volatile("v_exp_f32 %0, %0" : "+v"(x[e]));
+                if constexpr (KIND == 0 || KIND == 5) asm volatile("v_exp_f32 %0, %0" : "+v"(x[e]));
                 else if constexpr (KIND == 1) asm volatile("v_exp_f16 %0, %0" : "+v"(x[e]));
                 else if constexpr (KIND == 2) { asm volatile("v_exp_f32 %0, %0" : "+v"(x[e])); if (e & 1) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(x[e - 1]) : "v"(x[e - 1]), "v"(x[e])); }
                 else asm volatile("v_add_f32 %0, %0, %0" : "+v"(x[e]));
@@ -69,5 +71,7 @@ int main() {
     sweep<0>("v_exp_f32");
     sweep<1>("v_exp_f16");
     sweep<2>("v_exp_f32 + v_cvt_pk_f16_f32 per 2");
+    sweep<4>("v_add_f32, MFMA acc in AGPRs");
+    sweep<5>("v_exp_f32, MFMA acc in AGPRs");
     return 0;
 }
