@@ -342,7 +342,8 @@ def attention_roofline(device, launches=100):
     for chan in (128, 64):
         m2, a2, k2 = run(chan, launches, 200)
         by_d[str(chan // ATT_HEADS)] = {"achieved": a2, "frac": a2 / MFMA_F16_DENSE_PEAK_TFLOPS, "avg_launch_ms": m2, "kernel": k2,
-                                        "note": "exp-issue bound: <= ~42 % / ~21 % of the MFMA peak at d 32 / 16"}
+                                        "note": "VALU-issue bound (16 v_exp_f32 + 8 packs + 8 packed adds + the MFMAs' own issue slots per 32 x 32 score tile: "
+                                                "~265 cycles against 128 / 96 of matrix pipe at d 32 / 16; profiles/r05_i)"}
     busy, busy_head, busy_stale = measured_mfma_busy("set_attention_sp_kernel", "attention.hip")
     return {"bound": "mfma", "kernel": kname + " (QK^T, softmax, PV; d_head 64; software-pipelined, 2 query blocks per wave)",
             "achieved": achieved, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -1,6 +1,6 @@
 #!/bin/bash
-# SQ counters of the three kernels the headline numbers rest on: the dominant GEMM (gemm_xw_kernel), the widest store GEMM
-# (gemm_xs_kernel) and the d = 64 set-attention kernel (set_attention_sp_kernel).  One rocprofv3 --pmc pass each (7 SQ counters + GRBM_GUI_ACTIVE;
+# SQ counters of the kernels the headline numbers rest on: the dominant GEMM (gemm_xw_kernel), the widest store GEMM
+# (gemm_xs_kernel), the d = 64 set-attention kernel (set_attention_sp_kernel) and the d = 32 / 16 ones (set_attention_spn_kernel).  One rocprofv3 --pmc pass each (7 SQ counters + GRBM_GUI_ACTIVE;
 # --kernel-trace only, the program itself after `--`).  MFMA-pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), at the
 # clocks the chip holds UNDER the profiler (1.89-1.95 GHz; MI355X_MICROARCH.md DVFS item 2).
 # Run ON THE GPU BOX from the repo root:   GIT_HEAD=<hash> bash tools/pmc_sq.sh     -> gpurun_out/sq_pmc_latest.json (copy into profiles/)
@@ -13,6 +13,8 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc $CNT --kernel-trace -d $OUT/gf3 -o s --output-format csv -- python3 $ROOT/tools/one_gemm.py -1 10 > /dev/null 2>&1
 rocprofv3 --pmc $CNT --kernel-trace -d $OUT/store -o s --output-format csv -- python3 $ROOT/tools/one_gemm_store_wfrag.py 10 > /dev/null 2>&1
 rocprofv3 --pmc $CNT --kernel-trace -d $OUT/attn -o s --output-format csv -- python3 $ROOT/tools/one_attn.py 256 > /dev/null 2>&1
+rocprofv3 --pmc $CNT --kernel-trace -d $OUT/attn32 -o s --output-format csv -- python3 $ROOT/tools/one_attn.py 128 > /dev/null 2>&1
+rocprofv3 --pmc $CNT --kernel-trace -d $OUT/attn16 -o s --output-format csv -- python3 $ROOT/tools/one_attn.py 64 > /dev/null 2>&1
 cd $ROOT
 python3 - <<PY
 import csv, glob, hashlib, json, os
@@ -33,8 +35,10 @@ def dur(root, pat):
 rec = {"recipe": "tools/pmc_sq.sh", "git_head": os.environ.get("GIT_HEAD", "unknown"), "kernels": {},
        "note": "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); wait_* / active as fractions of SQ_WAVE_CYCLES; "
                "lds_active = SQ_LDS_IDX_ACTIVE / (256 CUs x GRBM_GUI_ACTIVE / 8); profiled clocks"}
-src = {"gemm_xw_kernel": "gemm_f16.hip", "gemm_xs_kernel": "gemm_f16.hip", "set_attention_sp_kernel": "attention.hip"}
-for key, sub, pat in (("gemm_xw_kernel", "gf3", "gemm_xw_kernel"), ("gemm_xs_kernel", "store", "gemm_xs_kernel"), ("set_attention_sp_kernel", "attn", "set_attention_sp_kernel")):
+src = {"gemm_xw_kernel": "gemm_f16.hip", "gemm_xs_kernel": "gemm_f16.hip", "set_attention_sp_kernel": "attention.hip",
+       "set_attention_spn_kernel<32>": "attention.hip", "set_attention_spn_kernel<16>": "attention.hip"}
+for key, sub, pat in (("gemm_xw_kernel", "gf3", "gemm_xw_kernel"), ("gemm_xs_kernel", "store", "gemm_xs_kernel"), ("set_attention_sp_kernel", "attn", "set_attention_sp_kernel"),
+                      ("set_attention_spn_kernel<32>", "attn32", "set_attention_spn_kernelILi32"), ("set_attention_spn_kernel<16>", "attn16", "set_attention_spn_kernelILi16")):
     c = counters("$OUT/" + sub, pat)
     cyc = c["GRBM_GUI_ACTIVE"] / 8.0
     rec["kernels"][key] = {
