@@ -237,6 +237,7 @@ _SIGS = {
     "pcd_wide_ffn_supported": (i32, [i32, i64]),
     "pcd_wide_ffn_pack": (i32, [vp, vp, vp, vp, vp, vp, vp, vp]),
     "pcd_wide_ffn_f16": (i32, [vp, vp, i64, vp, vp]),
+    "pcd_wide_ffn_bias_f16": (i32, [vp, vp, i64, i32, vp, i64, vp, vp]),
     "pcd_wide_ffn_config": (i32, [i32]),
     "pcd_pw_wide_config": (i32, [i32]),
     "pcd_sab_tail_packed_bytes": (sz, [i32]),

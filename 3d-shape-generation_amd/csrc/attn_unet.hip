@@ -54,7 +54,8 @@ static int sab_run(const pcd_sab_desc_t& d, const void* x, int batch, int n, int
     // C = 256 with packed images: LayerNorm + Linear as one launch of the wide-chain kernel (widechain.hip), B fragments normalised as they are loaded
     const bool lnlin = pcd_sab_tail_enabled() && pcd_pw_wide_ln_linear_supported(C, m);
     const bool fused128 = sab_fuses(d, m);
-    if (!fused128 && (pre_e != nullptr || post_e != nullptr)) { set_error("sab_run: embeddings need the fused head / tail launches"); return PCD_ERR_ARG; }
+    const bool wide_ffn = d.ffn_packed != nullptr && pcd_sab_tail_enabled() && pcd_wide_ffn_supported(C, m);
+    if (!fused128 && (pre_e != nullptr || (post_e != nullptr && !wide_ffn))) { set_error("sab_run: embeddings need the fused head / tail launches"); return PCD_ERR_ARG; }
     if (lnlin && d.ln_in_packed != nullptr) {
         RUN(pcd_pw_wide_ln_linear(d.ln_in_packed, 3, 0, x, m, qkv, s));                  // LN1 + in_proj C -> 3C
     } else if (fused128) {
@@ -67,8 +68,8 @@ static int sab_run(const pcd_sab_desc_t& d, const void* x, int batch, int n, int
     if (fused128)
         return pcd_sab_tail_bias_f16(C, d.tail_packed, t2, x, m, rps, pre_e, post_e, estride, y, s);                   // C <= 128: the rest of the block as one launch (sab_tail.hip)
     RUN(gemm(t2, C, nullptr, 0, d.w_out, d.b_out, 0, m, C, x, t1, s));               // x + out_proj(.)
-    if (d.ffn_packed != nullptr && pcd_sab_tail_enabled() && pcd_wide_ffn_supported(C, m))
-        return pcd_wide_ffn_f16(d.ffn_packed, t1, m, y, s);                              // C = 256: LN2 + FFN + residual as one launch (wideffn.hip), no hidden tensor
+    if (wide_ffn)                                                                        // C = 256: LN2 + FFN + residual (+ the embedding behind the block) as one launch (wideffn.hip)
+        return pcd_wide_ffn_bias_f16(d.ffn_packed, t1, m, rps, post_e, estride, y, s);
     if (lnlin && d.ln_ff1_packed != nullptr) {
         RUN(pcd_pw_wide_ln_linear(d.ln_ff1_packed, 4, 1, t1, m, ffh, s));                // LN2 + Linear(C,4C) + ReLU
     } else {
@@ -260,8 +261,12 @@ extern "C" int pcd_attn_unet_forward(pcd_attn_unet_t* h, const float* x, int bat
     }
     LIN(5, x2, nullptr, 0, p0); LIN(6, p0, nullptr, 0, p1); LIN(7, p1, nullptr, 0, p0);   // enc3
     RUN(sab_run(d.sab[2], p0, batch, N, H, x3, sws, s));                                  // att3 -> x3
-    RUN(sab_run(d.sab[3], x3, batch, N, H, p0, sws, s));                                  // bottleneck
-    RUN(pcd_add_shape_bias_strided_f16(p0, m, 256, rps, tb_d3, estr, p1, s));
+    if (d.sab[3].ffn_packed != nullptr && pcd_sab_tail_enabled() && pcd_wide_ffn_supported(256, m)) {
+        RUN(sab_run(d.sab[3], x3, batch, N, H, p1, sws, s, nullptr, tb_d3, estr, rps));   // bottleneck, + emb_dec3 on the way out of its feed-forward launch
+    } else {
+        RUN(sab_run(d.sab[3], x3, batch, N, H, p0, sws, s));                              // bottleneck
+        RUN(pcd_add_shape_bias_strided_f16(p0, m, 256, rps, tb_d3, estr, p1, s));
+    }
     RUN(sab_run(d.sab[4], p1, batch, N, H, p0, sws, s));                                  // att_dec3
     LIN(8, p0, x3, 256, p1);                                                              // dec3 on cat[xb | x3]: 512 -> 128 -> 128 -> 128
     if (chain) { RUN(pcd_pw_chain_128(p1, m, d.lin[9].w, d.lin[9].b, d.lin[10].w, d.lin[10].b, p2, s)); }

@@ -30,6 +30,8 @@ struct WfParams {
     const char* wpacked;               // 32 stage images, then the constants
     half_t* y;                         // [M][256]
     int64_t m;
+    const float* post_e;               // optional: y leaves as fp16(y + post_e[row / rps][c]) (the additive time embedding behind the block, networks.py:688)
+    int64_t estride; int rps;
 };
 
 __device__ __forceinline__ void wf_dma(const char* g, unsigned lds_addr) {
@@ -248,6 +250,12 @@ __global__ __launch_bounds__(WF_THREADS, 2) void wide_ffn_kernel(WfParams p) {
                     const half8 r = *(const half8*)(xrow + 32 * b + 16 * gp);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = to_half_sat((float)v[e] + (float)r[e]);
+                    if (p.post_e != nullptr) {                 // the rounding points of pcd_add_shape_bias_strided_f16 behind the block: bitwise the two launches
+                        const float* er = p.post_e + (pt / p.rps) * p.estride + 128 * h + 8 * hh + 32 * b + 16 * gp;
+                        const f32x4 e0 = *(const f32x4*)er, e1 = *(const f32x4*)(er + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] = to_half_sat((float)v[e] + e0[e]); v[4 + e] = to_half_sat((float)v[4 + e] + e1[e]); }
+                    }
                     *(half8*)(yrow + 32 * b + 16 * gp) = v;
                 }
         }
@@ -297,12 +305,19 @@ extern "C" int pcd_wide_ffn_pack(const void* w1, const float* b1, const void* w2
 }
 
 extern "C" int pcd_wide_ffn_f16(const void* packed, const void* x, int64_t rows, void* y, void* stream) {
+    return pcd_wide_ffn_bias_f16(packed, x, rows, 1, nullptr, 0, y, stream);
+}
+
+// the same with y + post_e[row / rows_per_shape][.] (fp32 rows of 256, e_stride floats apart, 16-byte aligned) on the way out
+extern "C" int pcd_wide_ffn_bias_f16(const void* packed, const void* x, int64_t rows, int rows_per_shape, const float* post_e, int64_t e_stride, void* y, void* stream) {
     PCD_CHECK_ARG(packed && x && y && rows > 0 && rows % WF_TILE == 0);
+    PCD_CHECK_ARG(post_e == nullptr || (rows_per_shape > 0 && e_stride >= 0 && e_stride % 4 == 0 && ((uintptr_t)post_e & 15) == 0));
     static PcdLdsOnce once, once_split;
     PCD_CHECK_HIP(pcd_allow_lds(once, (const void*)wide_ffn_kernel<false>, (int)WF_LDS));
     PCD_CHECK_HIP(pcd_allow_lds(once_split, (const void*)wide_ffn_kernel<true>, (int)WF_LDS));
     WfParams p{};
     p.x = (const half_t*)x; p.wpacked = (const char*)packed; p.y = (half_t*)y; p.m = rows;
+    p.post_e = post_e; p.estride = e_stride; p.rps = rows_per_shape > 0 ? rows_per_shape : 1;
     const int64_t tiles = rows / WF_TILE;
     const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
     if (g_wf_split) hipLaunchKernelGGL(wide_ffn_kernel<true>, dim3(grid), dim3(WF_THREADS), WF_LDS, (hipStream_t)stream, p);

@@ -604,6 +604,9 @@ size_t pcd_wide_ffn_packed_bytes(void);
 int pcd_wide_ffn_supported(int dim, int64_t rows);
 int pcd_wide_ffn_pack(const void* w1, const float* b1, const void* w2, const float* b2, const float* ln_g, const float* ln_b, void* packed, void* stream);
 int pcd_wide_ffn_f16(const void* packed, const void* x, int64_t rows, void* y, void* stream);
+/* the same with the additive per-shape rows of networks.py:688 on the way out: y = fp16(y + post_e[row / rows_per_shape][c]) (fp32 rows of 256, e_stride floats
+ * apart, 16-byte aligned; NULL = none) -- the rounding points of pcd_add_shape_bias_strided_f16 behind the block, bitwise the two launches */
+int pcd_wide_ffn_bias_f16(const void* packed, const void* x, int64_t rows, int rows_per_shape, const float* post_e, int64_t e_stride, void* y, void* stream);
 /* A/B hook (TEST / BENCHMARK ONLY, process-global): which waves request the weight images, see csrc/wideffn.hip; same bits either way */
 int pcd_wide_ffn_config(int split);
 /* bytes of scratch one block needs for `rows` = B*N points */

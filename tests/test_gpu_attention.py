@@ -176,6 +176,22 @@ def test_attention_pipelined_kernel_d32_d16(pattern, C, N):
     assert float(rows.max()) < 2e-2, (pattern, C, N, int(rows.argmax()))
 
 
+@pytest.mark.parametrize("C", [64, 128, 256])
+@pytest.mark.parametrize("B", [1, 3, 5])
+def test_attention_pipelined_kernels_block_map(B, C):
+    """The pipelined kernels deal (shape, head) pairs to XCDs when batch x heads is a multiple of 8 and fall back to the plain block order otherwise
+    (B = 1, 3, 5 with 4 heads: 4, 12, 20 pairs): every query block of every pair is computed exactly once either way."""
+    from shapegen_amd import ops
+    N, H = 768, 4
+    g = torch.Generator().manual_seed(100 + B + C)
+    qkv16 = (torch.randn(B * N, 3 * C, generator=g) * 0.8).half()
+    want = _attention_fp64(qkv16, B, N, C, H)
+    got = ops.set_attention_f16(qkv16.cuda(), B, N, C, H).float().cpu()
+    rows = ((got - want).norm(dim=1) / want.norm(dim=1).clamp_min(1e-3))
+    assert torch.isfinite(got).all() and float(rows.max()) < 2e-2, (B, C, int(rows.argmax()))
+    assert rel_l2(got, want) < 2e-3
+
+
 @pytest.mark.parametrize("rows,c", [(4096 + 5, 64), (1000, 128), (777, 256), (64, 96), (3, 256)])
 def test_layernorm_rows(rows, c):
     """nn.LayerNorm over the channel axis (reference networks.py:66-67, eps 1e-5, biased variance) on fp16 rows: the vectorised
@@ -499,6 +515,21 @@ def test_wide_ffn_one_launch_against_fp64(rows):
         assert torch.equal(y, y2)
     assert lib.pcd_wide_ffn_f16(packed.data_ptr(), xd.data_ptr(), rows + 8, y.data_ptr(), _lib.stream_ptr()) != 0
     assert lib.pcd_wide_ffn_f16(None, xd.data_ptr(), rows, y.data_ptr(), _lib.stream_ptr()) != 0
+    # the per-shape rows behind the block (networks.py:688) on the way out of the same launch: bitwise the FFN launch + pcd_add_shape_bias_strided_f16
+    rps = 128 if rows > 128 else 64
+    shapes = rows // rps
+    for estride in (704, 0):
+        e = (torch.randn(max(1, shapes if estride else 1), 704, generator=g) * 0.7).float().cuda()
+        ev = e[:, 256:]                                                          # an offset view, as the time-bias table hands it over (16-byte aligned)
+        eptr = e.data_ptr() + 256 * 4
+        two = torch.empty_like(y)
+        _lib.check(lib.pcd_add_shape_bias_strided_f16(y.data_ptr(), rows, 256, rps, eptr, estride, two.data_ptr(), _lib.stream_ptr()))
+        one = torch.full_like(y, float("nan"))
+        _lib.check(lib.pcd_wide_ffn_bias_f16(packed.data_ptr(), xd.data_ptr(), rows, rps, eptr, estride, one.data_ptr(), _lib.stream_ptr()), "wide_ffn_bias")
+        assert torch.equal(one, two), estride
+        assert not torch.equal(one, y) and ev.shape[1] == 448
+    assert lib.pcd_wide_ffn_bias_f16(packed.data_ptr(), xd.data_ptr(), rows, 0, eptr, 704, y2.data_ptr(), _lib.stream_ptr()) != 0        # rows per shape
+    assert lib.pcd_wide_ffn_bias_f16(packed.data_ptr(), xd.data_ptr(), rows, rps, eptr + 4, 704, y2.data_ptr(), _lib.stream_ptr()) != 0   # alignment
 
 
 def test_set_attention_block_256_layernorm_in_the_linear_launches():
