@@ -66,7 +66,9 @@ __device__ __forceinline__ half8 wf_regroup(const f32x16& acc, int gp, const flo
 
 // SPLIT: the 32 LDS-DMA pieces of an image are requested by ONE wave of each SIMD (waves 0-3 for even images, 4-7 for odd ones, 8 pieces each) instead of 4 pieces by
 // every wave: a piece holds its wave's issue for 60-180 cycles, and with every wave requesting behind the barrier no wave of a SIMD issues MFMAs meanwhile
-template <bool SPLIT>
+// ABL: timing ablations for tools/bench_wide_ffn.py (pcd_wide_ffn_config(16 + bits); OUTPUTS ARE WRONG while set): 1 = no image requests in the loop (the ring keeps the
+// first three images), 2 = no fragment reads (every MFMA takes the fragments of the first one), 4 = no waits / barriers in the loop, 8 = no MFMAs
+template <bool SPLIT, int ABL = 0>
 __global__ __launch_bounds__(WF_THREADS, 2) void wide_ffn_kernel(WfParams p) {
     extern __shared__ __attribute__((aligned(16))) char wf_smem[];          // [WF_RING][WF_STAGE] | exchange [8 waves][4 KB] | b1 | b2 | gamma | beta
     const int lane = threadIdx.x & 63;
@@ -86,6 +88,7 @@ __global__ __launch_bounds__(WF_THREADS, 2) void wide_ffn_kernel(WfParams p) {
     const int total_stages = my_tiles * WF_STAGES_PER_TILE;
     // image n of this workgroup's run = stage image n % 32; wave w moves pieces 4 w .. 4 w + 3 of its 32 (SPLIT: the waves of group n & 1 move 8 w' .. 8 w' + 7)
     auto issue = [&](int n) __attribute__((always_inline)) {
+        if ((ABL & 1) && n >= WF_RING) return;
         if (n < total_stages) {
             if constexpr (SPLIT) {
                 if ((wave >> 2) == (n & 1)) {
@@ -110,6 +113,12 @@ __global__ __launch_bounds__(WF_THREADS, 2) void wide_ffn_kernel(WfParams p) {
     // image n has landed (all but this wave's 4 youngest LDS-DMA pieces; SPLIT: every piece of the group that requested it), every wave is done with image n - 1
     // (its LDS reads included): its slot takes image n + 2
     auto acquire = [&]() __attribute__((always_inline)) -> const char* {
+        if constexpr ((ABL & 4) != 0) {
+            issue(n + 2);
+            const char* img0 = wf_smem + (n % WF_RING) * WF_STAGE + lane * 16;
+            ++n;
+            return img0;
+        }
         if constexpr (SPLIT) {
             if ((wave >> 2) == (n & 1)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -198,11 +207,14 @@ __global__ __launch_bounds__(WF_THREADS, 2) void wide_ffn_kernel(WfParams p) {
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
 #pragma unroll
-                        for (int b = 0; b < 2; ++b) af[u][b] = *(const half8*)(img + (b * 8 + qq + u) * 1024);
+                        for (int b = 0; b < 2; ++b) af[u][b] = *(const half8*)(img + ((ABL & 2) ? 0 : (b * 8 + qq + u) * 1024));
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
 #pragma unroll
-                        for (int b = 0; b < 2; ++b) accH[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u][b], xin[8 * j + qq + u], accH[b], 0, 0, 0);
+                        for (int b = 0; b < 2; ++b) {
+                            if constexpr ((ABL & 8) != 0) accH[b][0] += (float)af[u][b][0];
+                            else accH[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u][b], xin[8 * j + qq + u], accH[b], 0, 0, 0);
+                        }
                 }
             }
             // bias + ReLU + fp16 -> this wave's half of the slab as B fragments (4 k-steps of 16 hidden channels), shared with the partner through LDS
@@ -230,10 +242,13 @@ __global__ __launch_bounds__(WF_THREADS, 2) void wide_ffn_kernel(WfParams p) {
                 for (int qq = 0; qq < 4; ++qq) {
                     half8 af[4];
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) af[b] = *(const half8*)(img + (b * 4 + qq) * 1024);
+                    for (int b = 0; b < 4; ++b) af[b] = *(const half8*)(img + ((ABL & 2) ? 0 : (b * 4 + qq) * 1024));
                     const half8 hf = (j == h) ? hown[qq] : hoth[qq];
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) accY[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[b], hf, accY[b], 0, 0, 0);
+                    for (int b = 0; b < 4; ++b) {
+                        if constexpr ((ABL & 8) != 0) accY[b][0] += (float)af[b][0] * (float)hf[0];
+                        else accY[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[b], hf, accY[b], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -276,7 +291,12 @@ using namespace pcd;
 
 static int g_wf_split = 1;          // pcd_wide_ffn_config: who requests the weight images (0: every wave 4 pieces; 1, default: one wave per SIMD 8 pieces, alternating
                                     // groups: 187 v. 210 us at B = 64, N = 2048, same bits)
-extern "C" int pcd_wide_ffn_config(int split) { g_wf_split = split ? 1 : 0; return PCD_OK; }
+static int g_wf_abl = 0;            // timing ablations (pcd_wide_ffn_config(16 + bits)); outputs are wrong while set
+extern "C" int pcd_wide_ffn_config(int split) {
+    if (split >= 16 && split < 32) { g_wf_abl = split - 16; return PCD_OK; }
+    g_wf_split = split ? 1 : 0;
+    return PCD_OK;
+}
 
 extern "C" size_t pcd_wide_ffn_packed_bytes(void) { return WF_IMG_BYTES + (size_t)WF_NCONST * sizeof(float); }
 
@@ -320,6 +340,16 @@ extern "C" int pcd_wide_ffn_bias_f16(const void* packed, const void* x, int64_t 
     p.post_e = post_e; p.estride = e_stride; p.rps = rows_per_shape > 0 ? rows_per_shape : 1;
     const int64_t tiles = rows / WF_TILE;
     const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+#define PCD_WF_ABL(A)                                                                                                  \
+    if (g_wf_abl == A) {                                                                                                \
+        static PcdLdsOnce once_a;                                                                                       \
+        PCD_CHECK_HIP(pcd_allow_lds(once_a, (const void*)wide_ffn_kernel<true, A>, (int)WF_LDS));                       \
+        hipLaunchKernelGGL((wide_ffn_kernel<true, A>), dim3(grid), dim3(WF_THREADS), WF_LDS, (hipStream_t)stream, p);   \
+        PCD_CHECK_LAUNCH();                                                                                             \
+        return PCD_OK;                                                                                                  \
+    }
+    PCD_WF_ABL(1) PCD_WF_ABL(2) PCD_WF_ABL(3) PCD_WF_ABL(4) PCD_WF_ABL(5) PCD_WF_ABL(8) PCD_WF_ABL(9) PCD_WF_ABL(10) PCD_WF_ABL(7) PCD_WF_ABL(11)
+#undef PCD_WF_ABL
     if (g_wf_split) hipLaunchKernelGGL(wide_ffn_kernel<true>, dim3(grid), dim3(WF_THREADS), WF_LDS, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(wide_ffn_kernel<false>, dim3(grid), dim3(WF_THREADS), WF_LDS, (hipStream_t)stream, p);
     PCD_CHECK_LAUNCH();

@@ -608,7 +608,7 @@ int pcd_wide_ffn_f16(const void* packed, const void* x, int64_t rows, void* y, v
  * apart, 16-byte aligned; NULL = none) -- the rounding points of pcd_add_shape_bias_strided_f16 behind the block, bitwise the two launches */
 int pcd_wide_ffn_bias_f16(const void* packed, const void* x, int64_t rows, int rows_per_shape, const float* post_e, int64_t e_stride, void* y, void* stream);
 /* A/B hook (TEST / BENCHMARK ONLY, process-global): which waves request the weight images, see csrc/wideffn.hip; same bits either way */
-int pcd_wide_ffn_config(int split);
+int pcd_wide_ffn_config(int split);   /* 0 / 1 request form; 16 + bits = timing ablations of the kernel (OUTPUTS WRONG while set; 16 clears): TEST / BENCHMARK ONLY */
 /* bytes of scratch one block needs for `rows` = B*N points */
 size_t pcd_sab_workspace_bytes(int64_t rows, int dim);
 /* the block's tail behind the attention kernel as one launch (csrc/sab_tail.hip; reference networks.py:78-83, the second half of SetAttentionBlock.forward):

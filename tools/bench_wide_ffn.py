@@ -42,6 +42,14 @@ for split in (0, 1):
     t = ev(lambda: lib.pcd_wide_ffn_f16(packed.data_ptr(), x.data_ptr(), M, y.data_ptr(), _lib.stream_ptr()))
     outs.append(y.clone())
     print(f"fused FFN, request form {split}: {t:7.1f} us  {fl / t / 1e6:6.0f} TF/s", flush=True)
+lib.pcd_wide_ffn_config(1)
+for bits, name in ((1, "no image requests in the loop"), (2, "no fragment reads"), (3, "neither"), (4, "no waits / barriers"), (5, "no requests, no barriers"),
+                   (8, "no MFMAs"), (9, "no MFMAs, no requests"), (10, "no MFMAs, no fragment reads"), (7, "no requests / reads / barriers (MFMAs only)"),
+                   (11, "no MFMAs / requests / reads")):
+    lib.pcd_wide_ffn_config(16 + bits)
+    t = ev(lambda: lib.pcd_wide_ffn_f16(packed.data_ptr(), x.data_ptr(), M, y.data_ptr(), _lib.stream_ptr()), n=10, reps=2)
+    print(f"  timing ablation (outputs wrong): {name:48s} {t:7.1f} us", flush=True)
+lib.pcd_wide_ffn_config(16)
 lib.pcd_wide_ffn_config(0)
 t2 = ev(two)
 print(f"two launches (LN + Linear + ReLU, then GEMM + residual): {t2:7.1f} us  {fl / t2 / 1e6:6.0f} TF/s; request forms bitwise equal {torch.equal(outs[0], outs[1])}; "
