@@ -176,6 +176,23 @@ def test_attention_pipelined_kernel_d32_d16(pattern, C, N):
     assert float(rows.max()) < 2e-2, (pattern, C, N, int(rows.argmax()))
 
 
+@pytest.mark.parametrize("C,H", [(256, 8), (128, 8), (512, 16), (1024, 16)])
+def test_attention_pipelined_kernels_other_head_counts(C, H):
+    """Head widths 32 / 16 / 64 reached with other head counts (row stride 3 C up to 3072 halfs, 8 / 16 heads): the staging offsets and the head slices of the
+    pipelined kernels against fp64."""
+    from shapegen_amd import _lib, ops
+    B, N = 2, 512
+    g = torch.Generator().manual_seed(7 + C + H)
+    qkv16 = (torch.randn(B * N, 3 * C, generator=g) * 0.9).half()
+    want = _attention_fp64(qkv16, B, N, C, H)
+    got = ops.set_attention_f16(qkv16.cuda(), B, N, C, H).float().cpu()
+    d = C // H
+    name = _lib.load().pcd_set_attention_last_kernel().decode()
+    assert name == ("set_attention_sp_kernel" if d == 64 else f"set_attention_spn_kernel<{d}>")
+    rows = ((got - want).norm(dim=1) / want.norm(dim=1).clamp_min(1e-3))
+    assert torch.isfinite(got).all() and float(rows.max()) < 2e-2 and rel_l2(got, want) < 2e-3
+
+
 @pytest.mark.parametrize("C", [64, 128, 256])
 @pytest.mark.parametrize("B", [1, 3, 5])
 def test_attention_pipelined_kernels_block_map(B, C):
