@@ -640,10 +640,10 @@ __global__ __launch_bounds__(64 * NW, 2) void set_attention_sp_kernel(const half
     // one key sub-tile i (32 keys): kf holds K(i+1) and vf V(i-1) on entry; V(i) at voff, K(i+2) at koff; when STAGE_ON,
     // pieces j0 and j0 + 1 of tile st leave for ring slot sslot, one in front of each phase
     auto sub_iter = [&](int voff, int koff, bool stage_on, int st, int sslot, int j0) __attribute__((always_inline)) {
-        if (!(ABL & 1) && stage_on) stage_piece(st, sslot, j0);
+        if (!(ABL & 1) && stage_on) stage_piece((ABL & 8) ? (st & 3) : st, sslot, j0);
         tA = sp_phase<true>(sA, pA0, pA1, kf, qA, negmA, sAn, oB, vf, pB0, pB1, tB, lB, [&]() { load_v(voff, vf); });
         if (!(ABL & 2) && __builtin_expect(__any(__builtin_bit_cast(unsigned, tA) > SP_BIG_BITS), 0)) tA = sp_fix(sA, sAn, negmA, oA, lA, pA0, pA1);
-        if (!(ABL & 1) && stage_on) stage_piece(st, sslot, j0 + 1);
+        if (!(ABL & 1) && stage_on) stage_piece((ABL & 8) ? (st & 3) : st, sslot, j0 + 1);
         tB = sp_phase<false>(sB, pB0, pB1, kf, qB, negmB, sBn, oA, vf, pA0, pA1, tA, lA, [&]() { load_k(koff, kf); });
         if (!(ABL & 2) && __builtin_expect(__any(__builtin_bit_cast(unsigned, tB) > SP_BIG_BITS), 0)) tB = sp_fix(sB, sBn, negmB, oB, lB, pB0, pB1);
         sA = sAn; sB = sBn;
@@ -803,7 +803,7 @@ __device__ __forceinline__ half2_ spn_phase(f32x16& s, half8& p0, half8& p1, con
 }
 
 // ABL: timing ablations for tools/bench_attn_small_d.py (pcd_set_attention_config(16 + bits); outputs are wrong while set): 1 = no K/V restaging in the loop,
-// 2 = no rare-path test, 4 = no waits / barriers in the loop
+// 2 = no rare-path test, 4 = no waits / barriers in the loop, 8 = restaging reads the first four tiles over and over (cache-resident sources)
 template <int D, int ABL = 0>
 __global__ __launch_bounds__(256, 3) void set_attention_spn_kernel(const half_t* __restrict__ qkv, int n, int c, int heads,
                                                                     float scale_log2e, half_t* __restrict__ out) {
@@ -950,7 +950,7 @@ __global__ __launch_bounds__(256, 3) void set_attention_spn_kernel(const half_t*
     // one key sub-tile i (32 keys): kf holds K(i+1), vf V(i-1), sA / sB the scores S(i) on entry; V(i) (and K(i), for the rare path) at voff, K(i+2) at koff;
     // when stage_on, piece j of tile st leaves for ring slot sslot in front of the first phase
     auto sub_iter = [&](int voff, int koff, bool stage_on, int st, int sslot, int j) __attribute__((always_inline)) {
-        if (!(ABL & 1) && stage_on && j < PPW) stage_piece(st, sslot, j);
+        if (!(ABL & 1) && stage_on && j < PPW) stage_piece((ABL & 8) ? (st & 3) : st, sslot, j);
         tA = spn_phase<D>(sA, pA0, pA1, kf, qA, negmA, oB, vf, pB0, pB1, tB, lB, [&]() { load_v(voff, vf); });
         asm volatile("" : "+v"(vf[0]), "+v"(vf[1]));           // V(i) is read HERE (the compiler would sink the reads to their use, the first MFMA of the next phase)
         if (!(ABL & 2) && __builtin_expect(__any(__builtin_bit_cast(unsigned, tA) > SP_BIG_BITS), 0)) tA = spn_fix<D>(kaddr, voff, qA, sA, negmA, oA, lA, pA0, pA1);
@@ -1216,7 +1216,7 @@ static int g_attn_spn = 1;             // tuning/testing hook (pcd_set_attention
 extern "C" int pcd_set_attention_config(int force_generic) {
     if (force_generic == 3 || force_generic == 4) { g_attn_spn = force_generic == 4; return PCD_OK; }
     if (force_generic == 5 || force_generic == 6) { g_attn_sp_waves = force_generic == 6 ? 8 : 4; return PCD_OK; }
-    if (force_generic >= 16 && force_generic < 24) { g_attn_spn_abl = force_generic - 16; return PCD_OK; }
+    if (force_generic >= 16 && force_generic < 32) { g_attn_spn_abl = force_generic - 16; return PCD_OK; }
     g_attn_force_generic = force_generic < 0 ? 0 : (force_generic > 2 ? 2 : force_generic);
     return PCD_OK;
 }
@@ -1241,6 +1241,7 @@ extern "C" int pcd_set_attention_f16(const void* qkv, int batch, int n_points, i
         dim3 sgrid((unsigned)((n_points / 256) * batch * heads));
         if (g_attn_spn_abl == 1) hipLaunchKernelGGL(set_attention_sp_kernel<1>, sgrid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads, scale_log2e, (half_t*)out);
         else if (g_attn_spn_abl == 2) hipLaunchKernelGGL(set_attention_sp_kernel<2>, sgrid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads, scale_log2e, (half_t*)out);
+        else if (g_attn_spn_abl == 8) hipLaunchKernelGGL(set_attention_sp_kernel<8>, sgrid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads, scale_log2e, (half_t*)out);
         else if (g_attn_spn_abl == 3) hipLaunchKernelGGL(set_attention_sp_kernel<3>, sgrid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads, scale_log2e, (half_t*)out);
         else if (g_attn_sp_waves == 8 && n_points % 512 == 0)
             hipLaunchKernelGGL((set_attention_sp_kernel<0, 8>), dim3(sgrid.x / 2), dim3(512), 0, s, (const half_t*)qkv, n_points, c, heads, scale_log2e, (half_t*)out);
@@ -1261,7 +1262,7 @@ extern "C" int pcd_set_attention_f16(const void* qkv, int batch, int n_points, i
             PCD_CHECK_LAUNCH();                                                                                                                              \
             return PCD_OK;                                                                                                                                   \
         }
-        PCD_SPN_ABL(1) PCD_SPN_ABL(2) PCD_SPN_ABL(3) PCD_SPN_ABL(7)
+        PCD_SPN_ABL(1) PCD_SPN_ABL(2) PCD_SPN_ABL(3) PCD_SPN_ABL(7) PCD_SPN_ABL(8)
 #undef PCD_SPN_ABL
         if (d == 32) hipLaunchKernelGGL((set_attention_spn_kernel<32>), sgrid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads, scale_log2e, (half_t*)out);
         else hipLaunchKernelGGL((set_attention_spn_kernel<16>), sgrid, dim3(256), 0, s, (const half_t*)qkv, n_points, c, heads, scale_log2e, (half_t*)out);

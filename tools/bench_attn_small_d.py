@@ -7,7 +7,7 @@ import shapegen_amd
 from shapegen_amd import _lib
 lib = _lib.load()
 B, N, H = 64, 2048, 4
-LEGS = [("one block per wave (om)", [3]), ("two blocks per wave (spn)", [4]), ("  spn, no K/V restaging", [4, 17]), ("  spn, no rare-path test", [4, 18]),
+LEGS = [("one block per wave (om)", [3]), ("two blocks per wave (spn)", [4]), ("  spn, no K/V restaging", [4, 17]), ("  spn, restaging from four resident tiles", [4, 24]), ("  spn, no rare-path test", [4, 18]),
         ("  spn, neither", [4, 19]), ("  spn, neither, no waits / barriers", [4, 23])]
 for C in (256, 128, 64):
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -15,7 +15,7 @@ for C in (256, 128, 64):
     out = torch.empty(B * N, C, dtype=torch.float16, device="cuda")
     def fn():
         _lib.check(lib.pcd_set_attention_f16(qkv.data_ptr(), B, N, C, H, out.data_ptr(), 0, 0, _lib.stream_ptr()))
-    for name, cfgs in (LEGS if C < 256 else [("two blocks per wave (sp)", [4, 5]), ("  sp, eight waves per workgroup", [4, 6]), ("two blocks per wave (sp)", [4, 5]), ("  sp, eight waves per workgroup", [4, 6]), ("  sp, no K/V restaging", [4, 17]), ("  sp, no rare-path test", [4, 18]), ("  sp, neither", [4, 19])]):
+    for name, cfgs in (LEGS if C < 256 else [("two blocks per wave (sp)", [4, 5]), ("  sp, eight waves per workgroup", [4, 6]), ("two blocks per wave (sp)", [4, 5]), ("  sp, eight waves per workgroup", [4, 6]), ("  sp, no K/V restaging", [4, 17]), ("  sp, restaging from four resident tiles", [4, 24]), ("  sp, no rare-path test", [4, 18]), ("  sp, neither", [4, 19])]):
         _lib.check(lib.pcd_set_attention_config(16))
         for c in cfgs:
             _lib.check(lib.pcd_set_attention_config(c))
