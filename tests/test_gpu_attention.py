@@ -162,6 +162,8 @@ def test_attention_pipelined_kernel_d32_d16(pattern, C, N):
     lib = _lib.load()
     got = ops.set_attention_f16(qkv16.cuda(), B, N, C, H).float().cpu()
     assert lib.pcd_set_attention_last_kernel().decode() == f"set_attention_spn_kernel<{C // H}>"
+    for _ in range(3):                                          # race screen: the ring, its barriers and the in-place score tiles give the same bits every launch
+        assert torch.equal(ops.set_attention_f16(qkv16.cuda(), B, N, C, H).float().cpu(), got)
     assert torch.isfinite(got).all()
     assert rel_l2(got, want) < 2e-3, (pattern, C, N)
     _lib.check(lib.pcd_set_attention_config(3))                  # the one-block kernel on the same input
