@@ -1636,6 +1636,117 @@ __global__ __launch_bounds__(512, 4) void conv3d_last_mfma8_kernel(const half_t*
     }
 }
 
+// The same layer as PER-TAP PARTIAL PRODUCTS (round 5, default).  The form above reads one 1-KB B fragment from LDS per MFMA: 108 KB per wave and 64 voxels, the LDS
+// port is busy 3.2 us per workgroup of a 2048-workgroup grid (26 us) and the layer took 51-56 us for 0.9 GFLOP.  Here a wave owns one 8 x 8 output slice and turns the
+// product inside out: for each of the three input slices above it (dz = -1, 0, +1) it forms, for every voxel u of that slice's 10 x 10 halo,
+//       p[u][t] = sum_c w[dz][t][c] x[u][c]        for the nine taps t = 3 dy + dx of that dz
+// as D[tap][voxel] = W[tap][K = 32 c] . X[c][voxel] on v_mfma_f32_16x16x32_f16 -- the A operand holds nine tap rows (the fp32 weights as hi + lo + lo2 fp16 parts,
+// three MFMAs into one accumulator), the B operand 16 voxels x 32 channels straight from global memory (64 contiguous bytes per voxel: no input staging) -- writes
+// the 16 x 9 partials to a WAVE-PRIVATE 5-KB LDS tile and gathers out[y][x] += p[(y + dy, x + dx)][3 dy + dx]: nine 4-byte reads per dz and lane, a fixed
+// summation order.  21 B-fragment loads (all in flight), 63 MFMAs, 27 + 21 LDS operations per wave; no workgroup barrier (LDS operations of one wave execute in order).
+// Each input slice is read by the three waves around it: L1 / L2 absorb that.  d a multiple of 4, h and w of 8.
+template <int TZ, int ABL = 0>  // TZ: output slices = waves per workgroup (4: three workgroups per CU at this kernel's 131 registers); ABL (tools/bench_last_layer.py,
+                                // outputs wrong): 1 = loads only (their sum instead of products and gathers), 2 = no loads
+__global__ __launch_bounds__(64 * TZ, 4) void conv3d_last_taps_kernel(const half_t* __restrict__ in, int B, int D, int H, int W, const half_t* __restrict__ wfrag, float bias,
+                                                               float* __restrict__ out, int ntz, int nty, int ntx) {
+    constexpr int CIN = 32, HH = 10, NV = HH * HH, NG = (NV + 15) / 16, PITCH = 12;
+    __shared__ __attribute__((aligned(16))) float psm[TZ][NG * 16][PITCH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int t = blockIdx.x;
+    const int tx = t % ntx; t /= ntx;
+    const int ty = t % nty; t /= nty;
+    const int tz = t % ntz; const int b = t / ntz;
+    const int z0 = tz * TZ, y0 = ty * 8, x0 = tx * 8;
+    const int n = lane & 15, q = lane >> 4;
+    // A operands: row m = n is tap 3 dy + dx of slice dz (rows 9 .. 15 zero), k = 8 q .. 8 q + 7; three fp16 parts of the fp32 weight
+    // (from pcd_conv3d_last_pack's copy [27 taps][64 lanes][8]: there lane part + 16 q of tap t holds part `part` of w[t][8 q .. 8 q + 7]); one slice's set at a time
+    half8 wa[3];
+    auto load_w = [&](int dz) __attribute__((always_inline)) {
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {
+            wa[part] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (n < 9) wa[part] = *(const half8*)(wfrag + ((dz * 9 + n) * 64 + part + 16 * q) * 8);
+        }
+    };
+    load_w(0);
+    float (*pw)[PITCH] = psm[wave];
+    const int oy = lane >> 3, ox = lane & 7;
+    float o = bias;
+    // the B fragments of the first two input slices are requested before the first is used; the third slice's take the first slice's registers behind its MFMAs
+    // (56 + 12 weight registers: four waves per SIMD).  A lane's in-plane offsets and bounds are the same for the three slices: formed once; the loads are raw
+    // buffer loads over the slice (a lane outside the grid carries an offset past its end and receives zeros: no branch, no per-load address arithmetic).
+    half8 xb[3][NG];
+    unsigned voff[NG];                                               // byte offset inside a slice, or past the end of every slice: the buffer load returns zeros there
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int v = g * 16 + n, hy = v / HH, hx = v - hy * HH;
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const bool ok = !(ABL & 2) && v < NV && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        voff[g] = ok ? (unsigned)(((iy * W + ix) * CIN + 8 * q) * 2) : 0xffffffffu;
+    }
+    auto request = [&](int dz) __attribute__((always_inline)) {
+        const int iz = z0 + wave - 1 + dz;
+        const bool zok = (unsigned)iz < (unsigned)D;                 // wave-uniform: a slice outside the grid is a buffer of zero bytes
+        const half_t* slice = in + ((int64_t)b * D + (zok ? iz : 0)) * H * W * CIN;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)slice, 0, zok ? H * W * CIN * 2 : 0, 0x00020000);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+            const u32x4_ r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[g], 0, 0);
+            xb[dz][g] = __builtin_bit_cast(half8, r);
+        }
+    };
+    request(0);
+    request(1);
+    if constexpr ((ABL & 1) != 0) request(2);
+    if constexpr ((ABL & 1) != 0) {
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) o += (float)xb[dz][g][0] + (float)xb[dz][g][7];
+        out[(((int64_t)b * D + z0 + wave) * H + y0 + oy) * W + x0 + ox] = o;
+        return;
+    }
+#pragma unroll
+    for (int dz = 0; dz < 3; ++dz) {
+        f32x4 accs[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[2], xb[dz][g], acc, 0, 0, 0);      // smallest part first
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[1], xb[dz][g], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[0], xb[dz][g], acc, 0, 0, 0);
+            accs[g] = acc;
+        }
+        // lane (voxel n, q) holds taps 4 q .. 4 q + 3 of voxel g * 16 + n (taps 9 .. 11 are zero rows of the A operand; taps 12 .. 15 have no place in the tile)
+        if (q < 3) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) *(f32x4*)&pw[g * 16 + n][4 * q] = accs[g];
+        }
+        if (dz < 2) {
+            __builtin_amdgcn_sched_barrier(0);                       // (not earlier: the compiler would hoist these loads to the top and need 50 more registers)
+            load_w(dz + 1);
+            if (dz == 0) request(2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // Lanes exchange data through the tile: to the language that is communication between threads and needs synchronisation, or the compiler may (and did)
+        // keep a lane's reads in front of stores the lane itself does not execute.  Within one wave the hardware needs nothing (its LDS operations execute in
+        // order): wavefront-scope fences + a wave barrier emit no instruction and pin the order.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) o += pw[(oy + dy) * HH + ox + dx][3 * dy + dx];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the next slice's stores stay behind these reads
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    out[(((int64_t)b * D + z0 + wave) * H + y0 + oy) * W + x0 + ox] = 1.f / (1.f + expf(-o));
+}
+
 // VAE3D's last layer (networks.py:2018-2019): ConvTranspose3d(CIN, 1, k3, s2, p1, output_padding 1) + Sigmoid.
 // o = 2 i - 1 + k per dimension: even o takes (k=1, i=o/2); odd o takes (k=0, i=(o+1)/2) and (k=2, i=(o-1)/2).
 // in fp16 NDHWC [B][D][H][W][CIN]; w fp32 [27][CIN] (tap-major); out fp32 [B][2D][2H][2W].
@@ -1797,14 +1908,16 @@ extern "C" int pcd_conv3d_f16(const pcd_conv3d_desc_t* d, void* stream) {
 }
 
 static int g_halo_tall = 1;          // tuning / testing hook (pcd_conv3d_config)
-static int g_last8 = 2;       // the last layer (Conv3d 32 -> 1 + sigmoid): 2 = 8 x 8 x 8 blocks on the matrix pipe (default), 1 = 8 x 8 x 8 on the VALU (pcd_conv3d_config
-                              // + 16), 0 = 4 x 4 x 8 blocks (+ 8)
+static int g_last_abl = 0;    // timing ablations of conv3d_last_taps_kernel (pcd_conv3d_config + 128 / + 256; outputs wrong)
+static int g_last8 = 3;       // the last layer (Conv3d 32 -> 1 + sigmoid): 3 = per-tap partial products (default), 2 = 8 x 8 x 8 blocks with one MFMA per tap and 16 voxels
+                              // (pcd_conv3d_config + 24), 1 = 8 x 8 x 8 on the VALU (+ 16), 0 = 4 x 4 x 8 blocks (+ 8)
 
 extern "C" int pcd_conv3d_config(int tall_halo_tiles) {
-    PCD_CHECK_ARG(tall_halo_tiles >= 0 && (tall_halo_tiles & 7) <= 2 && tall_halo_tiles < 128);
+    PCD_CHECK_ARG(tall_halo_tiles >= 0 && (tall_halo_tiles & 7) <= 2 && tall_halo_tiles < 512);
+    g_last_abl = (tall_halo_tiles >> 7) & 3;
     g_split_target = (tall_halo_tiles & 96) == 96 ? 1024 : (tall_halo_tiles & 32) ? 768 : ((tall_halo_tiles & 64) ? 384 : 512);
     g_halo_tall = tall_halo_tiles & 7;
-    g_last8 = (tall_halo_tiles & 8) ? 0 : ((tall_halo_tiles & 16) ? 1 : 2);
+    g_last8 = (tall_halo_tiles & 24) == 24 ? 2 : ((tall_halo_tiles & 8) ? 0 : ((tall_halo_tiles & 16) ? 1 : 3));
     return PCD_OK;
 }
 
@@ -2020,6 +2133,15 @@ extern "C" int pcd_conv3d_last_sigmoid_packed(const void* in, int batch, int d, 
                                               void* stream) {
     PCD_CHECK_ARG(in && wgt && out && batch > 0 && d > 0 && h > 0 && w > 0 && cin == 32);
     const int64_t total = (int64_t)batch * d * h * w;
+    if (wfrag != nullptr && g_last8 == 3 && d % 4 == 0 && h % 8 == 0 && w % 8 == 0 && total / 256 <= 0x7fffffff) {
+        if (g_last_abl == 1) hipLaunchKernelGGL((conv3d_last_taps_kernel<4, 1>), dim3((unsigned)(total / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)in, batch, d, h, w, (const half_t*)wfrag, bias, out, d / 4, h / 8, w / 8);
+        else if (g_last_abl == 2) hipLaunchKernelGGL((conv3d_last_taps_kernel<4, 2>), dim3((unsigned)(total / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)in, batch, d, h, w, (const half_t*)wfrag, bias, out, d / 4, h / 8, w / 8);
+        else
+        hipLaunchKernelGGL((conv3d_last_taps_kernel<4>), dim3((unsigned)(total / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)in, batch, d, h, w, (const half_t*)wfrag, bias, out,
+                           d / 4, h / 8, w / 8);
+        PCD_CHECK_LAUNCH();
+        return PCD_OK;
+    }
     if (wfrag == nullptr || g_last8 != 2 || d % 8 || h % 8 || w % 8 || total / 512 > 0x7fffffff)
         return pcd_conv3d_last_sigmoid(in, batch, d, h, w, cin, wgt, bias, out, stream);
     hipLaunchKernelGGL(conv3d_last_mfma8_kernel, dim3((unsigned)(total / 512)), dim3(512), 0, (hipStream_t)stream, (const half_t*)in, batch, d, h, w,

@@ -283,7 +283,7 @@ def test_conv1x1_pointwise_exact_integers(k, c, ldw, m, relu):
     assert lib.pcd_conv1x1_f16(x.data_ptr(), m, 48, w.data_ptr(), ldw, b.data_ptr(), relu, c, out.data_ptr(), 0) != 0
 
 
-@pytest.mark.parametrize("dims,stride", [((8, 8, 8), 1), ((4, 8, 16), 1), ((6, 5, 7), 1), ((8, 8, 8), 2)])
+@pytest.mark.parametrize("dims,stride", [((8, 8, 8), 1), ((16, 8, 24), 1), ((4, 8, 16), 1), ((6, 5, 7), 1), ((8, 8, 8), 2)])
 def test_conv3d_first_and_last_layers(dims, stride):
     """encoder.0 (Cin = 1, ReLU, fp16 NDHWC out) and decoder.12/13 (Cout = 1, sigmoid) against F.conv3d in fp64:
     the LDS-halo last-layer path (dims multiples of 4, 4, 8), its direct fallback (6, 5, 7), and the cout = 32
@@ -319,7 +319,20 @@ def test_conv3d_first_and_last_layers(dims, stride):
         _lib.check(lib.pcd_conv3d_last_sigmoid_packed(h.data_ptr(), b, dims[0], dims[1], dims[2], 32, dwl.data_ptr(), wf.data_ptr(), bl,
                                                       o4.data_ptr(), _lib.stream_ptr()))
         assert (o4.cpu().double() - want2).abs().max() <= 2e-6
-        # the default where the grid divides by 8: 8 x 8 x 8 blocks on the matrix pipe (hi / lo / lo2 rows of the fp32 weights); + 16: the same blocks on the VALU;
+        # (default where the grid divides by 8: per-tap partial products, conv3d_last_taps_kernel; + 24: one MFMA per tap and 16 voxels from the packed copy)
+        _lib.check(lib.pcd_conv3d_config(24 + 1))
+        try:
+            o5 = torch.empty_like(o2)
+            _lib.check(lib.pcd_conv3d_last_sigmoid_packed(h.data_ptr(), b, dims[0], dims[1], dims[2], 32, dwl.data_ptr(), wf.data_ptr(), bl,
+                                                          o5.data_ptr(), _lib.stream_ptr()))
+        finally:
+            _lib.check(lib.pcd_conv3d_config(1))
+        assert (o5.cpu().double() - want2).abs().max() <= 2e-6
+        o6 = torch.empty_like(o2)
+        _lib.check(lib.pcd_conv3d_last_sigmoid_packed(h.data_ptr(), b, dims[0], dims[1], dims[2], 32, dwl.data_ptr(), wf.data_ptr(), bl,
+                                                      o6.data_ptr(), _lib.stream_ptr()))
+        assert torch.equal(o6, o4)                                                   # bitwise repeatable
+        # the other forms where the grid divides by 8: 8 x 8 x 8 blocks on the matrix pipe (hi / lo / lo2 rows of the fp32 weights); + 16: the same blocks on the VALU;
         # + 8: 4 x 4 x 8 blocks
         for cfg in (16 + 1, 8 + 1):
             _lib.check(lib.pcd_conv3d_config(cfg))
