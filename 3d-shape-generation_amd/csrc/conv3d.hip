@@ -1341,10 +1341,14 @@ __global__ __launch_bounds__(256) void conv3d_first32_kernel(const float* __rest
 // weights (rounded to fp16 like every other layer's) are the A operand, held in registers; a workgroup keeps the fp16 image of
 // its 6 x 6 x 10 input halo in LDS (720 B) and a lane gathers the eight taps of its k chunk for its voxel from it; the
 // accumulator of a lane is 4 consecutive channels of one voxel = an 8-byte piece of the NDHWC output row.
+// TZ x TY x 8 output voxels per tile (4 x 4 x 8, or 8 x 8 x 8 where the grid divides: the kernel is bound by instruction ISSUE -- 470 instructions per wave and
+// 4 x 4 x 8 tile, of which 120 stage the halo and 60 decode the tile index; with 512 voxels per tile they are spread over four times the MFMA groups: 31 -> ~20 us)
+template <int TZ, int TY>
 __global__ __launch_bounds__(256) void conv3d_first32_mfma_kernel(const float* __restrict__ x, int B, int D, int H, int W,
                                                                    const float* __restrict__ w,
                                                                    const float* __restrict__ bias, half_t* __restrict__ out,
                                                                    int ntz, int nty, int ntx, int ntiles) {
+    constexpr int HTZ = TZ, HTY = TY, HHY = HTY + 2, HROWS = (HTZ + 2) * HHY * HHX, GROUPS = TZ * TY * 8 / 16 / 4, YB = TY == 8 ? 3 : 2;   // (shadow the file's 128-row geometry)
     __shared__ half_t halo[2][HROWS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1369,20 +1373,29 @@ __global__ __launch_bounds__(256) void conv3d_first32_mfma_kernel(const float* _
         const int ty = t % nty; t /= nty;
         const int tz = t % ntz; const int b = t / ntz;
         const int z0 = tz * HTZ, y0 = ty * HTY, x0 = tx * HTX;
-        for (int i = tid; i < HROWS; i += 256) {
+        constexpr int SIT = (HROWS + 255) / 256;
+        float hv[SIT];
+#pragma unroll
+        for (int it = 0; it < SIT; ++it) {                 // every load of the halo in flight before the first LDS store
+            const int i = it * 256 + tid;
             const int hx = i % HHX; const int r2 = i / HHX;
             const int hy = r2 % HHY, hz = r2 / HHY;
             const int iz = z0 - 1 + hz, iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-            const bool ok = (unsigned)iz < (unsigned)D && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const bool ok = i < HROWS && (unsigned)iz < (unsigned)D && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
             const int cz = min(max(iz, 0), D - 1), cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
             const float v = x[(((int64_t)b * D + cz) * H + cy) * W + cx];
-            halo[buf][i] = (half_t)(ok ? v : 0.f);
+            hv[it] = ok ? v : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < SIT; ++it) {
+            const int i = it * 256 + tid;
+            if (i < HROWS) halo[buf][i] = (half_t)hv[it];
         }
         __syncthreads();                                   // two halo buffers: one barrier per tile is enough
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int m = (wave * 2 + i) * 16 + r;         // this lane's voxel: the MFMA column
-            const int vx = m & 7, vy = (m >> 3) & 3, vz = m >> 5;
+        for (int i = 0; i < GROUPS; ++i) {
+            const int m = (wave * GROUPS + i) * 16 + r;    // this lane's voxel: the MFMA column
+            const int vx = m & 7, vy = (m >> 3) & (TY - 1), vz = m >> (3 + YB);
             const int base = (vz * HHY + vy) * HHX + vx;
             half8 col;
 #pragma unroll
@@ -1908,12 +1921,14 @@ extern "C" int pcd_conv3d_f16(const pcd_conv3d_desc_t* d, void* stream) {
 }
 
 static int g_halo_tall = 1;          // tuning / testing hook (pcd_conv3d_config)
+static int g_first8 = 1;      // the first layer (Conv3d 1 -> 32): 8 x 8 x 8 tiles where the grid divides (default), 0 = 4 x 4 x 8 tiles (pcd_conv3d_config + 512)
 static int g_last_abl = 0;    // timing ablations of conv3d_last_taps_kernel (pcd_conv3d_config + 128 / + 256; outputs wrong)
 static int g_last8 = 3;       // the last layer (Conv3d 32 -> 1 + sigmoid): 3 = per-tap partial products (default), 2 = 8 x 8 x 8 blocks with one MFMA per tap and 16 voxels
                               // (pcd_conv3d_config + 24), 1 = 8 x 8 x 8 on the VALU (+ 16), 0 = 4 x 4 x 8 blocks (+ 8)
 
 extern "C" int pcd_conv3d_config(int tall_halo_tiles) {
-    PCD_CHECK_ARG(tall_halo_tiles >= 0 && (tall_halo_tiles & 7) <= 2 && tall_halo_tiles < 512);
+    PCD_CHECK_ARG(tall_halo_tiles >= 0 && (tall_halo_tiles & 7) <= 2 && tall_halo_tiles < 1024);
+    g_first8 = (tall_halo_tiles & 512) ? 0 : 1;
     g_last_abl = (tall_halo_tiles >> 7) & 3;
     g_split_target = (tall_halo_tiles & 96) == 96 ? 1024 : (tall_halo_tiles & 32) ? 768 : ((tall_halo_tiles & 64) ? 384 : 512);
     g_halo_tall = tall_halo_tiles & 7;
@@ -2077,9 +2092,16 @@ extern "C" int pcd_conv3d_first(const float* x, int batch, int d, int h, int w, 
     PCD_CHECK_ARG(x && wgt && bias && out && batch > 0 && d > 0 && h > 0 && w > 0 && cout > 0 && cout % 8 == 0);
     PCD_CHECK_ARG(stride == 1 || stride == 2);
     const int64_t ovox = (int64_t)((d - 1) / stride + 1) * ((h - 1) / stride + 1) * ((w - 1) / stride + 1);
+    if (cout == 32 && stride == 1 && g_first8 && d % 8 == 0 && h % 8 == 0 && w % 8 == 0 && (int64_t)batch * ovox / 512 <= 0x7fffffff) {
+        const int64_t tiles = (int64_t)batch * ovox / 512;
+        hipLaunchKernelGGL((conv3d_first32_mfma_kernel<8, 8>), dim3((unsigned)(tiles < 2048 ? tiles : 2048)), dim3(256), 0,
+                           (hipStream_t)stream, x, batch, d, h, w, wgt, bias, (half_t*)out, d / 8, h / 8, w / 8, (int)tiles);
+        PCD_CHECK_LAUNCH();
+        return PCD_OK;
+    }
     if (cout == 32 && stride == 1 && d % HTZ == 0 && h % HTY == 0 && w % HTX == 0 && (int64_t)batch * ovox / 128 <= 0x7fffffff) {
         const int64_t tiles = (int64_t)batch * ovox / 128;
-        hipLaunchKernelGGL(conv3d_first32_mfma_kernel, dim3((unsigned)(tiles < 2048 ? tiles : 2048)), dim3(256), 0,
+        hipLaunchKernelGGL((conv3d_first32_mfma_kernel<4, 4>), dim3((unsigned)(tiles < 2048 ? tiles : 2048)), dim3(256), 0,
                            (hipStream_t)stream, x, batch, d, h, w, wgt, bias, (half_t*)out, d / HTZ, h / HTY, w / HTX,
                            (int)tiles);
         PCD_CHECK_LAUNCH();

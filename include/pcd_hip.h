@@ -445,7 +445,8 @@ int pcd_conv3d_f16_multi(const pcd_conv3d_desc_t* descs, int n, void* workspace,
  * pcd_conv3d_last_sigmoid_packed: default = per-tap partial products on the matrix pipe (a wave per 8 x 8 output slice, the fp32 weights as fp16 hi + lo + lo2
  * parts); + 24: 8 x 8 x 8 output blocks with one MFMA per tap and 16 voxels (from the packed copy); + 16: the same blocks on the VALU (fp32 weights); + 8:
  * 4 x 4 x 8 blocks on the VALU.  The four forms agree to 1e-6.  + 64 / + 32 / + 96: split-K aims at 384 / 768 / 1024 workgroups
- * instead of 512 (all measured slower on VAE3DLarge).  TEST / BENCHMARK ONLY: process-global. */
+ * instead of 512 (all measured slower on VAE3DLarge); + 512: pcd_conv3d_first on 4 x 4 x 8 tiles where 8 x 8 x 8 would fit (same bits); + 128 / + 256: timing
+ * ablations of the last layer's kernel (OUTPUTS WRONG).  TEST / BENCHMARK ONLY: process-global. */
 int pcd_conv3d_config(int tall_halo_tiles);
 /* Conv3d(k3, stride 1, pad 1) (+ folded BN, residual, ReLU) with the input halo of a 4x4x8 output block held in
  * LDS and reused by all 27 taps -- the 32^3 layers of VAE3DLarge (encoder.2, decoder.8-11; networks.py:2227,

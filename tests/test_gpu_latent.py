@@ -302,6 +302,15 @@ def test_conv3d_first_and_last_layers(dims, stride):
                                     out.data_ptr(), _lib.stream_ptr()))
     got = out.float().cpu().reshape((b,) + od + (32,)).permute(0, 4, 1, 2, 3).double()
     assert (got - want).abs().max() <= 2e-3 * max(1.0, float(want.abs().max()))       # one fp16 rounding
+    if stride == 1 and all(d % 8 == 0 for d in dims):                                  # 8 x 8 x 8 tiles (default) against 4 x 4 x 8 tiles: the same bits
+        out4 = torch.empty_like(out)
+        _lib.check(lib.pcd_conv3d_config(512 + 1))
+        try:
+            _lib.check(lib.pcd_conv3d_first(dx.data_ptr(), b, dims[0], dims[1], dims[2], stride, dw.data_ptr(), db.data_ptr(), 32,
+                                            out4.data_ptr(), _lib.stream_ptr()))
+        finally:
+            _lib.check(lib.pcd_conv3d_config(1))
+        assert torch.equal(out4, out)
     if stride == 1:
         h = out                                                                        # fp16 NDHWC, 32 channels
         wl, bl = torch.randn(1, 32, 3, 3, 3, generator=g) * 0.1, 0.05
