@@ -79,7 +79,8 @@ __device__ __forceinline__ void conv_reads_landed() {
 // the barrier that publishes it and NST - 2 younger stages stay in flight behind that barrier's counted vmcnt: with two
 // stages the gather of K tile kt+1 has one K tile of MFMAs (~500 cycles per wave) to come back from L2, and the waves
 // spend more than half their time at the wait (SQ_WAIT_ANY 56 % of SQ_WAVE_CYCLES on the 128 -> 128 layers).
-template <int BM, int BN, int BKT, int NST>
+// ABL: timing ablations (pcd_conv3d_config + 1024 / + 2048; OUTPUTS WRONG): 1 = the weight rows are staged for the first NST - 1 K tiles only, 2 = the same for the gathered rows
+template <int BM, int BN, int BKT, int NST, int ABL = 0>
 __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
     constexpr int CBK = BKT, CROWB = BKT * 2;                 // shadow the file-level K tile
     constexpr int LPR = BKT / 8, RPW = 64 / LPR, RPI = 4 * RPW;   // lanes per staged row, rows per wave instruction / per round
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
     constexpr int OUT_LD = BN * 2 + 16;
     constexpr int LDS_BYTES = (NST * STAGE_BYTES > BM * OUT_LD) ? NST * STAGE_BYTES : BM * OUT_LD;
     constexpr int AR = BM / RPI, BR = BN / RPI, LPT = AR + BR;  // LPT: LDS-DMA instructions per thread and stage
+    static_assert(ABL == 0 || NST == 2, "the ablations drop LDS-DMA instructions: only the two-stage form, whose waits are vmcnt(0)");
     static_assert(BM % RPI == 0 && BN % RPI == 0 && NST >= 2 && NST <= 4, "stage layout");
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
     __shared__ int4 taps_s[TAP_SLOTS];
@@ -158,6 +160,9 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
     auto stage = [&](int kt, int buf) {
         char* base = smem + buf * STAGE_BYTES;
         const int kidx = kt * CBK + lchunk * 8;
+        const bool first = kt < kt0 + NST - 1;
+        if ((ABL & 2) && !first) {
+        } else
         if (kt >= p.kt2) {
             // second source (uniform per K tile): row m of in2, channels kidx - kt2 * CBK .. ; the row grid IS in2's grid (stride 1), so its
             // voxel index is rbase / Cin and no bound can fail
@@ -176,6 +181,7 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
                 cglds16_asm(g, base + (r * RPI + wave * RPW) * CROWB);
             }
         }
+        if ((ABL & 1) && !first) return;
 #pragma unroll
         for (int r = 0; r < BR; ++r) cglds16_asm(wrow[r] + kidx, base + BM * CROWB + (r * RPI + wave * RPW) * CROWB);
     };
@@ -1805,6 +1811,7 @@ __global__ __launch_bounds__(256) void convT3d_last_kernel(const half_t* __restr
 using namespace pcd;
 
 // split-K factor for a launch of `blocks` workgroups over `nk` K tiles: aim for ~2 workgroups per CU
+static int g_igemm_abl = 0;   // timing ablations of the 128 x 128 implicit GEMM (pcd_conv3d_config + 1024 / + 2048; outputs wrong)
 static int g_split_target = 512;      // split-K aims at this many workgroups (tuning hook: pcd_conv3d_config + 64: 384, + 32: 768, + 96: 1024; VAE3DLarge encode at B = 32:
                                       // 834 / 913 / 888 us against 817 at 512: tools/bench_vae.py with PCD_CONV3D_CONFIG)
 static int conv_splits(int64_t blocks, int nk) {
@@ -1903,6 +1910,10 @@ extern "C" int pcd_conv3d_f16_multi(const pcd_conv3d_desc_t* descs, int n, void*
         if (d->kpad / CBK >= 32) hipLaunchKernelGGL((conv3d_igemm_kernel<128, 64, 64, 3>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((conv3d_igemm_kernel<128, 64, 64, 2>), grid, dim3(256), 0, s, p);
     } else {
+        if (g_igemm_abl == 1) hipLaunchKernelGGL((conv3d_igemm_kernel<128, 128, 64, 2, 1>), grid, dim3(256), 0, s, p);
+        else if (g_igemm_abl == 2) hipLaunchKernelGGL((conv3d_igemm_kernel<128, 128, 64, 2, 2>), grid, dim3(256), 0, s, p);
+        else if (g_igemm_abl == 3) hipLaunchKernelGGL((conv3d_igemm_kernel<128, 128, 64, 2, 3>), grid, dim3(256), 0, s, p);
+        else
         hipLaunchKernelGGL((conv3d_igemm_kernel<128, 128, 64, 2>), grid, dim3(256), 0, s, p);
     }
     PCD_CHECK_LAUNCH();
@@ -1927,7 +1938,8 @@ static int g_last8 = 3;       // the last layer (Conv3d 32 -> 1 + sigmoid): 3 = 
                               // (pcd_conv3d_config + 24), 1 = 8 x 8 x 8 on the VALU (+ 16), 0 = 4 x 4 x 8 blocks (+ 8)
 
 extern "C" int pcd_conv3d_config(int tall_halo_tiles) {
-    PCD_CHECK_ARG(tall_halo_tiles >= 0 && (tall_halo_tiles & 7) <= 2 && tall_halo_tiles < 1024);
+    PCD_CHECK_ARG(tall_halo_tiles >= 0 && (tall_halo_tiles & 7) <= 2 && tall_halo_tiles < 4096);
+    g_igemm_abl = (tall_halo_tiles >> 10) & 3;
     g_first8 = (tall_halo_tiles & 512) ? 0 : 1;
     g_last_abl = (tall_halo_tiles >> 7) & 3;
     g_split_target = (tall_halo_tiles & 96) == 96 ? 1024 : (tall_halo_tiles & 32) ? 768 : ((tall_halo_tiles & 64) ? 384 : 512);
