@@ -79,7 +79,8 @@ __device__ __forceinline__ void conv_reads_landed() {
 // the barrier that publishes it and NST - 2 younger stages stay in flight behind that barrier's counted vmcnt: with two
 // stages the gather of K tile kt+1 has one K tile of MFMAs (~500 cycles per wave) to come back from L2, and the waves
 // spend more than half their time at the wait (SQ_WAIT_ANY 56 % of SQ_WAVE_CYCLES on the 128 -> 128 layers).
-// ABL: timing ablations (pcd_conv3d_config + 1024 / + 2048; OUTPUTS WRONG): 1 = the weight rows are staged for the first NST - 1 K tiles only, 2 = the same for the gathered rows
+// ABL: timing ablations (pcd_conv3d_config + 1024 x bits; OUTPUTS WRONG): 1 = the weight rows are staged for the first NST - 1 K tiles only, 2 = the same for the gathered rows,
+// 4 = every fragment read takes the first fragment's address, 8 = no MFMAs
 template <int BM, int BN, int BKT, int NST, int ABL = 0>
 __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
     constexpr int CBK = BKT, CROWB = BKT * 2;                 // shadow the file-level K tile
@@ -225,14 +226,16 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvParams p) {
         for (int ks = 0; ks < KS; ++ks) {
             half8 af[MI], bf[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = *(const half8*)(base + offa[ks] + i * 16 * CROWB);
+            for (int i = 0; i < MI; ++i) af[i] = *(const half8*)(base + offa[ks] + ((ABL & 4) ? 0 : i * 16 * CROWB));
 #pragma unroll
-            for (int j = 0; j < NI; ++j) bf[j] = *(const half8*)(base + offb[ks] + j * 16 * CROWB);
+            for (int j = 0; j < NI; ++j) bf[j] = *(const half8*)(base + offb[ks] + ((ABL & 4) ? 0 : j * 16 * CROWB));
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NI; ++j) {
+                    if constexpr ((ABL & 8) != 0) acc[i][j][0] += (float)af[i][0] * (float)bf[j][0];
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                }
         }
     }
 
@@ -1913,6 +1916,10 @@ extern "C" int pcd_conv3d_f16_multi(const pcd_conv3d_desc_t* descs, int n, void*
         if (g_igemm_abl == 1) hipLaunchKernelGGL((conv3d_igemm_kernel<128, 128, 64, 2, 1>), grid, dim3(256), 0, s, p);
         else if (g_igemm_abl == 2) hipLaunchKernelGGL((conv3d_igemm_kernel<128, 128, 64, 2, 2>), grid, dim3(256), 0, s, p);
         else if (g_igemm_abl == 3) hipLaunchKernelGGL((conv3d_igemm_kernel<128, 128, 64, 2, 3>), grid, dim3(256), 0, s, p);
+        else if (g_igemm_abl == 4) hipLaunchKernelGGL((conv3d_igemm_kernel<128, 128, 64, 2, 4>), grid, dim3(256), 0, s, p);
+        else if (g_igemm_abl == 7) hipLaunchKernelGGL((conv3d_igemm_kernel<128, 128, 64, 2, 7>), grid, dim3(256), 0, s, p);
+        else if (g_igemm_abl == 8) hipLaunchKernelGGL((conv3d_igemm_kernel<128, 128, 64, 2, 8>), grid, dim3(256), 0, s, p);
+        else if (g_igemm_abl == 15) hipLaunchKernelGGL((conv3d_igemm_kernel<128, 128, 64, 2, 15>), grid, dim3(256), 0, s, p);
         else
         hipLaunchKernelGGL((conv3d_igemm_kernel<128, 128, 64, 2>), grid, dim3(256), 0, s, p);
     }
@@ -1938,8 +1945,8 @@ static int g_last8 = 3;       // the last layer (Conv3d 32 -> 1 + sigmoid): 3 = 
                               // (pcd_conv3d_config + 24), 1 = 8 x 8 x 8 on the VALU (+ 16), 0 = 4 x 4 x 8 blocks (+ 8)
 
 extern "C" int pcd_conv3d_config(int tall_halo_tiles) {
-    PCD_CHECK_ARG(tall_halo_tiles >= 0 && (tall_halo_tiles & 7) <= 2 && tall_halo_tiles < 4096);
-    g_igemm_abl = (tall_halo_tiles >> 10) & 3;
+    PCD_CHECK_ARG(tall_halo_tiles >= 0 && (tall_halo_tiles & 7) <= 2 && tall_halo_tiles < 16384);
+    g_igemm_abl = (tall_halo_tiles >> 10) & 15;
     g_first8 = (tall_halo_tiles & 512) ? 0 : 1;
     g_last_abl = (tall_halo_tiles >> 7) & 3;
     g_split_target = (tall_halo_tiles & 96) == 96 ? 1024 : (tall_halo_tiles & 32) ? 768 : ((tall_halo_tiles & 64) ? 384 : 512);

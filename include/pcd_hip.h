@@ -446,7 +446,7 @@ int pcd_conv3d_f16_multi(const pcd_conv3d_desc_t* descs, int n, void* workspace,
  * parts); + 24: 8 x 8 x 8 output blocks with one MFMA per tap and 16 voxels (from the packed copy); + 16: the same blocks on the VALU (fp32 weights); + 8:
  * 4 x 4 x 8 blocks on the VALU.  The four forms agree to 1e-6.  + 64 / + 32 / + 96: split-K aims at 384 / 768 / 1024 workgroups
  * instead of 512 (all measured slower on VAE3DLarge); + 512: pcd_conv3d_first on 4 x 4 x 8 tiles where 8 x 8 x 8 would fit (same bits); + 128 / + 256: timing
- * ablations of the last layer's kernel, + 1024 / + 2048: of the 128 x 128 implicit GEMM's operand staging (OUTPUTS WRONG).  TEST / BENCHMARK ONLY: process-global. */
+ * ablations of the last layer's kernel, + 1024 x bits: of the 128 x 128 implicit GEMM (1 / 2 operand staging, 4 fragment reads, 8 MFMAs) (OUTPUTS WRONG).  TEST / BENCHMARK ONLY: process-global. */
 int pcd_conv3d_config(int tall_halo_tiles);
 /* Conv3d(k3, stride 1, pad 1) (+ folded BN, residual, ReLU) with the input halo of a 4x4x8 output block held in
  * LDS and reused by all 27 taps -- the 32^3 layers of VAE3DLarge (encoder.2, decoder.8-11; networks.py:2227,
