@@ -1769,6 +1769,104 @@ __global__ __launch_bounds__(64 * TZ, 4) void conv3d_last_taps_kernel(const half
     out[(((int64_t)b * D + z0 + wave) * H + y0 + oy) * W + x0 + ox] = 1.f / (1.f + expf(-o));
 }
 
+// The same per-tap partial products with every input slice read ONCE: a wave owns TZ consecutive output slices of one 8 x 8 tile and walks the TZ + 2 input
+// slices around them; for a slice it forms ALL 27 taps' partials (two MFMA row groups: taps 0-15 and 16-26, three weight parts each: six MFMAs per 16 voxels),
+// writes them to its LDS tile ([112 voxels][28 taps]) and every output slice the slice touches (z = s + 1 - dz) gathers its nine.  The kernel above issues ~650
+// instructions per output slice (it is bound by instruction issue); here the loads, their offsets and the prologue are shared by TZ slices: ~300 per slice at TZ = 4
+// (22.7 us against 32; TZ = 2: 26.6, TZ = 8: 24.4 -- 2048 waves do not fill the chip).
+// The next slice's B fragments are requested before the current slice's MFMAs.  Summation order per output: input slice ascending, then (dy, dx): deterministic.
+template <int TZ>
+__global__ __launch_bounds__(256, 2) void conv3d_last_roll_kernel(const half_t* __restrict__ in, int B, int D, int H, int W, const half_t* __restrict__ wfrag, float bias,
+                                                                  float* __restrict__ out, int ntz, int nty, int ntx, int nwork) {
+    constexpr int CIN = 32, HH = 10, NV = HH * HH, NG = (NV + 15) / 16, PITCH = 28;
+    __shared__ __attribute__((aligned(16))) float psm[4][NG * 16][PITCH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int t = blockIdx.x * 4 + wave;                                   // one (sample, z chunk, y tile, x tile) per wave; no workgroup-level synchronisation below
+    if (t >= nwork) return;
+    const int tx = t % ntx; t /= ntx;
+    const int ty = t % nty; t /= nty;
+    const int tz = t % ntz; const int b = t / ntz;
+    const int z0 = tz * TZ, y0 = ty * 8, x0 = tx * 8;
+    const int n = lane & 15, q = lane >> 4;
+    // A operands: row group rg, row m = n is tap 16 rg + n (taps 27 .. 31: zero rows), k = 8 q ..; from pcd_conv3d_last_pack's copy (lane part + 16 q of tap t)
+    half8 wa[2][3];
+#pragma unroll
+    for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {
+            wa[rg][part] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (16 * rg + n < 27) wa[rg][part] = *(const half8*)(wfrag + ((16 * rg + n) * 64 + part + 16 * q) * 8);
+        }
+    unsigned voff[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int v = g * 16 + n, hy = v / HH, hx = v - hy * HH;
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const bool ok = v < NV && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        voff[g] = ok ? (unsigned)(((iy * W + ix) * CIN + 8 * q) * 2) : 0xffffffffu;
+    }
+    half8 xb[2][NG];
+    auto request = [&](int s, half8 (&dst)[NG]) __attribute__((always_inline)) {      // input slice z0 - 1 + s
+        const int iz = z0 - 1 + s;
+        const bool zok = (unsigned)iz < (unsigned)D;                 // wave-uniform: a slice outside the grid is a buffer of zero bytes
+        const half_t* slice = in + ((int64_t)b * D + (zok ? iz : 0)) * H * W * CIN;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)slice, 0, zok ? H * W * CIN * 2 : 0, 0x00020000);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+            dst[g] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[g], 0, 0));
+        }
+    };
+    float (*pw)[PITCH] = psm[wave];
+    const int oy = lane >> 3, ox = lane & 7;
+    float o[TZ];
+#pragma unroll
+    for (int z = 0; z < TZ; ++z) o[z] = bias;
+    request(0, xb[0]);
+#pragma unroll
+    for (int s = 0; s < TZ + 2; ++s) {
+        if (s + 1 < TZ + 2) request(s + 1, xb[(s + 1) & 1]);
+        // lane (voxel n, q) holds taps 16 rg + 4 q .. + 3 of voxel g * 16 + n; taps 28 .. 31 (rg 1, q 3) have no place in the tile
+        f32x4 acc1[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[0][2], xb[s & 1][g], acc, 0, 0, 0);      // smallest part first
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[0][1], xb[s & 1][g], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[0][0], xb[s & 1][g], acc, 0, 0, 0);
+            *(f32x4*)&pw[g * 16 + n][4 * q] = acc;
+            acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[1][2], xb[s & 1][g], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[1][1], xb[s & 1][g], acc, 0, 0, 0);
+            acc1[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[1][0], xb[s & 1][g], acc, 0, 0, 0);
+        }
+        if (q < 3) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) *(f32x4*)&pw[g * 16 + n][16 + 4 * q] = acc1[g];
+        }
+        // lanes exchange data through the tile: wavefront-scope fences + a wave barrier pin the order for the compiler (conv3d_last_taps_kernel)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz) {
+            const int z = s - dz;                                    // output slice z0 + z reads input slice z0 - 1 + s with its taps of dz
+            if (z >= 0 && z < TZ) {
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) o[z] += pw[(oy + dy) * HH + ox + dx][9 * dz + 3 * dy + dx];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the next slice's stores stay behind these reads
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#pragma unroll
+    for (int z = 0; z < TZ; ++z) out[(((int64_t)b * D + z0 + z) * H + y0 + oy) * W + x0 + ox] = 1.f / (1.f + expf(-o[z]));
+}
+
 // VAE3D's last layer (networks.py:2018-2019): ConvTranspose3d(CIN, 1, k3, s2, p1, output_padding 1) + Sigmoid.
 // o = 2 i - 1 + k per dimension: even o takes (k=1, i=o/2); odd o takes (k=0, i=(o+1)/2) and (k=2, i=(o-1)/2).
 // in fp16 NDHWC [B][D][H][W][CIN]; w fp32 [27][CIN] (tap-major); out fp32 [B][2D][2H][2W].
@@ -1940,12 +2038,14 @@ extern "C" int pcd_conv3d_f16(const pcd_conv3d_desc_t* d, void* stream) {
 
 static int g_halo_tall = 1;          // tuning / testing hook (pcd_conv3d_config)
 static int g_first8 = 1;      // the first layer (Conv3d 1 -> 32): 8 x 8 x 8 tiles where the grid divides (default), 0 = 4 x 4 x 8 tiles (pcd_conv3d_config + 512)
+static int g_last_roll = 1;   // the per-tap form with every input slice read once by a wave that owns four output slices (default); 0 = a wave per output slice (pcd_conv3d_config + 16384)
 static int g_last_abl = 0;    // timing ablations of conv3d_last_taps_kernel (pcd_conv3d_config + 128 / + 256; outputs wrong)
 static int g_last8 = 3;       // the last layer (Conv3d 32 -> 1 + sigmoid): 3 = per-tap partial products (default), 2 = 8 x 8 x 8 blocks with one MFMA per tap and 16 voxels
                               // (pcd_conv3d_config + 24), 1 = 8 x 8 x 8 on the VALU (+ 16), 0 = 4 x 4 x 8 blocks (+ 8)
 
 extern "C" int pcd_conv3d_config(int tall_halo_tiles) {
-    PCD_CHECK_ARG(tall_halo_tiles >= 0 && (tall_halo_tiles & 7) <= 2 && tall_halo_tiles < 16384);
+    PCD_CHECK_ARG(tall_halo_tiles >= 0 && (tall_halo_tiles & 7) <= 2 && tall_halo_tiles < 32768);
+    g_last_roll = (tall_halo_tiles & 16384) ? 0 : 1;
     g_igemm_abl = (tall_halo_tiles >> 10) & 15;
     g_first8 = (tall_halo_tiles & 512) ? 0 : 1;
     g_last_abl = (tall_halo_tiles >> 7) & 3;
@@ -2174,6 +2274,13 @@ extern "C" int pcd_conv3d_last_sigmoid_packed(const void* in, int batch, int d, 
                                               void* stream) {
     PCD_CHECK_ARG(in && wgt && out && batch > 0 && d > 0 && h > 0 && w > 0 && cin == 32);
     const int64_t total = (int64_t)batch * d * h * w;
+    if (wfrag != nullptr && g_last8 == 3 && g_last_roll && d % 4 == 0 && h % 8 == 0 && w % 8 == 0 && total / 256 <= 0x7fffffff) {
+        const int64_t nwork = total / 256;                          // (sample, 4 output slices, 8 x 8 tile) units, one per wave
+        hipLaunchKernelGGL(conv3d_last_roll_kernel<4>, dim3((unsigned)ceil_div(nwork, 4)), dim3(256), 0, (hipStream_t)stream, (const half_t*)in, batch, d, h, w,
+                           (const half_t*)wfrag, bias, out, d / 4, h / 8, w / 8, (int)nwork);
+        PCD_CHECK_LAUNCH();
+        return PCD_OK;
+    }
     if (wfrag != nullptr && g_last8 == 3 && d % 4 == 0 && h % 8 == 0 && w % 8 == 0 && total / 256 <= 0x7fffffff) {
         if (g_last_abl == 1) hipLaunchKernelGGL((conv3d_last_taps_kernel<4, 1>), dim3((unsigned)(total / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)in, batch, d, h, w, (const half_t*)wfrag, bias, out, d / 4, h / 8, w / 8);
         else if (g_last_abl == 2) hipLaunchKernelGGL((conv3d_last_taps_kernel<4, 2>), dim3((unsigned)(total / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)in, batch, d, h, w, (const half_t*)wfrag, bias, out, d / 4, h / 8, w / 8);

@@ -442,9 +442,9 @@ int pcd_conv3d_f16_multi(const pcd_conv3d_desc_t* descs, int n, void* workspace,
                          void* stream);
 /* testing / tuning hook for pcd_conv3d_k3s1_f16 at C_in = 32, C_out <= 32: 0 = 128-row workgroups, 1 (default) = 256-row workgroups
  * (4 x 8 x 8 voxels, eight waves) where the grid has at least 512 of them, 2 = wherever H % 8 == 0 (tests).  Same bits.
- * pcd_conv3d_last_sigmoid_packed: default = per-tap partial products on the matrix pipe (a wave per 8 x 8 output slice, the fp32 weights as fp16 hi + lo + lo2
- * parts); + 24: 8 x 8 x 8 output blocks with one MFMA per tap and 16 voxels (from the packed copy); + 16: the same blocks on the VALU (fp32 weights); + 8:
- * 4 x 4 x 8 blocks on the VALU.  The four forms agree to 1e-6.  + 64 / + 32 / + 96: split-K aims at 384 / 768 / 1024 workgroups
+ * pcd_conv3d_last_sigmoid_packed: default = per-tap partial products on the matrix pipe (a wave per four 8 x 8 output slices, every input slice read once; the fp32
+ * weights as fp16 hi + lo + lo2 parts); + 16384: a wave per output slice; + 24: 8 x 8 x 8 output blocks with one MFMA per tap and 16 voxels (from the packed copy); + 16: the same blocks on the VALU (fp32 weights); + 8:
+ * 4 x 4 x 8 blocks on the VALU.  The five forms agree to 1e-6.  + 64 / + 32 / + 96: split-K aims at 384 / 768 / 1024 workgroups
  * instead of 512 (all measured slower on VAE3DLarge); + 512: pcd_conv3d_first on 4 x 4 x 8 tiles where 8 x 8 x 8 would fit (same bits); + 128 / + 256: timing
  * ablations of the last layer's kernel, + 1024 x bits: of the 128 x 128 implicit GEMM (1 / 2 operand staging, 4 fragment reads, 8 MFMAs) (OUTPUTS WRONG).  TEST / BENCHMARK ONLY: process-global. */
 int pcd_conv3d_config(int tall_halo_tiles);

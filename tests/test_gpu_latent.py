@@ -329,6 +329,14 @@ def test_conv3d_first_and_last_layers(dims, stride):
                                                       o4.data_ptr(), _lib.stream_ptr()))
         assert (o4.cpu().double() - want2).abs().max() <= 2e-6
         # (default where the grid divides by 8: per-tap partial products, conv3d_last_taps_kernel; + 24: one MFMA per tap and 16 voxels from the packed copy)
+        _lib.check(lib.pcd_conv3d_config(16384 + 1))                                  # + 16384: a wave per output slice instead of per four
+        try:
+            o7 = torch.empty_like(o2)
+            _lib.check(lib.pcd_conv3d_last_sigmoid_packed(h.data_ptr(), b, dims[0], dims[1], dims[2], 32, dwl.data_ptr(), wf.data_ptr(), bl,
+                                                          o7.data_ptr(), _lib.stream_ptr()))
+        finally:
+            _lib.check(lib.pcd_conv3d_config(1))
+        assert (o7.cpu().double() - want2).abs().max() <= 2e-6
         _lib.check(lib.pcd_conv3d_config(24 + 1))
         try:
             o5 = torch.empty_like(o2)

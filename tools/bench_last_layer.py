@@ -31,15 +31,16 @@ def ev(fn, n=50):
 wf = torch.empty(lib.pcd_conv3d_last_packed_bytes(), dtype=torch.uint8, device="cuda")
 _lib.check(lib.pcd_conv3d_last_pack(w32.data_ptr(), wf.data_ptr(), _lib.stream_ptr()))
 o.append(torch.empty_like(o[0]))
+o.append(torch.empty_like(o[0]))
 for rep in range(3):
     t = []
-    for k, cfg in enumerate((9, 17, 25, 1)):
+    for k, cfg in enumerate((9, 17, 25, 16385, 1)):
         _lib.check(lib.pcd_conv3d_config(cfg))
         t.append(ev(lambda: _lib.check(lib.pcd_conv3d_last_sigmoid_packed(h.data_ptr(), B, 32, 32, 32, 32, w32.data_ptr(), wf.data_ptr(), 0.05, o[k].data_ptr(),
                                                                           _lib.stream_ptr()))))
-    print(f"4x4x8 blocks {t[0]:6.1f} us | 8x8x8 blocks, VALU {t[1]:6.1f} us | 8x8x8 blocks, one MFMA per tap {t[2]:6.1f} us | per-tap partial products (default) {t[3]:6.1f} us | "
-          f"max diff {float((o[0] - o[1]).abs().max()):.1e} {float((o[0] - o[2]).abs().max()):.1e} {float((o[0] - o[3]).abs().max()):.1e}", flush=True)
-for cfg, name in ((1 + 128, "loads only"), (1 + 256, "no loads")):
+    print(f"4x4x8 blocks {t[0]:6.1f} us | 8x8x8 blocks, VALU {t[1]:6.1f} us | 8x8x8 blocks, one MFMA per tap {t[2]:6.1f} us | per-tap partial products, a wave per slice {t[3]:6.1f} us | a wave per four slices (default) {t[4]:6.1f} us | "
+          f"max diff {float((o[0] - o[1]).abs().max()):.1e} {float((o[0] - o[2]).abs().max()):.1e} {float((o[0] - o[3]).abs().max()):.1e} {float((o[0] - o[4]).abs().max()):.1e}", flush=True)
+for cfg, name in ((1 + 128 + 16384, "loads only"), (1 + 256 + 16384, "no loads")):
     _lib.check(lib.pcd_conv3d_config(cfg))
     t = ev(lambda: _lib.check(lib.pcd_conv3d_last_sigmoid_packed(h.data_ptr(), B, 32, 32, 32, 32, w32.data_ptr(), wf.data_ptr(), 0.05, o[3].data_ptr(), _lib.stream_ptr())))
     print(f"per-tap partial products, timing ablation (outputs wrong): {name:12s} {t:6.1f} us", flush=True)
