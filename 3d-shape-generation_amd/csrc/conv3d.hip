@@ -1017,7 +1017,9 @@ struct HaloWregParams {
 // CIN = 64 or 32 (32: one k step per tap, 64-byte voxel rows, 38.4 KB of halo: four workgroups per CU); NWC = wave columns: a tile is 32 NWC channels
 // wide and a workgroup NWR x NWC waves (C_out = 32 layers: NWC = 1).  CIN = 128: 256-byte voxel rows (the swizzle of convT3d_halo_kernel), a 153.6-KB halo
 // = ONE workgroup per CU, so it runs eight waves (tiles of 128 channels, NWC = 4); a tap is then two weight stages of 64 channels.
-template <int CIN, int NWC, int NWR = 2>
+// ABL: timing ablations of the <64, 2> instance (pcd_conv3d_config + 32768 x bits; OUTPUTS WRONG): 1 = the halo is not loaded (zeros are written to LDS), 2 = no halo staging
+// at all, 4 = no taps (no fragment reads, no MFMAs, no weight loads)
+template <int CIN, int NWC, int NWR = 2, int ABL = 0>
 __global__ __launch_bounds__(64 * NWR * NWC, 2) void conv3d_halo_wreg_kernel(HaloWregParams p) {      // >= two waves per SIMD: at most 256 registers
     constexpr int P = CIN * 2, CPV = CIN / 8, NT = 64 * NWR * NWC, TY8 = 8, HHY8 = TY8 + 2, TC = 32 * NWC;
     constexpr int SPT = CIN > 64 ? CIN / 64 : 1, KSS = (CIN > 64 ? 64 : CIN) / 32, NSTG = 27 * SPT;      // weight stages per tap, k steps per stage, stages
@@ -1039,7 +1041,7 @@ __global__ __launch_bounds__(64 * NWR * NWC, 2) void conv3d_halo_wreg_kernel(Hal
     const int z0 = tz * HTZ, y0 = ty * TY8, x0 = tx * HTX;
 
     // ---- halo: global -> registers (all loads in flight) -> LDS, chunk c of voxel (hz, hy, hx) at slot c ^ s(hx, hy) (the C_in = 64 image above)
-    {
+    if constexpr (!(ABL & 2)) {
         half8 hv[HIT];
         unsigned okmask = 0;
 #pragma unroll
@@ -1052,7 +1054,8 @@ __global__ __launch_bounds__(64 * NWR * NWC, 2) void conv3d_halo_wreg_kernel(Hal
             const bool ok = row < HV && (unsigned)iz < (unsigned)p.D && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             okmask |= ok ? 1u << it : 0u;
             const int cz = min(max(iz, 0), p.D - 1), cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
-            hv[it] = *(const half8*)(p.in + ((((int64_t)b * p.D + cz) * p.H + cy) * p.W + cx) * CIN + ch * 8);
+            if constexpr ((ABL & 1) != 0) hv[it] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            else hv[it] = *(const half8*)(p.in + ((((int64_t)b * p.D + cz) * p.H + cy) * p.W + cx) * CIN + ch * 8);
         }
 #pragma unroll
         for (int it = 0; it < HIT; ++it) {
@@ -1094,7 +1097,7 @@ __global__ __launch_bounds__(64 * NWR * NWC, 2) void conv3d_halo_wreg_kernel(Hal
     __syncthreads();                                           // the halo is in place; no barrier from here on
 
 #pragma unroll
-    for (int g = 0; g < NSTG; ++g) {
+    for (int g = 0; g < ((ABL & 4) ? 0 : NSTG); ++g) {
         if (g + 2 < NSTG) wload((g + 2) % 3, g + 2);
         __builtin_amdgcn_sched_barrier(0);                     // the loads stay HERE, two stages ahead of their use (left alone the scheduler sinks them to it)
         const int tap = g / SPT, kh = g % SPT;                 // kh: which 64 channels of the tap
@@ -1912,6 +1915,7 @@ __global__ __launch_bounds__(256) void convT3d_last_kernel(const half_t* __restr
 using namespace pcd;
 
 // split-K factor for a launch of `blocks` workgroups over `nk` K tiles: aim for ~2 workgroups per CU
+static int g_wreg_abl = 0;    // timing ablations of conv3d_halo_wreg_kernel<64, 2> (pcd_conv3d_config + 32768 x bits; outputs wrong)
 static int g_igemm_abl = 0;   // timing ablations of the 128 x 128 implicit GEMM (pcd_conv3d_config + 1024 / + 2048; outputs wrong)
 static int g_split_target = 512;      // split-K aims at this many workgroups (tuning hook: pcd_conv3d_config + 64: 384, + 32: 768, + 96: 1024; VAE3DLarge encode at B = 32:
                                       // 834 / 913 / 888 us against 817 at 512: tools/bench_vae.py with PCD_CONV3D_CONFIG)
@@ -2044,7 +2048,8 @@ static int g_last8 = 3;       // the last layer (Conv3d 32 -> 1 + sigmoid): 3 = 
                               // (pcd_conv3d_config + 24), 1 = 8 x 8 x 8 on the VALU (+ 16), 0 = 4 x 4 x 8 blocks (+ 8)
 
 extern "C" int pcd_conv3d_config(int tall_halo_tiles) {
-    PCD_CHECK_ARG(tall_halo_tiles >= 0 && (tall_halo_tiles & 7) <= 2 && tall_halo_tiles < 32768);
+    PCD_CHECK_ARG(tall_halo_tiles >= 0 && (tall_halo_tiles & 7) <= 2 && tall_halo_tiles < 262144);
+    g_wreg_abl = (tall_halo_tiles >> 15) & 7;
     g_last_roll = (tall_halo_tiles & 16384) ? 0 : 1;
     g_igemm_abl = (tall_halo_tiles >> 10) & 15;
     g_first8 = (tall_halo_tiles & 512) ? 0 : 1;
@@ -2152,6 +2157,10 @@ extern "C" int pcd_conv3d_k3s1_wreg_f16(const pcd_conv3d_desc_t* d, const void* 
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)blocks);
     if (d->cin == 128) hipLaunchKernelGGL((conv3d_halo_wreg_kernel<128, 4>), grid, dim3(512), 0, s, p);              // eight waves, one workgroup per CU
+    else if (d->cin == 64 && nwc == 2 && g_wreg_abl == 1) hipLaunchKernelGGL((conv3d_halo_wreg_kernel<64, 2, 2, 1>), grid, dim3(256), 0, s, p);
+    else if (d->cin == 64 && nwc == 2 && g_wreg_abl == 2) hipLaunchKernelGGL((conv3d_halo_wreg_kernel<64, 2, 2, 2>), grid, dim3(256), 0, s, p);
+    else if (d->cin == 64 && nwc == 2 && g_wreg_abl == 4) hipLaunchKernelGGL((conv3d_halo_wreg_kernel<64, 2, 2, 4>), grid, dim3(256), 0, s, p);
+    else if (d->cin == 64 && nwc == 2 && g_wreg_abl == 6) hipLaunchKernelGGL((conv3d_halo_wreg_kernel<64, 2, 2, 6>), grid, dim3(256), 0, s, p);
     else if (d->cin == 64 && nwc == 2) hipLaunchKernelGGL((conv3d_halo_wreg_kernel<64, 2>), grid, dim3(256), 0, s, p);
     else if (d->cin == 64) hipLaunchKernelGGL((conv3d_halo_wreg_kernel<64, 1, 4>), grid, dim3(256), 0, s, p);     // C_out 32: four waves of 64 voxels
     else if (nwc == 2) hipLaunchKernelGGL((conv3d_halo_wreg_kernel<32, 2>), grid, dim3(256), 0, s, p);
